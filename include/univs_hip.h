@@ -1,0 +1,130 @@
+/*
+ * univs_hip.h -- C ABI of libunivs_hip.so: the MI355X (gfx950) native operators of the UniVS
+ * per-clip inference hot path.
+ *
+ * Conventions (the same for every entry point; they mirror what the reference's native operator
+ * enforces at mask2former/modeling/pixel_decoder/ops/src/cuda/ms_deform_attn_cuda.cu:33-59):
+ *   - all data pointers are DEVICE pointers to dense, contiguous, row-major buffers;
+ *     shape tables (`spatial_shapes`, `level_start_index`) are HOST pointers (they parameterise the
+ *     launch; the reference keeps them in device memory and re-reads them per thread,
+ *     ms_deform_im2col_cuda.cuh:277-280);
+ *   - `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous, never
+ *     synchronise the host, and are legal inside hipGraph stream capture;
+ *   - outputs are caller-allocated and fully overwritten (no zero-fill needed beforehand);
+ *   - return value: UNIVS_OK (0) or a negative UNIVS_ERR_* code; univs_last_error() returns a
+ *     thread-local human-readable message for the last failure.  Launch errors are RETURNED
+ *     (the reference only printf's them, ms_deform_im2col_cuda.cuh:953-957).
+ *   - no torch / ATen types anywhere in this ABI.
+ */
+#ifndef UNIVS_HIP_H
+#define UNIVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNIVS_OK 0
+#define UNIVS_ERR_INVALID_ARGUMENT (-1)
+#define UNIVS_ERR_NOT_IMPLEMENTED (-2)
+#define UNIVS_ERR_LAUNCH (-3)
+
+#define UNIVS_MAX_LEVELS 8
+
+/* Library identification: "univs_hip <semver> gfx950". */
+const char* univs_version(void);
+/* Message for the last non-OK return on this thread ("" if none). */
+const char* univs_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward.
+ * Replaces: ms_deform_attn_forward  (ops/src/vision.cpp:19, ops/src/ms_deform_attn.h:25-44)
+ *           -> ms_deform_attn_cuda_forward (ops/src/cuda/ms_deform_attn_cuda.cu:25-85)
+ *           -> ms_deformable_im2col_gpu_kernel (ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304).
+ *
+ *   value          [N, S, M, D]        S = sum_l H_l*W_l
+ *   spatial_shapes [L, 2] (H_l, W_l)   HOST int64
+ *   level_start    [L]                 HOST int64
+ *   sampling_loc   [N, Lq, M, L, P, 2] (x, y) normalised to [0,1] per level
+ *   attn_weight    [N, Lq, M, L, P]
+ *   out            [N, Lq, M*D]
+ *   out[n,q,m,:] = sum_{l,p} attn[n,q,m,l,p] * bilinear(value_l[n,:,m,:], x*W_l-0.5, y*H_l-0.5)
+ *   with zero padding outside the level (== grid_sample(align_corners=False, padding='zeros')).
+ * The reference's `im2col_step` batching argument has no effect on results and is not part of this
+ * ABI (one launch covers the whole batch); the Python shim still validates it like the reference
+ * (batch % min(batch, im2col_step) == 0, ms_deform_attn_cuda.cu:55-57).
+ * ------------------------------------------------------------------------------------------- */
+int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const float* sampling_loc,
+                           const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                           int P, float* out, void* stream);
+int univs_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const double* sampling_loc,
+                           const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                           int P, double* out, void* stream);
+
+/* Backward of the above (ops/src/ms_deform_attn.h:46-66).  Training is out of scope for the
+ * inference hot path: the symbol exists so a binding can resolve it, and always returns
+ * UNIVS_ERR_NOT_IMPLEMENTED. */
+int univs_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start, const float* sampling_loc,
+                            const float* attn_weight, const float* grad_output, int N, int S, int M,
+                            int D, int L, int Lq, int P, float* grad_value, float* grad_sampling_loc,
+                            float* grad_attn_weight, void* stream);
+
+/* Selects the MSDA forward implementation: 0 = auto (default), 1 = generic direct-gather kernel,
+ * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
+ * Used by the parity tests and bench to exercise each path explicitly. */
+int univs_msda_set_impl(int impl);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mask decode: per-frame contraction of mask embeddings with per-pixel features.
+ * Replaces: torch.einsum("btqc,btchw->btqhw", mask_embed, mask_features).transpose(1, 2)
+ *           (univs/modeling/transformer_decoder/video_mask2former_transformer_decoder_univs.py:527-528)
+ *   mask_embed    [T, Q, C]
+ *   mask_features [T, C, HW]      (NCHW feature map, HW flattened)
+ *   out           [Q, T, HW]      (the [B=1, Q, T, H, W] layout callers consume)
+ * fp32 in / fp32 accumulate on the f32 MFMA path (exact fmaf chain, no reduced precision).
+ * ------------------------------------------------------------------------------------------- */
+int univs_mask_decode_f32(const float* mask_embed, const float* mask_features, int T, int Q, int C,
+                          int HW, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused attention-mask generation for the next decoder layer.
+ * Replaces: the mask einsum above followed by F.interpolate(..., size=(h,w), mode="bilinear",
+ *           align_corners=False), sigmoid() < 0.5, and the all-masked-row reset
+ *           (...decoder_univs.py:527, :555-566 and :390) WITHOUT materialising full-resolution logits:
+ *           bilinear resampling commutes with the channel contraction, so the caller passes mask
+ *           features already resampled to the target level size.
+ *   mask_embed   [T, Q, C]
+ *   feat_lowres  [T, C, hw]        mask_features bilinearly resampled to (h, w)
+ *   attn_mask    [T, Q, hw] uint8  1 = key masked out (logit < 0), 0 = key visible; a row that
+ *                                  would be fully masked is written as all 0 (":390" rule)
+ *   row_any_ws   [T*Q] uint32      caller-provided scratch (no allocation inside the library, so the
+ *                                  call is legal under hipGraph capture); contents are clobbered
+ *   The reference repeats the mask over the attention heads; consumers broadcast instead.
+ * ------------------------------------------------------------------------------------------- */
+int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres, int T, int Q,
+                               int C, int hw, uint8_t* attn_mask, uint32_t* row_any_ws,
+                               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin window attention core.
+ * Replaces: WindowAttention.forward between the qkv and proj linears
+ *           (mask2former/modeling/backbone/swin.py:137-168):
+ *           softmax((q*scale) @ k^T + rel_pos_bias[h] (+ shift_mask[window % nW])) @ v
+ *   qkv        [B_, Ntok, 3, nH, hd]   output of the qkv Linear, B_ = batch * windows (window fastest)
+ *   bias       [nH, Ntok, Ntok]        relative position bias already gathered per head (swin.py:148-155)
+ *   shift_mask [nW, Ntok, Ntok] or NULL (0 / -100 entries, swin.py:437-440)
+ *   out        [B_, Ntok, nH*hd]
+ *   hd must be 32 (Swin-T/B/L); Ntok <= 144 (window 12).
+ * ------------------------------------------------------------------------------------------- */
+int univs_window_attention_f32(const float* qkv, const float* bias, const float* shift_mask,
+                               int B_, int nW, int Ntok, int nH, int hd, float scale, float* out,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIVS_HIP_H */

@@ -1,0 +1,252 @@
+"""Dev-container-only harness that imports the *reference* UniVS hot-path modules.
+
+TEST INFRASTRUCTURE -- never imported by the product (`univs_amd/`), never shipped to the GPU box
+as a dependency: `/root/reference` does not exist there.  It exists to (i) generate the golden
+fixtures under `tests/golden/` (see `oracle/gen_golden.py`) and (ii) validate the CPU restatement
+in `oracle/torch_ref.py` against the real reference while developing.
+
+How the import works:
+  * the reference's package `__init__` files import cv2 / kornia / pycocotools / torchvision, which are
+    absent here, so we register empty *parent packages* (with `__path__` pointing at the reference
+    directories) and then import only the leaf modules of the hot path;
+  * the handful of third-party symbols those leaf modules need at import / construction time
+    (detectron2 `configurable`, `Conv2d(norm=, activation=)`, `get_norm`, `ShapeSpec`, registries,
+    `point_sample`; fvcore `c2_xavier_fill`; timm `DropPath/to_2tuple/trunc_normal_`) are provided
+    as small behavioural stand-ins written from the public documentation of those libraries;
+  * the compiled extension `MultiScaleDeformableAttention` is replaced by a module forwarding to the
+    reference's own `ms_deform_attn_core_pytorch` (ops/functions/ms_deform_attn_func.py:52-72), the
+    swap the reference itself documents at ops/modules/ms_deform_attn.py:118-119 and uses as the
+    oracle in ops/test.py:35-63.
+"""
+import importlib
+import math
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF_ROOT = os.environ.get("UNIVS_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REF_ROOT, "univs"))
+
+
+def _pkg(name, path=None):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    m.__package__ = name
+    sys.modules[name] = m
+    return m
+
+
+class _Registry:
+    def __init__(self, name):
+        self._name = name
+        self._map = {}
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(o):
+                self._map[o.__name__] = o
+                return o
+            return deco
+        self._map[obj.__name__] = obj
+        return obj
+
+    def get(self, name):
+        return self._map[name]
+
+
+def _configurable(init_func=None, *, from_config=None):
+    # explicit-kwargs construction only (the oracle never builds from a cfg)
+    if init_func is not None:
+        return init_func
+
+    def wrapper(f):
+        return f
+    return wrapper
+
+
+class _ShapeSpec:
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+
+class _Conv2d(nn.Conv2d):
+    """detectron2.layers.Conv2d: conv -> optional norm -> optional activation."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def _get_norm(norm, out_channels):
+    if norm is None or norm == "":
+        return None
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    if norm == "LN":
+        return nn.LayerNorm(out_channels)
+    raise ValueError(norm)
+
+
+def _point_sample(input, point_coords, **kwargs):
+    add_dim = False
+    if point_coords.dim() == 3:
+        add_dim = True
+        point_coords = point_coords.unsqueeze(2)
+    output = F.grid_sample(input, 2.0 * point_coords - 1.0, **kwargs)
+    if add_dim:
+        output = output.squeeze(3)
+    return output
+
+
+def _c2_xavier_fill(module):
+    nn.init.kaiming_uniform_(module.weight, a=1)
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+class _DropPath(nn.Module):
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return x  # eval only
+
+
+def _to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+
+_INSTALLED = False
+
+
+def install():
+    """Register parent packages + third-party stand-ins, then make reference leaf modules importable."""
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REF_ROOT} (this harness only works in the dev container)")
+
+    R = REF_ROOT
+    # --- third-party stand-ins -------------------------------------------------------------
+    d2 = _pkg("detectron2")
+    cfgm = _pkg("detectron2.config"); cfgm.configurable = _configurable
+    cfgm.CfgNode = dict
+    lay = _pkg("detectron2.layers")
+    lay.Conv2d, lay.ShapeSpec, lay.get_norm = _Conv2d, _ShapeSpec, _get_norm
+    lay.DeformConv = object
+    mod = _pkg("detectron2.modeling")
+    mod.BACKBONE_REGISTRY = _Registry("BACKBONE")
+    mod.SEM_SEG_HEADS_REGISTRY = _Registry("SEM_SEG_HEADS")
+    mod.META_ARCH_REGISTRY = _Registry("META_ARCH")
+    mod.Backbone = nn.Module
+    mod.ShapeSpec = _ShapeSpec
+    ut = _pkg("detectron2.utils")
+    reg = _pkg("detectron2.utils.registry"); reg.Registry = _Registry
+    _pkg("detectron2.projects")
+    _pkg("detectron2.projects.point_rend")
+    pf = _pkg("detectron2.projects.point_rend.point_features"); pf.point_sample = _point_sample
+    d2.config, d2.layers, d2.modeling, d2.utils = cfgm, lay, mod, ut
+
+    fv = _pkg("fvcore"); fvnn = _pkg("fvcore.nn"); wi = _pkg("fvcore.nn.weight_init")
+    wi.c2_xavier_fill = _c2_xavier_fill
+    wi.c2_msra_fill = _c2_xavier_fill
+    fv.nn = fvnn; fvnn.weight_init = wi
+
+    tm = _pkg("timm"); tmm = _pkg("timm.models"); tml = _pkg("timm.models.layers")
+    tml.DropPath, tml.to_2tuple, tml.trunc_normal_ = _DropPath, _to_2tuple, _trunc_normal_
+    tm.models = tmm; tmm.layers = tml
+
+    _pkg("torchvision")
+
+    # --- reference parent packages (no __init__ executed) -----------------------------------
+    sys.path.insert(0, R)
+    _pkg("mask2former", f"{R}/mask2former")
+    _pkg("mask2former.modeling", f"{R}/mask2former/modeling")
+    _pkg("mask2former.modeling.backbone", f"{R}/mask2former/modeling/backbone")
+    _pkg("mask2former.modeling.meta_arch", f"{R}/mask2former/modeling/meta_arch")
+    _pkg("mask2former.modeling.pixel_decoder", f"{R}/mask2former/modeling/pixel_decoder")
+    _pkg("mask2former.modeling.transformer_decoder", f"{R}/mask2former/modeling/transformer_decoder")
+    _pkg("univs", f"{R}/univs")
+    _pkg("univs.modeling", f"{R}/univs/modeling")
+    _pkg("univs.modeling.transformer_decoder", f"{R}/univs/modeling/transformer_decoder")
+    _pkg("univs.modeling.prompt_encoder", f"{R}/univs/modeling/prompt_encoder")
+    _pkg("univs.utils", f"{R}/univs/utils")
+    langm = _pkg("univs.modeling.language")
+    langm.pre_tokenize_expression = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no tokenizer in oracle"))
+    _pkg("datasets", f"{R}/datasets")
+    _pkg("datasets.concept_emb", f"{R}/datasets/concept_emb")
+
+    # --- the compiled op -> the reference's own pure-PyTorch core ---------------------------
+    msda = types.ModuleType("MultiScaleDeformableAttention")
+    sys.modules["MultiScaleDeformableAttention"] = msda
+
+    def _fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+        core = sys.modules["mask2former.modeling.pixel_decoder.ops.functions.ms_deform_attn_func"].ms_deform_attn_core_pytorch
+        return core(value, spatial_shapes, sampling_loc, attn_weight)
+
+    def _bwd(*a, **k):
+        raise NotImplementedError
+    msda.ms_deform_attn_forward, msda.ms_deform_attn_backward = _fwd, _bwd
+
+    # prompt_encoder's __init__ re-exports; make `from univs.modeling.prompt_encoder import X` work
+    pe_leaf = importlib.import_module("univs.modeling.prompt_encoder.prompt_encoder")
+    pe_pkg = sys.modules["univs.modeling.prompt_encoder"]
+    for n in ("TextPromptEncoder", "VisualPromptEncoder", "VisualPromptSampler"):
+        setattr(pe_pkg, n, getattr(pe_leaf, n))
+    _INSTALLED = True
+
+
+def ref():
+    """Namespace of the reference classes/functions on the hot path."""
+    install()
+    ns = types.SimpleNamespace()
+    f = importlib.import_module("mask2former.modeling.pixel_decoder.ops.functions.ms_deform_attn_func")
+    ns.ms_deform_attn_core_pytorch = f.ms_deform_attn_core_pytorch
+    m = importlib.import_module("mask2former.modeling.pixel_decoder.ops.modules.ms_deform_attn")
+    ns.MSDeformAttn = m.MSDeformAttn
+    pd = importlib.import_module("mask2former.modeling.pixel_decoder.msdeformattn")
+    ns.MSDeformAttnPixelDecoder = pd.MSDeformAttnPixelDecoder
+    ns.MSDeformAttnTransformerEncoderLayer = pd.MSDeformAttnTransformerEncoderLayer
+    sw = importlib.import_module("mask2former.modeling.backbone.swin")
+    ns.SwinTransformer = sw.SwinTransformer
+    ns.WindowAttention = sw.WindowAttention
+    pe2 = importlib.import_module("mask2former.modeling.transformer_decoder.position_encoding")
+    ns.PositionEmbeddingSine = pe2.PositionEmbeddingSine
+    pe3 = importlib.import_module("univs.modeling.transformer_decoder.position_encoding")
+    ns.PositionEmbeddingSine3D = pe3.PositionEmbeddingSine3D
+    ns.PositionEmbeddingSine3DArbitraryT = pe3.PositionEmbeddingSine3DArbitraryT
+    dec = importlib.import_module("univs.modeling.transformer_decoder.video_mask2former_transformer_decoder_univs")
+    ns.Decoder = dec.VideoMultiScaleMaskedTransformerDecoderUniVS
+    pr = importlib.import_module("univs.modeling.prompt_encoder.prompt_encoder")
+    ns.VisualPromptSampler = pr.VisualPromptSampler
+    ns.VisualPromptEncoder = pr.VisualPromptEncoder
+    hd = importlib.import_module("mask2former.modeling.meta_arch.mask_former_head")
+    ns.MaskFormerHead = hd.MaskFormerHead
+    cm = importlib.import_module("univs.utils.comm")
+    ns.comm = cm
+    ns.ShapeSpec = _ShapeSpec
+    return ns

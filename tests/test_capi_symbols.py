@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/univs_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from univs_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "univs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(univs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/univs_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES table out of sync with the header"
+
+
+def test_version_and_error_paths_without_gpu():
+    lib = _lib.load()
+    assert lib.univs_version().decode().startswith("univs_hip ")
+    assert lib.univs_msda_set_impl(7) == _lib.ERR_INVALID_ARGUMENT
+    assert b"impl=7" in lib.univs_last_error()
+    assert lib.univs_msda_set_impl(0) == _lib.OK
+    # backward is a declared-but-unimplemented entry (inference-only scope)
+    rc = lib.univs_msda_backward_f32(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None, None, None, None)
+    assert rc == _lib.ERR_NOT_IMPLEMENTED
+
+
+def test_product_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from univs_amd import ops
+    v = torch.zeros(1, 4, 1, 4)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.ms_deform_attn_forward(v, [(2, 2)], [0], torch.zeros(1, 4, 1, 1, 1, 2), torch.zeros(1, 4, 1, 1, 1))
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.mask_decode(torch.zeros(1, 2, 4), torch.zeros(1, 4, 2, 2))

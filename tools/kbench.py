@@ -1,0 +1,82 @@
+"""Kernel micro-benchmarks at the BASELINE config-2 geometry (run on the GPU box).
+Prints one line per kernel: average launch time (HIP events on the launch stream), achieved algorithmic
+GB/s (SURVEY.md section 8d figures) and fraction of the 8 TB/s HBM peak."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import cases  # noqa: E402
+from univs_amd import ops, synth  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--T", type=int, default=5)
+    ap.add_argument("--locs", default="local", choices=["local", "uniform"])
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = {}
+    T = args.T
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    case = dict(name="kb", shapes=shapes, N=T, M=8, D=32, P=4, encoder=True)
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    if args.locs == "uniform":
+        loc = synth.uniform("kb/uloc", tuple(loc.shape), 0.0, 1.0)
+    value, loc, attn = value.to(dev), loc.to(dev), attn.to(dev)
+    S = value.shape[1]
+    alg = 3200.0 * S * T
+    if not args.only or "msda" in args.only:
+        for impl, nm in ((1, "msda_generic"), (2, "msda_tiled")):
+            ops.msda_set_impl(impl)
+            t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
+            res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+        ops.msda_set_impl(0)
+    if not args.only or "mask" in args.only:
+        Q, C, H, W = 100, 256, 184, 320
+        e = synth.normal("kb/e", (T, Q, C)).to(dev)
+        f = synth.normal("kb/f", (T, C, H, W)).to(dev)
+        t = timeit(lambda: ops.mask_decode(e, f))
+        algm = 4.0 * (C * H * W + Q * C + Q * H * W) * T
+        res["mask_decode"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=algm / t / 1e9, frac_hbm=algm / t / HBM_PEAK,
+                                  TFLOPs=2.0 * Q * C * H * W * T / t / 1e12)
+        t = timeit(lambda: torch.einsum("tqc,tchw->tqhw", e, f))
+        res["mask_decode_torch_einsum"] = dict(ms=t * 1e3, TFLOPs=2.0 * Q * C * H * W * T / t / 1e12)
+        for (h, w) in shapes:
+            fl = torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+            t = timeit(lambda: ops.mask_decode_attn(e, fl))
+            res[f"mask_decode_attn_{h}x{w}"] = dict(ms=t * 1e3)
+    if not args.only or "win" in args.only:
+        # Swin-T stage 1 at 720p: 27x46 windows of 49 tokens, 3 heads, per frame
+        nW, nH, ntok, hd = 27 * 46, 3, 49, 32
+        qkv = synth.normal("kb/qkv", (T * nW, ntok, 3, nH, hd)).to(dev)
+        bias = synth.normal("kb/bias", (nH, ntok, ntok)).to(dev)
+        mask = torch.zeros(nW, ntok, ntok, device=dev)
+        t = timeit(lambda: ops.window_attention(qkv, bias, mask, nW, hd ** -0.5))
+        byts = (qkv.numel() + qkv.numel() / 3) * 4.0
+        res["window_attn_stage1"] = dict(ms=t * 1e3, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+    for k, v in res.items():
+        print(k, json.dumps({kk: round(vv, 4) for kk, vv in v.items()}))
+
+
+if __name__ == "__main__":
+    main()

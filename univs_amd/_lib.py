@@ -1,0 +1,66 @@
+"""ctypes binding of libunivs_hip.so (the C ABI declared in include/univs_hip.h).
+
+No fallback: if the shared library is missing or a symbol cannot be resolved this raises.  The
+product path never routes through `oracle/` or a CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunivs_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_NOT_IMPLEMENTED = -2
+ERR_LAUNCH = -3
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+
+# name -> (restype, argtypes); must list every symbol of include/univs_hip.h (tests check this)
+SIGNATURES = {
+    "univs_version": (_c.c_char_p, []),
+    "univs_last_error": (_c.c_char_p, []),
+    "univs_msda_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_msda_forward_f64": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_msda_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "univs_msda_set_impl": (_I, [_I]),
+    "univs_mask_decode_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "univs_mask_decode_attn_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "univs_window_attention_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _c.c_float, _P, _P]),
+}
+
+_lib = None
+
+
+class UnivsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library is absent -- build it with
+    `python -m univs_amd.build` (or `__graft_entry__.build()`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UnivsHipError(
+            f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
+            "Build it with `python -m univs_amd.build`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    msg = load().univs_last_error().decode("utf-8", "replace")
+    if rc == ERR_NOT_IMPLEMENTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise UnivsHipError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,176 @@
+// extern "C" entry points of libunivs_hip.so (declared in include/univs_hip.h).
+// Argument validation + dispatch only; kernels live in the sibling .hip files.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace univs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int g_msda_impl = 0;  // 0 auto, 1 generic, 2 tiled
+
+int msda_forward_generic_f32(const float*, const LevelTable&, const float*, const float*, int, int,
+                             int, int, int, int, int, float*, hipStream_t);
+int msda_forward_generic_f64(const double*, const LevelTable&, const double*, const double*, int,
+                             int, int, int, int, int, int, double*, hipStream_t);
+// returns 1 if the tiled kernel was launched, 0 if its preconditions do not hold, <0 on error
+int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
+                           int, int, int, int, int, float*, hipStream_t);
+int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
+int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
+                         hipStream_t);
+
+int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
+                         float*, hipStream_t);
+
+static int make_levels(const int64_t* shapes, const int64_t* starts, int L, int S, LevelTable* lv,
+                       const char* what) {
+  if (L < 1 || L > UNIVS_MAX_LEVELS) {
+    set_error("%s: num_levels=%d outside [1,%d]", what, L, UNIVS_MAX_LEVELS);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (!shapes || !starts) {
+    set_error("%s: spatial_shapes / level_start_index must be host pointers, got NULL", what);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  for (int l = 0; l < L; ++l) {
+    const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], st = starts[l];
+    if (H <= 0 || W <= 0 || st < 0 || st + H * W > (int64_t)S) {
+      set_error("%s: level %d (H=%lld, W=%lld, start=%lld) does not fit value length S=%d", what, l,
+                (long long)H, (long long)W, (long long)st, S);
+      return UNIVS_ERR_INVALID_ARGUMENT;
+    }
+    lv->H[l] = (int)H;
+    lv->W[l] = (int)W;
+    lv->start[l] = (int)st;
+  }
+  for (int l = L; l < UNIVS_MAX_LEVELS; ++l) lv->H[l] = lv->W[l] = lv->start[l] = 0;
+  return UNIVS_OK;
+}
+
+}  // namespace univs
+
+using namespace univs;
+
+extern "C" {
+
+const char* univs_version(void) { return "univs_hip 0.1.0 gfx950"; }
+const char* univs_last_error(void) { return g_err; }
+
+int univs_msda_set_impl(int impl) {
+  if (impl < 0 || impl > 2) {
+    set_error("univs_msda_set_impl: impl=%d not in {0,1,2}", impl);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  g_msda_impl = impl;
+  return UNIVS_OK;
+}
+
+int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const float* sampling_loc,
+                           const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                           int P, float* out, void* stream) {
+  if (N < 0 || S < 0 || M < 0 || D < 0 || Lq < 0 || P < 0) {
+    set_error("univs_msda_forward_f32: negative dimension");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;  // empty output
+  if (!value || !sampling_loc || !attn_weight || !out) {
+    set_error("univs_msda_forward_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_f32");
+  if (rc != UNIVS_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_msda_impl != 1) {
+    rc = msda_forward_tiled_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
+    if (rc != 0) return rc < 0 ? rc : UNIVS_OK;
+  }
+  return msda_forward_generic_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
+}
+
+int univs_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const double* sampling_loc,
+                           const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                           int P, double* out, void* stream) {
+  if (N < 0 || S < 0 || M < 0 || D < 0 || Lq < 0 || P < 0) {
+    set_error("univs_msda_forward_f64: negative dimension");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
+  if (!value || !sampling_loc || !attn_weight || !out) {
+    set_error("univs_msda_forward_f64: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_f64");
+  if (rc != UNIVS_OK) return rc;
+  return msda_forward_generic_f64(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out,
+                                  (hipStream_t)stream);
+}
+
+int univs_msda_backward_f32(const float*, const int64_t*, const int64_t*, const float*,
+                            const float*, const float*, int, int, int, int, int, int, int, float*,
+                            float*, float*, void*) {
+  set_error("univs_msda_backward_f32: backward is out of scope of the inference hot path");
+  return UNIVS_ERR_NOT_IMPLEMENTED;
+}
+
+int univs_mask_decode_f32(const float* mask_embed, const float* mask_features, int T, int Q, int C,
+                          int HW, float* out, void* stream) {
+  if (T < 0 || Q < 0 || C <= 0 || HW < 0) {
+    set_error("univs_mask_decode_f32: bad dimensions T=%d Q=%d C=%d HW=%d", T, Q, C, HW);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)T * Q * HW == 0) return UNIVS_OK;
+  if (!mask_embed || !mask_features || !out) {
+    set_error("univs_mask_decode_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return mask_decode_f32(mask_embed, mask_features, T, Q, C, HW, out, (hipStream_t)stream);
+}
+
+int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres, int T, int Q,
+                               int C, int hw, uint8_t* attn_mask, uint32_t* row_any_ws,
+                               void* stream) {
+  if (T < 0 || Q < 0 || C <= 0 || hw < 0) {
+    set_error("univs_mask_decode_attn_f32: bad dimensions T=%d Q=%d C=%d hw=%d", T, Q, C, hw);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)T * Q * hw == 0) return UNIVS_OK;
+  if (!mask_embed || !feat_lowres || !attn_mask || !row_any_ws) {
+    set_error("univs_mask_decode_attn_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return mask_decode_attn_f32(mask_embed, feat_lowres, T, Q, C, hw, attn_mask, row_any_ws,
+                              (hipStream_t)stream);
+}
+
+int univs_window_attention_f32(const float* qkv, const float* bias, const float* shift_mask,
+                               int B_, int nW, int Ntok, int nH, int hd, float scale, float* out,
+                               void* stream) {
+  if (B_ < 0 || Ntok <= 0 || nH <= 0 || hd <= 0 || (shift_mask && (nW <= 0 || B_ % nW != 0))) {
+    set_error("univs_window_attention_f32: bad dimensions B_=%d nW=%d Ntok=%d nH=%d hd=%d", B_, nW,
+              Ntok, nH, hd);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (B_ == 0) return UNIVS_OK;
+  if (!qkv || !bias || !out) {
+    set_error("univs_window_attention_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return window_attention_f32(qkv, bias, shift_mask, B_, nW > 0 ? nW : 1, Ntok, nH, hd, scale, out,
+                              (hipStream_t)stream);
+}
+
+}  // extern "C"

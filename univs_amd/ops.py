@@ -1,0 +1,165 @@
+"""Tensor-level wrappers over the C ABI (include/univs_hip.h): checks + allocation + launch on the
+current torch stream.  PyTorch is plumbing here (device memory, streams); the compute is in
+libunivs_hip.so.  Every function raises on non-GPU tensors -- the reference does the same for its
+operator ("Not implemented on the CPU", ops/src/ms_deform_attn.h:43) and there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_shape_cache = {}
+
+
+def _stream_ptr(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_gpu(name, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}: Not implemented on the CPU (tensor on {t.device}); the HIP "
+                               "extension is the only implementation")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name}: all tensors have to be contiguous")
+
+
+def _host_shapes(spatial_shapes, level_start_index):
+    """Level table as host int64 ctypes arrays.  Accepts tensors (device or host), lists or tuples.
+    Device tensors cost one D2H copy the first time a given table is seen; the encoder passes the
+    Python lists it already owns, so the hot path never syncs."""
+    def to_list(x):
+        if isinstance(x, torch.Tensor):
+            key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
+            hit = _shape_cache.get(key)
+            if hit is None:
+                if len(_shape_cache) > 256:
+                    _shape_cache.clear()
+                hit = [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
+                _shape_cache[key] = hit
+            return hit
+        out = []
+        for v in x:
+            if isinstance(v, (list, tuple)):
+                out.extend(int(u) for u in v)
+            else:
+                out.append(int(v))
+        return out
+    sh = to_list(spatial_shapes)
+    st = to_list(level_start_index)
+    L = len(st)
+    if len(sh) != 2 * L:
+        raise RuntimeError(f"spatial_shapes has {len(sh)} entries, expected 2*{L}")
+    return (ctypes.c_int64 * len(sh))(*sh), (ctypes.c_int64 * L)(*st), L
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step=128):
+    """Same contract as the reference's `MSDA.ms_deform_attn_forward`
+    (ops/src/vision.cpp:19; checks from ops/src/cuda/ms_deform_attn_cuda.cu:33-57).
+    value [N,S,M,D], sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P] -> [N,Lq,M*D]."""
+    _require_gpu("ms_deform_attn_forward", value, sampling_loc, attn_weight)
+    if value.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"ms_deform_attn_forward: unsupported dtype {value.dtype} (float/double only, "
+                           "as the reference's AT_DISPATCH_FLOATING_TYPES)")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("ms_deform_attn_forward: value / sampling_loc / attn_weight dtypes differ")
+    N, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_loc.shape
+    if M2 != M or two != 2 or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError("ms_deform_attn_forward: inconsistent shapes "
+                           f"value={tuple(value.shape)} loc={tuple(sampling_loc.shape)} w={tuple(attn_weight.shape)}")
+    step = min(N, int(im2col_step)) if N > 0 else 1
+    if step <= 0 or N % step != 0:
+        raise RuntimeError(f"batch({N}) must divide im2col_step({step})")
+    sh, st, L2 = _host_shapes(spatial_shapes, level_start_index)
+    if L2 != L:
+        raise RuntimeError(f"ms_deform_attn_forward: {L2} levels in spatial_shapes, {L} in sampling_loc")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    lib = _lib.load()
+    fn = lib.univs_msda_forward_f32 if value.dtype == torch.float32 else lib.univs_msda_forward_f64
+    with torch.cuda.device(value.device):
+        rc = fn(_ptr(value), sh, st, _ptr(sampling_loc), _ptr(attn_weight), N, S, M, D, L, Lq, P,
+                _ptr(out), _stream_ptr(value))
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step=128):
+    """Exported for interface parity (ops/src/vision.cpp:20); inference-only scope -> raises."""
+    lib = _lib.load()
+    rc = lib.univs_msda_backward_f32(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None,
+                                     None, None, None)
+    _lib.check(rc, "ms_deform_attn_backward")
+
+
+def msda_set_impl(impl: int):
+    """0 auto, 1 generic direct-gather kernel, 2 LDS-tiled encoder kernel."""
+    _lib.check(_lib.load().univs_msda_set_impl(int(impl)), "msda_set_impl")
+
+
+def mask_decode(mask_embed, mask_features):
+    """einsum('tqc,tchw->qthw'): mask_embed [T,Q,C], mask_features [T,C,H,W] -> logits [Q,T,H,W]
+    (== ...decoder_univs.py:527-528 for batch 1)."""
+    _require_gpu("mask_decode", mask_embed, mask_features)
+    if mask_embed.dtype != torch.float32 or mask_features.dtype != torch.float32:
+        raise RuntimeError("mask_decode: float32 only")
+    T, Q, C = mask_embed.shape
+    T2, C2, H, W = mask_features.shape
+    if T2 != T or C2 != C:
+        raise RuntimeError(f"mask_decode: shape mismatch {tuple(mask_embed.shape)} vs {tuple(mask_features.shape)}")
+    out = torch.empty((Q, T, H, W), dtype=torch.float32, device=mask_embed.device)
+    with torch.cuda.device(mask_embed.device):
+        rc = _lib.load().univs_mask_decode_f32(_ptr(mask_embed), _ptr(mask_features), T, Q, C, H * W,
+                                               _ptr(out), _stream_ptr(mask_embed))
+    _lib.check(rc, "mask_decode")
+    return out
+
+
+def mask_decode_attn(mask_embed, feat_lowres):
+    """Fused attention-mask generation: mask_embed [T,Q,C], feat_lowres [T,C,h,w] (mask features
+    resampled to the next level's size) -> bool [T,Q,h*w], True = key masked out; rows that would be
+    fully masked come back all-False (...decoder_univs.py:555-566 + :390)."""
+    _require_gpu("mask_decode_attn", mask_embed, feat_lowres)
+    if mask_embed.dtype != torch.float32 or feat_lowres.dtype != torch.float32:
+        raise RuntimeError("mask_decode_attn: float32 only")
+    T, Q, C = mask_embed.shape
+    T2, C2, h, w = feat_lowres.shape
+    if T2 != T or C2 != C:
+        raise RuntimeError("mask_decode_attn: shape mismatch")
+    mask = torch.empty((T, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
+    ws = torch.empty((max(T * Q, 1),), dtype=torch.int32, device=mask_embed.device)
+    with torch.cuda.device(mask_embed.device):
+        rc = _lib.load().univs_mask_decode_attn_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w,
+                                                    _ptr(mask), _ptr(ws), _stream_ptr(mask_embed))
+    _lib.check(rc, "mask_decode_attn")
+    return mask.view(torch.bool)
+
+
+def window_attention(qkv, bias, shift_mask, num_windows, scale):
+    """Swin window-attention core (swin.py:137-168 between the qkv and proj linears).
+    qkv [B_, Ntok, 3, nH, hd]; bias [nH, Ntok, Ntok]; shift_mask [nW, Ntok, Ntok] or None
+    -> [B_, Ntok, nH*hd]."""
+    _require_gpu("window_attention", qkv, bias)
+    if qkv.dtype != torch.float32:
+        raise RuntimeError("window_attention: float32 only")
+    B_, Ntok, three, nH, hd = qkv.shape
+    if three != 3 or tuple(bias.shape) != (nH, Ntok, Ntok):
+        raise RuntimeError("window_attention: bad shapes")
+    if shift_mask is not None:
+        _require_gpu("window_attention", shift_mask)
+        if tuple(shift_mask.shape) != (num_windows, Ntok, Ntok) or B_ % num_windows != 0:
+            raise RuntimeError("window_attention: bad shift_mask shape")
+    out = torch.empty((B_, Ntok, nH * hd), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = _lib.load().univs_window_attention_f32(
+            _ptr(qkv), _ptr(bias), _ptr(shift_mask) if shift_mask is not None else None, B_,
+            int(num_windows), Ntok, nH, hd, float(scale), _ptr(out), _stream_ptr(qkv))
+    _lib.check(rc, "window_attention")
+    return out
