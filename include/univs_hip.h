@@ -77,6 +77,9 @@ int univs_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
  * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
  * Used by the parity tests and bench to exercise each path explicitly. */
 int univs_msda_set_impl(int impl);
+/* Which implementation the last univs_msda_forward_f32 call on this thread launched: 1 generic,
+ * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
+int univs_msda_last_impl(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Mask decode: per-frame contraction of mask embeddings with per-pixel features.

@@ -54,10 +54,13 @@ def msda_inputs(case, dtype=torch.float32):
         ref = torch.cat(refs, 0)  # [S, 2]
         off = synth.normal(nm + "/off", (N, Lq, M, L, P, 2), std=2.0)  # pixels of the target level
         # every 7th query gets far offsets (out of the tile halo, partly out of the image)
-        far = (torch.arange(Lq) % 7 == 3).view(1, Lq, 1, 1, 1, 1)
-        off = torch.where(far, off * 6.0, off)
+        if case.get("far", True):
+            far = (torch.arange(Lq) % 7 == 3).view(1, Lq, 1, 1, 1, 1)
+            off = torch.where(far, off * 6.0, off)
         norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
         loc = ref.view(1, Lq, 1, 1, 1, 2) + off / norm
+        if not case.get("far", True):
+            loc = loc.clamp(-0.05, 1.05)  # SURVEY.md section 8d "realistic locality" micro-benchmark input
     else:
         Lq = case["Lq"]
         loc = synth.uniform(nm + "/loc", (N, Lq, M, L, P, 2), -0.15, 1.15)

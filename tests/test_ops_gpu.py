@@ -18,6 +18,9 @@ def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl):
     try:
         out = ops.ms_deform_attn_forward(value.to(dev), shapes, lsi, loc.to(dev), attn.to(dev), 128)
         torch.cuda.synchronize()
+        ran = ops.msda_last_impl()
+        tiled_ok = (value.shape[3] == 32 and loc.shape[4] == 4 and loc.shape[1] == value.shape[1])
+        assert ran == (2 if (impl == 2 and tiled_ok) else 1), f"impl {impl} requested, {ran} ran"
     finally:
         ops.msda_set_impl(0)
     return out.cpu()

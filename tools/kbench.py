@@ -31,14 +31,14 @@ def timeit(fn, iters=20, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=5)
-    ap.add_argument("--locs", default="local", choices=["local", "uniform"])
+    ap.add_argument("--locs", default="local", choices=["local", "uniform", "far"])
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     res = {}
     T = args.T
     shapes = [(23, 40), (46, 80), (92, 160)]
-    case = dict(name="kb", shapes=shapes, N=T, M=8, D=32, P=4, encoder=True)
+    case = dict(name="kb", shapes=shapes, N=T, M=8, D=32, P=4, encoder=True, far=(args.locs == "far"))
     value, shapes, lsi, loc, attn = cases.msda_inputs(case)
     if args.locs == "uniform":
         loc = synth.uniform("kb/uloc", tuple(loc.shape), 0.0, 1.0)

@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...) {
 }
 
 static int g_msda_impl = 0;  // 0 auto, 1 generic, 2 tiled
+static thread_local int g_msda_last = 0;
 
 int msda_forward_generic_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                              int, int, int, int, int, float*, hipStream_t);
@@ -75,6 +76,8 @@ int univs_msda_set_impl(int impl) {
   return UNIVS_OK;
 }
 
+int univs_msda_last_impl(void) { return g_msda_last; }
+
 int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* sampling_loc,
                            const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
@@ -94,8 +97,12 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   hipStream_t st = (hipStream_t)stream;
   if (g_msda_impl != 1) {
     rc = msda_forward_tiled_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
-    if (rc != 0) return rc < 0 ? rc : UNIVS_OK;
+    if (rc != 0) {
+      if (rc > 0) g_msda_last = 2;
+      return rc < 0 ? rc : UNIVS_OK;
+    }
   }
+  g_msda_last = 1;
   return msda_forward_generic_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
 }
 

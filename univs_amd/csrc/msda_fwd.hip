@@ -17,7 +17,7 @@
 //   * kernel "tiled" (msda_tiled.hip): encoder self-attention geometry, value tiles staged in LDS.
 //   * kernel "scalar": any D / double precision, one thread per output element (KAT shapes of
 //     ops/test.py use D=2).
-#include "common.h"
+#include "msda_common.h"
 
 namespace univs {
 
@@ -68,35 +68,28 @@ __global__ __launch_bounds__(256) void msda_fwd_scalar(const T* __restrict__ val
 // ------------------------------------------------------------------------------------------------
 // vec4 direct-gather kernel (float, D % 4 == 0, D/4 in {1,2,4,8,16})
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 fma4(float s, float4 v, float4 a) {
-  a.x = fmaf(s, v.x, a.x);
-  a.y = fmaf(s, v.y, a.y);
-  a.z = fmaf(s, v.z, a.z);
-  a.w = fmaf(s, v.w, a.w);
-  return a;
-}
-
-// One sample: 4 corner rows, each a float4 per lane.  `vl` already points at (level, head, lane
-// channels); `rowf4` is the pixel stride in float4 units (M*D/4).
-__device__ __forceinline__ float4 sample_accum(const float4* __restrict__ vl, int H, int W,
-                                               int rowf4, float x, float y, float aw, float4 acc) {
-  const float him = y * (float)H - 0.5f, wim = x * (float)W - 0.5f;
-  if (him > -1.f && wim > -1.f && him < (float)H && wim < (float)W) {
-    const float hf = floorf(him), wf = floorf(wim);
-    const int h0 = (int)hf, w0 = (int)wf;
-    const float lh = him - hf, lw = wim - wf, hh = 1.f - lh, hw = 1.f - lw;
-    const bool t = h0 >= 0, b = h0 + 1 <= H - 1, lft = w0 >= 0, rgt = w0 + 1 <= W - 1;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long p00 = ((long long)h0 * W + w0) * rowf4;
-    // issue all four loads before use (independent addresses)
-    const float4 v1 = (t && lft) ? vl[p00] : z;
-    const float4 v2 = (t && rgt) ? vl[p00 + rowf4] : z;
-    const float4 v3 = (b && lft) ? vl[p00 + (long long)W * rowf4] : z;
-    const float4 v4 = (b && rgt) ? vl[p00 + (long long)W * rowf4 + rowf4] : z;
-    acc = fma4(aw * hh * hw, v1, acc);
-    acc = fma4(aw * hh * lw, v2, acc);
-    acc = fma4(aw * lh * hw, v3, acc);
-    acc = fma4(aw * lh * lw, v4, acc);
+// NS samples of one level: all 4*NS gathers are issued before the first use.
+template <int NS>
+__device__ __forceinline__ float4 gather_level(const float4* __restrict__ vl, int rowf4, int H, int W,
+                                               const float* xs, const float* ys, const float* aws,
+                                               float4 acc) {
+  Footprint f[NS];
+  float4 v[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f[s] = footprint(H, W, xs[s], ys[s], aws[s]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    v[s][0] = vl[(long long)(f[s].h0 * W + f[s].w0) * rowf4];
+    v[s][1] = vl[(long long)(f[s].h0 * W + f[s].w1) * rowf4];
+    v[s][2] = vl[(long long)(f[s].h1 * W + f[s].w0) * rowf4];
+    v[s][3] = vl[(long long)(f[s].h1 * W + f[s].w1) * rowf4];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    acc = fma4(f[s].w00, v[s][0], acc);
+    acc = fma4(f[s].w01, v[s][1], acc);
+    acc = fma4(f[s].w10, v[s][2], acc);
+    acc = fma4(f[s].w11, v[s][3], acc);
   }
   return acc;
 }
@@ -143,10 +136,10 @@ __global__ __launch_bounds__(256) void msda_fwd_vec4(const float* __restrict__ v
       for (int l = 0; l < L_CT; ++l) {
         const int H = lv.H[l], W = lv.W[l];
         const float4* vl = vb + (long long)lv.start[l] * rowf4;
-        acc = sample_accum(vl, H, W, rowf4, lc[2 * l].x, lc[2 * l].y, aw[l].x, acc);
-        acc = sample_accum(vl, H, W, rowf4, lc[2 * l].z, lc[2 * l].w, aw[l].y, acc);
-        acc = sample_accum(vl, H, W, rowf4, lc[2 * l + 1].x, lc[2 * l + 1].y, aw[l].z, acc);
-        acc = sample_accum(vl, H, W, rowf4, lc[2 * l + 1].z, lc[2 * l + 1].w, aw[l].w, acc);
+        const float xs[4] = {lc[2 * l].x, lc[2 * l].z, lc[2 * l + 1].x, lc[2 * l + 1].z};
+        const float ys[4] = {lc[2 * l].y, lc[2 * l].w, lc[2 * l + 1].y, lc[2 * l + 1].w};
+        const float ws[4] = {aw[l].x, aw[l].y, aw[l].z, aw[l].w};
+        acc = gather_level<4>(vl, rowf4, H, W, xs, ys, ws, acc);
       }
     } else {
       for (int l = 0; l < Lr; ++l) {
@@ -154,7 +147,8 @@ __global__ __launch_bounds__(256) void msda_fwd_vec4(const float* __restrict__ v
         const float4* vl = vb + (long long)lv.start[l] * rowf4;
         for (int p = 0; p < Pr; ++p) {
           const float2 xy = reinterpret_cast<const float2*>(lp)[l * Pr + p];
-          acc = sample_accum(vl, H, W, rowf4, xy.x, xy.y, ap[l * Pr + p], acc);
+          const float w1 = ap[l * Pr + p];
+          acc = gather_level<1>(vl, rowf4, H, W, &xy.x, &xy.y, &w1, acc);
         }
       }
     }

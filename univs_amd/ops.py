@@ -104,6 +104,11 @@ def msda_set_impl(impl: int):
     _lib.check(_lib.load().univs_msda_set_impl(int(impl)), "msda_set_impl")
 
 
+def msda_last_impl() -> int:
+    """1 = generic kernel, 2 = LDS-tiled kernel ran for the last forward on this thread."""
+    return int(_lib.load().univs_msda_last_impl())
+
+
 def mask_decode(mask_embed, mask_features):
     """einsum('tqc,tchw->qthw'): mask_embed [T,Q,C], mask_features [T,C,H,W] -> logits [Q,T,H,W]
     (== ...decoder_univs.py:527-528 for batch 1)."""
