@@ -1,0 +1,207 @@
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+One "step" = one pass of the per-clip inference hot path over one synthetic clip per rank:
+  BASELINE config 2 -- Swin-T UniVS, T=5 frames @ 720p (zero-padded to 736x1280), 100 learnable queries,
+  first clip of a video (no prompt queries): normalise+pad -> Swin-T -> MSDeformAttn pixel decoder ->
+  UniVS decoder (9 layers, 10 prediction heads) -> pred_masks [1,100,5,184,320].
+Inputs (frames, closed-form weights) are resident in HBM before the timed region.  fp32 end to end (the
+parity contract is 1e-3 max-abs on mask logits against the reference's fp32 CPU path).
+
+N > 1: one process per GPU (RCCL via torch.distributed "nccl"); each rank runs its own clip (clips of
+different videos are independent: SURVEY.md section 8e "replicas", no data-path collective), so scaling
+is weak and `value` is the whole-job frames/s.
+
+Extra objects on the JSON line (tier contract): `roofline` for the dominant hand-written kernel (the
+LDS-tiled MSDeformAttn forward; algorithmic bytes 3200*S per frame per launch),
+`roofline_mask_decode`, and `cpu_baseline` (rank 0, N=1 only: the CPU oracle path on the host cores, one
+clip).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+F32_MFMA_PEAK = 157.3e12   # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def build_model(dev):
+    from tests import cases, helpers
+    swin = helpers.build_swin(dev)
+    head = helpers.build_head(cases.CFG2, dev, return_aux=False)
+    return swin, head
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the launch stream == torch's current stream, which is the stream
+    the C ABI is handed) around every launch of one operator during the timed region."""
+
+    def __init__(self, module, name):
+        self.module, self.name, self.orig = module, name, getattr(module, name)
+        self.events, self.enabled = [], False
+
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return self.orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = self.orig(*a, **k)
+            e.record()
+            self.events.append((s, e))
+            return out
+        setattr(module, name, wrapped)
+
+    def avg_seconds(self):
+        if not self.events:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.events) / len(self.events) * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension is the only implementation)"
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from tests import cases
+    from univs_amd import ops
+
+    swin, head = build_model(dev)
+    case = cases.CFG2
+    frames = cases.cfg2_frames().to(dev)                      # [5,3,720,1280], 0..255
+    mean = torch.tensor([123.675, 116.28, 103.53], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375], device=dev).view(1, 3, 1, 1)
+
+    def targets():
+        return [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}]
+
+    @torch.no_grad()
+    def step():
+        x = torch.nn.functional.pad((frames - mean) / std, (0, 0, 0, 16))   # 720 -> 736 rows
+        return head(swin(x), targets=targets())
+
+    msda_t = KernelTimer(ops, "ms_deform_attn_forward")
+    mdec_t = KernelTimer(ops, "mask_decode")
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    msda_t.enabled = mdec_t.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    msda_t.enabled = mdec_t.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    T, Q = case["T"], case["Q"]
+    S = 23 * 40 + 46 * 80 + 92 * 160
+    res = {
+        "metric": "frames/sec per node, 720p T=5 clip, Swin-T 100Q; mask-logit max-abs-err",
+        "value": world * T * args.steps / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: Swin-T UniVS, T=5 @ 720p (736x1280 padded), 100 queries, "
+                               "first clip (no prompt queries); one clip per GPU",
+                   "frames_per_clip": T, "queries": Q, "parallelism": f"clip-replicas x{world}"},
+    }
+    # parity of the timed path against the reference's own CPU run (tests/golden/g12)
+    try:
+        import numpy as np
+        g = np.load(os.path.join(ROOT, "tests", "golden", "g12_cfg2_full_size.npz"))
+        got = out["pred_masks"][0, :, :, ::16, ::16].cpu().numpy()
+        res["mask_logit_max_abs_err"] = float(np.abs(got - g["pred_masks_s"]).max())
+        res["mask_sign_flips"] = int((((got > 0) != (g["pred_masks_s"] > 0)) & (np.abs(g["pred_masks_s"]) > 1e-3)).sum())
+    except Exception as e:  # pragma: no cover
+        res["mask_logit_max_abs_err"] = None
+        res["parity_note"] = f"golden unavailable: {e}"
+
+    t_msda = msda_t.avg_seconds()
+    if t_msda:
+        alg = 3200.0 * S * T   # bytes per launch (one launch = T frames of one encoder layer)
+        res["roofline"] = {"kernel": "msda_fwd_tiled<3,512> (MSDeformAttn forward, LDS-tiled)",
+                           "bound": "hbm", "achieved": alg / t_msda / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": alg / t_msda / HBM_PEAK, "traffic": None,
+                           "avg_launch_us": t_msda * 1e6, "launches_per_step": len(msda_t.events) // args.steps,
+                           "algorithmic_bytes_per_launch": alg}
+    t_md = mdec_t.avg_seconds()
+    if t_md:
+        H, W, C = 184, 320, 256
+        algb = 4.0 * (C * H * W + Q * C + Q * H * W) * T
+        flops = 2.0 * Q * C * H * W * T
+        res["roofline_mask_decode"] = {"kernel": "skinny_gemm_f32<4,StoreLogits> (mask decode, f32 MFMA)",
+                                       "bound": "mfma", "achieved": flops / t_md / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+                                       "unit": "TFLOP/s", "frac": flops / t_md / F32_MFMA_PEAK,
+                                       "hbm_GBps": algb / t_md / 1e9, "avg_launch_us": t_md * 1e6}
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_path import cpu_ops
+        from tests import helpers
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        swin_c = helpers.build_swin("cpu")
+        head_c = helpers.build_head(case, "cpu", return_aux=False)
+        fr = cases.cfg2_frames()
+        with cpu_ops(), torch.no_grad():
+            t1 = time.perf_counter()
+            x = cases.preprocess(fr)
+            head_c(swin_c(x), targets=cases.targets_first_clip(case))
+            dtc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": T / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "one config-2 clip (5 frames) through the CPU oracle path "
+                                         "(oracle/cpu_path.py: ATen CPU + plain-C MSDA), cold, single run"}
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

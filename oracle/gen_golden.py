@@ -97,6 +97,191 @@ def g_window_attention():
     save("g_window_attention", **arrays)
 
 
+# ---------------------------------------------------------------------------------------------------
+# module-level goldens
+# ---------------------------------------------------------------------------------------------------
+def _ref_swin(R):
+    m = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_T)
+    m.eval()  # the reference's SwinTransformer.train() returns None (swin.py:680-683): no chaining
+    synth.load_synthetic(m, prefix="backbone.")
+    return m
+
+
+def _ref_pixel_decoder(R, shapes):
+    ish = {k: R.ShapeSpec(channels=c, stride=s) for k, (c, s) in shapes.items()}
+    m = R.MSDeformAttnPixelDecoder(ish, **cases.PIXDEC).eval()
+    synth.load_synthetic(m, prefix="sem_seg_head.pixel_decoder.")
+    return m, ish
+
+
+def _ref_head(R, case, **dec_over):
+    pd, ish = _ref_pixel_decoder(R, case["shapes"])
+    clip_path = "/tmp/univs_clip_cls_emb.pth"
+    torch.save(cases.clip_table(), clip_path)
+    sampler = R.VisualPromptSampler(**cases.sampler_kwargs(case))
+    dec = R.Decoder(clip_class_embed_path=clip_path, visual_prompt_sampler=sampler,
+                    **cases.decoder_kwargs(case, **dec_over)).eval()
+    synth.load_synthetic(dec, prefix="sem_seg_head.predictor.")
+    head = R.MaskFormerHead(ish, num_classes=133, pixel_decoder=pd, pixel_decoder_name="MSDeformAttnPixelDecoder",
+                            transformer_predictor=dec, transformer_in_feature="multi_scale_pixel_decoder").eval()
+    return head
+
+
+def _tensor_fields(tv):
+    return {k: v for k, v in tv.items() if isinstance(v, torch.Tensor)}
+
+
+@gen
+def g_state_dict_layout():
+    """Parameter names + shapes of the reference module tree (checkpoint compatibility)."""
+    R = rh.ref()
+    layout = {}
+    for k, v in _ref_swin(R).state_dict().items():
+        layout["backbone." + k] = list(v.shape)
+    head = _ref_head(R, cases.HEAD_CASE, text_to_image=True)
+    for k, v in head.state_dict().items():
+        layout["sem_seg_head." + k] = list(v.shape)
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "state_dict_layout.json"), "w") as f:
+        json.dump({"note": "Swin-T backbone + MaskFormerHead(R50-channel pixel decoder, UniVS decoder Q=20, "
+                           "text_prompt_to_image_enable=True)", "layout": layout}, f, indent=0)
+    print("wrote state_dict_layout.json", len(layout), "entries")
+
+
+@gen
+def g9_swin():
+    R = rh.ref()
+    out = _ref_swin(R)(cases.swin_input())
+    save("g9_swin", **out)
+
+
+@gen
+def g10_position_embeddings():
+    R = rh.ref()
+    x = torch.zeros(2, 8, 5, 7)
+    arrays = {"sine2d": R.PositionEmbeddingSine(4, normalize=True)(x)}
+    x5 = torch.zeros(1, 3, 8, 5, 7)
+    fi = torch.tensor([[4, 5, 9]])
+    pts = synth.uniform("pe/pts", (6, 2), 0.0, 1.0)
+    arb = R.PositionEmbeddingSine3DArbitraryT(4, normalize=True)
+    fix = R.PositionEmbeddingSine3D(4, normalize=True)
+    arrays["arb3d"] = arb(x5, fi)
+    arrays["arb3d_default_t"] = arb(x5)
+    arrays["arb_points"] = arb.forward_points_with_size((3, 40, 56), pts, 7)
+    arrays["arb_points_vec"] = arb.forward_points_with_size((3, 40, 56), pts, torch.tensor([2, 3, 4]))
+    arrays["fix3d"] = fix(x5)
+    arrays["fix_points"] = fix.forward_points_with_size((3, 40, 56), pts)
+    save("g10_position_embeddings", **arrays)
+
+
+@gen
+def g3_pixel_decoder():
+    R = rh.ref()
+    pd, _ = _ref_pixel_decoder(R, cases.HEAD_CASE["shapes"])
+    mf, mf_bfe, enc0, ms = pd.forward_features(cases.backbone_features())
+    save("g3_pixel_decoder", mask_features=mf, mask_features_bfe_conv=mf_bfe, enc0=enc0,
+         ms0=ms[0], ms1=ms[1], ms2=ms[2])
+
+
+def _head_outputs(out):
+    d = {k: out[k] for k in ("pred_logits", "pred_masks", "pred_embds")}
+    if isinstance(out.get("pred_reid_logits"), torch.Tensor):
+        d["pred_reid_logits"] = out["pred_reid_logits"]
+    # every layer's mask logits as well: lets tests tell "wrong" from "an attention-mask bit flipped"
+    for i, a in enumerate(out["aux_outputs"]):
+        d[f"aux{i}_pred_masks"] = a["pred_masks"]
+    return d
+
+
+@gen
+def g6_head_first_clip():
+    R = rh.ref()
+    head = _ref_head(R, cases.HEAD_CASE)
+    out = head(cases.backbone_features(), targets=cases.targets_first_clip())
+    save("g6_head_first_clip", **_head_outputs(out))
+
+
+@gen
+def g7_head_visual_prompts():
+    """Second clip with visual prompts: creates the memory pool.  torch.manual_seed(0) right before the
+    call fixes the sampler's randperm draws (prompt_encoder.py:420,424,481)."""
+    R = rh.ref()
+    head = _ref_head(R, cases.HEAD_CASE)
+    targets = cases.targets_with_entities()
+    torch.manual_seed(0)
+    out = head(cases.backbone_features(), targets=targets)
+    d = _head_outputs(out)
+    for k in ("prompt_feats", "prompt_pe", "prompt_attn_masks", "prompt_obj_ids"):
+        d["pool_" + k] = targets[0][k]
+    # third clip on the same dict: exercises zero_pad_prompt + pool update + memory read
+    tv = targets[0]
+    T = cases.HEAD_CASE["T"]
+    tv["first_frame_idx"] = 2
+    tv["frame_indices"] = torch.arange(2, 2 + T)
+    tv["masks"] = torch.cat([tv["masks"], torch.zeros_like(tv["masks"][:, :1])], 1)
+    tv["masks"][:, -2] = tv["masks"][:, -3]
+    tv["boxes"] = torch.cat([tv["boxes"], torch.zeros_like(tv["boxes"][:, :1])], 1)
+    tv["boxes"][:, -2] = tv["boxes"][:, -3]
+    tv["ids"] = torch.cat([tv["ids"], tv["ids"][:, :1]], 1)
+    torch.manual_seed(1)
+    out3 = head(cases.backbone_features(), targets=targets)
+    for k, v in _head_outputs(out3).items():
+        if not k.startswith("aux"):
+            d["clip3_" + k] = v
+    for k in ("prompt_feats", "prompt_pe", "prompt_attn_masks"):
+        d["clip3_pool_" + k] = targets[0][k]
+    save("g7_head_visual_prompts", **d)
+
+
+@gen
+def g8_head_grounding():
+    R = rh.ref()
+    head = _ref_head(R, cases.HEAD_CASE, text_to_image=True, sa_mask="sep-blocked")
+    out = head(cases.backbone_features(), targets=cases.targets_grounding())
+    save("g8_head_grounding", **_head_outputs(out))
+
+
+@gen
+def g8b_head_detection_text():
+    """Category-guided path (task 'detection', prompt_type 'text', dataset 'vspw': 124 class prompts)."""
+    R = rh.ref()
+    head = _ref_head(R, cases.HEAD_CASE, text_to_image=True)
+    out = head(cases.backbone_features(), targets=cases.targets_first_clip(prompt_type="text", dataset="vspw"))
+    d = _head_outputs(out)
+    d = {k: v for k, v in d.items() if not k.startswith("aux")}   # 144 queries: keep the fixture small
+    save("g8b_head_detection_text", **d)
+
+
+@gen
+def g12_cfg2_full_size():
+    """BASELINE config 2 through the real reference on CPU (about half a minute): strided samples and
+    checksums of every stage, so that full-size GPU runs can be compared with the reference itself."""
+    import hashlib
+    R = rh.ref()
+    case = cases.CFG2
+    swin = _ref_swin(R)
+    head = _ref_head(R, case)
+    x = cases.preprocess(cases.cfg2_frames())
+    feats = swin(x)
+    out = head(feats, targets=cases.targets_first_clip(case))
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k + "_s"] = v[:, ::8, ::4, ::4]
+        d["feat_" + k + "_abs_mean"] = v.double().abs().mean()
+    pm = out["pred_masks"]
+    d["pred_masks_s"] = pm[0, :, :, ::16, ::16]
+    d["pred_masks_abs_mean"] = pm.double().abs().mean()
+    d["pred_masks_pos_count"] = (pm > 0).sum()
+    d["pred_masks_near_zero_1e-3"] = (pm.abs() < 1e-3).sum()
+    d["pred_masks_sign_sha256"] = np.frombuffer(
+        hashlib.sha256(np.packbits((pm > 0).numpy()).tobytes()).digest(), dtype=np.uint8)
+    d["pred_logits"] = out["pred_logits"]
+    d["pred_embds"] = out["pred_embds"]
+    for i in (0, 4, 8):   # a few intermediate layers: tells "wrong" from "an attention-mask bit flipped"
+        d[f"aux{i}_pred_masks_s"] = out["aux_outputs"][i]["pred_masks"][0, :, :, ::16, ::16]
+    save("g12_cfg2_full_size", **d)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

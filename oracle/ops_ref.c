@@ -25,6 +25,7 @@
 #define MSDA_IMPL(NAME, T)                                                                          \
   void NAME(const T* value, const int64_t* shapes, const int64_t* starts, const T* loc,             \
             const T* attn, int N, int S, int M, int D, int L, int Lq, int P, T* out) {              \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                                         \
     for (int n = 0; n < N; ++n)                                                                     \
       for (int q = 0; q < Lq; ++q)                                                                  \
         for (int m = 0; m < M; ++m) {                                                               \

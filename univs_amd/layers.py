@@ -1,0 +1,136 @@
+"""Small torch building blocks with the parameter names of the classes they stand in for
+(so reference checkpoints load unchanged, SURVEY.md section 5 "Checkpoint / resume").  Dense GEMM /
+conv / norm work goes to ATen (hipBLASLt / MIOpen) -- host glue around the HIP kernels.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class Conv2d(nn.Conv2d):
+    """detectron2.layers.Conv2d: conv -> optional norm -> optional activation, with the sub-module
+    name `norm` (state-dict keys `<name>.weight`, `<name>.norm.weight`, ...)."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def get_norm(norm, out_channels):
+    """detectron2.layers.get_norm for the values the hot path uses ("GN" = GroupNorm(32), "" = none)."""
+    if norm is None or norm == "":
+        return None
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    if norm == "LN":
+        return nn.LayerNorm(out_channels)
+    raise ValueError(f"unsupported norm {norm!r}")
+
+
+def point_sample(input, point_coords, **kwargs):
+    """detectron2 PointRend `point_sample`: grid_sample on [0,1]^2 coordinates
+    (used by the prompt encoder, univs/modeling/prompt_encoder/prompt_encoder.py:127-131)."""
+    add_dim = False
+    if point_coords.dim() == 3:
+        add_dim = True
+        point_coords = point_coords.unsqueeze(2)
+    output = F.grid_sample(input, 2.0 * point_coords - 1.0, **kwargs)
+    if add_dim:
+        output = output.squeeze(3)
+    return output
+
+
+class MultiheadAttention(nn.Module):
+    """Inference-only multi-head attention with `nn.MultiheadAttention`'s parameter layout
+    (`in_proj_weight [3E,E]`, `in_proj_bias`, `out_proj.{weight,bias}`) and calling convention
+    (sequence-first `[L, N, E]`, boolean `attn_mask` with True = masked out, shape `[L,S]`,
+    `[N*h, L, S]` or -- our extension -- `[N, L, S]` broadcast over heads, which is what the fused
+    attention-mask op emits).  Used where the reference uses nn.MultiheadAttention
+    (univs/modeling/transformer_decoder/transformer_layers.py:11-148)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def forward(self, query, key, value, attn_mask: Optional[torch.Tensor] = None, need_weights=False,
+                average_attn_weights=True):
+        L, N, E = query.shape
+        S = key.shape[0]
+        h, d = self.num_heads, self.head_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        if query is key and key is value:
+            q, k, v = F.linear(query, w, b).chunk(3, dim=-1)
+        else:
+            q = F.linear(query, w[:E], b[:E])
+            if key is value:
+                k, v = F.linear(key, w[E:], b[E:]).chunk(2, dim=-1)
+            else:
+                k = F.linear(key, w[E:2 * E], b[E:2 * E])
+                v = F.linear(value, w[2 * E:], b[2 * E:])
+        # [L, N, h, d] -> [N, h, L, d]
+        q = q.reshape(L, N, h, d).permute(1, 2, 0, 3)
+        k = k.reshape(S, N, h, d).permute(1, 2, 0, 3)
+        v = v.reshape(S, N, h, d).permute(1, 2, 0, 3)
+        scores = torch.matmul(q * (1.0 / math.sqrt(d)), k.transpose(-1, -2))  # [N, h, L, S]
+        if attn_mask is not None:
+            if attn_mask.dim() == 2:
+                m = attn_mask.view(1, 1, L, S)
+            elif attn_mask.shape[0] == N * h:
+                m = attn_mask.view(N, h, L, S)
+            else:
+                m = attn_mask.view(N, 1, L, S)
+            if m.dtype == torch.bool:
+                scores = scores.masked_fill(m, float("-inf"))
+            else:
+                scores = scores + m
+        attn = torch.softmax(scores, dim=-1)
+        out = torch.matmul(attn, v)  # [N, h, L, d]
+        out = out.permute(2, 0, 1, 3).reshape(L, N, E)
+        out = self.out_proj(out)
+        if need_weights:
+            return out, (attn.mean(dim=1) if average_attn_weights else attn)
+        return out, None
+
+
+class MLP(nn.Module):
+    """transformer_layers.py:205-217"""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+def get_activation_fn(activation):
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {activation}.")

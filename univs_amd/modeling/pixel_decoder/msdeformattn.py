@@ -1,0 +1,247 @@
+"""MSDeformAttn pixel decoder for the MI355X hot path.
+
+Interface / state-dict layout: the reference's `MSDeformAttnPixelDecoder`
+(mask2former/modeling/pixel_decoder/msdeformattn.py:166-360), `MSDeformAttn`
+(ops/modules/ms_deform_attn.py:34-121) and the encoder classes (:23-163).  Differences in how the
+work is organised (results are the same):
+
+  * the deformable-attention core is the HIP operator (`ops.ms_deform_attn_forward`, LDS-tiled for the
+    encoder geometry) fed with the Python-side level table, so there is no device read-back and no
+    per-call int64 tensors;
+  * quantities that depend only on the feature-map shapes -- sine position embeddings + level embed,
+    reference points, the offset normaliser -- are cached per (shape, device) instead of being rebuilt
+    per call (msdeformattn.py:61-89, :143-158; position_encoding.py:29-52);
+  * the all-False padding mask and the `masked_fill` pass it triggers (ms_deform_attn.py:99-100,
+    msdeformattn.py:62) are dropped: valid_ratio is identically 1;
+  * everything stays fp32 regardless of autocast (msdeformattn.py:316,322).
+"""
+import math
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import ops
+from ...layers import Conv2d, get_activation_fn, get_norm
+from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
+from ..position_encoding import PositionEmbeddingSine
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        """query [N,Lq,C]; reference_points [N|1,Lq,L,2]; input_flatten [N,S,C];
+        input_spatial_shapes / input_level_start_index: python lists (or tensors)."""
+        N, Len_q, _ = query.shape
+        _, Len_in, _ = input_flatten.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
+        if reference_points.shape[-1] == 2:
+            if isinstance(input_spatial_shapes, torch.Tensor):
+                normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(query)
+            else:
+                normalizer = torch.tensor([[w, h] for (h, w) in input_spatial_shapes], dtype=query.dtype,
+                                          device=query.device)
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+        output = ops.ms_deform_attn_forward(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                            sampling_locations.contiguous(), attention_weights.contiguous(),
+                                            self.im2col_step)
+        return self.output_proj(output)
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = get_activation_fn(activation)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        src2 = self.self_attn(src if pos is None else src + pos, reference_points, src, spatial_shapes,
+                              level_start_index, padding_mask)
+        src = self.norm1(src + src2)
+        src = self.norm2(src + self.linear2(self.activation(self.linear1(src))))
+        return src
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, d_model, d_ffn, dropout, activation, n_levels, n_heads, n_points, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            MSDeformAttnTransformerEncoderLayer(d_model, d_ffn, dropout, activation, n_levels, n_heads, n_points)
+            for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, device):
+        """Pixel centres normalised per level, valid_ratio == 1 (msdeformattn.py:143-158): [1, S, L, 2]."""
+        refs = []
+        for (H_, W_) in spatial_shapes:
+            ref_y, ref_x = torch.meshgrid(
+                torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device),
+                torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device), indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / H_
+            ref_x = ref_x.reshape(-1)[None] / W_
+            refs.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(refs, 1)
+        return reference_points[:, :, None].expand(-1, -1, len(spatial_shapes), -1).contiguous()
+
+    def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None):
+        output = src
+        for layer in self.layers:
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, None)
+        return output
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, enc_n_points, num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        nn.init.normal_(self.level_embed)
+        self._ref_cache = {}
+
+    def forward(self, srcs, pos_embeds):
+        spatial_shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
+        level_start_index, acc = [], 0
+        for (h, w) in spatial_shapes:
+            level_start_index.append(acc)
+            acc += h * w
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                             for lvl, p in enumerate(pos_embeds)], 1)
+        key = (tuple(spatial_shapes), str(src_flatten.device))
+        ref = self._ref_cache.get(key)
+        if ref is None:
+            if len(self._ref_cache) > 8:
+                self._ref_cache.clear()
+            ref = MSDeformAttnTransformerEncoder.get_reference_points(spatial_shapes, src_flatten.device)
+            self._ref_cache[key] = ref
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, ref, lvl_pos)
+        return memory, spatial_shapes, level_start_index
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MSDeformAttnPixelDecoder(nn.Module):
+    @configurable
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, transformer_dropout: float, transformer_nheads: int,
+                 transformer_dim_feedforward: int, transformer_enc_layers: int, conv_dim: int, mask_dim: int,
+                 norm: Optional[Union[str, Callable]] = None, transformer_in_features: List[str],
+                 common_stride: int):
+        super().__init__()
+        transformer_input_shape = {k: v for k, v in input_shape.items() if k in transformer_in_features}
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.feature_strides = [v.stride for k, v in input_shape]
+        self.feature_channels = [v.channels for k, v in input_shape]
+        transformer_input_shape = sorted(transformer_input_shape.items(), key=lambda x: x[1].stride)
+        self.transformer_in_features = [k for k, v in transformer_input_shape]
+        transformer_in_channels = [v.channels for k, v in transformer_input_shape]
+        self.transformer_feature_strides = [v.stride for k, v in transformer_input_shape]
+        self.transformer_num_feature_levels = len(self.transformer_in_features)
+        chans = transformer_in_channels[::-1] if self.transformer_num_feature_levels > 1 else [transformer_in_channels[-1]]
+        self.input_proj = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans])
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dim, dropout=transformer_dropout, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_encoder_layers=transformer_enc_layers,
+            num_feature_levels=self.transformer_num_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dim // 2, normalize=True)
+        self.mask_dim = mask_dim
+        self.mask_features = Conv2d(conv_dim, mask_dim, kernel_size=1, stride=1, padding=0)
+        self.maskformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        stride = min(self.transformer_feature_strides)
+        self.num_fpn_levels = int(np.log2(stride) - np.log2(self.common_stride))
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(self.feature_channels[:self.num_fpn_levels]):
+            lateral_conv = Conv2d(in_channels, conv_dim, kernel_size=1, bias=use_bias, norm=get_norm(norm, conv_dim))
+            output_conv = Conv2d(conv_dim, conv_dim, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                 norm=get_norm(norm, conv_dim), activation=F.relu)
+            self.add_module(f"adapter_{idx + 1}", lateral_conv)
+            self.add_module(f"layer_{idx + 1}", output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+        self._pe_cache = {}
+
+    @classmethod
+    def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
+        ret = {}
+        ret["input_shape"] = {k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES}
+        ret["conv_dim"] = cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM
+        ret["mask_dim"] = cfg.MODEL.SEM_SEG_HEAD.MASK_DIM
+        ret["norm"] = cfg.MODEL.SEM_SEG_HEAD.NORM
+        ret["transformer_dropout"] = cfg.MODEL.MASK_FORMER.DROPOUT
+        ret["transformer_nheads"] = cfg.MODEL.MASK_FORMER.NHEADS
+        ret["transformer_dim_feedforward"] = 1024  # fixed for the deformable encoder (msdeformattn.py:307)
+        ret["transformer_enc_layers"] = cfg.MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS
+        ret["transformer_in_features"] = cfg.MODEL.SEM_SEG_HEAD.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES
+        ret["common_stride"] = cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE
+        return ret
+
+    def _pos(self, x):
+        key = (tuple(x.shape[-2:]), str(x.device))
+        p = self._pe_cache.get(key)
+        if p is None:
+            if len(self._pe_cache) > 16:
+                self._pe_cache.clear()
+            p = self.pe_layer(x[:1])  # [1, C, H, W]; identical for every frame
+            self._pe_cache[key] = p
+        return p
+
+    def forward_features(self, features):
+        with torch.autocast(device_type=next(iter(features.values())).device.type, enabled=False):
+            return self._forward_features(features)
+
+    def _forward_features(self, features):
+        srcs, pos = [], []
+        for idx, f in enumerate(self.transformer_in_features[::-1]):
+            x = features[f].float()
+            srcs.append(self.input_proj[idx](x))
+            pos.append(self._pos(x))
+        y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
+        bs = y.shape[0]
+        sizes = [h * w for (h, w) in spatial_shapes]
+        y = torch.split(y, sizes, dim=1)
+        out = [z.transpose(1, 2).reshape(bs, -1, spatial_shapes[i][0], spatial_shapes[i][1]) for i, z in enumerate(y)]
+        for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
+            x = features[f].float()
+            cur_fpn = self.lateral_convs[idx](x)
+            y_ = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+            out.append(self.output_convs[idx](y_))
+        multi_scale_features = out[:self.maskformer_num_feature_levels]
+        return self.mask_features(out[-1]), out[-1], out[0], multi_scale_features

@@ -1,0 +1,136 @@
+"""Sine position embeddings of the hot path, written in closed form.
+
+Same values as the reference classes (up to fp32 rounding of identical formulas):
+  PositionEmbeddingSine               mask2former/modeling/transformer_decoder/position_encoding.py:12-52
+  PositionEmbeddingSine3D ("FixedT")  univs/modeling/transformer_decoder/position_encoding.py:12-110
+  PositionEmbeddingSine3DArbitraryT   univs/modeling/transformer_decoder/position_encoding.py:113-236
+The reference builds them from cumulative sums of an all-True mask on every call; without padding
+masks the cumulative sums are just 1..H / 1..W / 1..T, so the embeddings are pure functions of the
+shape (and of the absolute frame indices for ArbitraryT) -- callers cache them per shape.
+Channel layout: for a coordinate v, channel 2i = sin(v / T^(2i/F)), channel 2i+1 = cos(v / T^(2i/F)).
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _dim_t(num_feats, temperature, device):
+    i = torch.arange(num_feats, dtype=torch.float32, device=device)
+    return temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_feats)
+
+
+def _interleaved_sincos(v, dim_t):
+    """v [...], dim_t [F] -> [..., F] with sin on even channels and cos on odd channels."""
+    a = v[..., None] / dim_t
+    return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), dim=-1).flatten(-2)
+
+
+def _axis(n, scale, device, normalize=True):
+    """cumsum of ones (1..n), normalised like the reference: k / (n + eps) * scale."""
+    k = torch.arange(1, n + 1, dtype=torch.float32, device=device)
+    if normalize:
+        k = k / (float(n) + 1e-6) * scale
+    return k
+
+
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, x, mask=None):
+        assert mask is None, "padding masks are not used on the inference hot path"
+        N, _, H, W = x.shape
+        dev = x.device
+        dim_t = _dim_t(self.num_pos_feats, self.temperature, dev)
+        pos_y = _interleaved_sincos(_axis(H, self.scale, dev, self.normalize), dim_t)  # [H, F]
+        pos_x = _interleaved_sincos(_axis(W, self.scale, dev, self.normalize), dim_t)  # [W, F]
+        pos = torch.cat((pos_y[:, None, :].expand(H, W, -1), pos_x[None, :, :].expand(H, W, -1)), dim=2)
+        return pos.permute(2, 0, 1)[None].expand(N, -1, -1, -1).contiguous()
+
+
+class _Sine3DBase(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def _compose(self, z, y, x, device):
+        """z [..t], y [h], x [w] already scaled -> [..t, 2F, h, w] = cat(sin/cos(y), sin/cos(x)) + sin/cos(z)."""
+        F_ = self.num_pos_feats
+        dim_t = _dim_t(F_, self.temperature, device)
+        dim_t_z = _dim_t(2 * F_, self.temperature, device)
+        pos_y = _interleaved_sincos(y, dim_t)     # [h, F]
+        pos_x = _interleaved_sincos(x, dim_t)     # [w, F]
+        pos_z = _interleaved_sincos(z, dim_t_z)   # [..t, 2F]
+        h, w = y.shape[0], x.shape[0]
+        yx = torch.cat((pos_y[:, None, :].expand(h, w, -1), pos_x[None, :, :].expand(h, w, -1)), dim=2)  # [h,w,2F]
+        pos = yx + pos_z[..., None, None, :]       # [..t, h, w, 2F]
+        return pos.movedim(-1, -3)                 # [..t, 2F, h, w]
+
+    def _points(self, z, xy):
+        """z [t] scaled, xy [n,2] normalised -> [t, n, 2F]."""
+        dev = xy.device
+        F_ = self.num_pos_feats
+        dim_t = _dim_t(F_, self.temperature, dev)
+        dim_t_z = _dim_t(2 * F_, self.temperature, dev)
+        x, y = xy.unbind(-1)
+        pos_x = _interleaved_sincos(x * self.scale, dim_t)   # [n, F]
+        pos_y = _interleaved_sincos(y * self.scale, dim_t)
+        pos_z = _interleaved_sincos(z, dim_t_z)              # [t, 2F]
+        return torch.cat((pos_y, pos_x), dim=-1)[None] + pos_z[:, None, :]
+
+
+class PositionEmbeddingSine3D(_Sine3DBase):
+    """"FixedT": z is the frame's position inside the clip (1..T)/T."""
+
+    def forward(self, x, mask=None):
+        assert x.dim() == 5 and mask is None
+        b, t, _, h, w = x.shape
+        dev = x.device
+        assert self.normalize
+        pos = self._compose(_axis(t, self.scale, dev), _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev)
+        return pos[None].expand(b, -1, -1, -1, -1)
+
+    def forward_points_with_size(self, size, xy_embed_normalized):
+        t, h, w = size
+        assert self.normalize
+        z = _axis(t, self.scale, xy_embed_normalized.device)
+        return self._points(z, xy_embed_normalized)
+
+
+class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
+    """z is the ABSOLUTE frame index / num_max_frames (position_encoding.py:123,158)."""
+
+    def __init__(self, num_pos_feats=64, num_max_frames=128, temperature=10000, normalize=False, scale=None):
+        super().__init__(num_pos_feats, temperature, normalize, scale)
+        assert normalize, "Must enable normalization!"
+        self.num_max_frames = num_max_frames
+
+    def forward(self, x, t_indices=None, mask=None):
+        assert x.dim() == 5 and mask is None
+        b, t, _, h, w = x.shape
+        dev = x.device
+        if t_indices is None:
+            t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
+        z = t_indices.to(dev) / self.num_max_frames * self.scale  # [b, t]
+        return self._compose(z, _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev)
+
+    def forward_points_with_size(self, size, xy_embed_normalized, t_indices=None):
+        dev = xy_embed_normalized.device
+        t, h, w = size
+        if t_indices is None:
+            t_indices = torch.arange(t, device=dev)
+        if not isinstance(t_indices, torch.Tensor):
+            t_indices = torch.as_tensor(t_indices, device=dev)
+        assert t_indices.nelement() == 1 or t_indices.nelement() == t, "Unvalid length for frame indices"
+        if t_indices.nelement() == 1:
+            t_indices = t_indices.reshape(1).repeat(t)
+        z = t_indices.to(dev).reshape(t) / self.num_max_frames * self.scale
+        return self._points(z, xy_embed_normalized)

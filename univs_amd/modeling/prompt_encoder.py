@@ -1,0 +1,387 @@
+"""Visual prompt encoder and the per-video prompt memory pool (inference).
+
+Restates the inference branches of univs/modeling/prompt_encoder/prompt_encoder.py:
+  VisualPromptEncoder.get_mask_prompt (:168-263), get_point_prompt (:82-165), get_box_prompt (:266-359),
+  select_points_from_box_mask (:362-442), get_dense_features (:445-497);
+  VisualPromptSampler.process_per_batch_inference (:782-842), process_per_video_inference (:845-960),
+  process_per_video_inference_prev_frame (:963-1057), zero_pad_prompt (:1060-1071).
+
+Contract kept bit-for-bit with the reference: the pool lives in the caller's
+`targets[0]` dict and is mutated in place under the same keys (`prompt_feats`, `prompt_pe` [N_ent, R,
+T_hist, C], `prompt_attn_masks` [T_hist, 1, N_ent, HW], `prompt_obj_ids`, `img_emb_per_video`,
+`pos_emb_per_video`).  Random point selection uses `torch.randperm` on the default CPU generator in the
+same call order as the reference, so a seeded run reproduces the reference's sampled tokens.
+Known quirk kept on purpose: the "avoid NaN" block multiplies by `isblank` instead of `~isblank`
+(:836-840), so blank prompt tokens are filled with zeros.
+"""
+import torch
+import torch.nn.functional as F
+
+from ..layers import point_sample
+from .position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
+
+
+# ---- box / mask helpers (univs/utils/comm.py:6-91) ---------------------------------------------------
+def box_xyxy_to_cxcywh(x):
+    x0, y0, x1, y1 = x.unbind(-1)
+    return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0), (y1 - y0)], dim=-1)
+
+
+def convert_box_to_mask(outputs_box, h, w):
+    """normalised xyxy boxes [..., 4] -> bool masks [..., h, w] (comm.py:6-39)."""
+    box_shape = outputs_box.shape
+    dev = outputs_box.device
+    norm = torch.as_tensor([w, h, w, h], dtype=outputs_box.dtype, device=dev).reshape(1, -1)
+    b = outputs_box.flatten(0, -2) * norm
+    b = torch.cat([b[..., :2].floor(), b[..., 2:].ceil()], dim=-1)
+    gy, gx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    gy, gx = gy.reshape(1, h, w), gx.reshape(1, h, w)
+    m = (gx > b[..., 0, None, None]) & (gx <= b[..., 2, None, None]) & \
+        (gy > b[..., 1, None, None]) & (gy <= b[..., 3, None, None])
+    return m.reshape((*box_shape[:-1], h, w))
+
+
+def convert_mask_to_box(masks):
+    """bool masks [..., H, W] -> xyxy pixel boxes [..., 4], zeros for empty masks (comm.py:41-84)."""
+    if torch.numel(masks) == 0:
+        return torch.zeros(*masks.shape[:-2], 4, device=masks.device)
+    shape = masks.shape
+    h, w = shape[-2:]
+    masks = masks.flatten(0, -3) if len(shape) > 2 else masks.unsqueeze(0)
+    in_h, _ = torch.max(masks, dim=-1)
+    ch = in_h * torch.arange(h, device=in_h.device)[None, :]
+    bottom, _ = torch.max(ch, dim=-1)
+    top, _ = torch.min(ch + h * (~in_h), dim=-1)
+    in_w, _ = torch.max(masks, dim=-2)
+    cw = in_w * torch.arange(w, device=in_w.device)[None, :]
+    right, _ = torch.max(cw, dim=-1)
+    left, _ = torch.min(cw + w * (~in_w), dim=-1)
+    empty = (right < left) | (bottom < top)
+    out = torch.stack([left, top, right, bottom], dim=-1) * (~empty).unsqueeze(-1)
+    return out.reshape(*shape[:-2], 4) if len(shape) > 2 else out[0]
+
+
+class VisualPromptEncoder:
+    def __init__(self, pretrain_img_size=1024, hidden_dim=256, num_frames=1, num_dense_points=32,
+                 position_embedding_sin3d_type="FixedT"):
+        N_steps = hidden_dim // 2
+        if position_embedding_sin3d_type == "FixedT":
+            self.pe_layer = PositionEmbeddingSine3D(N_steps, normalize=True)
+        else:
+            self.pe_layer = PositionEmbeddingSine3DArbitraryT(N_steps, normalize=True)
+        self.num_frames = num_frames
+        self.pretrain_img_size = pretrain_img_size
+        self.num_dense_points = num_dense_points
+        self.position_embedding_sin3d_type = position_embedding_sin3d_type
+        self.key_fid = int((num_frames - 1) / 2)
+        self.img_feats_scale = 8  # prompts are read from the 1/8-resolution level
+
+    def _point_pe(self, h_img, w_img, point_coords, key_fid, key_fid_original):
+        size = (self.num_frames, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
+        if self.position_embedding_sin3d_type == "FixedT":
+            pe = self.pe_layer.forward_points_with_size(size, point_coords)
+            return pe[key_fid].unsqueeze(1).repeat(1, self.num_frames, 1)
+        return self.pe_layer.forward_points_with_size(size, point_coords, key_fid_original).transpose(0, 1)
+
+    @torch.no_grad()
+    def get_point_prompt(self, img_features, img_pos, point_coords=None, boxes=None, masks=None, key_fid=None,
+                         key_fid_original=None, is_train=False, enable_dense_prompt=True):
+        key_fid = self.key_fid if key_fid is None else key_fid
+        key_fid_original = key_fid if key_fid_original is None else key_fid_original
+        h_img, w_img = img_features.shape[-2:]
+        if point_coords is None:
+            assert boxes is not None or masks is not None
+            point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes)
+        device = img_features.device
+        point_coords = point_coords.to(device)
+        valid = ((point_coords >= 0) & ((1 - point_coords) >= 0)).sum(-1) == 2
+        point_coords = point_coords * valid.float().view(-1, 1)
+        n = point_coords.shape[0]
+        query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
+        point_feats = point_sample(img_features.unsqueeze(0), point_coords.unsqueeze(0), align_corners=False)
+        query_feats = point_feats.permute(2, 0, 1).repeat(1, self.num_frames, 1)
+        masks_ = torch.ones((self.num_frames, 1, n, h_img * w_img), dtype=torch.bool, device=device)
+        wh = point_coords * torch.as_tensor([w_img, h_img], device=device).view(1, -1)
+        fl, ce = wh.floor().long(), wh.ceil().long()
+        rng = torch.arange(n, device=device)
+        for yy, xx in ((fl[:, 1], fl[:, 0]), (ce[:, 1], ce[:, 0]), (fl[:, 1], ce[:, 0]), (ce[:, 1], fl[:, 0])):
+            idx = (yy * w_img + xx).clamp(min=0, max=w_img * h_img - 1)
+            masks_[key_fid, :, rng, idx] = False
+        fd, pd = query_feats[:, None], query_pe[:, None]
+        if enable_dense_prompt:
+            fd = fd.repeat(1, self.num_dense_points, 1, 1)
+            pd = pd.repeat(1, self.num_dense_points, 1, 1)
+        if (~valid).any():
+            pd = pd * valid.view(-1, 1, 1, 1)
+            fd = fd * valid.view(-1, 1, 1, 1)
+            masks_[:, :, ~valid] = False
+        return point_coords, pd, fd, masks_
+
+    @torch.no_grad()
+    def get_mask_prompt(self, img_features, img_pos, masks, boxes=None, mask_thresh=0.5, key_fid=None,
+                        key_fid_original=None, is_train=False, enable_dense_prompt=True):
+        key_fid = self.key_fid if key_fid is None else key_fid
+        key_fid_original = key_fid if key_fid_original is None else key_fid_original
+        h_img, w_img = img_features.shape[-2:]
+        device = img_features.device
+        assert masks.dim() == 3, f"Mask shape shoule be num_instsxHxW, but get {masks.shape}"
+        valid = masks.gt(mask_thresh).flatten(1).sum(-1) > 0
+        n, h, w = masks.shape
+        point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes)
+        query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
+        s = self.img_feats_scale
+        img_masks = torch.zeros((n, h_img * s, w_img * s), device=masks.device)
+        img_masks[:, :h, :w] = masks.float()
+        feat_masks = F.interpolate(img_masks.unsqueeze(1), (h_img, w_img), mode="nearest").squeeze(1)
+        feat_masks_binary = feat_masks >= min(mask_thresh, feat_masks.max())
+        fw = feat_masks * feat_masks_binary
+        pf = torch.einsum("qn,nc->qc", fw.flatten(-2).float(), img_features.flatten(-2).t())
+        pf = pf / fw.sum((-2, -1)).clamp(min=mask_thresh)[:, None]
+        query_feats = pf[:, None].repeat(1, self.num_frames, 1)
+        if boxes is None:
+            normlizer = torch.tensor([w_img * s, h_img * s, w_img * s, h_img * s]).reshape(1, -1)
+            boxes = convert_mask_to_box(masks > mask_thresh) / normlizer
+        attn = torch.zeros((self.num_frames, 1, n, h_img * w_img), dtype=torch.bool, device=device)
+        attn[key_fid, 0] = torch.logical_not(convert_box_to_mask(boxes, h_img, w_img).flatten(-2))
+        fd, pd = query_feats[:, None], query_pe[:, None]
+        if enable_dense_prompt:
+            fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
+                                             prompt_type="masks", is_train=is_train)
+        if (~valid).any():
+            pd = pd * valid.view(-1, 1, 1, 1).float()
+            fd = fd * valid.view(-1, 1, 1, 1).float()
+            attn[:, :, ~valid] = False
+        return point_coords, pd, fd, attn
+
+    @torch.no_grad()
+    def get_box_prompt(self, img_features, img_pos, boxes, key_fid=None, key_fid_original=None, is_train=False,
+                       enable_dense_prompt=True):
+        key_fid = self.key_fid if key_fid is None else key_fid
+        key_fid_original = key_fid if key_fid_original is None else key_fid_original
+        h_img, w_img = img_features.shape[-2:]
+        device = img_features.device
+        assert boxes.dim() == 2
+        valid = (box_xyxy_to_cxcywh(boxes)[..., 2:] > 0).all(-1)
+        point_coords = self.select_points_from_box_mask(h_img, w_img, boxes=boxes)
+        query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
+        box_masks = convert_box_to_mask(boxes, h_img, w_img)
+        qf = (box_masks[:, None] * img_features[None]).flatten(-2).sum(-1) / \
+            box_masks[:, None].flatten(-2).sum(-1).clamp(min=1)
+        blank = box_masks.flatten(-2).sum(-1) == 0
+        if blank.any():
+            qf[blank] = point_sample(img_features.unsqueeze(0), point_coords[blank].unsqueeze(0),
+                                     align_corners=False).squeeze(0).t()
+        query_feats = qf[:, None].repeat(1, self.num_frames, 1)
+        attn = torch.zeros((self.num_frames, 1, box_masks.shape[0], h_img * w_img), dtype=torch.bool, device=device)
+        attn[key_fid, 0] = torch.logical_not(box_masks.flatten(-2))
+        fd, pd = query_feats[:, None], query_pe[:, None]
+        if enable_dense_prompt:
+            fd, pd = self.get_dense_features(img_features, img_pos, box_masks, query_pe, query_feats, is_train=is_train)
+        if (~valid).any():
+            pd = pd * valid.view(-1, 1, 1, 1)
+            fd = fd * valid.view(-1, 1, 1, 1)
+            attn[:, :, ~valid] = False
+        return point_coords, pd, fd, attn
+
+    @torch.no_grad()
+    def select_points_from_box_mask(self, h_img, w_img, boxes=None, masks=None, is_train=False, mask_thresh=0.75,
+                                    num_points=1):
+        assert (boxes is not None) or (masks is not None)
+        assert not is_train
+        if masks is not None:
+            device = masks.device
+            n, h, w = masks.shape
+            masks = masks.float()
+            s = self.img_feats_scale
+            assert (h_img * s == h) and (w_img * s == w), \
+                f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
+            i, j = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            coords = (torch.stack([j, i], dim=-1) + 0.5) / torch.as_tensor([w, h]).view(1, 1, -1)
+            if boxes is None:
+                boxes = convert_mask_to_box(masks > mask_thresh) / torch.as_tensor([w, h, w, h]).view(1, 1, -1)
+            bc = box_xyxy_to_cxcywh(boxes)
+            thr = masks.flatten(1).max(1)[0].clamp(max=mask_thresh).reshape(-1, 1)
+            masks_binary = masks.flatten(-2, -1) >= thr
+            coords = coords[:h, :w].flatten(0, 1).to(device)
+            rel = torch.abs(coords[None] - bc[:, None, :2])
+            in_ctr = (rel < 0.25 * bc[:, None, 2:]).all(-1) & masks_binary
+            pts = []
+            for k, c in enumerate(in_ctr):
+                if c.any():
+                    idxs = torch.randperm(int(c.sum())).repeat(num_points)[:num_points]
+                    pts.append(coords[c][idxs.to(device)])
+                else:
+                    hi = masks[k].flatten() >= min(0.95, masks[k].max())
+                    idxs = torch.randperm(int(hi.sum())).repeat(num_points)[:num_points]
+                    pts.append(coords[hi][idxs.to(device)])
+            point_coords = torch.stack(pts)
+            assert (point_coords <= 1).all(), "Point coordinates should be smaller than 1"
+        else:
+            device = boxes.device
+            bc = box_xyxy_to_cxcywh(boxes)
+            cxcy = bc[:, :2][:, None].repeat(1, num_points, 1)
+            wh = bc[:, 2:][:, None].repeat(1, num_points, 1)
+            offsets = torch.rand(wh.shape).to(device) * 2 - 1
+            point_coords = cxcy + offsets * 0.25 * wh
+        return point_coords[:, 0] if num_points == 1 else point_coords
+
+    @torch.no_grad()
+    def get_dense_features(self, img_features, img_pos, masks_binary, query_pe, query_feats, prompt_type="masks",
+                           is_train=True):
+        assert img_features.shape[-2:] == masks_binary.shape[-2:]
+        feats = img_features.flatten(-2).t()
+        pos = img_pos.flatten(-2).t()
+        R = self.num_dense_points
+        fd, pd = [], []
+        for i, m in enumerate(masks_binary):
+            idx = torch.nonzero(m.flatten()).reshape(-1)
+            if len(idx) == 0:
+                fd.append(query_feats[i, 0].reshape(1, -1).repeat(R, 1))
+                pd.append(query_pe[i, 0].reshape(1, -1).repeat(R, 1))
+                continue
+            if len(idx) < R:
+                idx = idx.repeat(int(R / len(idx)) + 1)[:R]
+            else:
+                idx = idx[torch.randperm(len(idx))[:R].to(idx.device)]
+                assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
+            fd.append(feats[idx])
+            pd.append(pos[idx])
+        fd = torch.stack(fd)[:, :, None].repeat(1, 1, self.num_frames, 1)
+        pd = torch.stack(pd)[:, :, None].repeat(1, 1, self.num_frames, 1)
+        return fd, pd
+
+
+class VisualPromptSampler:
+    def __init__(self, pretrain_img_size=1024, hidden_dim=256, num_heads=8, num_frames=1, num_prev_frames_memory=1,
+                 num_dense_points=32, position_embedding_sin3d_type="FixedT", clip_stride=1):
+        self.num_heads = num_heads
+        self.num_frames = num_frames
+        self.key_fid = int((num_frames - 1) / 2)
+        self.num_dense_points = num_dense_points
+        self.clip_stride = clip_stride
+        self.num_prev_frames_memory = max(num_prev_frames_memory, num_frames)
+        self.visual_prompt_encoder = VisualPromptEncoder(pretrain_img_size, hidden_dim, num_frames, num_dense_points,
+                                                         position_embedding_sin3d_type)
+        self.prompt_feature_level_index = -1  # 1/8 resolution
+
+    @torch.no_grad()
+    def process_per_batch(self, img_emb_list, pos_emb_list, img_size_list, targets, training=True,
+                          prompt_type="masks", use_all_prev_frames=False):
+        if training:
+            raise NotImplementedError("training-time prompt sampling is out of scope of the inference hot path")
+        return self.process_per_batch_inference(img_emb_list, pos_emb_list, img_size_list, targets, prompt_type,
+                                                use_all_prev_frames)
+
+    @torch.no_grad()
+    def process_per_batch_inference(self, img_emb_list, pos_emb_list, img_size_list, targets, prompt_type="masks",
+                                    use_all_prev_frames=False):
+        assert len(targets) == 1, "Only support batch size = 1 now"
+        li = self.prompt_feature_level_index
+        H, W = img_size_list[li]
+        # '(H W) (N T) C -> N T C H W' with N = 1
+        def to_ntchw(e):
+            return e.view(H, W, 1, -1, e.shape[-1]).permute(2, 3, 4, 0, 1)
+        img_emb, pos_emb = to_ntchw(img_emb_list[li]), to_ntchw(pos_emb_list[li])
+        pe_l, f_l, m_l = [], [], []
+        for ie, pe, tv in zip(img_emb, pos_emb, targets):
+            tv["img_emb_per_video"] = ie
+            tv["pos_emb_per_video"] = pe
+            if "masks" not in tv or tv["masks"].nelement() == 0:
+                return None, None, None
+            o = self.process_per_video_inference(ie, pe, tv, prompt_type, False)
+            pe_l.append(o[0]); f_l.append(o[1]); m_l.append(o[2])
+        if len(f_l) == 0 or any(f is None for f in f_l):
+            return None, None, None
+        prompt_pe_dense = torch.stack(pe_l, dim=-3).flatten(-3, -2)       # n x R x NT x C
+        prompt_feats_dense = torch.stack(f_l, dim=-3).flatten(-3, -2)
+        prompt_attn_masks = torch.stack(m_l, dim=0).flatten(0, 1).repeat(1, self.num_heads, 1, 1).flatten(0, 1)
+        # "avoid NaN" block, quirk kept (:836-840): multiplies by isblank, i.e. fills blanks with zeros
+        isblank = (prompt_feats_dense == 0).all(-1)
+        mean = (prompt_feats_dense * isblank.unsqueeze(-1)).flatten(1, 2).sum(1)
+        mean = mean / isblank.flatten(1, 2).sum(1).unsqueeze(-1).clamp(min=1)
+        mean = mean[:, None, None].repeat(1, prompt_feats_dense.shape[1], prompt_feats_dense.shape[2], 1)
+        prompt_feats_dense[isblank] = mean[isblank].clone().detach()
+        return prompt_pe_dense, prompt_feats_dense, prompt_attn_masks
+
+    @torch.no_grad()
+    def process_per_video_inference(self, img_emb, pos_emb, tv, prompt_type="masks", use_all_prev_frames=False):
+        device = img_emb.device
+        num_frames = img_emb.shape[0]
+        first_frame_idx = tv["first_frame_idx"]
+        frame_indices = tv["frame_indices"]
+        is_first_clip = first_frame_idx == 0
+        if not is_first_clip:
+            self.zero_pad_prompt(tv)
+            self.process_per_video_inference_prev_frame(tv, prompt_type="masks")
+        gt_boxes = tv["boxes"][:, -num_frames:].to(device)
+        gt_masks = tv["masks"][:, -num_frames:].to(device)
+        # Important (reference comment): first clip encodes frame 0 only (none for grounding); later
+        # clips re-encode all but the last `clip_stride` frames
+        update_frames = 1 - int(tv["task"] == "grounding") if is_first_clip else num_frames - self.clip_stride
+        enc = self.visual_prompt_encoder
+        for key_fid in range(update_frames):
+            kfo = frame_indices[key_fid]
+            x_key, x_pos = img_emb[key_fid], pos_emb[key_fid]
+            assert prompt_type in {"boxes", "masks"}, "point prompts at inference are not supported"
+            if prompt_type == "boxes":
+                tup = enc.get_box_prompt(x_key, x_pos, gt_boxes[:, key_fid], is_train=False, key_fid=key_fid,
+                                         key_fid_original=kfo)
+            else:
+                tup = enc.get_mask_prompt(x_key, x_pos, masks=gt_masks[:, key_fid], boxes=gt_boxes[:, key_fid],
+                                          is_train=False, key_fid=key_fid, key_fid_original=kfo)
+            pe_d, f_d, m_d = tup[1], tup[2], tup[3]
+            tv["prompt_obj_ids"] = tv["ids"]
+            if is_first_clip:
+                tv["prompt_pe"], tv["prompt_feats"], tv["prompt_attn_masks"] = pe_d, f_d, m_d
+            else:
+                s_idx = -num_frames + key_fid
+                valid = gt_masks[:, key_fid].flatten(1).sum(1) > 0
+                tv["prompt_pe"][valid, :, s_idx:] = pe_d[valid, :, key_fid:]
+                tv["prompt_feats"][valid, :, s_idx:] = f_d[valid, :, key_fid:]
+                tv["prompt_attn_masks"][s_idx:] = m_d[key_fid:]
+        if "prompt_pe" not in tv:
+            return None, None, None
+        return (tv["prompt_pe"][:, :, -num_frames:], tv["prompt_feats"][:, :, -num_frames:],
+                tv["prompt_attn_masks"][-num_frames:])
+
+    @torch.no_grad()
+    def process_per_video_inference_prev_frame(self, tv, prompt_type="masks"):
+        device = tv["img_emb_per_video"].device
+        n_inst = tv["masks"].shape[0]
+        num_frames = tv["img_emb_per_video"].shape[0]
+        prev_frame_idx = max(0, tv["first_frame_idx"] - 1)
+        fa = tv["first_appear_frame_idxs"]
+        has_appeared = (fa <= prev_frame_idx) & (fa != -1)
+        update_prev_frame = (self.num_frames == 1) or ("prompt_feats" not in tv)
+        if has_appeared.sum() == 0 or not update_prev_frame:
+            return
+        cs = self.clip_stride
+        for key_fid in range(cs):
+            gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[has_appeared]
+            gt_masks = tv["masks"][:, -(num_frames + cs) + key_fid].to(device)[has_appeared]
+            kfo = tv["frame_indices"][0] - (cs - key_fid)
+            x_key, x_pos = tv["img_emb_per_video"][key_fid], tv["pos_emb_per_video"][key_fid]
+            assert prompt_type == "masks"
+            tup = self.visual_prompt_encoder.get_mask_prompt(x_key, x_pos, masks=gt_masks, boxes=gt_boxes,
+                                                             is_train=False, key_fid=key_fid, key_fid_original=kfo)
+            pe_d, f_d, m_d = tup[1], tup[2], tup[3]
+            if "prompt_feats" not in tv:
+                _, R, T, C = pe_d.shape
+                tv["prompt_pe"] = torch.zeros([n_inst, R, T + cs, C], device=device)
+                tv["prompt_feats"] = torch.zeros([n_inst, R, T + cs, C], device=device)
+                tv["prompt_attn_masks"] = torch.zeros([T + cs, m_d.shape[1], n_inst, m_d.shape[-1]], device=device).bool()
+            col = -(num_frames + cs) + key_fid
+            tv["prompt_pe"][has_appeared, :, col] = pe_d[:, :, key_fid]
+            tv["prompt_feats"][has_appeared, :, col] = f_d[:, :, key_fid]
+            tv["prompt_attn_masks"][col, :, has_appeared] = m_d[key_fid]
+
+    @torch.no_grad()
+    def zero_pad_prompt(self, tv):
+        if "prompt_feats" not in tv:
+            return
+        cs = self.clip_stride
+        z = torch.zeros_like(tv["prompt_pe"][:, :, -cs:])
+        tv["prompt_pe"] = torch.cat([tv["prompt_pe"], z], dim=2)
+        tv["prompt_feats"] = torch.cat([tv["prompt_feats"], z], dim=2)
+        tv["prompt_attn_masks"] = torch.cat([tv["prompt_attn_masks"], tv["prompt_attn_masks"][-cs:]])
+        tv["prompt_attn_masks"][-cs:] = False

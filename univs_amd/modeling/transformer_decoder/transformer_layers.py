@@ -1,0 +1,72 @@
+"""Post/pre-norm attention + FFN layers with the reference's parameter names
+(univs/modeling/transformer_decoder/transformer_layers.py:11-191); attention itself is
+`layers.MultiheadAttention` (nn.MultiheadAttention-compatible state dict)."""
+from typing import Optional
+
+from torch import Tensor, nn
+
+from ...layers import MLP, MultiheadAttention, get_activation_fn  # noqa: F401  (MLP re-exported)
+
+
+def _with_pos(t, pos):
+    return t if pos is None else t + pos
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.activation = get_activation_fn(activation)
+        self.normalize_before = normalize_before
+
+    def forward(self, tgt, tgt_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
+                query_pos: Optional[Tensor] = None):
+        assert tgt_key_padding_mask is None
+        if self.normalize_before:
+            t2 = self.norm(tgt)
+            q = k = _with_pos(t2, query_pos)
+            return tgt + self.self_attn(q, k, t2, attn_mask=tgt_mask)[0]
+        q = k = _with_pos(tgt, query_pos)
+        return self.norm(tgt + self.self_attn(q, k, tgt, attn_mask=tgt_mask)[0])
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False,
+                 need_weights=False, average_attn_weights=False):
+        super().__init__()
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.activation = get_activation_fn(activation)
+        self.normalize_before = normalize_before
+        self.need_weights = need_weights
+        self.average_attn_weights = average_attn_weights
+
+    def forward(self, tgt, memory, memory_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
+                query_pos: Optional[Tensor] = None):
+        assert memory_key_padding_mask is None
+        src = self.norm(tgt) if self.normalize_before else tgt
+        # nn.MultiheadAttention's default averages the returned weights over heads; the reference
+        # never passes `average_attn_weights` through, so neither do we (transformer_layers.py:101-105)
+        out, w = self.multihead_attn(_with_pos(src, query_pos), _with_pos(memory, pos), memory,
+                                     attn_mask=memory_mask, need_weights=self.need_weights)
+        tgt = tgt + out
+        if not self.normalize_before:
+            tgt = self.norm(tgt)
+        return (tgt, w) if self.need_weights else tgt
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.activation = get_activation_fn(activation)
+        self.normalize_before = normalize_before
+
+    def forward(self, tgt):
+        if self.normalize_before:
+            return tgt + self.linear2(self.activation(self.linear1(self.norm(tgt))))
+        return self.norm(tgt + self.linear2(self.activation(self.linear1(tgt))))
