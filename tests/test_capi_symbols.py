@@ -45,3 +45,32 @@ def test_product_ops_refuse_cpu_tensors():
         ops.ms_deform_attn_forward(v, [(2, 2)], [0], torch.zeros(1, 4, 1, 1, 1, 2), torch.zeros(1, 4, 1, 1, 1))
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ops.mask_decode(torch.zeros(1, 2, 4), torch.zeros(1, 4, 2, 2))
+
+
+def test_compat_module_exposes_reference_entry_points():
+    """B2: the module name and the two functions the reference's autograd Function calls
+    (ops/functions/ms_deform_attn_func.py:36,45)."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "univs_amd", "compat"))
+    try:
+        m = importlib.import_module("MultiScaleDeformableAttention")
+    finally:
+        sys.path.pop(0)
+    assert callable(m.ms_deform_attn_forward) and callable(m.ms_deform_attn_backward)
+
+
+def test_config_surface_loads_reference_style_yaml(tmp_path):
+    from univs_amd.config import load_cfg
+    base = tmp_path / "Base.yaml"
+    base.write_text("MODEL:\n  BACKBONE:\n    NAME: build_resnet_backbone\n  MASK_FORMER:\n    NUM_OBJECT_QUERIES: 200\n"
+                    "INPUT:\n  CROP:\n    SIZE: (600, 1024)\n")
+    child = tmp_path / "swint.yaml"
+    child.write_text("_BASE_: Base.yaml\nMODEL:\n  BACKBONE:\n    NAME: D2SwinTransformer\n  SWIN:\n    EMBED_DIM: 96\n"
+                     "INPUT:\n  SAMPLING_FRAME_NUM: 4\n")
+    cfg = load_cfg(str(child), ["MODEL.MASK_FORMER.NUM_OBJECT_QUERIES", "100", "INPUT.MIN_SIZE_TEST", "720"])
+    assert cfg.MODEL.BACKBONE.NAME == "D2SwinTransformer"
+    assert cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES == 100 and cfg.INPUT.MIN_SIZE_TEST == 720
+    assert cfg.INPUT.CROP.SIZE == (600, 1024) and cfg.INPUT.SAMPLING_FRAME_NUM == 4
+    assert cfg.MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME == "MSDeformAttnPixelDecoder"   # default kept

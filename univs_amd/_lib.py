@@ -6,6 +6,11 @@ product path never routes through `oracle/` or a CPU implementation.
 import ctypes
 import os
 
+# Load order matters: PyTorch-ROCm bundles its own libamdhip64 and must bring the HIP runtime into the
+# process FIRST.  If libunivs_hip.so (linked against the system ROCm) is dlopen'ed before torch, two
+# runtime instances coexist and launches on torch's streams fail with "no ROCm-capable device".
+import torch  # noqa: F401  (kept first on purpose)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunivs_hip.so")
 

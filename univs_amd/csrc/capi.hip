@@ -87,6 +87,7 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if ((long long)N * Lq * M * D == 0) return UNIVS_OK;  // empty output
+  clear_sticky_error();
   if (!value || !sampling_loc || !attn_weight || !out) {
     set_error("univs_msda_forward_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -115,6 +116,7 @@ int univs_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
+  clear_sticky_error();
   if (!value || !sampling_loc || !attn_weight || !out) {
     set_error("univs_msda_forward_f64: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -140,6 +142,7 @@ int univs_mask_decode_f32(const float* mask_embed, const float* mask_features, i
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if ((long long)T * Q * HW == 0) return UNIVS_OK;
+  clear_sticky_error();
   if (!mask_embed || !mask_features || !out) {
     set_error("univs_mask_decode_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -155,6 +158,7 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if ((long long)T * Q * hw == 0) return UNIVS_OK;
+  clear_sticky_error();
   if (!mask_embed || !feat_lowres || !attn_mask || !row_any_ws) {
     set_error("univs_mask_decode_attn_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -172,6 +176,7 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (B_ == 0) return UNIVS_OK;
+  clear_sticky_error();
   if (!qkv || !bias || !out) {
     set_error("univs_window_attention_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;

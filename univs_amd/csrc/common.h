@@ -29,6 +29,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
   return base + idx;
 }
 
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a device query made before
+// the runtime was initialised) would otherwise be reported as OUR launch failing.  Entry points call
+// this first.
+inline void clear_sticky_error() { (void)hipGetLastError(); }
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
