@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "frames"],
+                    help="N>1: one clip per rank (default) or ONE clip of 5*N frames sharded by frame with an RCCL "
+                         "all-gather of the query states per decoder layer (config 3 at N=8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,8 +101,18 @@ def main():
     mean = torch.tensor([123.675, 116.28, 103.53], device=dev).view(1, 3, 1, 1)
     std = torch.tensor([58.395, 57.12, 57.375], device=dev).view(1, 3, 1, 1)
 
+    frames_mode = args.mode == "frames" and world > 1
+    if frames_mode:
+        from univs_amd.distributed import FrameShard
+        head.predictor.frame_shard = FrameShard()
+        from univs_amd import synth
+        frames = synth.synthetic_frames(case["T"], case["H"], case["W"], f"frames/rank{rank}").to(dev)
+
     def targets():
-        return [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}]
+        tv = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}
+        if frames_mode:  # the clip's frames of ALL ranks
+            tv["frame_indices"] = torch.arange(case["T"] * world, device=dev)
+        return [tv]
 
     @torch.no_grad()
     def step():
@@ -151,12 +164,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE config 2: Swin-T UniVS, T=5 @ 720p (736x1280 padded), 100 queries, "
                                "first clip (no prompt queries); one clip per GPU",
-                   "frames_per_clip": T, "queries": Q, "parallelism": f"clip-replicas x{world}"},
+                   "frames_per_clip": T * world if frames_mode else T, "queries": Q,
+                   "parallelism": (f"frame-sharded x{world} (RCCL all-gather of query states per decoder layer)"
+                                   if frames_mode else f"clip-replicas x{world}")},
     }
     # parity of the timed path against the reference's own CPU run (tests/golden/g12)
     try:
         import numpy as np
         g = np.load(os.path.join(ROOT, "tests", "golden", "g12_cfg2_full_size.npz"))
+        assert not frames_mode, "golden is the 5-frame clip"
         got = out["pred_masks"][0, :, :, ::16, ::16].cpu().numpy()
         res["mask_logit_max_abs_err"] = float(np.abs(got - g["pred_masks_s"]).max())
         res["mask_sign_flips"] = int((((got > 0) != (g["pred_masks_s"] > 0)) & (np.abs(g["pred_masks_s"]) > 1e-3)).sum())

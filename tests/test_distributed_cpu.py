@@ -1,0 +1,65 @@
+"""CPU, world_size 2, gloo: the N>1 paths.
+  * frame-sharded decoder (univs_amd/distributed.py): a clip's frames split over 2 ranks, one all-gather of the
+    query states per decoder layer, all-reduced means over T -- must reproduce the single-process result;
+  * the bench's clip-replica mode needs no collective on the data path; only its timing reduction is exercised.
+The four HIP operators are replaced by the oracle's CPU stand-ins (oracle/cpu_path.py), as in test_modules_cpu."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scenario):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle.cpu_path import cpu_ops
+        from tests import cases, helpers
+        from univs_amd.distributed import FrameShard, shard_frames
+
+        case = dict(cases.HEAD_CASE, name="head_dist", T=4)
+        feats = cases.backbone_features(case)
+        if scenario == "first_clip":
+            dec_over, targets_fn = {}, lambda: cases.targets_first_clip(case)
+        else:
+            dec_over = dict(text_to_image=True, sa_mask="sep-blocked")
+            targets_fn = lambda: cases.targets_grounding(case)  # noqa: E731
+        head = helpers.build_head(case, "cpu", return_aux=False, **dec_over)
+        with cpu_ops(), torch.no_grad():
+            ref = head(feats, targets=targets_fn())                       # single-process result (all 4 frames)
+            shard = FrameShard()
+            head.predictor.frame_shard = shard
+            out = head(shard_frames(feats, shard, case["T"]), targets=targets_fn())
+        sl = shard.local_slice(case["T"] // world)
+        assert out["pred_masks"].shape[2] == case["T"] // world
+        err_m = (out["pred_masks"] - ref["pred_masks"][:, :, sl]).abs().max().item()
+        err_l = (out["pred_logits"] - ref["pred_logits"]).abs().max().item()
+        err_e = (out["pred_embds"] - ref["pred_embds"][:, :, sl]).abs().max().item()
+        assert err_m < 2e-4 and err_l < 2e-4 and err_e < 2e-4, (rank, err_m, err_l, err_e)
+        flips = ((out["pred_masks"] > 0) != (ref["pred_masks"][:, :, sl] > 0))[ref["pred_masks"][:, :, sl].abs() > 1e-3]
+        assert flips.sum() == 0
+        # bench-style timing reduction: max over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["first_clip", "grounding"])
+def test_frame_sharded_decoder_matches_single_process(scenario):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), scenario), nprocs=world, join=True)

@@ -1,0 +1,56 @@
+"""Frame sharding of one clip over the GPUs of a node.
+
+Everything on the hot path is per-frame (backbone, pixel decoder incl. every MSDeformAttn call, masked
+cross-attention, ProCA, FFN, mask decode) except the spatio-temporal self-attention over the Q'*T query
+tokens and three tiny means over T (class logits, grounding re-id).  So rank r owns a contiguous block of
+frames, keeps its feature maps local (80 MB/frame at 720p never moves) and, once per decoder layer,
+all-gathers the query states `[Q', T_loc, 256]` (~0.6 MB per rank at Q'=120, T_loc=5) over RCCL/xGMI --
+latency-bound, no ring needed.  The reference has no such mode (it has no model-side collective at all on
+the inference path, SURVEY.md section 2 "Parallelism"); semantics are fixed by the single-process result,
+which `tests/test_distributed_cpu.py` checks with a 2-rank gloo group.
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FrameShard:
+    """Equal contiguous blocks of frames per rank (T_total = world * T_loc)."""
+
+    def __init__(self, group=None):
+        assert dist.is_available() and dist.is_initialized(), "init torch.distributed first"
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def total(self, t_local: int) -> int:
+        return t_local * self.world
+
+    def local_slice(self, t_local: int) -> slice:
+        return slice(self.rank * t_local, (self.rank + 1) * t_local)
+
+    def all_gather_frames(self, x: torch.Tensor, dim: int) -> torch.Tensor:
+        """Concatenate every rank's block along `dim` in rank order (one collective)."""
+        if self.world == 1:
+            return x
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(self.world)]
+        dist.all_gather(parts, x, group=self.group)
+        return torch.cat(parts, dim=dim)
+
+    def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return x
+        x = x.contiguous()
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
+
+def shard_frames(tensor_or_dict, shard: FrameShard, t_total: int):
+    """Slice dim 0 (frames) of a tensor / every tensor of a dict to this rank's block."""
+    assert t_total % shard.world == 0, "frames must divide evenly over the ranks"
+    sl = shard.local_slice(t_total // shard.world)
+    if isinstance(tensor_or_dict, dict):
+        return {k: v[sl] for k, v in tensor_or_dict.items()}
+    return tensor_or_dict[sl]

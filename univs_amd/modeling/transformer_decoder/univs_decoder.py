@@ -140,6 +140,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         self.enabled_prev_visual_prompts_for_grounding = enabled_prev_visual_prompts_for_grounding
         self.semantic_extraction_enable = semantic_extraction_enable
         self.return_aux_outputs = return_aux_outputs
+        self.frame_shard = None  # univs_amd.distributed.FrameShard: frames of the clip sharded over ranks
         self._clip_norm_cache = None
         self._sa_mask_cache = {}
         with torch.no_grad():  # the reference's init for the two temperatures (:233-236)
@@ -194,10 +195,17 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         del mask
         dev = mask_features.device
         src, pos, size_list = [], [], []
+        fs = self.frame_shard  # None, or this rank's view of a clip whose frames are sharded over ranks
+        t_total = t if fs is None else fs.total(t)
         if "frame_indices" in targets[0]:
             frame_indices = torch.stack([tv["frame_indices"] for tv in targets]).to(dev)
         else:
-            frame_indices = torch.arange(t, device=dev)[None].repeat(bs, 1)
+            frame_indices = torch.arange(t_total, device=dev)[None].repeat(bs, 1)
+        if fs is not None:
+            assert frame_indices.shape[1] == t_total, "targets['frame_indices'] must list the frames of ALL ranks"
+            frame_indices = frame_indices[:, fs.local_slice(t)]
+            if targets[0].get("prompt_type") == "visual" and "masks" in targets[0] and targets[0]["masks"].nelement():
+                raise NotImplementedError("frame-sharded mode does not cover visual prompts / the memory pool yet")
         for i in range(self.num_feature_levels):
             size_list.append(tuple(int(s) for s in x[i].shape[-2:]))
             xi = x[i].view(bs, t, -1, size_list[-1][0], size_list[-1][1])
@@ -236,7 +244,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
 
         def heads(out_tokens, target_size, last):
             cls_, msk_, attn_, reid_ = self.forward_prediction_heads(
-                out_tokens, mf, feat_lowres[target_size], task, targets, t, need_masks=(last or want_full))
+                out_tokens, mf, feat_lowres[target_size], task, targets, t, need_masks=(last or want_full),
+                t_total=t_total)
             predictions_class.append(cls_)
             predictions_mask.append(msk_)
             predictions_embds.append(out_tokens.view(out_tokens.shape[0], bs, t, -1).permute(1, 0, 2, 3))
@@ -245,7 +254,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
 
         attn_mask = heads(output, size_list[0], self.num_layers == 0)
         num_queries_lp = output.shape[0]
-        self_attn_mask = self.generate_self_attn_mask(bs, t, num_queries_lp, dev, targets[0]["dataset_name"], task)
+        self_attn_mask = self.generate_self_attn_mask(bs, t_total, num_queries_lp, dev, targets[0]["dataset_name"], task)
+        query_embed_all = query_embed if fs is None else fs.all_gather_frames(query_embed, dim=1)
         for i in range(self.num_layers):
             if self.prompt_as_queries and 0 < i < self.prompt_self_attn_layers:
                 output = self.forward_transformer_prompt_self_attention_layer(
@@ -256,10 +266,20 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 output, src[lvl], memory_mask=attn_mask, pos=pos[lvl], query_pos=query_embed)
             # spatio-temporal self-attention over Q'*T tokens: 'Q (B T) C -> (Q T) B C'
             Qn = output.shape[0]
-            o = output.reshape(Qn * t, bs, -1)
-            qe = query_embed.reshape(Qn * t, bs, -1)
-            o = self.transformer_self_attention_layers[i](o, tgt_mask=self_attn_mask, query_pos=qe)
-            output = o.reshape(Qn, bs * t, -1)
+            if fs is None:
+                o = output.reshape(Qn * t, bs, -1)
+                qe = query_embed.reshape(Qn * t, bs, -1)
+                o = self.transformer_self_attention_layers[i](o, tgt_mask=self_attn_mask, query_pos=qe)
+                output = o.reshape(Qn, bs * t, -1)
+            else:
+                # the one collective of the layer: every rank gets the query states of all frames
+                # ([Q', T_loc, C] -> [Q', T, C]); the (tiny) self-attention is then evaluated redundantly
+                # on every rank and the local frames are sliced back out.
+                full = fs.all_gather_frames(output, dim=1)
+                o = full.reshape(Qn * t_total, bs, -1)
+                qe = query_embed_all.reshape(Qn * t_total, bs, -1)
+                o = self.transformer_self_attention_layers[i](o, tgt_mask=self_attn_mask, query_pos=qe)
+                output = o.reshape(Qn, t_total, -1)[:, fs.local_slice(t)].contiguous()
             output = self.transformer_ffn_layers[i](output)
             attn_mask = heads(output, size_list[(i + 1) % self.num_feature_levels], i == self.num_layers - 1)
 
@@ -310,21 +330,30 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             self._clip_norm_cache = c
         return c
 
-    def forward_prediction_heads(self, output, mask_features, feat_lowres, task, targets, t, need_masks):
+    def forward_prediction_heads(self, output, mask_features, feat_lowres, task, targets, t, need_masks,
+                                 t_total=None):
         """:498-567.  output [Q', T, C] (batch 1); mask_features [T, C, H, W]; feat_lowres [T, C, h, w].
         Returns (class logits [1,Q',K], mask logits [1,Q',T,H,W] or None, attn mask bool [T,Q',hw], reid)."""
         bs = 1
+        fs = self.frame_shard
+        t_total = t if t_total is None else t_total
+
+        def mean_over_frames(x):  # x [T_loc, ...] -> [1, ...]: mean over the clip's frames (all ranks)
+            if fs is None:
+                return x.view(bs, t, *x.shape[1:]).mean(1)
+            return fs.all_reduce_sum(x.sum(0, keepdim=True)) / float(t_total)
+
         decoder_output = self.decoder_norm(output).transpose(0, 1)  # [T, Q', C]
         outputs_class = self.vis2text_projection(decoder_output)
         if task != "grounding":
             clip = self._clip_normalized(outputs_class)
             outputs_class = F.normalize(outputs_class, p=2, dim=-1)
             outputs_class = torch.einsum("bqc,kc->bqk", outputs_class, clip)
-            outputs_class = outputs_class.view(bs, t, *outputs_class.shape[1:]).mean(1)
+            outputs_class = mean_over_frames(outputs_class)
             outputs_class = outputs_class * self.cls_temp.weight.exp()
         else:
             clip_exp = torch.stack([tv["exp_sentence_feats"][:, 0] for tv in targets]).to(outputs_class).detach()
-            outputs_class = outputs_class.view(bs, t, *outputs_class.shape[1:]).mean(1)
+            outputs_class = mean_over_frames(outputs_class)
             outputs_class = torch.einsum("bqc,bkc->bqk", outputs_class, clip_exp)
 
         mask_embed = self.mask_embed(decoder_output)  # [T, Q', C]
@@ -334,7 +363,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             nq = self.num_queries
             output_norm = F.normalize(decoder_output, p=2, dim=-1)
             outputs_reid = torch.einsum("BqC,BkC->Bqk", output_norm, output_norm[:, nq:])
-            outputs_reid = outputs_reid.view(bs, t, *outputs_reid.shape[1:]).mean(1)
+            outputs_reid = mean_over_frames(outputs_reid)
             l4p_indices = outputs_reid[:, :nq].flatten(0, -2).argmax(0)  # [Q_p]
             # mask_p <- (mask_p + mask_{l4p}) / 2  (:547) is linear in the mask embedding
             mask_embed = torch.cat([mask_embed[:, :nq], (mask_embed[:, nq:] + mask_embed[:, l4p_indices]) * 0.5], 1)
@@ -394,8 +423,9 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         if tasks[0] == "grounding":
             batch = []
             for tv in targets:
-                w = tv["exp_word_feats"][..., :num_frames, :]       # num_exp x 77 x T x 640
-                s = tv["exp_sentence_feats"][..., :num_frames, :]   # num_exp x T x 640
+                fsl = slice(0, num_frames) if self.frame_shard is None else self.frame_shard.local_slice(num_frames)
+                w = tv["exp_word_feats"][..., fsl, :]       # num_exp x 77 x T x 640 (this rank's frames)
+                s = tv["exp_sentence_feats"][..., fsl, :]   # num_exp x T x 640
                 num_exps, len_sentence = w.shape[:2]
                 ef = torch.cat([s[:, None], w], dim=1).flatten(0, 1).to(device)
                 batch.append(self.text2vis_projection(self.text_norm(ef)))
