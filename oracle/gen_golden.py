@@ -282,6 +282,17 @@ def g12_cfg2_full_size():
     save("g12_cfg2_full_size", **d)
 
 
+@gen
+def g9b_swin_b():
+    """Swin-B (window 12): exercises the 144-token window-attention kernel inside the full backbone."""
+    R = rh.ref()
+    m = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_B)
+    m.eval()
+    synth.load_synthetic(m, prefix="backbone.")
+    out = m(cases.swin_input(cases.SWINB_CASE))
+    save("g9b_swin_b", **{k: v[:, ::2] for k, v in out.items()})   # every 2nd channel keeps the fixture small
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

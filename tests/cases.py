@@ -221,3 +221,11 @@ def preprocess(frames, divisibility=32):
     H, W = x.shape[-2:]
     Hp, Wp = (H + divisibility - 1) // divisibility * divisibility, (W + divisibility - 1) // divisibility * divisibility
     return torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
+
+
+# Swin-B (configs/univs_inf/vids/refvos/univs_swinb_refvos_davis_c1+univs.yaml:5-9): window 12 -> 144-token
+# windows, the second instantiation of the window-attention kernel
+SWIN_B = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=128, depths=[2, 2, 18, 2],
+              num_heads=[4, 8, 16, 32], window_size=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+              ape=False, patch_norm=True)
+SWINB_CASE = dict(name="swin_b", N=1, H=96, W=160)

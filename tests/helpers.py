@@ -7,9 +7,9 @@ from univs_amd import synth
 from univs_amd.registry import ShapeSpec
 
 
-def build_swin(device="cpu"):
+def build_swin(device="cpu", variant=None):
     from univs_amd.modeling.backbone.swin import SwinTransformer
-    k = dict(cases.SWIN_T)
+    k = dict(variant or cases.SWIN_T)
     m = SwinTransformer(k["pretrain_img_size"], k["patch_size"], k["in_chans"], k["embed_dim"], k["depths"],
                         k["num_heads"], k["window_size"], k["mlp_ratio"], k["qkv_bias"], k["qk_scale"], k["ape"],
                         k["patch_norm"]).eval()

@@ -96,3 +96,46 @@ def test_head_matches_reference(golden_dir, name, dec_over, targets_fn, seed):
         helpers.check_head_outputs(out3, g, "clip3_", tol=1e-3)
         for k in ("prompt_feats", "prompt_pe"):
             assert np.abs(targets[0][k].numpy() - g["clip3_pool_" + k]).max() < 1e-4, k
+
+
+def test_config1_resnet50_plumbing_cpu():
+    """BASELINE config 1: ResNet-50 UniVS, 1 clip x T=2 frames @ 256x448, 20 queries, CPU path (plumbing).
+    ResNet parity is unpinned (detectron2 source is not in the reference tree): shapes, strides and the
+    Detectron2 key layout are checked, then the clip runs end to end through the config-built model."""
+    from univs_amd.config import get_cfg
+    from univs_amd.modeling.build import UniVSHotPath
+    cfg = get_cfg()
+    cfg.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES = 20
+    cfg.INPUT.SAMPLING_FRAME_NUM = 2
+    cfg.MODEL.UniVS.CLIP_CLASS_EMBED_PATH = cases.clip_table()
+    model = UniVSHotPath(cfg).eval()
+    synth.load_synthetic(model)
+    shp = model.backbone.output_shape()
+    assert {k: (v.channels, v.stride) for k, v in shp.items()} == \
+        {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
+    keys = set(model.backbone.state_dict())
+    for k in ("stem.conv1.weight", "stem.conv1.norm.running_var", "res2.0.shortcut.weight", "res2.0.conv2.norm.bias",
+              "res4.5.conv3.weight", "res5.2.conv1.norm.running_mean"):
+        assert k in keys, k
+    frames = synth.synthetic_frames(2, 250, 440, "cfg1/frames")     # pads to 256x448
+    case = dict(cases.HEAD_CASE, T=2)
+    with cpu_ops(), torch.no_grad():
+        x = model.preprocess(frames)
+        assert tuple(x.shape) == (2, 3, 256, 448)
+        feats = model.backbone(x)
+        assert tuple(feats["res5"].shape) == (2, 2048, 8, 14) and tuple(feats["res2"].shape) == (2, 256, 64, 112)
+        out = model.sem_seg_head(feats, targets=cases.targets_first_clip(case))
+    assert tuple(out["pred_masks"].shape) == (1, 20, 2, 64, 112)
+    assert tuple(out["pred_logits"].shape) == (1, 20, 3938)
+    assert torch.isfinite(out["pred_masks"]).all() and out["aux_outputs"] == []
+
+
+def test_swin_b_window12_matches_reference(golden_dir):
+    g = _g(golden_dir, "g9b_swin_b")
+    swin = helpers.build_swin(variant=cases.SWIN_B)
+    with cpu_ops(), torch.no_grad():
+        out = swin(cases.swin_input(cases.SWINB_CASE))
+    for k in ("res2", "res3", "res4", "res5"):
+        err = np.abs(out[k][:, ::2].numpy() - g[k]).max()
+        assert err < 5e-4, (k, err)

@@ -123,3 +123,39 @@ def test_head_gpu_equals_cpu_oracle_path(cuda):
         err = (out[k].cpu() - ref[k]).abs().max().item()
         assert err < 1e-3, (k, err)
     assert ((out["pred_masks"].cpu() > 0) != (ref["pred_masks"] > 0))[ref["pred_masks"].abs() > 1e-3].sum() == 0
+
+
+def test_swin_b_window12_matches_reference(cuda, golden_dir):
+    """Swin-B (BASELINE config 4's backbone): 144-token windows -> window_attn_f32<9>."""
+    g = _g(golden_dir, "g9b_swin_b")
+    swin = helpers.build_swin(cuda, variant=cases.SWIN_B)
+    with torch.no_grad():
+        out = swin(cases.swin_input(cases.SWINB_CASE).to(cuda))
+    for k in ("res2", "res3", "res4", "res5"):
+        err = np.abs(out[k][:, ::2].cpu().numpy() - g[k]).max()
+        assert err < 1e-3, (k, err)
+
+
+def test_config1_resnet50_plumbing_gpu(cuda):
+    """BASELINE config 1 on the device: config-built model (ResNet-50 + head), T=2 @ 256x448, 20 queries."""
+    from univs_amd import synth
+    from univs_amd.config import get_cfg
+    from univs_amd.modeling.build import UniVSHotPath
+    cfg = get_cfg()
+    cfg.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES = 20
+    cfg.INPUT.SAMPLING_FRAME_NUM = 2
+    cfg.MODEL.UniVS.CLIP_CLASS_EMBED_PATH = cases.clip_table()
+    model = UniVSHotPath(cfg).eval()
+    synth.load_synthetic(model)
+    model = model.to(cuda)
+    frames = synth.synthetic_frames(2, 250, 440, "cfg1/frames").to(cuda)
+    out = model(frames, _targets_to(cases.targets_first_clip(dict(cases.HEAD_CASE, T=2)), cuda))
+    assert tuple(out["pred_masks"].shape) == (1, 20, 2, 64, 112) and torch.isfinite(out["pred_masks"]).all()
+    # same clip through the CPU oracle path
+    model_c = UniVSHotPath(cfg).eval()
+    synth.load_synthetic(model_c)
+    with cpu_ops():
+        ref = model_c(frames.cpu(), cases.targets_first_clip(dict(cases.HEAD_CASE, T=2)))
+    err = (out["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
+    assert err < 1e-3, err

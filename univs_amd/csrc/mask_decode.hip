@@ -17,9 +17,9 @@ namespace univs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MD_THREADS = 256;   // 4 waves
+constexpr int MD_THREADS = 512;   // 8 waves = 2 per SIMD: one wave's HBM latency hides under the other's MFMAs
 constexpr int MD_WAVE_N = 32;     // columns per wave per tile
-constexpr int MD_BLOCK_N = 128;   // 4 waves x 32 columns
+constexpr int MD_BLOCK_N = 256;   // 8 waves x 32 columns
 
 // Epilogue 1: write logits to out[(q*T + t)*N + n]
 struct StoreLogits {
@@ -44,6 +44,11 @@ struct StoreAttnMask {
 };
 
 // MI = number of 32-row blocks of A handled by each wave (rows per block-tile = 32*MI).
+// B fragments are fetched with raw buffer loads: the per-lane byte offset (column, k parity) is
+// computed once, the k-row offset travels in an SGPR, out-of-range columns are clamped (their results
+// are never stored) -- no per-load VALU address arithmetic and no divergent control flow, so the 16
+// loads of a chunk are in flight together and the NEXT chunk is fetched while the current one feeds
+// the MFMAs (register double buffer).
 template <int MI, typename Epilogue>
 __global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32(const float* __restrict__ A,  // [T,Q,K]
                                                                   const float* __restrict__ B,  // [T,K,N]
@@ -52,6 +57,7 @@ __global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32(const float* __
   extern __shared__ __attribute__((aligned(16))) float At[];  // [K][LDP]
   constexpr int QP = 32 * MI;
   constexpr int LDP = QP + 1;
+  constexpr int UNR = 16;  // k-steps (of 2) per chunk
   const int t = blockIdx.z;
   const int q0 = blockIdx.y * QP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,16 +70,20 @@ __global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32(const float* __
   }
   __syncthreads();
 
-  const float* Bt = B + (long long)t * K * N;
   const int khalf = lane >> 5;   // which of the two k's of an MFMA this lane feeds
   const int l31 = lane & 31;
+  const int Ni = (int)N;
+  // buffer resource over this frame's B matrix (K*N floats); wave-uniform by construction
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(B + (long long)t * K * N), 0, (int)((long long)K * N * 4), 0x00020000);
+  const int Kc = (K + 2 * UNR - 1) / (2 * UNR);  // chunks; rows >= K read as 0 (buffer bounds check)
 
   for (int tile = 0; tile < tiles_per_block; ++tile) {
     const long long col0 = ((long long)blockIdx.x * tiles_per_block + tile) * MD_BLOCK_N + wave * MD_WAVE_N;
     if (col0 >= N) break;                    // wave-uniform
-    const long long col = col0 + l31;
-    const bool cv = col < N;
-    const float* bp = Bt + (cv ? col : 0);
+    const int col = (int)col0 + l31;
+    const bool cv = col < Ni;
+    const int voff = (min(col, Ni - 1) + khalf * Ni) * 4;  // bytes
 
     f32x16 acc[MI];
 #pragma unroll
@@ -81,24 +91,30 @@ __global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    constexpr int UNR = 16;  // k-steps (of 2) whose B fragments are in flight together
-    for (int k0 = 0; k0 < K; k0 += 2 * UNR) {
-      float bf[UNR];
+    float bcur[UNR], bnext[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int k = k0 + 2 * u + khalf;
-        bf[u] = (cv && k < K) ? bp[(long long)k * N] : 0.f;
+    for (int u = 0; u < UNR; ++u)
+      bcur[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (2 * u) * Ni * 4, 0));
+
+    for (int c = 0; c < Kc; ++c) {
+      const int k0 = c * 2 * UNR;
+      if (c + 1 < Kc) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          bnext[u] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + 2 * UNR + 2 * u) * Ni * 4, 0));
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int k = k0 + 2 * u + khalf;
-        const float* arow = At + (k < K ? k : 0) * LDP + l31;
+        const float* arow = At + min(k, K - 1) * LDP + l31;
+        const float bsel = (k < K) ? bcur[u] : 0.f;  // K not a multiple of 2: the odd tail row
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const float a = (k < K) ? arow[32 * i] : 0.f;
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[u], acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < MI; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[32 * i], bsel, acc[i], 0, 0, 0);
       }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) bcur[u] = bnext[u];
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -124,10 +140,15 @@ static int launch_skinny(const float* A, const float* B, int T, int Q, int K, lo
   const int QP = 32 * MI;
   const int qtiles = (Q + QP - 1) / QP;
   const long long ctiles = (N + MD_BLOCK_N - 1) / MD_BLOCK_N;
-  // amortise the A staging: aim for ~2 block-waves over 256 CUs
-  long long tpb = (ctiles * qtiles * T + 511) / 512;
+  // amortise the A staging and balance the grid: just under one block per CU (256 CUs) when the
+  // problem is large enough, one tile per block otherwise
+  long long tpb = (ctiles * qtiles * T + 255) / 256;
   if (tpb < 1) tpb = 1;
-  if (tpb > 8) tpb = 8;
+  if (tpb > 16) tpb = 16;
+  if ((long long)K * N * 4 >= (1LL << 31)) {
+    set_error("%s: K*N too large for a 32-bit buffer range", what);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
   const long long gx = (ctiles + tpb - 1) / tpb;
   const size_t lds = (size_t)K * (QP + 1) * sizeof(float);
   if (lds > 160 * 1024) {

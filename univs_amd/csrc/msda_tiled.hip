@@ -39,6 +39,7 @@ struct TileGeom {
   int tiles_y, tiles_x;
   int R;         // halo radius in pixels of each value level
   int cap_px;    // LDS window capacity in pixels (device clamps the window to it)
+  int ablate;    // profiling only (UNIVS_MSDA_ABLATE): bit0 skip window copy, bit1 skip records, bit2 skip gathers
 };
 
 struct Window {  // staged window of the current level (workgroup-uniform)
@@ -196,11 +197,14 @@ __global__ __launch_bounds__(THREADS) void msda_fwd_tiled(const float* __restric
     // per step; out-of-window groups re-read a clamped pixel instead of branching
     const int rx = min(oct & 31, win.w - 1);
     const float4* src0 = vn + ((long long)lv.start[l] + (long long)win.y0 * W + win.x0 + rx) * rowf4;
+    if (!(tg.ablate & 1)) {
 #pragma unroll
-    for (int u = 0; u < WR; ++u) {
-      const int ry = min(u * (OCTETS / 32) + (oct >> 5), win.h - 1);
-      wreg[u] = *reinterpret_cast<const v4f*>(src0 + (long long)ry * W * rowf4);
+      for (int u = 0; u < WR; ++u) {
+        const int ry = min(u * (OCTETS / 32) + (oct >> 5), win.h - 1);
+        wreg[u] = *reinterpret_cast<const v4f*>(src0 + (long long)ry * W * rowf4);
+      }
     }
+    if (!(tg.ablate & 2))
 #pragma unroll
     for (int s = 0; s < SR; ++s) {
       const int i = min(tid + s * THREADS, total * 4 - 1);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(THREADS) void msda_fwd_tiled(const float* __restric
 #pragma unroll
     for (int s = 0; s < SR; ++s) {
       const int i = tid + s * THREADS;
-      if (i < total * 4) {
+      if (i < total * 4 && !(tg.ablate & 2)) {
         float4 wv;
         int slot;
         make_record(win, H, W, sxy[s].x, sxy[s].y, sa[s], wv, slot);
@@ -249,30 +253,35 @@ __global__ __launch_bounds__(THREADS) void msda_fwd_tiled(const float* __restric
 #pragma unroll
     for (int k = 0; k < QMAX; ++k) {
       const int qi = oct + k * OCTETS;
-      if (qi < total) {
-        float4 wv[4];
+      if (qi < total && !(tg.ablate & 4)) {
+        // SB samples per batch: 4 (all of the level) at 512 threads, 2 at 1024 threads (128-VGPR budget)
+        constexpr int SB = (THREADS == 1024) ? 2 : 4;
         int sl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          wv[p] = rec_w[qi * 4 + p];
-          sl[p] = rec_s[qi * 4 + p];
-        }
-        float4 v[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float4* b = win_lane + (sl[p] & 0x7fffffff);
-          v[p][0] = b[0];
-          v[p][1] = b[8];
-          v[p][2] = b[win.w * 8];
-          v[p][3] = b[win.w * 8 + 8];
-        }
         float4 a = acc[k];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          a = fma4(wv[p].x, v[p][0], a);
-          a = fma4(wv[p].y, v[p][1], a);
-          a = fma4(wv[p].z, v[p][2], a);
-          a = fma4(wv[p].w, v[p][3], a);
+        for (int p0 = 0; p0 < 4; p0 += SB) {
+          float4 wv[SB];
+          float4 v[SB][4];
+#pragma unroll
+          for (int p = 0; p < SB; ++p) {
+            wv[p] = rec_w[qi * 4 + p0 + p];
+            sl[p0 + p] = rec_s[qi * 4 + p0 + p];
+          }
+#pragma unroll
+          for (int p = 0; p < SB; ++p) {
+            const float4* b = win_lane + (sl[p0 + p] & 0x7fffffff);
+            v[p][0] = b[0];
+            v[p][1] = b[8];
+            v[p][2] = b[win.w * 8];
+            v[p][3] = b[win.w * 8 + 8];
+          }
+#pragma unroll
+          for (int p = 0; p < SB; ++p) {
+            a = fma4(wv[p].x, v[p][0], a);
+            a = fma4(wv[p].y, v[p][1], a);
+            a = fma4(wv[p].z, v[p][2], a);
+            a = fma4(wv[p].w, v[p][3], a);
+          }
         }
         if ((sl[0] | sl[1] | sl[2] | sl[3]) < 0) {
           // rare: footprint(s) outside the staged window -> those samples come from global memory,
@@ -367,6 +376,7 @@ int msda_forward_tiled_f32(const float* value, const LevelTable& lv, const float
   tg.TH = env_int("UNIVS_MSDA_TILE_H", 16);
   tg.TW = env_int("UNIVS_MSDA_TILE_W", 16);
   tg.R = env_int("UNIVS_MSDA_HALO", 6);
+  tg.ablate = env_int("UNIVS_MSDA_ABLATE", 0);
   const int threads = env_int("UNIVS_MSDA_THREADS", 512) == 1024 ? 1024 : 512;
   if (tg.TH < 1 || tg.TW < 1 || tg.R < 0) return 0;
   tg.tiles_y = (lv.H[fine] + tg.TH - 1) / tg.TH;

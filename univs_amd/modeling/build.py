@@ -5,6 +5,7 @@ from torch import nn
 
 from ..registry import BACKBONE_REGISTRY, SEM_SEG_HEADS_REGISTRY, ShapeSpec
 # importing the modules registers the classes
+from .backbone import resnet as _resnet  # noqa: F401
 from .backbone import swin as _swin  # noqa: F401
 from .meta_arch import mask_former_head as _head  # noqa: F401
 from .pixel_decoder import msdeformattn as _pd  # noqa: F401

@@ -17,6 +17,7 @@ blocks + 6 encoder layers + 10 decoder layers and mask logits come out O(1..10):
   * `cls_temp` / `reid_temp`:                      log(1/0.07), the reference's init value
       (video_mask2former_transformer_decoder_univs.py:234-236)
   * `relative_position_bias_table`:                0.5 u
+  * frozen-BN `running_var`:                       1 + 0.1 u
 Integer buffers (e.g. Swin's `relative_position_index`) are left untouched.
 """
 import math
@@ -86,6 +87,8 @@ def make_param(name: str, shape, gain: float = 1.0) -> torch.Tensor:
         return uniform(name, shape) * (gain * math.sqrt(3.0) / math.sqrt(fan_in))
     if name.endswith("sampling_offsets.bias"):
         return uniform(name, shape) * 2.0
+    if name.endswith("running_var"):          # frozen BatchNorm statistics must stay positive
+        return 1.0 + 0.1 * uniform(name, shape)
     if name.endswith("weight"):
         return 1.0 + 0.1 * uniform(name, shape)
     return 0.05 * uniform(name, shape)
