@@ -1,0 +1,86 @@
+"""Phase timing of the LDS-tiled MSDA kernel from inside the kernel (run on the GPU box).
+
+`python tools/msda_trace.py --build` (here, no GPU) compiles the product sources with -DUNIVS_MSDA_TRACE
+into tools/_trace/libunivs_hip_trace.so; `python tools/msda_trace.py` (GPU box) loads that build through
+UNIVS_HIP_LIB, launches the kernel at the BASELINE config-2 geometry and prints, per phase, the mean /
+p90 s_memtime delta over all workgroups plus the kernel's wall time, so that stamps can be converted
+to a share of the launch."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tools", "_trace", "libunivs_hip_trace.so")
+NAMES = {0: "prologue(box math)", 1: "qglob+sync", 2: "issue(0) issued", 3: "L0 top", 4: "L0 commit+sync",
+         5: "L0 phaseB", 6: "L1 barrier", 7: "L1 commit+sync", 8: "L1 phaseB", 9: "L2 barrier",
+         10: "L2 commit+sync", 11: "L2 phaseB", 15: "stores"}
+
+
+def build():
+    sys.path.insert(0, ROOT)
+    from univs_amd import build as b
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    srcs = [os.path.join(b.CSRC, s) for s in b.SOURCES]
+    cmd = [b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUNIVS_MSDA_TRACE",
+           "-I", os.path.join(ROOT, "include"), *srcs, "-o", OUT]
+    subprocess.check_call(cmd)
+    print("built", OUT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--T", type=int, default=5)
+    args = ap.parse_args()
+    if args.build:
+        return build()
+    os.environ["UNIVS_HIP_LIB"] = OUT
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from tests import cases
+    from univs_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    T = args.T
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    case = dict(name="kb", shapes=shapes, N=T, M=8, D=32, P=4, encoder=True, far=False)
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    value, loc, attn = value.to(dev), loc.to(dev), attn.to(dev)
+    ops.msda_set_impl(2)
+    for _ in range(5):
+        ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    nblk = T * 8 * 6 * 10
+    buf = np.zeros((nblk, 16), dtype=np.uint64)
+    lib = _lib.load()
+    fn = lib.univs_msda_trace_read
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    rc = fn(buf.ctypes.data, nblk)
+    assert rc == 0, rc
+    t = buf.astype(np.int64)
+    span = t[:, 15].max() - t[:, 0].min()
+    print(f"kernel (1 launch, events incl. launch overhead): {ms * 1e3:.1f} us;  stamp span {span} ticks "
+          f"-> {span / (ms * 1e3):.1f} ticks/us")
+    tot = (t[:, 15] - t[:, 0])
+    print(f"per-WG lifetime: mean {tot.mean():.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f} ticks; "
+          f"sum/256 CUs = {tot.sum() / 256:.0f} ticks")
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15]
+    for i, j in zip(order[:-1], order[1:]):
+        d = t[:, j] - t[:, i]
+        print(f"  {NAMES[j]:<20s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}  "
+              f"share {d.sum() / tot.sum() * 100:5.1f} %")
+    # gaps between consecutive workgroups on the same CU cannot be seen from here; report the implied idle share
+    print(f"implied launch/idle share: {(1 - tot.sum() / 256 / span) * 100:.1f} % of the span")
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (kept first on purpose)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunivs_hip.so")
+# UNIVS_HIP_LIB: debug override (tools/msda_trace.py loads an instrumented build of the same sources)
+LIB_PATH = os.environ.get("UNIVS_HIP_LIB") or os.path.join(_HERE, "libunivs_hip.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
