@@ -23,7 +23,7 @@ def build():
     from univs_amd import build as b
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = [os.path.join(b.CSRC, s) for s in b.SOURCES]
-    cmd = [b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUNIVS_MSDA_TRACE",
+    cmd = [b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUNIVS_MSDA_TRACE", *os.environ.get("UNIVS_TRACE_DEFS", "").split(),
            "-I", os.path.join(ROOT, "include"), *srcs, "-o", OUT]
     subprocess.check_call(cmd)
     print("built", OUT)
@@ -58,7 +58,7 @@ def main():
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b)
-    nblk = T * 8 * 6 * 10
+    nblk = int(os.environ.get("UNIVS_MSDA_GRID", "256"))
     buf = np.zeros((nblk, 16), dtype=np.uint64)
     lib = _lib.load()
     fn = lib.univs_msda_trace_read
@@ -67,19 +67,22 @@ def main():
     rc = fn(buf.ctypes.data, nblk)
     assert rc == 0, rc
     t = buf.astype(np.int64)
-    span = t[:, 15].max() - t[:, 0].min()
+    # stamps 13 / 14: workgroup start / end; 0, 3..11, 15: phases of the workgroup's SECOND item (steady state)
+    span = t[:, 14].max() - t[:, 13].min()
+    life = t[:, 14] - t[:, 13]
     print(f"kernel (1 launch, events incl. launch overhead): {ms * 1e3:.1f} us;  stamp span {span} ticks "
           f"-> {span / (ms * 1e3):.1f} ticks/us")
-    tot = (t[:, 15] - t[:, 0])
-    print(f"per-WG lifetime: mean {tot.mean():.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f} ticks; "
-          f"sum/256 CUs = {tot.sum() / 256:.0f} ticks")
-    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15]
+    print(f"workgroup lifetime: mean {life.mean():.0f}  min {life.min()}  max {life.max()} ticks "
+          f"(start skew {t[:, 13].max() - t[:, 13].min()}, end skew {t[:, 14].max() - t[:, 14].min()})")
+    tot = t[:, 15] - t[:, 0]
+    print(f"steady-state item: mean {tot.mean():.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f} ticks")
+    names = {3: "top (decode, acc=0, barrier)", 4: "L0 commit+sync", 5: "L0 loads+gathers", 6: "L1 barrier", 7: "L1 commit+sync",
+             8: "L1 loads+gathers", 9: "L2 barrier", 10: "L2 commit(+qglob)+sync", 11: "L2 prefetch+gathers", 15: "reduce+stores"}
+    order = [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15]
     for i, j in zip(order[:-1], order[1:]):
         d = t[:, j] - t[:, i]
-        print(f"  {NAMES[j]:<20s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}  "
+        print(f"  {names[j]:<30s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}  "
               f"share {d.sum() / tot.sum() * 100:5.1f} %")
-    # gaps between consecutive workgroups on the same CU cannot be seen from here; report the implied idle share
-    print(f"implied launch/idle share: {(1 - tot.sum() / 256 / span) * 100:.1f} % of the span")
 
 
 if __name__ == "__main__":

@@ -72,7 +72,7 @@ constexpr int TL_NSMP = TL_QCAP * 4;              // sample records per level
 constexpr int TL_GROUPS = TL_THREADS / 16;        // 16-lane gather groups per workgroup
 constexpr int TL_QMAX = TL_QCAP / TL_GROUPS;      // queries per gather group
 constexpr int TL_OCTETS = TL_THREADS / 8;         // 8-lane copy groups (one 128-B row each)
-constexpr int TL_WR = 1024 / TL_OCTETS;           // window float4 per lane (covers 32 x 32 pixels)
+constexpr int TL_WR = 15;                         // window float4 per lane: 960 pixels (a 30 x 30 window = 16 + 2 x 6 + 2)
 constexpr int TL_SR = TL_NSMP / TL_THREADS;       // samples per thread
 constexpr int TL_WIN_MAX = 64;                    // window edge limit (the product ww*wh is bounded by the LDS carve)
 
@@ -85,6 +85,12 @@ __device__ __forceinline__ v4f fma4v(float s, v4f v, v4f a) {
 //   geo[l * tiles_x + tx]                  = {qx0, qnx, wx0, ww}   query columns / window columns
 //   geo[L * tiles_x + l * tiles_y + ty]    = {qy0, qny, wy0, wh}   query rows    / window rows
 // Window coordinates are image coordinates and may start at -1 / end at H (W): the zero ring.
+// Every tile owns at least one query (host-checked).
+//
+// Persistent: the grid is a multiple of the CU count, each workgroup walks a strided list of items
+// (frame, tile, head) inside its XCD's chunk of the item space, and the loads of the NEXT item's first
+// level are issued during the gathers of the current item's last level, so neither the launch gap nor
+// the first window's latency is paid per item.
 template <int L>
 __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __restrict__ value,
                                                               LevelTable lv, TileGeom tg,
@@ -92,24 +98,17 @@ __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __rest
                                                               const float* __restrict__ loc,
                                                               const float* __restrict__ attn, int N, int S,
                                                               int M, float* __restrict__ out,
-                                                              unsigned nblocks) {
+                                                              unsigned nitems) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) v4f lds[];
-  // LDS carve: [records v4f x NSMP][query ids int x QCAP][window]
+  // LDS carve: [records v4f x NSMP][query ids int x QCAP, two buffers][window]
   v4f* rec = lds;
-  int* qglob = reinterpret_cast<int*>(lds + TL_NSMP);
-  v4f* win_lds = lds + TL_NSMP + TL_QCAP / 4;
+  int* qgbuf = reinterpret_cast<int*>(lds + TL_NSMP);
+  v4f* win_lds = lds + TL_NSMP + 2 * TL_QCAP / 4;
 
-  const unsigned bid = xcd_remap(blockIdx.x, nblocks);
-  const int m = bid % M;
-  const int ntiles = tg.tiles_y * tg.tiles_x;
-  const int tile = (bid / M) % ntiles;
-  const int n = bid / (M * ntiles);
-  const int ty = tile / tg.tiles_x, tx = tile % tg.tiles_x;
   const int tid = threadIdx.x, lane8 = tid & 7, oct = tid >> 3;
   const int rowf4 = M * (D / 4);
-  const int4* geox = geo + tx;
-  const int4* geoy = geo + L * tg.tiles_x + ty;
+  const int ntiles = tg.tiles_y * tg.tiles_x;
 
   // ---- 16-lane gather groups = the ds_read_b128 hardware lane groups
   const int lane = tid & 63, hl = lane & 31;
@@ -119,83 +118,133 @@ __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __rest
   const int grp = (tid >> 6) * 4 + (lane >> 5) * 2 + g;        // 0 .. TL_GROUPS-1
   const int side = pos >> 3, chunk = pos & 7;                  // corner column (0 left, 1 right), 16-B chunk
   const float xw_c0 = side ? 0.f : 1.f, xw_c1 = side ? 1.f : -1.f;  // column weight = c0 + c1 * lw
+  const int ppos = pos ^ 8;                                    // partner lane: same query, other column
+  const int phl = g ? (ppos < 8 ? ppos + 4 : ppos < 12 ? ppos + 8 : ppos + 16)
+                    : (ppos < 4 ? ppos : ppos < 8 ? ppos + 8 : ppos + 12);
+  const int partner = (lane & 32) | phl;
 
-  // ---- queries owned by this tile
-  int pre[L + 1];
-  pre[0] = 0;
+  // ---- this workgroup's items: XCD x (= blockIdx % 8 in hardware dispatch order) owns a contiguous
+  // chunk of the item space; its workgroups take every nw-th item of the chunk, so at any time the
+  // workgroups of an XCD work on the heads of a few neighbouring tiles (shared halo rows and sample
+  // lines in that XCD's L2).  (A ticket counter per XCD instead of the fixed stride was measured: no
+  // gain -- the makespan is set by ceil(items / workgroups), not by variance.)
+  const unsigned nxcd = min(8u, gridDim.x);
+  const unsigned xcd = blockIdx.x % nxcd, widx = blockIdx.x / nxcd;
+  const unsigned nw = gridDim.x / nxcd + (xcd < gridDim.x % nxcd ? 1u : 0u);
+  const unsigned cq = nitems / nxcd, cr = nitems % nxcd;
+  const unsigned cbase = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const unsigned csize = cq + (xcd < cr ? 1u : 0u);
+  if (widx >= csize) return;   // uniform, before any barrier
+
+  // workgroup-uniform item state, kept small on purpose (it lives in SGPRs twice: current + next):
+  // element offset of (frame n, query 0, head m) and the tile's geometry rows
+  struct Item {
+    long long nm;   // n * S * M + m
+    int tx, ty, total;
+  };
+  struct Coord { int n, m, tx, ty; };   // workgroup-uniform item coordinates
+  auto make_item = [&](const Coord& c) __attribute__((always_inline)) {
+    Item it;
+    it.nm = (long long)c.n * S * M + c.m;
+    it.tx = c.tx;
+    it.ty = c.ty;
+    int tot = 0;
 #pragma unroll
-  for (int l = 0; l < L; ++l) pre[l + 1] = pre[l] + geox[l * tg.tiles_x].y * geoy[l * tg.tiles_y].y;
-  const int total = pre[L];  // <= TL_QCAP (host-checked)
-  // Workgroup-uniform early exit (no barrier has been passed yet).  Also keeps every later load /
-  // commit pair on ONE control-flow path: with separate `if (total > 0)` guards hipcc's waitcnt pass
-  // sees an (infeasible) path "loads issued, commit skipped" and serialises the next level's loads.
-  if (total == 0) return;
-  TSTAMP(0);
-
-  // global query index of every query of the tile, once
-  for (int i = tid; i < total; i += TL_THREADS) {
-    int l = 0;
+    for (int l = 0; l < L; ++l) tot += geo[l * tg.tiles_x + c.tx].y * geo[L * tg.tiles_x + l * tg.tiles_y + c.ty].y;
+    it.total = tot;   // 1 .. TL_QCAP (host-checked)
+    return it;
+  };
+  auto geo_x = [&](const Item& it, int l) __attribute__((always_inline)) { return geo[l * tg.tiles_x + it.tx]; };
+  auto geo_y = [&](const Item& it, int l) __attribute__((always_inline)) {
+    return geo[L * tg.tiles_x + l * tg.tiles_y + it.ty];
+  };
+  auto decode = [&](unsigned idx) __attribute__((always_inline)) {   // chunk-relative index -> coordinates
+    const unsigned item = cbase + idx;
+    Coord c;
+    c.m = item % M;
+    const int tile = (item / M) % ntiles;
+    c.n = item / (M * ntiles);
+    c.ty = tile / tg.tiles_x;
+    c.tx = tile % tg.tiles_x;
+    return c;
+  };
+  // global query index of every query of the item's tile
+  auto fill_qglob = [&](const Item& it, int* qg) __attribute__((always_inline)) {
+    int pre[L + 1];
+    int4 gxl[L], gyl[L];   // scalar loads, selected per thread below (no per-thread global load)
+    pre[0] = 0;
 #pragma unroll
-    for (int j = 1; j < L; ++j) l += (i >= pre[j]) ? 1 : 0;
-    const int4 gx = geox[l * tg.tiles_x], gy = geoy[l * tg.tiles_y];
-    int li = i;
+    for (int l = 0; l < L; ++l) {
+      gxl[l] = geo_x(it, l);
+      gyl[l] = geo_y(it, l);
+      pre[l + 1] = pre[l] + gxl[l].y * gyl[l].y;
+    }
+    for (int i = tid; i < it.total; i += TL_THREADS) {
+      int li = i, qx0 = gxl[0].x, qnx = gxl[0].y, qy0 = gyl[0].x, Wq = lv.W[0], st = lv.start[0];
 #pragma unroll
-    for (int j = 1; j < L; ++j)
-      if (l == j) li = i - pre[j];
-    const int row = (int)(((float)li + 0.5f) * __builtin_amdgcn_rcpf((float)gx.y));   // exact: li < 2^10, margin 0.5/nx
-    qglob[i] = lv.start[l] + (gy.x + row) * lv.W[l] + gx.x + (li - row * gx.y);
-  }
+      for (int j = 1; j < L; ++j)
+        if (i >= pre[j]) { li = i - pre[j]; qx0 = gxl[j].x; qnx = gxl[j].y; qy0 = gyl[j].x; Wq = lv.W[j]; st = lv.start[j]; }
+      const int row = (int)(((float)li + 0.5f) * __builtin_amdgcn_rcpf((float)qnx));   // exact: li < 2^10, margin 0.5/nx
+      qg[i] = st + (qy0 + row) * Wq + qx0 + (li - row * qnx);
+    }
+  };
 
-  v4f acc[TL_QMAX];
-#pragma unroll
-  for (int k = 0; k < TL_QMAX; ++k) acc[k] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-  const v4f* vn = reinterpret_cast<const v4f*>(value + (long long)n * S * M * D + (long long)m * D);
-  const float* locn = loc + ((long long)n * S * M + m) * (L * P * 2);
-  const float* attn_n = attn + ((long long)n * S * M + m) * (L * P);
-
-  // Register-staged software pipeline (issue early / write late): the global loads of level l+1's
-  // window and sample inputs are issued right before the gather loop of level l and only written to
-  // LDS after it.  (Spreading them over the gather steps was tried: hipcc then puts s_waitcnt vmcnt(0)
-  // in front of every load and serialises them.)
+  // Register-staged software pipeline (issue early / write late): the global loads of the next
+  // window and sample inputs are issued right before a gather loop and only written to LDS after it.
   struct LevelGeo {   // workgroup-uniform
     int H, W, wx0, wy0, ww, npx;
-    float rcp_ww;
-    const v4f* src;
+    int sx, sy;                    // 64 = sy * ww + sx: window-row / column step of one copy step
+    __amdgpu_buffer_rsrc_t rsrc;   // this (frame, head, level)'s value rows: out-of-range offsets read 0
   };
-  auto level_geo = [&](int l) __attribute__((always_inline)) {
-    const int4 gx = geox[l * tg.tiles_x], gy = geoy[l * tg.tiles_y];
+  auto level_geo = [&](const Item& it, int l) __attribute__((always_inline)) {
+    const int4 gx = geo_x(it, l), gy = geo_y(it, l);
     LevelGeo q;
     q.H = lv.H[l]; q.W = lv.W[l];
     q.wx0 = gx.z; q.ww = gx.w; q.wy0 = gy.z; q.npx = gx.w * gy.w;
-    q.rcp_ww = __builtin_amdgcn_rcpf((float)gx.w);   // 1 ulp is plenty, see load_window
-    q.src = vn + (long long)lv.start[l] * rowf4 + lane8;
+    q.sy = (int)(((float)TL_OCTETS + 0.5f) * __builtin_amdgcn_rcpf((float)gx.w));   // exact, see below
+    q.sx = TL_OCTETS - q.sy * gx.w;
+    // rows of head m only: the last valid byte is the end of the last pixel's 128-B row
+    q.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value + (it.nm + (long long)lv.start[l] * M) * D), 0,
+        (int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4), 0x00020000);
     return q;
   };
   v4f wreg[TL_WR];
-  unsigned vmask = 0;   // bit u: wreg[u] is an image pixel (else: zero ring)
   float2 sxy[TL_SR];
   float sa[TL_SR];
-  // window pixel j = oct + 64 u (row-major over the window) -> one 128-B row per octet
-  auto load_window = [&](const LevelGeo& q, int u) __attribute__((always_inline)) {
-    if (u * TL_OCTETS < q.npx && !(tg.ablate & 1)) {   // uniform
-      const int j = min(oct + u * TL_OCTETS, q.npx - 1);
-      const int ry = (int)(((float)j + 0.5f) * q.rcp_ww);   // exact: j < 2^10, margin 0.5/ww
-      const int px = q.wx0 + (j - ry * q.ww), py = q.wy0 + ry;
-      const bool in = (unsigned)px < (unsigned)q.W && (unsigned)py < (unsigned)q.H;
-      vmask = in ? (vmask | (1u << u)) : (vmask & ~(1u << u));
-      wreg[u] = q.src[((long long)min(max(py, 0), q.H - 1) * q.W + min(max(px, 0), q.W - 1)) * rowf4];
+  // Window copy: pixel j = oct + 64 u (row-major over the window), one 128-B row per octet and step.
+  // The zero ring costs nothing: rows above / below the image fall outside the buffer resource (the
+  // hardware returns 0), columns left / right of it get an out-of-range offset on purpose.  (ry, rx)
+  // and the byte offset advance incrementally -- no division, no clamps.
+  auto load_windows = [&](const LevelGeo& q) __attribute__((always_inline)) {
+    if (tg.ablate & 1) return;
+    const unsigned pstride = (unsigned)(M * D * 4);
+    int ry = (int)(((float)oct + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));   // exact: oct < 64, margin 0.5/ww
+    int rx = oct - ry * q.ww;
+    unsigned off = (unsigned)((q.wy0 + ry) * q.W + q.wx0 + rx) * pstride + (unsigned)lane8 * 16u;
+    const unsigned step_n = (unsigned)(q.sy * q.W + q.sx) * pstride;              // same window row + sy
+    const unsigned step_c = (unsigned)((q.sy + 1) * q.W + q.sx - q.ww) * pstride;  // wrapped to the next row
+#pragma unroll
+    for (int u = 0; u < TL_WR; ++u) {
+      if (u * TL_OCTETS < q.npx) {   // uniform
+        const bool xin = (unsigned)(q.wx0 + rx) < (unsigned)q.W;
+        wreg[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(q.rsrc, xin ? off : 0x80000000u, 0, 0));
+        rx += q.sx;
+        const bool carry = rx >= q.ww;
+        rx -= carry ? q.ww : 0;
+        off += carry ? step_c : step_n;
+      }
     }
   };
-  auto load_sample = [&](int l, int s) __attribute__((always_inline)) {
+  auto load_sample = [&](const Item& it, const int* qg, int l, int s) __attribute__((always_inline)) {
     if (!(tg.ablate & 2)) {
-      const int i = min(tid + s * TL_THREADS, total * 4 - 1);
-      const long long e = ((long long)qglob[i >> 2] * M * L + l) * P + (i & 3);
-      sxy[s] = reinterpret_cast<const float2*>(locn)[e];
-      sa[s] = attn_n[e];
+      const int i = min(tid + s * TL_THREADS, it.total * 4 - 1);
+      const unsigned e = (unsigned)((qg[i >> 2] * M * L + l) * P + (i & 3));   // < 2^28 (host-checked)
+      sxy[s] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(loc + it.nm * (L * P * 2)) + e * 8u);
+      sa[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(attn + it.nm * (L * P)) + e * 4u);
     }
   };
-  auto commit = [&](const LevelGeo& q) __attribute__((always_inline)) {
+  auto commit = [&](const LevelGeo& q, int total) __attribute__((always_inline)) {
     // All staged loads have landed from here on.  Explicit and unconditional on purpose: the loads and
     // their consumers sit in (uniform) conditional blocks, and without this hipcc's waitcnt pass assumes
     // a load of the previous level may still be pending on some path and puts s_waitcnt vmcnt(0) in
@@ -205,7 +254,7 @@ __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __rest
     for (int u = 0; u < TL_WR; ++u) {
       if (u * TL_OCTETS < q.npx) {   // uniform
         const int j = oct + u * TL_OCTETS;
-        if (j < q.npx) win_lds[j * 8 + lane8] = ((vmask >> u) & 1) ? wreg[u] : (v4f){0.f, 0.f, 0.f, 0.f};
+        if (j < q.npx) win_lds[j * 8 + lane8] = wreg[u];
       }
     }
     const int wh = q.npx / max(q.ww, 1);
@@ -231,104 +280,129 @@ __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __rest
     }
   };
 
-  __syncthreads();  // qglob visible
-  TSTAMP(1);
-  LevelGeo cur = level_geo(0);
+  // ---- prologue: first item's query list and first window
+  Item cur = make_item(decode(widx));
+  TSTAMP(13);
+  fill_qglob(cur, qgbuf);
+  __syncthreads();
+  LevelGeo geo_cur = level_geo(cur, 0);
+  load_windows(geo_cur);
 #pragma unroll
-  for (int u = 0; u < TL_WR; ++u) load_window(cur, u);
-#pragma unroll
-  for (int s = 0; s < TL_SR; ++s) load_sample(0, s);
-  TSTAMP(2);
+  for (int s = 0; s < TL_SR; ++s) load_sample(cur, qgbuf, 0, s);
 
-  // fully unrolled on purpose: with a rolled level loop hipcc's waitcnt pass serialises the staged
-  // loads (s_waitcnt vmcnt(0) in front of each, see commit()); L <= 4, so the code stays small
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int H = cur.H, W = cur.W;
-    const int rowstride = cur.ww * 8;   // window row stride in float4
-    const v4f* vl = vn + (long long)lv.start[l] * rowf4 + chunk;
-    const v4f* wl = win_lds + pos;   // pixel p's chunk `chunk` (+8 float4 = pixel p+1 for the right column)
-
-    if (l > 0) __syncthreads();  // previous level's phase B is done with the window and the records
-    TSTAMP(3 + 3 * l);
-    commit(cur);
-    __syncthreads();
-    TSTAMP(4 + 3 * l);
-    const bool more = l + 1 < L;
-    const LevelGeo nxt = level_geo(min(l + 1, L - 1));
-
-    if (more) {   // in flight during phase B below
-#pragma unroll
-      for (int u = 0; u < TL_WR; ++u) load_window(nxt, u);
-#pragma unroll
-      for (int s = 0; s < TL_SR; ++s) load_sample(l + 1, s);
-    }
-
-    // ---- phase B: 16 lanes per query; per sample two 256-B spans (top pair, bottom pair)
-#pragma unroll
-    for (int k = 0; k < TL_QMAX; ++k) {
-      const int qi = grp + k * TL_GROUPS;
-      if (qi < total && !(tg.ablate & 4)) {
-        v4f r[4], t[4], b[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) r[p] = rec[qi * 4 + p];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const v4f* base = wl + (__float_as_int(r[p].x) & 0x7fffffff);
-          t[p] = base[0];
-          b[p] = base[rowstride];
-        }
-        v4f a = acc[k];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float xw = fmaf(xw_c1, r[p].w, xw_c0);
-          a = fma4v(r[p].y * xw, t[p], a);
-          a = fma4v(r[p].z * xw, b[p], a);
-        }
-        const int s0 = __float_as_int(r[0].x), s1 = __float_as_int(r[1].x), s2 = __float_as_int(r[2].x),
-                  s3 = __float_as_int(r[3].x);
-        if ((s0 | s1 | s2 | s3) < 0 && !(tg.ablate & 8)) {
-          // rare: footprint(s) outside the staged window -> those samples come from global memory,
-          // one sample at a time (this lane's corner column: 2 clamped, always-valid loads).  Kept
-          // narrow on purpose: this path must not raise the register pressure of the common path.
-          const long long e = ((long long)qglob[qi] * M * L + l) * P;
+  int par = 0;
 #pragma unroll 1
+  for (unsigned idx = widx, itn = 0;; idx += nw, ++itn) {
+    if (itn == 1) TSTAMP(0);
+    const bool has_next = idx + nw < csize;
+    const Item nxt_item = make_item(decode(has_next ? idx + nw : idx));
+    const int* qg = qgbuf + par * TL_QCAP;
+    int* qg_next = qgbuf + (par ^ 1) * TL_QCAP;
+
+    v4f acc[TL_QMAX];
+#pragma unroll
+    for (int k = 0; k < TL_QMAX; ++k) acc[k] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // levels fully unrolled on purpose: with a rolled level loop hipcc's waitcnt pass serialises the
+    // staged loads (s_waitcnt vmcnt(0) in front of each, see commit()); L <= 4, so the code stays small
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = geo_cur.H, W = geo_cur.W;
+      const int rowstride = geo_cur.ww * 8;   // window row stride in float4
+      const v4f* vl = reinterpret_cast<const v4f*>(value + cur.nm * D) + (long long)lv.start[l] * rowf4 + chunk;
+      const v4f* wl = win_lds + pos;   // pixel p's chunk `chunk` (+8 float4 = pixel p+1 for the right column)
+
+      if (l > 0 || itn > 0) __syncthreads();  // the previous gather loop is done with window + records
+      if (itn == 1) TSTAMP(3 + 3 * l);
+      commit(geo_cur, cur.total);
+      if (l == L - 1 && has_next) fill_qglob(nxt_item, qg_next);
+      // next staged loads (in flight during the gathers below): next level, or the next item's level 0.
+      // (Spreading them over the gather steps instead was measured: slower.)  Their geometry is
+      // fetched before the barrier so that the scalar loads' latency hides in the barrier wait.
+      const bool do_loads = (l + 1 < L) || has_next;
+      const Item& ld_item = (l + 1 < L) ? cur : nxt_item;
+      const int ld_level = (l + 1 < L) ? l + 1 : 0;
+      const int* ld_qg = (l + 1 < L) ? qg : qg_next;
+      const LevelGeo geo_nxt = do_loads ? level_geo(ld_item, ld_level) : geo_cur;
+      __syncthreads();
+      if (itn == 1) TSTAMP(4 + 3 * l);
+      if (do_loads) {
+        load_windows(geo_nxt);
+#pragma unroll
+        for (int s = 0; s < TL_SR; ++s) load_sample(ld_item, ld_qg, ld_level, s);
+      }
+
+      // ---- gathers: 16 lanes per query; per sample two 256-B spans (top pair, bottom pair)
+#pragma unroll
+      for (int k = 0; k < TL_QMAX; ++k) {
+        const int qi = grp + k * TL_GROUPS;
+        if (qi < cur.total && !(tg.ablate & 4)) {
+          v4f r[4], t[4], b[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) r[p] = rec[qi * 4 + p];
+#pragma unroll
           for (int p = 0; p < 4; ++p) {
-            const int slp = (p == 0) ? s0 : (p == 1) ? s1 : (p == 2) ? s2 : s3;
-            if (slp < 0) {
-              const float2 xy = reinterpret_cast<const float2*>(locn)[e + p];
-              const Footprint f = footprint(H, W, xy.x, xy.y, attn_n[e + p]);
-              const int wc = side ? f.w1 : f.w0;
-              const v4f g0 = vl[(long long)(f.h0 * W + wc) * rowf4];
-              const v4f g1 = vl[(long long)(f.h1 * W + wc) * rowf4];
-              a = fma4v(side ? f.w01 : f.w00, g0, a);
-              a = fma4v(side ? f.w11 : f.w10, g1, a);
+            const v4f* base = wl + (__float_as_int(r[p].x) & 0x7fffffff);
+            t[p] = base[0];
+            b[p] = base[rowstride];
+          }
+          v4f a = acc[k];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float xw = fmaf(xw_c1, r[p].w, xw_c0);
+            a = fma4v(r[p].y * xw, t[p], a);
+            a = fma4v(r[p].z * xw, b[p], a);
+          }
+          const int s0 = __float_as_int(r[0].x), s1 = __float_as_int(r[1].x), s2 = __float_as_int(r[2].x),
+                    s3 = __float_as_int(r[3].x);
+          if ((s0 | s1 | s2 | s3) < 0 && !(tg.ablate & 8)) {
+            // rare: footprint(s) outside the staged window -> those samples come from global memory,
+            // one sample at a time (this lane's corner column: 2 clamped, always-valid loads).  Kept
+            // narrow on purpose: this path must not raise the register pressure of the common path.
+            const long long e = ((long long)qg[qi] * M * L + l) * P;
+#pragma unroll 1
+            for (int p = 0; p < 4; ++p) {
+              const int slp = (p == 0) ? s0 : (p == 1) ? s1 : (p == 2) ? s2 : s3;
+              if (slp < 0) {
+                const float2 xy = reinterpret_cast<const float2*>(loc + cur.nm * (L * P * 2))[e + p];
+                const Footprint f = footprint(H, W, xy.x, xy.y, (attn + cur.nm * (L * P))[e + p]);
+                const int wc = side ? f.w1 : f.w0;
+                const v4f g0 = vl[(long long)(f.h0 * W + wc) * rowf4];
+                const v4f g1 = vl[(long long)(f.h1 * W + wc) * rowf4];
+                a = fma4v(side ? f.w01 : f.w00, g0, a);
+                a = fma4v(side ? f.w11 : f.w10, g1, a);
+              }
             }
           }
+          acc[k] = a;
         }
-        acc[k] = a;
       }
+      geo_cur = geo_nxt;
+      if (itn == 1) TSTAMP(5 + 3 * l);
     }
-    cur = nxt;
-    TSTAMP(5 + 3 * l);
-  }
 
-  // ---- add the two corner columns (lane <-> partner lane with pos ^ 8) and store: the left lane
-  // finishes channels {0,1} of its chunk, the right lane channels {2,3} (two exchanges per query)
-  const int ppos = pos ^ 8;
-  const int phl = g ? (ppos < 8 ? ppos + 4 : ppos < 12 ? ppos + 8 : ppos + 16)
-                    : (ppos < 4 ? ppos : ppos < 8 ? ppos + 8 : ppos + 12);
-  const int partner = (lane & 32) | phl;
+    // ---- add the two corner columns (lane <-> partner lane, pos ^ 8) and store: of each pair of
+    // queries (k, k+1) the left lane finishes k and the right lane k+1 -> every lane stores 16 B
+    if (!(tg.ablate & 16))
 #pragma unroll
-  for (int k = 0; k < TL_QMAX; ++k) {
-    const int qi = grp + k * TL_GROUPS;
-    const float r0 = __shfl(side ? acc[k].x : acc[k].z, partner, 64);
-    const float r1 = __shfl(side ? acc[k].y : acc[k].w, partner, 64);
-    const float2 o = side ? make_float2(acc[k].z + r0, acc[k].w + r1) : make_float2(acc[k].x + r0, acc[k].y + r1);
-    if (qi < total)
-      reinterpret_cast<float2*>(out + (((long long)n * S + qglob[qi]) * M + m) * D)[chunk * 2 + side] = o;
+    for (int k = 0; k < TL_QMAX; k += 2) {
+      const v4f snd = side ? acc[k] : acc[k + 1], own = side ? acc[k + 1] : acc[k];
+      v4f o;
+      o.x = own.x + __shfl(snd.x, partner, 64);
+      o.y = own.y + __shfl(snd.y, partner, 64);
+      o.z = own.z + __shfl(snd.z, partner, 64);
+      o.w = own.w + __shfl(snd.w, partner, 64);
+      const int qi = grp + (k + side) * TL_GROUPS;
+      if (qi < cur.total)
+        *reinterpret_cast<v4f*>(reinterpret_cast<char*>(out + cur.nm * D) +
+                                ((unsigned)(qg[qi] * M * D) * 4u + (unsigned)chunk * 16u)) = o;
+    }
+    if (itn == 1) TSTAMP(15);
+    if (!has_next) break;
+    cur = nxt_item;
+    par ^= 1;
   }
-  TSTAMP(15);
+  TSTAMP(14);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -429,12 +503,12 @@ static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, i
 }
 
 template <int L>
-static void launch_tiled(unsigned nblocks, size_t lds, hipStream_t st, const float* value,
-                         const LevelTable& lv, const TileGeom& tg, const int4* geo, const float* loc,
-                         const float* attn, int N, int S, int M, float* out) {
+static void launch_tiled(unsigned grid, unsigned nblocks, size_t lds, hipStream_t st, const float* value,
+                         const LevelTable& lv, const TileGeom& tg, const int4* geo,
+                         const float* loc, const float* attn, int N, int S, int M, float* out) {
   auto k = msda_fwd_tiled<L>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(nblocks), dim3(TL_THREADS), lds, st, value, lv, tg, geo, loc, attn, N, S, M, out, nblocks);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(TL_THREADS), lds, st, value, lv, tg, geo, loc, attn, N, S, M, out, nblocks);
 }
 
 // returns 1 if launched, 0 if preconditions do not hold, <0 on error
@@ -442,6 +516,8 @@ int msda_forward_tiled_f32(const float* value, const LevelTable& lv, const float
                            const float* attn, int N, int S, int M, int D, int L, int Lq, int P,
                            float* out, hipStream_t st) {
   if (D != 32 || P != 4 || L < 1 || L > 4 || Lq != S || M < 1) return 0;
+  // per-frame byte offsets are kept in 32 bits on the device
+  if ((long long)S * M * D * 4 >= (1LL << 31) || (long long)S * M * L * P * 8 >= (1LL << 31)) return 0;
   // levels must tile [0, S) exactly, in order (the encoder's flatten+concat layout)
   long long expect = 0;
   int fine = 0;
@@ -455,7 +531,7 @@ int msda_forward_tiled_f32(const float* value, const LevelTable& lv, const float
   const int TH = env_int("UNIVS_MSDA_TILE_H", 16), TW = env_int("UNIVS_MSDA_TILE_W", 16);
   const int R = env_int("UNIVS_MSDA_HALO", 6);
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
-  const size_t fixed = (size_t)TL_NSMP * 16 + (size_t)TL_QCAP * 4;
+  const size_t fixed = (size_t)TL_NSMP * 16 + (size_t)TL_QCAP * 4 * 2;
   const long long cap_px = std::min<long long>((160 * 1024 - (long long)fixed) / 128, TL_WR * TL_OCTETS);
   const GeoEntry* ge = geometry(lv, L, fine, TH, TW, R, cap_px);
   if (!ge) return 0;
@@ -470,11 +546,23 @@ int msda_forward_tiled_f32(const float* value, const LevelTable& lv, const float
   const long long nb = (long long)N * M * tg.tiles_y * tg.tiles_x;
   if (nb <= 0 || nb > 0x7fffffffLL) return 0;
   const unsigned nblocks = (unsigned)nb;
+  // persistent grid: one workgroup per CU (LDS allows no more), each walking ~nb / CUs items
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n_cu = v;
+  }
+  const int gwant = env_int("UNIVS_MSDA_GRID", n_cu);
+  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(gwant, 1));
   switch (L) {
-    case 1: launch_tiled<1>(nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
-    case 2: launch_tiled<2>(nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
-    case 3: launch_tiled<3>(nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
-    default: launch_tiled<4>(nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
+    case 1: launch_tiled<1>(grid, nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
+    case 2: launch_tiled<2>(grid, nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
+    case 3: launch_tiled<3>(grid, nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
+    default: launch_tiled<4>(grid, nblocks, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
   }
   int rc = check_launch("msda_fwd_tiled");
   return rc == UNIVS_OK ? 1 : rc;
