@@ -10,6 +10,7 @@ the reference's OUTPUTS; tests rebuild the inputs from the same names.
 import json
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -291,6 +292,75 @@ def g9b_swin_b():
     synth.load_synthetic(m, prefix="backbone.")
     out = m(cases.swin_input(cases.SWINB_CASE))
     save("g9b_swin_b", **{k: v[:, ::2] for k, v in out.items()})   # every 2nd channel keeps the fixture small
+
+
+# ---------------------------------------------------------------------------------------------------
+# G11: the clip loop (SURVEY.md section 8c "clip loop counterpart"): the REFERENCE's
+# InferenceVideoEntity.inference_video on a 7-frame synthetic video, `targets[0]` dumped at the entry of
+# every head call (= the state the previous clip left behind) and at the end.
+# ---------------------------------------------------------------------------------------------------
+LOOP_STATE_KEYS = ("logits", "masks", "mask_logits", "boxes", "embds", "ids", "first_appear_frame_idxs",
+                   "mask_quality_scores", "occurrence", "prompt_pe", "prompt_feats", "prompt_attn_masks",
+                   "frame_indices")
+
+
+def _ref_loop(case, model, **over):
+    RI = rh.ref_inference()
+    kw = cases.loop_kwargs(case, **over)
+    kw.update(overlap_threshold=0.0, metadata=None, LSJ_aug_image_size=1024, LSJ_aug_enable_test=False,
+              sem_seg_postprocess_before_inference=False, num_classes=133, data_name="ytvis_2021_dev",
+              prompt_as_queries=True, zero_shot_inference=False, semantic_on=False, instance_on=True,
+              panoptic_on=False, tracker_type="", window_inference=False, is_multi_cls=True, merge_on_cpu=False,
+              num_max_inst_test=50, output_dir="/tmp")
+    inf = RI.InferenceVideoEntity(**kw)
+    inf.save_results_vis = lambda *a, **k: []                  # result formats are out of scope (needs pycocotools)
+    RI.module.vis_clip_instances_to_coco_json_video = lambda bi, res, **k: res
+    dumps = {}
+    head = model.sem_seg_head
+    calls = []
+
+    def snapshot(tag, tv):
+        for k in LOOP_STATE_KEYS:
+            if k in tv:
+                dumps[f"{tag}_{k}"] = tv[k].detach().clone().float() if tv[k].dtype == torch.bool else tv[k].detach().clone()
+
+    def hooked(features, targets=None, **k):
+        snapshot(f"clip{len(calls)}_in", targets[0])
+        calls.append(int(targets[0]["first_frame_idx"]))
+        return head(features, targets=targets, **k)
+    model = types.SimpleNamespace(backbone=model.backbone, sem_seg_head=hooked)
+    x = cases.preprocess(cases.loop_frames(case))
+    images = types.SimpleNamespace(tensor=x, image_sizes=[case["image_size"]] * case["n_frames"])
+    targets = cases.loop_targets(case)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):            # the reference prints shapes per new entity (:843)
+        torch.manual_seed(1)
+        inf.inference_video(model, cases.loop_batched_inputs(case), images, targets)
+    snapshot("final", targets[0])
+    dumps["clip_first_frames"] = torch.tensor(calls)
+    return dumps
+
+
+@gen
+def g11a_clip_loop_model():
+    """real backbone + head (synthetic weights): windowed backbone, stride rule, memory pool across 3 clips"""
+    R = rh.ref()
+    case = cases.LOOP_CASE
+    model = types.SimpleNamespace(backbone=_ref_swin(R), sem_seg_head=_ref_head(R, case))
+    d = _ref_loop(case, model, stability_score_thresh=0.0)
+    print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist())
+    save("g11a_clip_loop_model", **d)
+
+
+@gen
+def g11b_clip_loop_scripted():
+    """scripted scene (tests/cases.py ScriptedHead): several entities, NMS, a newcomer, a leaver"""
+    case = cases.SCRIPT_CASE
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(), sem_seg_head=cases.ScriptedHead())
+    d = _ref_loop(case, model)
+    print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist(),
+          "first seen", d["final_first_appear_frame_idxs"].tolist())
+    save("g11b_clip_loop_scripted", **d)
 
 
 def main():

@@ -229,3 +229,127 @@ SWIN_B = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=128, de
               num_heads=[4, 8, 16, 32], window_size=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
               ape=False, patch_norm=True)
 SWINB_CASE = dict(name="swin_b", N=1, H=96, W=160)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Clip loop (univs_amd/inference/video_entity.py  <->  univs/inference/inference_video_entity.py)
+# ---------------------------------------------------------------------------------------------------
+# (a) the real backbone + head on a 7-frame synthetic video: 3 clips of 3 frames, stride 2, window 5
+LOOP_CASE = dict(name="loop", T=3, H=64, W=96, Q=20, shapes=SWINT_SHAPES, n_frames=7, image_size=(60, 90))
+
+
+def loop_frames(case=LOOP_CASE):
+    h, w = case["image_size"]
+    return synth.synthetic_frames(case["n_frames"], h, w, "loop/frames")
+
+
+def loop_kwargs(case=LOOP_CASE, **over):
+    """Constructor arguments shared by the reference's InferenceVideoEntity and ours (the reference takes
+    a few more, see oracle/gen_golden.py); thresholds of configs/univs_inf/vids/vis/Base.yaml."""
+    kw = dict(hidden_dim=256, num_queries=case["Q"], overlap_threshold_entity=0.5, stability_score_thresh=0.5,
+              size_divisibility=32, pixel_mean=synth.PIXEL_MEAN, pixel_std=synth.PIXEL_STD, num_frames=case["T"],
+              test_topk_per_image=100, apply_cls_thres=0.25, box_nms_thresh=0.85, num_frames_window_test=5,
+              clip_stride=2, num_prev_frames_memory=5, video_unified_inference_entities="",
+              temporal_consistency_threshold=0.25, detect_newly_object_threshold=0.1,
+              detect_newly_interval_frames=1, custom_videos_enable=False)
+    kw.update(over)
+    return kw
+
+
+def loop_targets(case=LOOP_CASE):
+    return [{"task": "detection", "dataset_name": "ytvis_2021_dev", "prompt_type": "visual", "num_frames": case["T"],
+             "video_len": case["n_frames"], "sub_task": "vis"}]
+
+
+def loop_batched_inputs(case=LOOP_CASE):
+    return [{"video_len": case["n_frames"], "height": case["image_size"][0], "width": case["image_size"][1]}]
+
+
+# (b) a scripted scene instead of the network: rectangles that move, appear, leave and duplicate each
+# other, so that every branch of the per-clip bookkeeping runs with several entities.  Used as
+# `model.sem_seg_head` by BOTH the reference loop (golden generation) and ours.
+SCRIPT_CASE = dict(name="script", T=3, H=64, W=96, Q=8, K=16, n_frames=7, image_size=(60, 90))
+# class, class logit, x0, y0, w, h, vx, vy, first frame, last frame
+SCRIPT_OBJECTS = [
+    (3, 3.0, 4, 6, 30, 24, 3, 1, 0, 6),
+    (5, 2.5, 50, 30, 28, 22, 0, 0, 0, 6),
+    (5, 2.0, 50, 30, 28, 22, 0, 0, 0, 6),     # duplicate of object 1 with a lower score (box NMS)
+    (9, 3.0, 4, 40, 24, 18, 1, 0, 3, 6),      # appears at frame 3 -> new entity on the second clip
+    (1, 2.8, 70, 2, 18, 20, 0, 1, 0, 2),      # leaves after frame 2
+    (7, -1.2, 40, 2, 20, 14, 1, 0, 0, 6),     # never confident enough
+]
+
+
+class ScriptedBackbone:
+    def __call__(self, x):
+        return {"res2": x.new_zeros((x.shape[0], 1, 1, 1))}
+
+
+class ScriptedHead:
+    """Deterministic stand-in for `sem_seg_head(features, targets=targets)`: learnable query j reports
+    object j; one prompt query per entity of the pool reports the object that entity has been following
+    (largest overlap with its stored masks)."""
+
+    def __init__(self, case=SCRIPT_CASE, objects=SCRIPT_OBJECTS):
+        self.case, self.objects = case, objects
+        C = 256
+        self.emb = [torch.nn.functional.normalize(synth.normal(f"script/emb/{j}", (C,)), dim=0) * 8.0
+                    for j in range(len(objects))]
+        self.space = 0.3 * synth.normal("script/space", (C,))
+
+    def rect(self, j, f):
+        _, _, x0, y0, w, h, vx, vy, f0, f1 = self.objects[j]
+        if f < f0 or f > f1:
+            return None
+        return x0 + vx * f, y0 + vy * f, x0 + vx * f + w, y0 + vy * f + h
+
+    def mask_logits(self, j, f, stride=4):
+        H, W = self.case["H"] // stride, self.case["W"] // stride
+        r = None if j is None else self.rect(j, f)
+        if r is None:
+            return torch.full((H, W), -6.0)
+        ys = (torch.arange(H).float() * stride + stride / 2).view(-1, 1)
+        xs = (torch.arange(W).float() * stride + stride / 2).view(1, -1)
+        d = torch.maximum(torch.maximum(r[0] - xs, xs - r[2]), torch.maximum(r[1] - ys, ys - r[3]))
+        return (-0.75 * d).clamp(-6.0, 6.0)
+
+    def followed_object(self, masks):
+        """masks [t_hist, H, W] of one entity -> index of the object it overlaps most (None if none)."""
+        best, best_j = 0.0, None
+        for j in range(len(self.objects)):
+            ov = 0.0
+            for f in range(masks.shape[0]):
+                r = self.rect(j, f)
+                if r is not None:
+                    ov += float(masks[f, max(r[1], 0):max(r[3], 0), max(r[0], 0):max(r[2], 0)].float().sum())
+            if ov > best:
+                best, best_j = ov, j
+        return best_j
+
+    def row(self, j, frames, kind):
+        K = self.case["K"]
+        visible = j is not None and any(self.rect(j, f) is not None for f in frames)
+        tag = f"script/{kind}/{j}/{frames[0]}"
+        logits = torch.full((K,), -4.0) + 0.05 * synth.uniform(tag + "/cls", (K,))
+        if visible:
+            logits[self.objects[j][0]] = self.objects[j][1]
+        masks = torch.stack([self.mask_logits(j if visible else None, f) for f in frames])
+        noise = synth.normal(tag + "/emb", (len(frames), 256))
+        if visible:
+            embds = self.emb[j][None] + 0.1 * noise + (self.space[None] if kind == "p" else 0.0)
+        else:
+            embds = 0.5 * noise
+        return logits, masks, embds
+
+    def __call__(self, features, targets=None):
+        tv = targets[0]
+        frames = [int(f) for f in tv["frame_indices"]]
+        dev = features["res2"].device
+        rows = [self.row(j if j < len(self.objects) else None, frames, "l") for j in range(self.case["Q"])]
+        if "masks" in tv:
+            for e in range(tv["masks"].shape[0]):
+                rows.append(self.row(self.followed_object(tv["masks"][e].cpu()), frames, "p"))
+        return {"pred_logits": torch.stack([r[0] for r in rows])[None].to(dev),
+                "pred_masks": torch.stack([r[1] for r in rows])[None].to(dev),
+                "pred_embds": torch.stack([r[2] for r in rows])[None].to(dev),
+                "aux_outputs": []}

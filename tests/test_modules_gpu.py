@@ -159,3 +159,18 @@ def test_config1_resnet50_plumbing_gpu(cuda):
         ref = model_c(frames.cpu(), cases.targets_first_clip(dict(cases.HEAD_CASE, T=2)))
     err = (out["pred_masks"].cpu() - ref["pred_masks"]).abs().max().item()
     assert err < 1e-3, err
+
+
+def test_clip_loop_on_device_matches_reference(cuda, golden_dir):
+    """The whole clip loop on the GPU (HIP operators, device-resident bookkeeping) against the REFERENCE's
+    per-clip `targets[0]` states on the 7-frame synthetic video (g11a)."""
+    import types
+
+    from tests.test_clip_loop_cpu import compare_states, run_loop
+    g = _g(golden_dir, "g11a_clip_loop_model")
+    case = cases.LOOP_CASE
+    model = types.SimpleNamespace(backbone=helpers.build_swin(cuda), sem_seg_head=helpers.build_head(case, cuda))
+    got, results = run_loop(case, model, device=cuda, stability_score_thresh=0.0)
+    assert ops.msda_last_impl() in (1, 2)
+    compare_states(got, g, tol=1e-3, mask_margin=1e-3)
+    assert len(results) == 1 and results[0][0]["masks"].shape[-2:] == case["image_size"]

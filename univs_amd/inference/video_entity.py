@@ -1,0 +1,459 @@
+"""Clip loop for entity segmentation in videos (VIS-style sub-tasks) around the hot path.
+
+Counterpart of the reference's `InferenceVideoEntity` (univs/inference/inference_video_entity.py):
+the same method names, argument meaning and -- above all -- the same mutations of the per-video
+`targets[0]` dictionary, which is the state the prompt-as-query decoder reads on the next clip
+(`masks`, `boxes`, `ids`, `first_appear_frame_idxs`, the `prompt_*` memory pool, ...).
+
+    eval / inference_video          :236-431   windowed backbone, stride rule, clip schedule
+    write_prompt_predictions_into_annotations_per_clip   :432-513
+    detect_newly_entities_per_clip_instance              :515-651
+    write_newly_entities_into_annotations_per_clip       :767-877
+    pad_zero_annotations_for_next_clip                   :879-912
+    save_results_vis                                     :914-960 (masks returned as bool tensors; the
+                                                          COCO-RLE json is a result *format*)
+
+Everything stays on the device of the inputs; the only host round trip per clip is the Hungarian
+solve on the [entities x queries] similarity matrix (as in the reference, scipy).  The per-query
+Python loop of the reference's new-entity test (:640-645) is one batched mask-IoU here.
+
+Sub-tasks: 'vis' and 'entity_vis_*' (instance-style).  The panoptic / semantic variants ('vps', 'vss')
+are not part of this round's scope and raise NotImplementedError.
+"""
+import math
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..registry import configurable
+from ..utils.comm import batched_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou
+from .comm import check_consistency_with_prev_frames, match_from_learnable_embds  # noqa: F401  (API parity)
+from scipy.optimize import linear_sum_assignment
+
+# (num_classes, start index) of each dataset inside the concatenated CLIP class-embedding table: the
+# layout of the reference's `clip_class_embed_path` file (data, restated from
+# datasets/concept_emb/combined_datasets_category_info.py:7-24; 3938 rows in total)
+COMBINED_DATASETS_CATEGORY_INFO = {
+    "imagenet": (1000, 0), "lvis": (1203, 1000), "burst": (1203, 1000), "ytvis21": (40, 2203), "ovis": (25, 2243),
+    "bdd_track": (8, 2268), "objects365": (365, 2276), "coco_panoptic": (133, 2641), "coco": (80, 2641),
+    "ade20k": (150, 2774), "vipseg": (124, 2924), "vspw": (124, 2924), "viposeg": (124, 2924), "ytvis19": (40, 3048),
+    "entityseg_instance": (206, 3088), "entityseg_panoptic": (644, 3294),
+}
+ENTITY_SUBTASK_DATASET = {
+    "entity_vis_entityseg": "entityseg_instance",
+    "entity_vis_coco": "coco",
+}
+
+
+class ImageList:
+    """Minimal stand-in for detectron2.structures.ImageList: `.tensor` [N, C, Hp, Wp] zero-padded to a
+    multiple of `size_divisibility`, `.image_sizes` the unpadded (H, W) per image."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor, self.image_sizes = tensor, image_sizes
+
+    @staticmethod
+    def from_tensors(tensors, size_divisibility=0):
+        sizes = [tuple(t.shape[-2:]) for t in tensors]
+        H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if size_divisibility > 1:
+            d = size_divisibility
+            H, W = (H + d - 1) // d * d, (W + d - 1) // d * d
+        out = tensors[0].new_zeros((len(tensors),) + tuple(tensors[0].shape[:-2]) + (H, W))
+        for i, t in enumerate(tensors):
+            out[i, ..., : t.shape[-2], : t.shape[-1]] = t
+        return ImageList(out, sizes)
+
+
+def _resize(masks, size):
+    return F.interpolate(masks, size, mode="bilinear", align_corners=False)
+
+
+class InferenceVideoEntity(nn.Module):
+    @configurable
+    def __init__(
+        self,
+        *,
+        hidden_dim: int,
+        num_queries: int,
+        overlap_threshold_entity: float,
+        stability_score_thresh: float,
+        size_divisibility: int,
+        pixel_mean: Tuple[float],
+        pixel_std: Tuple[float],
+        num_frames: int,
+        test_topk_per_image: int,
+        apply_cls_thres: float,
+        box_nms_thresh: float,
+        num_frames_window_test: int,
+        clip_stride: int,
+        num_prev_frames_memory: int = 5,
+        video_unified_inference_entities: str = "",
+        temporal_consistency_threshold: float = 0.5,
+        detect_newly_object_threshold: float = 0.05,
+        detect_newly_interval_frames: int = 1,
+        custom_videos_enable: bool = False,
+        dataset_category_info=None,
+    ):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.num_queries = num_queries
+        self.overlap_threshold_entity = overlap_threshold_entity
+        self.stability_score_thresh = stability_score_thresh
+        self.size_divisibility = size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        self.num_frames = num_frames
+        self.test_topk_per_image = test_topk_per_image
+        self.apply_cls_thres = apply_cls_thres
+        self.box_nms_thresh = box_nms_thresh
+        # windowing (reference __init__ :150-155)
+        self.num_frames_window_test = max(num_frames_window_test, num_frames)
+        self.num_frames_window_output = (math.ceil(self.num_frames_window_test / 5) + 1) * 5
+        self.clip_stride = clip_stride
+        self.use_quasi_track = True
+        self.temporal_consistency_threshold = temporal_consistency_threshold
+        self.detect_newly_object_threshold = detect_newly_object_threshold
+        self.detect_newly_interval_frames = detect_newly_interval_frames
+        self.num_prev_frames_memory = num_prev_frames_memory
+        self.custom_videos_enable = custom_videos_enable
+        self.video_unified_inference_entities = video_unified_inference_entities
+        # {dataset name: (num_classes, start index)} slices of the class-embedding table; None = no slicing
+        self.dataset_category_info = COMBINED_DATASETS_CATEGORY_INFO if dataset_category_info is None else dataset_category_info
+
+    @classmethod
+    def from_config(cls, cfg, dataset_category_info=None):
+        test = cfg.MODEL.UniVS.TEST
+        return {
+            "hidden_dim": cfg.MODEL.MASK_FORMER.HIDDEN_DIM,
+            "num_queries": cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+            "overlap_threshold_entity": cfg.MODEL.MASK_FORMER.TEST.OVERLAP_THRESHOLD_ENTITY,
+            "stability_score_thresh": cfg.MODEL.MASK_FORMER.TEST.STABILITY_SCORE_THRESH,
+            "size_divisibility": cfg.MODEL.MASK_FORMER.SIZE_DIVISIBILITY,
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN,
+            "pixel_std": cfg.MODEL.PIXEL_STD,
+            "num_frames": cfg.INPUT.SAMPLING_FRAME_NUM,
+            "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
+            "apply_cls_thres": cfg.MODEL.BoxVIS.TEST.APPLY_CLS_THRES,
+            "box_nms_thresh": test.BOX_NMS_THRESH,
+            "num_frames_window_test": cfg.MODEL.BoxVIS.TEST.NUM_FRAMES_WINDOW,
+            "clip_stride": cfg.MODEL.BoxVIS.TEST.CLIP_STRIDE,
+            "num_prev_frames_memory": test.NUM_PREV_FRAMES_MEMORY,
+            "video_unified_inference_entities": test.VIDEO_UNIFIED_INFERENCE_ENTITIES,
+            "temporal_consistency_threshold": test.TEMPORAL_CONSISTENCY_THRESHOLD,
+            "detect_newly_object_threshold": test.DETECT_NEWLY_OBJECT_THRESHOLD,
+            "detect_newly_interval_frames": test.DETECT_NEWLY_INTERVAL_FRAMES,
+            "custom_videos_enable": test.CUSTOM_VIDEOS_ENABLE,
+            "dataset_category_info": dataset_category_info,
+        }
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------------------------------------
+    # entry points
+    # ------------------------------------------------------------------------------------------
+    def eval(self, model, batched_inputs, targets):
+        """batched_inputs: [{"image": [frame tensors CHW, 0..255], "video_len", "height", "width"}];
+        targets: the per-video dict list the reference's `PrepareTargets.process_inference` produces
+        (task / dataset_name / prompt_type / num_frames / video_len)."""
+        frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
+        images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        if self.video_unified_inference_entities:
+            targets[0]["sub_task"] = self.video_unified_inference_entities
+        else:
+            name = targets[0]["dataset_name"]
+            if name.startswith("ytvis") or name.startswith("ovis"):
+                targets[0]["sub_task"] = "vis"
+            elif name.startswith("vipseg"):
+                targets[0]["sub_task"] = "vps"
+            elif name.startswith("vspw"):
+                targets[0]["sub_task"] = "vss"
+            else:
+                raise ValueError(f"Not support to eval the dataset {name} yet")
+        return self.inference_video(model, batched_inputs, images, targets)
+
+    def _class_slice(self, sub_task, dataset_name):
+        if sub_task.startswith("entity"):
+            if sub_task not in ENTITY_SUBTASK_DATASET:
+                raise ValueError(sub_task)
+            dataset_name = ENTITY_SUBTASK_DATASET[sub_task]
+            return self.dataset_category_info[dataset_name]
+        return self.dataset_category_info.get(dataset_name)
+
+    def inference_video(self, model, batched_inputs, images, targets):
+        x = images.tensor
+        tv = targets[0]
+        sub_task = tv["sub_task"]
+        if "vis" not in sub_task:
+            raise NotImplementedError(f"sub_task {sub_task!r}: only the instance-style ('vis') clip loop is built")
+        n_total = len(x)
+        video_len = int(batched_inputs[0]["video_len"])
+        interim_size = tuple(x.shape[-2:])
+        image_size = tuple(images.image_sizes[0])
+        out_size = (batched_inputs[0].get("height", image_size[0]), batched_inputs[0].get("width", image_size[1]))
+        T = self.num_frames
+        stride = min(self.clip_stride, T)
+
+        results = []
+        is_last = False
+        win_start = win_end = 0
+        feats_window = None
+        for i in range(0, n_total, stride):
+            if is_last and i + T > n_total:
+                break
+            is_last = i + T >= n_total
+            tv["first_frame_idx"] = i
+            tv["frame_indices"] = torch.arange(i, min(i + T, n_total))
+
+            if i + T > win_end:      # the backbone runs once per window of frames
+                win_start, win_end = i, i + self.num_frames_window_test
+                feats_window = model.backbone(x[win_start:win_end])
+            o = i - win_start
+            feats = {k: v[o:o + T] for k, v in feats_window.items()}
+            out = model.sem_seg_head(feats, targets=targets)
+            out.pop("aux_outputs", None)
+
+            out["pred_logits"] = out["pred_logits"].sigmoid()
+            sl = self._class_slice(sub_task, tv["dataset_name"])
+            if sl is not None:
+                n_cls, start = sl
+                assert start + n_cls <= out["pred_logits"].shape[-1]
+                out["pred_logits"] = out["pred_logits"][..., start:start + n_cls]
+
+            out = {k: v[0] for k, v in out.items() if v is not None}       # batch of one video
+            out = {k: v for k, v in out.items() if v is not None}          # e.g. pred_reid_logits = [None]
+            out_learn = {k: v[: self.num_queries] for k, v in out.items()}
+            out_prompt = {k: v[self.num_queries:] for k, v in out.items()}
+
+            # 1. entities already in the pool: accumulate this clip's predictions of their prompt queries
+            self.write_prompt_predictions_into_annotations_per_clip(i, out_prompt, targets, interim_size, image_size, stride)
+            # 2. new entities from the learnable queries
+            if i % self.detect_newly_interval_frames == 0 or tv["masks"].nelement() == 0:
+                self.detect_newly_entities_per_clip_instance(out_learn, targets, interim_size)
+                self.write_newly_entities_into_annotations_per_clip(i, out_learn, targets, interim_size)
+            # 3. emit finished frames
+            is_out = i > self.num_prev_frames_memory and i % self.num_frames_window_output == self.num_prev_frames_memory
+            if is_out or is_last:
+                results.append(self.save_results_vis(i, targets, interim_size, image_size, out_size, is_last))
+                w = self.num_frames_window_output
+                tv["mask_logits"] = tv["mask_logits"][:, w:]
+                tv["masks"] = tv["masks"][:, w:]
+                tv["occurrence"] = tv["occurrence"][:, w:]
+            # 4. room for the next clip's new frames
+            if not is_last and "masks" in tv:
+                self.pad_zero_annotations_for_next_clip(targets, min(stride, video_len - i - T))
+        return results
+
+    # ------------------------------------------------------------------------------------------
+    # step 1: prompt-specified entities
+    # ------------------------------------------------------------------------------------------
+    def write_prompt_predictions_into_annotations_per_clip(self, first_frame_idx, out, targets, interim_size, image_size, stride):
+        if out["pred_masks"].nelement() == 0:
+            return                                            # no prompt queries on this clip
+        tv = targets[0]
+        pred_embds = out["pred_embds"]                        # [N, T, C]
+        pred_masks = _resize(out["pred_masks"], interim_size)  # [N, T, H, W] logits
+        T = pred_masks.shape[1]
+
+        thr = self.temporal_consistency_threshold * (0.5 if first_frame_idx < self.num_frames else 1.0)
+        n_prev = max(int(self.num_prev_frames_memory / stride), 3)
+        keep, sim = check_consistency_with_prev_frames(tv["embds"][:, -n_prev:], pred_embds, sim_threshold=thr,
+                                                       return_similarity=True)
+
+        cur = pred_masks[:, :, : image_size[0], : image_size[1]]
+        quality = calculate_mask_quality_scores(cur)
+        if "vis" in tv["sub_task"]:
+            # every pixel goes to the entity with the highest score x probability; an entity survives
+            # if it keeps enough of its own area
+            score = tv["logits"].mean(1).max(-1)[0] * sim * quality
+            prob = cur.sigmoid().flatten(1)                   # [N, T*h*w]
+            fg = prob > 0.5
+            owner = (score.view(-1, 1) * prob).argmax(0)
+            owner = torch.where((prob < 0.5).all(0), torch.full_like(owner, -1), owner)   # background pixels
+            own = owner[None] == torch.arange(len(prob), device=prob.device).view(-1, 1)
+            ratio = own.sum(1) / fg.sum(1).clamp(min=1)
+            keep = keep & (ratio > self.overlap_threshold_entity) & ((own & fg).sum(1) > 0)
+
+        if keep.any():
+            idx = keep.nonzero(as_tuple=True)[0]
+            m = pred_masks[idx]
+            norm = torch.as_tensor([interim_size[1], interim_size[0], interim_size[1], interim_size[0]], device=m.device)
+            tv["occurrence"][idx, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
+            tv["mask_logits"][idx, -T:] += m
+            tv["boxes"][idx, -T:] = convert_mask_to_box(tv["mask_logits"][idx, -T:] > 0) / norm.view(1, 1, -1)
+            last = tv["embds"][idx, -1]
+            nonblank = (last != 0).any(-1)
+            tv["embds"][idx, -1] = (last + pred_embds[idx].mean(1)) / (nonblank[..., None] + 1.0)
+            tv["mask_quality_scores"][idx] += quality[idx]
+        tv["masks"] = tv["mask_logits"].gt(0.0).float()
+
+    # ------------------------------------------------------------------------------------------
+    # step 2: new entities
+    # ------------------------------------------------------------------------------------------
+    def detect_newly_entities_per_clip_instance(self, out_learn, targets, interim_size):
+        tv = targets[0]
+        logits = out_learn["pred_logits"].float()     # [Q, K] probabilities
+        masks = out_learn["pred_masks"].float()       # [Q, T, h, w]
+        embds = out_learn["pred_embds"].float()       # [Q, T, C]
+        T = masks.shape[1]
+        first = "masks" not in tv
+
+        quality = calculate_mask_quality_scores(masks)
+        logits = logits * quality.view(-1, 1)
+        if self.stability_score_thresh > 0.0:
+            k = quality > self.stability_score_thresh
+            logits, masks, embds, quality = logits[k], masks[k], embds[k], quality[k]
+
+        scores = logits.max(-1)[0]
+        top = scores.sort(descending=True)[1][: self.test_topk_per_image]
+        logits, masks, embds, quality, scores = logits[top], masks[top], embds[top], quality[top], scores[top]
+
+        h, w = masks.shape[-2:]
+        boxes = convert_mask_to_box(masks > 0) / torch.as_tensor([w, h, w, h], device=masks.device)
+        if masks.shape[0] > 1:
+            # box-IoU NMS over the clip: drop a query whose boxes overlap a better one's in any frame
+            order = scores.sort(descending=True)[1]
+            biou = video_box_iou(boxes[order], boxes[order])[0].max(-1)[0]
+            worst = torch.triu(biou, diagonal=1).max(0)[0]
+            k = order[worst < self.box_nms_thresh]
+            logits, masks, embds, boxes, quality = logits[k], masks[k], embds[k], boxes[k], quality[k]
+
+        if first:
+            new = logits.max(-1)[0] > max(self.apply_cls_thres, 0.1)
+        else:
+            gt_embds = tv["embds"]
+            tgt = gt_embds[:, -3:]
+            if self.use_quasi_track:
+                sim = torch.einsum("ntc,mfc->nmtf", tgt, embds).flatten(2)
+                sim = (sim.softmax(1) + sim.softmax(0)).mean(-1) / 2.0
+                sim = torch.where(sim < self.detect_newly_object_threshold, torch.zeros_like(sim), sim)
+                rows, cols = linear_sum_assignment((1 - sim).cpu())
+            else:
+                (rows, cols), _ = match_from_learnable_embds(tgt, embds, return_similarity=True, return_src_indices=True,
+                                                             use_norm=True, thresh=self.detect_newly_object_threshold)
+            rows = torch.as_tensor(rows, device=sim.device)
+            cols = torch.as_tensor(cols, device=sim.device)
+            msim = sim[rows, cols]
+
+            ok = msim > self.detect_newly_object_threshold
+            r, c = rows[ok], cols[ok]
+            # the stored class scores / embeddings follow the learnable queries (prompt and learnable
+            # queries live in slightly different feature spaces)
+            tv["logits"][r, -1] = 0.5 * (tv["logits"][r, -1] + logits[c])
+            last = gt_embds[r, -1]
+            gt_embds[r, -1] = (last + embds[c].mean(1)) / ((last != 0).any(-1)[..., None] + 1.0)
+
+            ok2 = msim > 2 * self.detect_newly_object_threshold
+            r2, c2 = rows[ok2], cols[ok2]
+            m = _resize(masks[c2], interim_size)
+            tv["occurrence"][r2, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
+            tv["mask_logits"][r2, -T:] += m
+            tv["mask_quality_scores"][r2] += quality[c2]
+            tv["masks"] = tv["mask_logits"].gt(0.0).float()
+
+            # a query is a NEW entity if it is unmatched, confident, and overlaps no known entity
+            # (mask IoU < 0.5 in every frame of the clip)
+            known = _resize(tv["mask_logits"][:, -T:], masks.shape[-2:]).transpose(0, 1).gt(0.0)   # [T, N, h, w]
+            cand = torch.ones(len(masks), dtype=torch.bool, device=masks.device)
+            cand[c2] = False     # (the reference excludes the strongly matched queries here, :640-642)
+            cand &= logits.max(-1)[0] > self.apply_cls_thres
+            if known.shape[1] > 0 and len(masks) > 0:
+                miou = batched_mask_iou(masks.transpose(0, 1).gt(0.0), known)      # [T, Q, N]
+                cand &= miou.amax(dim=(0, 2)) < 0.5
+            else:
+                cand &= False          # reference: an empty IoU matrix never qualifies (:644)
+            new = cand
+
+        for k_, v in (("pred_logits", logits), ("pred_masks", masks), ("pred_embds", embds), ("pred_boxes", boxes),
+                      ("mask_quality_scores", quality)):
+            out_learn[k_] = v[new]
+
+    def write_newly_entities_into_annotations_per_clip(self, first_frame_idx, out, targets, interim_size):
+        tv = targets[0]
+        dev = out["pred_masks"].device
+        logits = out["pred_logits"].unsqueeze(1)                       # [n, 1, K]
+        embds = out["pred_embds"].mean(dim=1, keepdim=True)            # [n, 1, C]
+        boxes = out["pred_boxes"]                                      # [n, T, 4]
+        quality = out["mask_quality_scores"]
+        n, T = out["pred_masks"].shape[:2]
+        masks = _resize(out["pred_masks"], interim_size) if n else torch.zeros((0, self.num_frames) + tuple(interim_size), device=dev)
+        occ = torch.ones(masks.shape[:2], device=dev)
+        first_idx = torch.full((n,), first_frame_idx, dtype=torch.long, device=dev)
+
+        if "masks" not in tv:
+            tv.update({"logits": logits, "masks": masks.gt(0.0), "mask_logits": masks, "boxes": boxes, "embds": embds,
+                       "ids": torch.arange(n, device=dev), "first_appear_frame_idxs": first_idx,
+                       "mask_quality_scores": quality, "occurrence": occ})
+            return
+        if n == 0:
+            return
+
+        def left_pad(new, old):          # zero history in front so that the new rows line up with `old` in time
+            shape = list(old.shape)
+            shape[0], shape[1] = n, old.shape[1] - new.shape[1]
+            return torch.cat([new.new_zeros(shape), new], dim=1)
+
+        n_old = len(tv["ids"])
+        new_logits = left_pad(logits, tv["logits"])
+        new_masks = left_pad(masks, tv["mask_logits"])
+        tv.update({
+            "logits": torch.cat([tv["logits"], new_logits]),
+            "masks": torch.cat([tv["masks"], new_masks.gt(0.0)]),
+            "mask_logits": torch.cat([tv["mask_logits"], new_masks]),
+            "boxes": torch.cat([tv["boxes"], left_pad(boxes.float(), tv["boxes"])]),
+            "embds": torch.cat([tv["embds"], left_pad(embds, tv["embds"])]),
+            "ids": torch.cat([tv["ids"], torch.arange(n, device=dev) + n_old]),
+            "occurrence": torch.cat([tv["occurrence"], left_pad(occ, tv["occurrence"])]),
+            "first_appear_frame_idxs": torch.cat([tv["first_appear_frame_idxs"], first_idx]),
+            "mask_quality_scores": torch.cat([tv["mask_quality_scores"], quality]),
+        })
+        if "prompt_pe" in tv:
+            # the memory pool is indexed by entity: empty rows for the newcomers
+            pe, pf, pm = tv["prompt_pe"], tv["prompt_feats"], tv["prompt_attn_masks"]
+            tv["prompt_pe"] = torch.cat([pe, pe.new_zeros((n,) + tuple(pe.shape[1:]))])
+            tv["prompt_feats"] = torch.cat([pf, pf.new_zeros((n,) + tuple(pf.shape[1:]))])
+            tv["prompt_attn_masks"] = torch.cat(
+                [pm, torch.zeros(pm.shape[0], pm.shape[1], n, pm.shape[-1], dtype=torch.bool, device=pm.device)], dim=-2)
+
+    # ------------------------------------------------------------------------------------------
+    # step 4 / 3
+    # ------------------------------------------------------------------------------------------
+    def pad_zero_annotations_for_next_clip(self, targets, stride):
+        tv = targets[0]
+        n = tv["embds"].shape[0]
+        dev = tv["embds"].device
+        H, W = tv["masks"].shape[-2:]
+        zero_masks = torch.zeros((n, stride, H, W), dtype=torch.float, device=dev)
+        tv.update({
+            "logits": torch.cat([tv["logits"], tv["logits"][:, -1:].clone()], dim=1),
+            "masks": torch.cat([tv["masks"], zero_masks], dim=1),
+            "mask_logits": torch.cat([tv["mask_logits"], zero_masks], dim=1),
+            "boxes": torch.cat([tv["boxes"], torch.zeros((n, stride, 4), device=dev)], dim=1),
+            "embds": torch.cat([tv["embds"], tv["embds"][:, -3:].mean(dim=1, keepdim=True)], dim=1),
+            "occurrence": torch.cat([tv["occurrence"], torch.zeros((n, stride), device=dev)], dim=1),
+        })
+
+    def save_results_vis(self, first_frame_idx, targets, interim_size, image_size, out_size, is_last):
+        tv = targets[0]
+        if "masks" not in tv:
+            return []
+        frame_id_start = min(first_frame_idx + self.num_frames, tv["video_len"]) - tv["mask_logits"].shape[1]
+        masks, occ = tv["mask_logits"], tv["occurrence"]
+        if not is_last:
+            masks, occ = masks[:, : self.num_frames_window_output], occ[:, : self.num_frames_window_output]
+        masks = masks / occ[..., None, None].clamp(min=1)
+        masks = masks[:, :, : image_size[0], : image_size[1]]
+        masks = (_resize(masks.float(), out_size) > 0.0).cpu() if masks.numel() else masks.new_zeros(masks.shape[:2] + tuple(out_size)).bool().cpu()
+        scores = tv["logits"].mean(1).cpu()
+        quality = tv["mask_quality_scores"]
+        res = []
+        for i, obj_id in enumerate(tv["ids"].tolist()):
+            r = {"obj_id": int(obj_id), "score": scores[i], "masks": masks[i], "frame_id_start": frame_id_start}
+            if is_last:
+                r["mask_quality_score"] = quality[i] / (int(quality.max()) + 1)
+            res.append(r)
+        return res

@@ -1,0 +1,63 @@
+"""Mask / box helpers of the clip loop (device-resident, no host syncs).
+
+Counterparts of the reference's `univs/utils/comm.py` (same names, argument meaning and return
+conventions) used by `univs_amd.inference.video_entity`:
+  convert_mask_to_box            univs/utils/comm.py:41-86   XYXY of the set pixels, [0,0,0,0] if empty
+  calculate_mask_quality_scores  univs/utils/comm.py:88-91   SAM-style stability of a logit mask
+  video_box_iou                  univs/utils/comm.py:141-163
+  batched_mask_iou               univs/utils/comm.py:199-214
+The IoUs of binary masks are computed as matrix products of the flattened masks (inter = A B^T,
+union = |A| + |B| - inter) instead of materialising the [B, N, M, HW] pairwise sums.
+"""
+import torch
+
+
+def convert_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
+    """masks: bool [..., H, W] -> integer XYXY boxes [..., 4] (inclusive pixel indices), zeros for an
+    empty mask."""
+    if masks.numel() == 0:
+        return torch.zeros(*masks.shape[:-2], 4, device=masks.device)
+    H, W = masks.shape[-2:]
+    m = masks.bool()
+    rows = m.any(-1)           # [..., H]
+    cols = m.any(-2)           # [..., W]
+    ar_h = torch.arange(H, device=m.device)
+    ar_w = torch.arange(W, device=m.device)
+    # first / last set index along each axis; sentinels keep empty masks detectable
+    top = torch.where(rows, ar_h, H).amin(-1)
+    bottom = torch.where(rows, ar_h, -1).amax(-1)
+    left = torch.where(cols, ar_w, W).amin(-1)
+    right = torch.where(cols, ar_w, -1).amax(-1)
+    box = torch.stack([left, top, right, bottom], dim=-1)
+    return box * (bottom >= top).unsqueeze(-1)
+
+
+def calculate_mask_quality_scores(mask_pred: torch.Tensor, threshold: float = 1.0) -> torch.Tensor:
+    """|{logit > thr}| / max(|{logit > -thr}|, 1) per leading entry (mask_pred: [N, ...] logits)."""
+    hi = (mask_pred > threshold).flatten(1).sum(-1)
+    lo = (mask_pred > -threshold).flatten(1).sum(-1).clamp(min=1)
+    return hi / lo
+
+
+def box_area(boxes: torch.Tensor) -> torch.Tensor:
+    return (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
+
+
+def video_box_iou(boxes1: torch.Tensor, boxes2: torch.Tensor):
+    """boxes1 [N, T, 4], boxes2 [M, T, 4] (XYXY) -> (iou, inter, union), each [N, M, T]."""
+    a1, a2 = box_area(boxes1), box_area(boxes2)
+    lt = torch.maximum(boxes1[:, None, :, :2], boxes2[None, :, :, :2])
+    rb = torch.minimum(boxes1[:, None, :, 2:], boxes2[None, :, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = (a1[:, None] + a2[None] - inter).clamp(min=1e-3)
+    return inter / union, inter, union
+
+
+def batched_mask_iou(masks1: torch.Tensor, masks2: torch.Tensor) -> torch.Tensor:
+    """masks1 [B, N, H, W], masks2 [B, M, H, W] (binary) -> IoU [B, N, M]; union clamped to >= 1."""
+    a = masks1.flatten(-2).float()
+    b = masks2.flatten(-2).float()
+    inter = torch.bmm(a, b.transpose(1, 2))
+    union = (a.sum(-1)[:, :, None] + b.sum(-1)[:, None, :] - inter).clamp(min=1)
+    return inter / union
