@@ -127,6 +127,18 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
                                int B_, int nW, int Ntok, int nH, int hd, float scale, float* out,
                                void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear resampling of image planes, align_corners = false (PyTorch semantics).
+ * Replaces: F.interpolate(x, size=(Hout, Wout), mode="bilinear", align_corners=False) on the path of the
+ *           attention-mask heads (univs/modeling/transformer_decoder/
+ *           video_mask2former_transformer_decoder_univs.py:555-558; this build resamples the mask
+ *           features once per level instead of the mask logits of every layer).
+ *   in   [planes, Hin, Win]    (planes = T * C, contiguous)
+ *   out  [planes, Hout, Wout]
+ * ------------------------------------------------------------------------------------------- */
+int univs_bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win,
+                                int Hout, int Wout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

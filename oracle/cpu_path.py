@@ -10,7 +10,7 @@ on the host.  Nothing in `univs_amd/` imports this file.
   ms_deform_attn_forward : oracle/ops_ref.c (plain C, OpenMP over queries)     [cuh:242-304]
   mask_decode            : torch.einsum, the reference's own expression        [...decoder_univs.py:527-528]
   mask_decode_attn       : einsum -> sigmoid < 0.5 -> all-masked-row reset      [:527, :565, :390]
-  window_attention       : q*scale @ k^T + bias (+mask) -> softmax -> @ v       [swin.py:137-168]
+  window_attention       : q*scale @ k^T + bias (+mask) -> softmax -> @ v       [swin.py:137-168]\n  bilinear_resample      : F.interpolate(bilinear, align_corners=False)         [...decoder_univs.py:555-558]
 """
 import contextlib
 
@@ -53,6 +53,10 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
     return (attn @ v).transpose(1, 2).reshape(B_, N, nH * hd)
 
 
+def bilinear_resample(x, size):
+    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+
+
 def msda_set_impl(impl):
     return None
 
@@ -61,7 +65,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample")
 
 
 @contextlib.contextmanager

@@ -183,3 +183,17 @@ def test_window_attention_matches_oracle_and_golden(cuda, golden_dir, case):
     y = core @ w_proj.t() + b_proj
     g = np.load(os.path.join(golden_dir, "g_window_attention.npz"))
     assert (y - torch.from_numpy(g[f"{case['name']}/out"])).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("shape,size", [((3, 5, 184, 320), (92, 160)), ((2, 7, 46, 80), (23, 40)), ((2, 3, 16, 24), (64, 96)),
+                                        ((1, 4, 37, 53), (19, 31)), ((1, 2, 8, 12), (8, 12)), ((2, 2, 5, 7), (1, 1))],
+                         ids=lambda v: "x".join(map(str, v)))
+def test_bilinear_resample_matches_torch(cuda, shape, size):
+    """ops.bilinear_resample == F.interpolate(bilinear, align_corners=False): down / up / odd sizes / identity."""
+    x = synth.normal("resample/" + "x".join(map(str, shape)), shape)
+    ref = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    got = ops.bilinear_resample(x.to(cuda), size).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    with pytest.raises(RuntimeError):
+        ops.bilinear_resample(x, size)          # CPU tensors are refused (no fallback)

@@ -74,6 +74,14 @@ def main():
         t = timeit(lambda: ops.window_attention(qkv, bias, mask, nW, hd ** -0.5))
         byts = (qkv.numel() + qkv.numel() / 3) * 4.0
         res["window_attn_stage1"] = dict(ms=t * 1e3, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+    if not args.only or "resample" in args.only:
+        f = synth.normal("kb/f", (T, 256, 184, 320)).to(dev)
+        for (h, w) in ((92, 160), (46, 80), (23, 40)):
+            t = timeit(lambda: ops.bilinear_resample(f, (h, w)))
+            byts = (min(f.numel(), 4 * T * 256 * h * w) + T * 256 * h * w) * 4.0     # taps actually read + output
+            res[f"resample_{h}x{w}"] = dict(ms=t * 1e3, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+            t = timeit(lambda: torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False))
+            res[f"resample_{h}x{w}_aten"] = dict(ms=t * 1e3)
     for k, v in res.items():
         print(k, json.dumps({kk: round(vv, 4) for kk, vv in v.items()}))
 

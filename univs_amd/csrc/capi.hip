@@ -30,6 +30,7 @@ int mask_decode_f32(const float*, const float*, int, int, int, long long, float*
 int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
                          hipStream_t);
 
+int bilinear_resample_f32(const float*, float*, long long, int, int, int, int, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -183,6 +184,21 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
   }
   return window_attention_f32(qkv, bias, shift_mask, B_, nW > 0 ? nW : 1, Ntok, nH, hd, scale, out,
                               (hipStream_t)stream);
+}
+
+int univs_bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win, int Hout,
+                                int Wout, void* stream) {
+  clear_sticky_error();
+  if (planes < 0 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) {
+    set_error("univs_bilinear_resample_f32: bad dimensions planes=%lld in=%dx%d out=%dx%d", planes, Hin, Win, Hout, Wout);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (planes == 0) return UNIVS_OK;
+  if (!in || !out) {
+    set_error("univs_bilinear_resample_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return bilinear_resample_f32(in, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,88 @@
+// Bilinear plane resampling (align_corners = false), gfx950.
+//
+// Replaces the F.interpolate(mask_features, size, mode="bilinear", align_corners=False) calls that feed
+// the attention-mask heads (reference: video_mask2former_transformer_decoder_univs.py:555-558 resizes the
+// mask logits of every decoder layer; this build resamples the mask FEATURES once per level and
+// contracts at the target resolution -- bilinear resampling commutes with the channel contraction).
+// ATen's upsample_bilinear2d_out_frame runs this at ~220 GB/s on the [T*256, 184, 320] planes
+// (1.35 ms per level); it is a pure HBM-bound gather: one thread per 4 output pixels, 16 taps, one
+// 16-B store.
+//
+// Arithmetic follows ATen's kernel term by term (UpSampleBilinear2d.cu: area_pixel_compute_source_index,
+// h1p / w1p edge handling, the lambda products) so that results agree to rounding.
+#include "common.h"
+
+namespace univs {
+
+struct Tap {
+  int i0, di;      // first tap, +1 or +0 (last row / column)
+  float l0, l1;    // weights
+};
+
+__device__ __forceinline__ Tap make_tap(float scale, int dst, int in_size) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  Tap t;
+  t.i0 = (int)src;
+  t.di = (t.i0 < in_size - 1) ? 1 : 0;
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float* __restrict__ in,
+                                                                    float* __restrict__ out, int Hin, int Win,
+                                                                    int Hout, int Wout, float rh, float rw,
+                                                                    long long planes) {
+  const int wq = Wout / VEC;                                  // VEC-wide groups per output row
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Hout * wq) return;
+  const int oy = q / wq, ox = (q - oy * wq) * VEC;
+  const Tap ty = make_tap(rh, oy, Hin);
+  Tap tx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) tx[v] = make_tap(rw, ox + v, Win);
+  for (long long p = blockIdx.y; p < planes; p += gridDim.y) {
+    const float* r0 = in + (p * Hin + ty.i0) * (long long)Win;
+    const float* r1 = r0 + (long long)ty.di * Win;
+    float a[VEC], b[VEC], c[VEC], d[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      a[v] = r0[tx[v].i0];
+      b[v] = r0[tx[v].i0 + tx[v].di];
+      c[v] = r1[tx[v].i0];
+      d[v] = r1[tx[v].i0 + tx[v].di];
+    }
+    float o[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      o[v] = ty.l0 * (tx[v].l0 * a[v] + tx[v].l1 * b[v]) + ty.l1 * (tx[v].l0 * c[v] + tx[v].l1 * d[v]);
+    float* dst = out + (p * Hout + oy) * (long long)Wout + ox;
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dst[v] = o[v];
+    }
+  }
+}
+
+int bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win, int Hout, int Wout,
+                          hipStream_t st) {
+  const float rh = (float)Hin / (float)Hout, rw = (float)Win / (float)Wout;
+  const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
+  const bool vec4 = (Wout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (vec4) {
+    const unsigned gx = (unsigned)(((long long)Hout * (Wout / 4) + 255) / 256);
+    hipLaunchKernelGGL(bilinear_resample_f32_kernel<4>, dim3(gx, gy), dim3(256), 0, st, in, out, Hin, Win, Hout, Wout,
+                       rh, rw, planes);
+  } else {
+    const unsigned gx = (unsigned)(((long long)Hout * Wout + 255) / 256);
+    hipLaunchKernelGGL(bilinear_resample_f32_kernel<1>, dim3(gx, gy), dim3(256), 0, st, in, out, Hin, Win, Hout, Wout,
+                       rh, rw, planes);
+  }
+  return check_launch("bilinear_resample_f32");
+}
+
+}  // namespace univs

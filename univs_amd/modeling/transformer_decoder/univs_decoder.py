@@ -237,7 +237,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         mf = mask_features.float().contiguous()
         feat_lowres = {}
         for sz in set(size_list):
-            feat_lowres[sz] = F.interpolate(mf, size=sz, mode="bilinear", align_corners=False).contiguous()
+            feat_lowres[sz] = ops.bilinear_resample(mf, sz)
 
         predictions_class, predictions_mask, predictions_embds, predictions_reid = [], [], [], []
         want_full = self.return_aux_outputs

@@ -168,3 +168,20 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
             int(num_windows), Ntok, nH, hd, float(scale), _ptr(out), _stream_ptr(qkv))
     _lib.check(rc, "window_attention")
     return out
+
+
+def bilinear_resample(x, size):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for contiguous float32
+    [..., Hin, Win] on the GPU (decoder attention-mask path, ...decoder_univs.py:555-558)."""
+    _require_gpu("bilinear_resample", x)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise RuntimeError("bilinear_resample: float32 [..., H, W] only")
+    x = x.contiguous()
+    Hin, Win = x.shape[-2:]
+    Hout, Wout = int(size[0]), int(size[1])
+    planes = x.numel() // max(Hin * Win, 1)
+    out = torch.empty(tuple(x.shape[:-2]) + (Hout, Wout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(out), planes, Hin, Win, Hout, Wout, _stream_ptr(x))
+    _lib.check(rc, "bilinear_resample")
+    return out
