@@ -139,6 +139,21 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
 int univs_bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win,
                                 int Hout, int Wout, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row LayerNorm with an optional fused residual add.
+ * Replaces: nn.LayerNorm(C)(x) and nn.LayerNorm(C)(x + residual) on the token tensors of the path --
+ *           Swin blocks (mask2former/modeling/backbone/swin.py:236-262: norm1, the residual, norm2),
+ *           MSDeformAttn encoder layers (mask2former/modeling/pixel_decoder/msdeformattn.py:61-95:
+ *           `src = norm1(src + src2)`, `src = norm2(src + ffn)`), decoder layers (transformer_layers.py).
+ *   x, residual (or NULL)   [rows, C]
+ *   gamma, beta             [C]
+ *   sum_out (or NULL)       [rows, C]  receives x + residual (the un-normalised stream of pre-norm blocks)
+ *   out                     [rows, C]  = (s - mean(s)) / sqrt(var(s) + eps) * gamma + beta,  s = x (+ residual)
+ *   C % 4 == 0 and C <= 3072, else UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                         long long rows, int C, float eps, float* sum_out, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,12 @@ def bilinear_resample(x, size):
     return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
 
 
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
+    s = x if residual is None else x + residual
+    out = torch.nn.functional.layer_norm(s, (x.shape[-1],), weight, bias, eps)
+    return (s, out) if return_sum else out
+
+
 def msda_set_impl(impl):
     return None
 
@@ -65,7 +71,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm")
 
 
 @contextlib.contextmanager

@@ -197,3 +197,35 @@ def test_bilinear_resample_matches_torch(cuda, shape, size):
     assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
     with pytest.raises(RuntimeError):
         ops.bilinear_resample(x, size)          # CPU tensors are refused (no fallback)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 96), (513, 192), (300, 256), (257, 384), (129, 768), (65, 1536), (33, 3072), (7, 8), (0, 96)],
+                         ids=lambda v: str(v))
+def test_layer_norm_matches_torch(cuda, rows, C):
+    """ops.layer_norm == F.layer_norm(x [+ residual]) for every row length of the path (Swin 96..768, patch merging
+    384..3072, encoder / decoder 256), with and without the fused residual and the returned sum."""
+    x = synth.normal(f"ln/x/{rows}/{C}", (rows, C)) * 3.0 + 0.5
+    r = synth.normal(f"ln/r/{rows}/{C}", (rows, C))
+    w = 1.0 + 0.1 * synth.uniform(f"ln/w/{C}", (C,))
+    b = 0.05 * synth.uniform(f"ln/b/{C}", (C,))
+    F = torch.nn.functional
+    xd, rd, wd, bd = (t.to(cuda) for t in (x, r, w, b))
+    got = ops.layer_norm(xd, wd, bd, 1e-5).cpu()
+    assert (got - F.layer_norm(x, (C,), w, b, 1e-5)).abs().max().item() < 2e-5 if rows else got.shape == x.shape
+    s, got2 = ops.layer_norm(xd, wd, bd, 1e-5, residual=rd, return_sum=True)
+    if rows:
+        assert torch.equal(s.cpu(), x + r)
+        assert (got2.cpu() - F.layer_norm(x + r, (C,), w, b, 1e-5)).abs().max().item() < 2e-5
+        got3 = ops.layer_norm(xd.view(1, rows, C), wd, bd, 1e-5, residual=rd.view(1, rows, C))
+        assert torch.equal(got3.view(rows, C), got2)
+
+
+def test_layer_norm_argument_errors(cuda):
+    x = torch.zeros(4, 10, device=cuda)
+    w = torch.ones(10, device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(x, w, w)                      # C % 4 != 0: not covered, loud
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(x.cpu(), w.cpu(), w.cpu())    # no CPU fallback
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(torch.zeros(4, 8, device=cuda), w, w)

@@ -31,6 +31,8 @@ int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, u
                          hipStream_t);
 
 int bilinear_resample_f32(const float*, float*, long long, int, int, int, int, hipStream_t);
+int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*,
+                   hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -199,6 +201,23 @@ int univs_bilinear_resample_f32(const float* in, float* out, long long planes, i
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return bilinear_resample_f32(in, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
+}
+
+int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                         long long rows, int C, float eps, float* sum_out, float* out, void* stream) {
+  clear_sticky_error();
+  if (rows < 0 || C < 1) {
+    set_error("univs_layer_norm_f32: bad dimensions rows=%lld C=%d", rows, C);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (rows == 0) return UNIVS_OK;
+  if (!x || !gamma || !beta || !out || (sum_out && !residual)) {
+    set_error("univs_layer_norm_f32: NULL data pointer (sum_out needs a residual)");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = layer_norm_f32(x, residual, gamma, beta, rows, C, eps, sum_out, out, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_layer_norm_f32: C=%d not supported (C %% 4 == 0, C <= 3072)", C);
+  return rc;
 }
 
 }  // extern "C"

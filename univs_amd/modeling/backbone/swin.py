@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
+from ...layers import layer_norm
 from ...registry import BACKBONE_REGISTRY, ShapeSpec
 
 
@@ -116,7 +117,7 @@ class SwinTransformerBlock(nn.Module):
         assert L == H * W, "input feature has wrong size"
         ws = self.window_size
         shortcut = x
-        x = self.norm1(x).view(B, H, W, C)
+        x = layer_norm(self.norm1, x).view(B, H, W, C)
         pad_r = (ws - W % ws) % ws
         pad_b = (ws - H % ws) % ws
         if pad_r or pad_b:
@@ -136,8 +137,9 @@ class SwinTransformerBlock(nn.Module):
             x = shifted_x
         if pad_r > 0 or pad_b > 0:
             x = x[:, :H, :W, :].contiguous()
-        x = shortcut + x.view(B, H * W, C)
-        return x + self.mlp(self.norm2(x))
+        # residual add and norm2 in one pass: x = shortcut + attn branch, h = norm2(x)
+        x, h = layer_norm(self.norm2, x.reshape(B, H * W, C), residual=shortcut, return_sum=True)
+        return x + self.mlp(h)
 
 
 class PatchMerging(nn.Module):
@@ -155,7 +157,7 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
         x = x.view(B, -1, 4 * C)
-        return self.reduction(self.norm(x))
+        return self.reduction(layer_norm(self.norm, x))
 
 
 class BasicLayer(nn.Module):
@@ -222,7 +224,7 @@ class PatchEmbed(nn.Module):
         x = self.proj(x)
         if self.norm is not None:
             Wh, Ww = x.size(2), x.size(3)
-            x = self.norm(x.flatten(2).transpose(1, 2))
+            x = layer_norm(self.norm, x.flatten(2).transpose(1, 2))
             x = x.transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
         return x
 
@@ -260,7 +262,7 @@ class SwinTransformer(nn.Module):
         for i in range(self.num_layers):
             x_out, H, W, x, Wh, Ww = self.layers[i](x, Wh, Ww)
             if i in self.out_indices:
-                x_out = getattr(self, f"norm{i}")(x_out)
+                x_out = layer_norm(getattr(self, f"norm{i}"), x_out)
                 outs[f"res{i + 2}"] = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
         return outs
 

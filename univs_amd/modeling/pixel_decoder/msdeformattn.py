@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from ...layers import Conv2d, get_activation_fn, get_norm
+from ...layers import Conv2d, get_activation_fn, get_norm, layer_norm, linear_act
 from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
@@ -87,8 +87,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(src if pos is None else src + pos, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        src = self.norm1(src + src2)
-        src = self.norm2(src + self.linear2(self.activation(self.linear1(src))))
+        src = layer_norm(self.norm1, src2, residual=src)
+        src = layer_norm(self.norm2, self.linear2(linear_act(src, self.linear1, self.activation)), residual=src)
         return src
 
 

@@ -5,7 +5,7 @@ from typing import Optional
 
 from torch import Tensor, nn
 
-from ...layers import MLP, MultiheadAttention, get_activation_fn  # noqa: F401  (MLP re-exported)
+from ...layers import MLP, MultiheadAttention, get_activation_fn, layer_norm, linear_act  # noqa: F401  (MLP re-exported)
 
 
 def _with_pos(t, pos):
@@ -24,11 +24,11 @@ class SelfAttentionLayer(nn.Module):
                 query_pos: Optional[Tensor] = None):
         assert tgt_key_padding_mask is None
         if self.normalize_before:
-            t2 = self.norm(tgt)
+            t2 = layer_norm(self.norm, tgt)
             q = k = _with_pos(t2, query_pos)
             return tgt + self.self_attn(q, k, t2, attn_mask=tgt_mask)[0]
         q = k = _with_pos(tgt, query_pos)
-        return self.norm(tgt + self.self_attn(q, k, tgt, attn_mask=tgt_mask)[0])
+        return layer_norm(self.norm, self.self_attn(q, k, tgt, attn_mask=tgt_mask)[0], residual=tgt)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -46,14 +46,12 @@ class CrossAttentionLayer(nn.Module):
                 memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 query_pos: Optional[Tensor] = None):
         assert memory_key_padding_mask is None
-        src = self.norm(tgt) if self.normalize_before else tgt
+        src = layer_norm(self.norm, tgt) if self.normalize_before else tgt
         # nn.MultiheadAttention's default averages the returned weights over heads; the reference
         # never passes `average_attn_weights` through, so neither do we (transformer_layers.py:101-105)
         out, w = self.multihead_attn(_with_pos(src, query_pos), _with_pos(memory, pos), memory,
                                      attn_mask=memory_mask, need_weights=self.need_weights)
-        tgt = tgt + out
-        if not self.normalize_before:
-            tgt = self.norm(tgt)
+        tgt = tgt + out if self.normalize_before else layer_norm(self.norm, out, residual=tgt)
         return (tgt, w) if self.need_weights else tgt
 
 
@@ -68,5 +66,5 @@ class FFNLayer(nn.Module):
 
     def forward(self, tgt):
         if self.normalize_before:
-            return tgt + self.linear2(self.activation(self.linear1(self.norm(tgt))))
-        return self.norm(tgt + self.linear2(self.activation(self.linear1(tgt))))
+            return tgt + self.linear2(linear_act(layer_norm(self.norm, tgt), self.linear1, self.activation))
+        return layer_norm(self.norm, self.linear2(linear_act(tgt, self.linear1, self.activation)), residual=tgt)

@@ -185,3 +185,33 @@ def bilinear_resample(x, size):
         rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(out), planes, Hin, Win, Hout, Wout, _stream_ptr(x))
     _lib.check(rc, "bilinear_resample")
     return out
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
+    """LayerNorm over the last dimension of contiguous float32 `x` on the GPU, optionally of
+    `x + residual` (and then optionally also returning that sum): nn.LayerNorm in the Swin blocks
+    (swin.py:236-262), encoder layers (msdeformattn.py:61-95) and decoder layers.
+    Returns `out` or `(x + residual, out)`."""
+    x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()   # views (e.g. NCHW -> tokens) are copied once
+    _require_gpu("layer_norm", x, weight, bias)
+    if x.dtype != torch.float32:
+        raise RuntimeError("layer_norm: float32 only")
+    if return_sum and residual is None:
+        raise RuntimeError("layer_norm: return_sum needs a residual")
+    C = x.shape[-1]
+    if tuple(weight.shape) != (C,) or tuple(bias.shape) != (C,):
+        raise RuntimeError("layer_norm: weight / bias must be [C]")
+    if residual is not None:
+        residual = residual.contiguous()
+        _require_gpu("layer_norm", residual)
+        if residual.shape != x.shape or residual.dtype != torch.float32:
+            raise RuntimeError("layer_norm: residual must match x")
+    out = torch.empty_like(x)
+    s = torch.empty_like(x) if return_sum else None
+    rows = x.numel() // max(C, 1)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_layer_norm_f32(_ptr(x), _ptr(residual) if residual is not None else None,
+                                             _ptr(weight.contiguous()), _ptr(bias.contiguous()), rows, C, float(eps),
+                                             _ptr(s) if s is not None else None, _ptr(out), _stream_ptr(x))
+    _lib.check(rc, "layer_norm")
+    return (s, out) if return_sum else out
