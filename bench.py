@@ -188,6 +188,17 @@ def main():
                            "frac": alg / t_msda / HBM_PEAK, "traffic": None,
                            "avg_launch_us": t_msda * 1e6, "launches_per_step": len(msda_t.events) // args.steps,
                            "algorithmic_bytes_per_launch": alg}
+        res["roofline"]["kernel"] = "msda_fwd_tiled<3> (MSDeformAttn forward, LDS-tiled, persistent)"
+        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
+        # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_msda_traffic.json")) as f:
+                tr = json.load(f)
+            if abs(tr["algorithmic_bytes_per_launch"] - alg) < 1:
+                res["roofline"]["traffic"] = tr["fetch_bytes_corrected"] + tr["write_bytes"]
+                res["roofline"]["traffic_source"] = "profiles/r01_msda_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except (OSError, KeyError, ValueError):
+            pass
     t_md = mdec_t.avg_seconds()
     if t_md:
         H, W, C = 184, 320, 256

@@ -256,6 +256,9 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         num_queries_lp = output.shape[0]
         self_attn_mask = self.generate_self_attn_mask(bs, t_total, num_queries_lp, dev, targets[0]["dataset_name"], task)
         query_embed_all = query_embed if fs is None else fs.all_gather_frames(query_embed, dim=1)
+        # cross-attention inputs per level, contiguous and built once (every third layer reuses them)
+        mem = [s_.contiguous() for s_ in src]
+        mem_key = [(s_ + p_).contiguous() for s_, p_ in zip(src, pos)]
         for i in range(self.num_layers):
             if self.prompt_as_queries and 0 < i < self.prompt_self_attn_layers:
                 output = self.forward_transformer_prompt_self_attention_layer(
@@ -263,7 +266,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             lvl = i % self.num_feature_levels
             # per-frame masked cross-attention; attn_mask [T, Q', HW_l] (rows already reset per :390)
             output = self.transformer_cross_attention_layers[i](
-                output, src[lvl], memory_mask=attn_mask, pos=pos[lvl], query_pos=query_embed)
+                output, mem[lvl], memory_mask=attn_mask, pos=None, query_pos=query_embed, key=mem_key[lvl])
             # spatio-temporal self-attention over Q'*T tokens: 'Q (B T) C -> (Q T) B C'
             Qn = output.shape[0]
             if fs is None:
