@@ -64,9 +64,13 @@ int univs_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
                            const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
                            int P, double* out, void* stream);
 
-/* Backward of the above (ops/src/ms_deform_attn.h:46-66).  Training is out of scope for the
- * inference hot path: the symbol exists so a binding can resolve it, and always returns
- * UNIVS_ERR_NOT_IMPLEMENTED. */
+/* Backward of the above (ops/src/ms_deform_attn.h:46-66, cuda/ms_deform_attn_cuda.cu:88-153):
+ *   grad_output        [N, Lq, M*D]
+ *   grad_value         [N, S, M, D]       (zero-filled here, then accumulated with float atomics)
+ *   grad_sampling_loc  [N, Lq, M, L, P, 2]
+ *   grad_attn_weight   [N, Lq, M, L, P]
+ * Completes the operator boundary; training is not on the inference hot path, so this kernel is
+ * correctness-first (one thread per sample). */
 int univs_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
                             const int64_t* level_start, const float* sampling_loc,
                             const float* attn_weight, const float* grad_output, int N, int S, int M,

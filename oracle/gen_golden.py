@@ -363,6 +363,23 @@ def g11b_clip_loop_scripted():
     save("g11b_clip_loop_scripted", **d)
 
 
+@gen
+def g13_msda_backward():
+    """gradients of the REFERENCE's ms_deform_attn_core_pytorch by autograd (float64 -> stored as float32)"""
+    R = rh.ref()
+    case = cases.MSDA_BWD_CASE
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    go = synth.normal("msda_bwd/go/" + case["name"], (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3]))
+    with torch.enable_grad():
+        v = value.double().requires_grad_(True)
+        l_ = loc.double().requires_grad_(True)
+        a = attn.double().requires_grad_(True)
+        out = R.ms_deform_attn_core_pytorch(v, torch.as_tensor(shapes), l_, a)
+        out.backward(go.double())
+    save("g13_msda_backward", out=out.detach().float(), grad_value=v.grad.float(), grad_sampling_loc=l_.grad.float(),
+         grad_attn_weight=a.grad.float())
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

@@ -31,9 +31,9 @@ def test_version_and_error_paths_without_gpu():
     assert lib.univs_msda_set_impl(7) == _lib.ERR_INVALID_ARGUMENT
     assert b"impl=7" in lib.univs_last_error()
     assert lib.univs_msda_set_impl(0) == _lib.OK
-    # backward is a declared-but-unimplemented entry (inference-only scope)
+    # backward validates its arguments without touching the device (no levels -> invalid argument)
     rc = lib.univs_msda_backward_f32(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None, None, None, None)
-    assert rc == _lib.ERR_NOT_IMPLEMENTED
+    assert rc == _lib.ERR_INVALID_ARGUMENT
 
 
 def test_product_ops_refuse_cpu_tensors():

@@ -103,7 +103,7 @@ def test_msda_argument_errors(cuda):
         ops.ms_deform_attn_forward(v.transpose(2, 3), [(2, 4)], [0], loc, a)
     with pytest.raises(RuntimeError):  # half precision is not dispatched (reference: float/double only)
         ops.ms_deform_attn_forward(v.half(), [(2, 4)], [0], loc.half(), a.half())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):  # grad_output must be [N, Lq, M*D]
         ops.ms_deform_attn_backward(v, [(2, 4)], [0], loc, a, v)
     # empty query set is legal and returns an empty tensor
     out = ops.ms_deform_attn_forward(v, [(2, 4)], [0], loc[:, :0].contiguous(), a[:, :0].contiguous())
@@ -229,3 +229,30 @@ def test_layer_norm_argument_errors(cuda):
         ops.layer_norm(x.cpu(), w.cpu(), w.cpu())    # no CPU fallback
     with pytest.raises(RuntimeError):
         ops.layer_norm(torch.zeros(4, 8, device=cuda), w, w)
+
+
+@pytest.mark.parametrize("case", cases.MSDA_BWD_CASES, ids=lambda c: c["name"])
+def test_msda_backward_matches_autograd_oracle(cuda, case):
+    """univs_msda_backward_f32 against autograd through the oracle's differentiable restatement of
+    ms_deform_attn_core_pytorch (oracle/msda_torch.py), the construction the reference's own
+    ops/test.py:check_gradient_numerical uses."""
+    from oracle import msda_torch
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    go = synth.normal("msda_bwd/go/" + case["name"], (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3]))
+    ref = msda_torch.backward(value.double(), shapes, loc.double(), attn.double(), go.double())
+    got = ops.ms_deform_attn_backward(value.to(cuda), shapes, lsi, loc.to(cuda), attn.to(cuda), go.to(cuda))
+    for name, g, r in zip(("grad_value", "grad_sampling_loc", "grad_attn_weight"), got, ref):
+        scale = max(1.0, r.abs().max().item())
+        assert (g.cpu().double() - r).abs().max().item() < 2e-4 * scale, name
+
+
+def test_msda_backward_matches_reference_golden(cuda, golden_dir):
+    """... and against gradients of the REAL reference's core (tests/golden/g13_msda_backward.npz)."""
+    g = np.load(os.path.join(golden_dir, "g13_msda_backward.npz"))
+    case = cases.MSDA_BWD_CASE
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    go = synth.normal("msda_bwd/go/" + case["name"], (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3]))
+    got = ops.ms_deform_attn_backward(value.to(cuda), shapes, lsi, loc.to(cuda), attn.to(cuda), go.to(cuda))
+    for name, t in zip(("grad_value", "grad_sampling_loc", "grad_attn_weight"), got):
+        r = g[name]
+        assert np.abs(t.cpu().numpy() - r).max() < 2e-4 * max(1.0, np.abs(r).max()), name

@@ -95,3 +95,18 @@ def test_attn_mask_rule():
     m = c_ops.attn_mask_from_logits(x)
     assert m[0, 0].tolist() == [True, False, False, False]   # sigmoid(0) = 0.5 is not < 0.5
     assert m[0, 1].tolist() == [False] * 4                  # fully masked row is reset (:390)
+
+
+def test_msda_torch_oracle_backward_matches_reference(golden_dir):
+    """oracle/msda_torch.py (the differentiable restatement used by the GPU backward tests) against the
+    REAL reference's core + autograd (g13)."""
+    from oracle import msda_torch
+    g = np.load(os.path.join(golden_dir, "g13_msda_backward.npz"))
+    case = cases.MSDA_BWD_CASE
+    value, shapes, lsi, loc, attn = cases.msda_inputs(case)
+    go = synth.normal("msda_bwd/go/" + case["name"], (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3]))
+    out = msda_torch.forward(value.double(), shapes, loc.double(), attn.double())
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-5
+    for name, t in zip(("grad_value", "grad_sampling_loc", "grad_attn_weight"),
+                       msda_torch.backward(value.double(), shapes, loc.double(), attn.double(), go.double())):
+        assert np.abs(t.numpy() - g[name]).max() < 1e-5 * max(1.0, np.abs(g[name]).max()), name

@@ -30,6 +30,8 @@ int mask_decode_f32(const float*, const float*, int, int, int, long long, float*
 int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
                          hipStream_t);
 
+int msda_backward_f32(const float*, const LevelTable&, const float*, const float*, const float*, int, int, int, int,
+                      int, int, int, float*, float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, float*, long long, int, int, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*,
                    hipStream_t);
@@ -131,11 +133,30 @@ int univs_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
                                   (hipStream_t)stream);
 }
 
-int univs_msda_backward_f32(const float*, const int64_t*, const int64_t*, const float*,
-                            const float*, const float*, int, int, int, int, int, int, int, float*,
-                            float*, float*, void*) {
-  set_error("univs_msda_backward_f32: backward is out of scope of the inference hot path");
-  return UNIVS_ERR_NOT_IMPLEMENTED;
+int univs_msda_backward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                            const float* sampling_loc, const float* attn_weight, const float* grad_output, int N,
+                            int S, int M, int D, int L, int Lq, int P, float* grad_value,
+                            float* grad_sampling_loc, float* grad_attn_weight, void* stream) {
+  if (N < 0 || S < 0 || M < 0 || D < 0 || Lq < 0 || P < 0 || L < 0) {
+    set_error("univs_msda_backward_f32: negative dimension");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  clear_sticky_error();
+  if ((long long)N * S * M * D > 0 && !grad_value) {
+    set_error("univs_msda_backward_f32: NULL grad_value");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const long long nsamp = (long long)N * Lq * M * L * P;
+  if (nsamp > 0 && (!value || !sampling_loc || !attn_weight || !grad_output || !grad_sampling_loc || !grad_attn_weight)) {
+    set_error("univs_msda_backward_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_backward_f32");
+  if (rc != UNIVS_OK) return rc;
+  if ((long long)N * S * M * D == 0) return UNIVS_OK;
+  return msda_backward_f32(value, lv, sampling_loc, attn_weight, grad_output, N, S, M, D, L, Lq, P, grad_value,
+                           grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
 }
 
 int univs_mask_decode_f32(const float* mask_embed, const float* mask_features, int T, int Q, int C,

@@ -92,11 +92,25 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step=128):
-    """Exported for interface parity (ops/src/vision.cpp:20); inference-only scope -> raises."""
-    lib = _lib.load()
-    rc = lib.univs_msda_backward_f32(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None,
-                                     None, None, None)
+    """ops/src/vision.cpp:20 / ms_deform_attn.h:46-66: returns [grad_value, grad_sampling_loc,
+    grad_attn_weight] (float32; `im2col_step` accepted and ignored like in the forward)."""
+    _require_gpu("ms_deform_attn_backward", value, sampling_loc, attn_weight, grad_output)
+    if value.dtype != torch.float32:
+        raise RuntimeError("ms_deform_attn_backward: float32 only")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    shapes, starts, L2 = _host_shapes(spatial_shapes, level_start_index)
+    if L2 != L or tuple(grad_output.shape) != (N, Lq, M * D) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError("ms_deform_attn_backward: inconsistent shapes")
+    gv = torch.empty_like(value)
+    gl = torch.empty_like(sampling_loc)
+    ga = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        rc = _lib.load().univs_msda_backward_f32(_ptr(value), shapes, starts, _ptr(sampling_loc), _ptr(attn_weight),
+                                                 _ptr(grad_output), N, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
+                                                 _stream_ptr(value))
     _lib.check(rc, "ms_deform_attn_backward")
+    return [gv, gl, ga]
 
 
 def msda_set_impl(impl: int):
