@@ -137,11 +137,14 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
  *           attention-mask heads (univs/modeling/transformer_decoder/
  *           video_mask2former_transformer_decoder_univs.py:555-558; this build resamples the mask
  *           features once per level instead of the mask logits of every layer).
- *   in   [planes, Hin, Win]    (planes = T * C, contiguous)
- *   out  [planes, Hout, Wout]
+ *           and the FPN top-down step `lateral + F.interpolate(coarser, size=lateral.shape[-2:])`
+ *           (mask2former/modeling/pixel_decoder/msdeformattn.py:350-351) when `addend` is given.
+ *   in      [planes, Hin, Win]    (planes = T * C, contiguous)
+ *   addend  [planes, Hout, Wout] or NULL
+ *   out     [planes, Hout, Wout]  = (addend +) resample(in)
  * ------------------------------------------------------------------------------------------- */
-int univs_bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win,
-                                int Hout, int Wout, void* stream);
+int univs_bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes,
+                                int Hin, int Win, int Hout, int Wout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm with an optional fused residual add.
@@ -157,6 +160,30 @@ int univs_bilinear_resample_f32(const float* in, float* out, long long planes, i
  * ------------------------------------------------------------------------------------------- */
 int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                          long long rows, int C, float eps, float* sum_out, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional ReLU) on NCHW tensors.
+ * Replaces: detectron2 Conv2d(..., norm=GroupNorm(32, C)[, activation=F.relu]) epilogues of the pixel
+ *           decoder (mask2former/modeling/pixel_decoder/msdeformattn.py:214-232 input_proj,
+ *           :262-283 lateral_convs / output_convs).
+ *   x, out       [N, C, HW]   contiguous
+ *   gamma, beta  [C]
+ *   ws           workspace of ws_floats floats, at least N * C * 2 * ceil(HW / 8192)
+ *   biased variance, y = (x - mean) / sqrt(var + eps) * gamma + beta, then max(y, 0) if relu != 0
+ * ------------------------------------------------------------------------------------------- */
+int univs_group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C,
+                         long long HW, int groups, float eps, int relu, float* ws, long long ws_floats,
+                         float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked softmax over the last dimension of attention scores, in place.
+ * Replaces: `attn.masked_fill(attn_mask, -inf)` + `softmax(dim=-1)` inside nn.MultiheadAttention as used
+ *           by the decoder's cross-attention (univs/modeling/transformer_decoder/transformer_layers.py:
+ *           101-105, mask from ...decoder_univs.py:390-405).
+ *   scores  [N, h, L, S]
+ *   mask    [N, L, S] bytes, non-zero = masked out (broadcast over the h heads), or NULL
+ * ------------------------------------------------------------------------------------------- */
+int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, int L, int S, void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,14 +53,27 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
     return (attn @ v).transpose(1, 2).reshape(B_, N, nH * hd)
 
 
-def bilinear_resample(x, size):
-    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+def bilinear_resample(x, size, addend=None):
+    y = torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+    return y if addend is None else addend + y
 
 
 def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
     s = x if residual is None else x + residual
     out = torch.nn.functional.layer_norm(s, (x.shape[-1],), weight, bias, eps)
     return (s, out) if return_sum else out
+
+
+def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
+    y = torch.nn.functional.group_norm(x, num_groups, weight, bias, eps)
+    return torch.relu(y) if relu else y
+
+
+def masked_softmax_(scores, mask=None):
+    if mask is not None:
+        scores.masked_fill_(mask.bool().unsqueeze(1), float("-inf"))
+    scores.copy_(torch.softmax(scores, dim=-1))
+    return scores
 
 
 def msda_set_impl(impl):
@@ -71,7 +84,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_")
 
 
 @contextlib.contextmanager

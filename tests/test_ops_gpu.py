@@ -195,6 +195,11 @@ def test_bilinear_resample_matches_torch(cuda, shape, size):
     got = ops.bilinear_resample(x.to(cuda), size).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    add = synth.normal("resample/add/" + "x".join(map(str, shape)), tuple(ref.shape))
+    got2 = ops.bilinear_resample(x.to(cuda), size, addend=add.to(cuda)).cpu()
+    assert (got2 - (add + ref)).abs().max().item() < 4e-6 * max(1.0, ref.abs().max().item())
+    xt = x.transpose(0, 1)                      # non-contiguous inputs are copied once
+    assert torch.equal(ops.bilinear_resample(xt.to(cuda), size).cpu(), got.transpose(0, 1))
     with pytest.raises(RuntimeError):
         ops.bilinear_resample(x, size)          # CPU tensors are refused (no fallback)
 
@@ -256,3 +261,36 @@ def test_msda_backward_matches_reference_golden(cuda, golden_dir):
     for name, t in zip(("grad_value", "grad_sampling_loc", "grad_attn_weight"), got):
         r = g[name]
         assert np.abs(t.cpu().numpy() - r).max() < 2e-4 * max(1.0, np.abs(r).max()), name
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((5, 256, 23, 40), 32, False), ((2, 256, 46, 80), 32, True), ((1, 64, 184, 320), 32, True),
+                                               ((3, 32, 7, 9), 8, False), ((2, 16, 1, 1), 4, True)], ids=lambda v: str(v))
+def test_group_norm_matches_torch(cuda, shape, groups, relu):
+    """ops.group_norm == F.group_norm [+ relu]: pixel-decoder sizes, odd planes (scalar path), 1x1 planes."""
+    x = synth.normal("gn/x/" + "x".join(map(str, shape)), shape) * 2.0 + 0.7
+    w = 1.0 + 0.1 * synth.uniform(f"gn/w/{shape[1]}", (shape[1],))
+    b = 0.05 * synth.uniform(f"gn/b/{shape[1]}", (shape[1],))
+    ref = torch.nn.functional.group_norm(x, groups, w, b, 1e-5)
+    ref = torch.relu(ref) if relu else ref
+    got = ops.group_norm(x.to(cuda), groups, w.to(cuda), b.to(cuda), 1e-5, relu=relu).cpu()
+    assert (got - ref).abs().max().item() < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.group_norm(x, groups, w, b)
+
+
+@pytest.mark.parametrize("N,h,L,S", [(2, 8, 13, 920), (1, 8, 100, 3680), (1, 2, 5, 14720), (1, 1, 3, 20000), (3, 4, 7, 33)],
+                         ids=lambda v: str(v))
+def test_masked_softmax_matches_torch(cuda, N, h, L, S):
+    """ops.masked_softmax_ == masked_fill(-inf) + softmax, every register-resident size class and the streaming one."""
+    x = synth.normal(f"sm/x/{N}/{h}/{L}/{S}", (N, h, L, S)) * 3.0
+    m = synth.uniform(f"sm/m/{N}/{L}/{S}", (N, L, S)) > 0.3
+    m[..., 0] = False                       # no fully masked row (the caller guarantees that, ...decoder_univs.py:390)
+    ref = torch.softmax(x.masked_fill(m.unsqueeze(1), float("-inf")), dim=-1)
+    xd = x.to(cuda)
+    got = ops.masked_softmax_(xd, m.to(cuda))
+    assert got.data_ptr() == xd.data_ptr()
+    assert (got.cpu() - ref).abs().max().item() < 4e-6          # probabilities <= 1: a few ulp
+    got2 = ops.masked_softmax_(x.to(cuda), None).cpu()
+    assert (got2 - torch.softmax(x, dim=-1)).abs().max().item() < 4e-6
+    got3 = ops.masked_softmax_(x.to(cuda), m.to(cuda).to(torch.uint8)).cpu()
+    assert torch.equal(got3, got.cpu())

@@ -32,9 +32,12 @@ int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, u
 
 int msda_backward_f32(const float*, const LevelTable&, const float*, const float*, const float*, int, int, int, int,
                       int, int, int, float*, float*, float*, hipStream_t);
-int bilinear_resample_f32(const float*, float*, long long, int, int, int, int, hipStream_t);
+int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*,
                    hipStream_t);
+int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
+                   float*, hipStream_t);
+int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -209,8 +212,8 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
                               (hipStream_t)stream);
 }
 
-int univs_bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win, int Hout,
-                                int Wout, void* stream) {
+int univs_bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes, int Hin,
+                                int Win, int Hout, int Wout, void* stream) {
   clear_sticky_error();
   if (planes < 0 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) {
     set_error("univs_bilinear_resample_f32: bad dimensions planes=%lld in=%dx%d out=%dx%d", planes, Hin, Win, Hout, Wout);
@@ -221,7 +224,7 @@ int univs_bilinear_resample_f32(const float* in, float* out, long long planes, i
     set_error("univs_bilinear_resample_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  return bilinear_resample_f32(in, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
+  return bilinear_resample_f32(in, addend, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
 }
 
 int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
@@ -239,6 +242,35 @@ int univs_layer_norm_f32(const float* x, const float* residual, const float* gam
   const int rc = layer_norm_f32(x, residual, gamma, beta, rows, C, eps, sum_out, out, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_layer_norm_f32: C=%d not supported (C %% 4 == 0, C <= 3072)", C);
   return rc;
+}
+
+int univs_group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW,
+                         int groups, float eps, int relu, float* ws, long long ws_floats, float* out, void* stream) {
+  clear_sticky_error();
+  if (N < 0 || C < 1 || HW < 0 || groups < 1 || C % groups != 0 || (long long)N * C > 0x7fffffffLL) {
+    set_error("univs_group_norm_f32: bad dimensions N=%d C=%d HW=%lld groups=%d", N, C, HW, groups);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * HW == 0) return UNIVS_OK;
+  if (!x || !gamma || !beta || !ws || !out) {
+    set_error("univs_group_norm_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return group_norm_f32(x, gamma, beta, N, C, HW, groups, eps, relu, ws, ws_floats, out, static_cast<hipStream_t>(stream));
+}
+
+int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, int L, int S, void* stream) {
+  clear_sticky_error();
+  if (N < 0 || h < 0 || L < 0 || S < 0) {
+    set_error("univs_masked_softmax_f32: negative dimension");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * h * L * S == 0) return UNIVS_OK;
+  if (!scores) {
+    set_error("univs_masked_softmax_f32: NULL scores");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return masked_softmax_f32(scores, mask, N, h, L, S, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

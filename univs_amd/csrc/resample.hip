@@ -4,6 +4,9 @@
 // the attention-mask heads (reference: video_mask2former_transformer_decoder_univs.py:555-558 resizes the
 // mask logits of every decoder layer; this build resamples the mask FEATURES once per level and
 // contracts at the target resolution -- bilinear resampling commutes with the channel contraction).
+// The optional `addend` makes it the FPN top-down step `lateral + upsample(coarser)`
+// (mask2former/modeling/pixel_decoder/msdeformattn.py:350-351), which ATen runs as a channels-last
+// upsample followed by a mixed-layout add (1.3 ms at 184x320).
 // ATen's upsample_bilinear2d_out_frame runs this at ~220 GB/s on the [T*256, 184, 320] planes
 // (1.35 ms per level); it is a pure HBM-bound gather: one thread per 4 output pixels, 16 taps, one
 // 16-B store.
@@ -32,6 +35,7 @@ __device__ __forceinline__ Tap make_tap(float scale, int dst, int in_size) {
 
 template <int VEC>
 __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ addend,
                                                                     float* __restrict__ out, int Hin, int Win,
                                                                     int Hout, int Wout, float rh, float rw,
                                                                     long long planes) {
@@ -58,7 +62,12 @@ __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float*
 #pragma unroll
     for (int v = 0; v < VEC; ++v)
       o[v] = ty.l0 * (tx[v].l0 * a[v] + tx[v].l1 * b[v]) + ty.l1 * (tx[v].l0 * c[v] + tx[v].l1 * d[v]);
-    float* dst = out + (p * Hout + oy) * (long long)Wout + ox;
+    const long long off = (p * Hout + oy) * (long long)Wout + ox;
+    if (addend) {   // FPN top-down path: lateral + upsampled coarser level in one pass
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = addend[off + v] + o[v];
+    }
+    float* dst = out + off;
     if (VEC == 4) {
       *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
@@ -68,18 +77,18 @@ __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float*
   }
 }
 
-int bilinear_resample_f32(const float* in, float* out, long long planes, int Hin, int Win, int Hout, int Wout,
-                          hipStream_t st) {
+int bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes, int Hin, int Win,
+                          int Hout, int Wout, hipStream_t st) {
   const float rh = (float)Hin / (float)Hout, rw = (float)Win / (float)Wout;
   const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
   const bool vec4 = (Wout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   if (vec4) {
     const unsigned gx = (unsigned)(((long long)Hout * (Wout / 4) + 255) / 256);
-    hipLaunchKernelGGL(bilinear_resample_f32_kernel<4>, dim3(gx, gy), dim3(256), 0, st, in, out, Hin, Win, Hout, Wout,
+    hipLaunchKernelGGL(bilinear_resample_f32_kernel<4>, dim3(gx, gy), dim3(256), 0, st, in, addend, out, Hin, Win, Hout, Wout,
                        rh, rw, planes);
   } else {
     const unsigned gx = (unsigned)(((long long)Hout * Wout + 255) / 256);
-    hipLaunchKernelGGL(bilinear_resample_f32_kernel<1>, dim3(gx, gy), dim3(256), 0, st, in, out, Hin, Win, Hout, Wout,
+    hipLaunchKernelGGL(bilinear_resample_f32_kernel<1>, dim3(gx, gy), dim3(256), 0, st, in, addend, out, Hin, Win, Hout, Wout,
                        rh, rw, planes);
   }
   return check_launch("bilinear_resample_f32");

@@ -23,6 +23,12 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if isinstance(self.norm, nn.GroupNorm) and x.dtype == torch.float32:
+            # GroupNorm (+ ReLU) epilogue through the HIP operator; the module only holds the parameters
+            from . import ops
+            relu = self.activation is F.relu
+            x = ops.group_norm(x, self.norm.num_groups, self.norm.weight, self.norm.bias, self.norm.eps, relu=relu)
+            return x if relu or self.activation is None else self.activation(x)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
@@ -91,18 +97,20 @@ class MultiheadAttention(nn.Module):
         k = k.reshape(S, N, h, d).permute(1, 2, 0, 3)
         v = v.reshape(S, N, h, d).permute(1, 2, 0, 3)
         scores = torch.matmul(q * (1.0 / math.sqrt(d)), k.transpose(-1, -2))  # [N, h, L, S]
-        if attn_mask is not None:
-            if attn_mask.dim() == 2:
-                m = attn_mask.view(1, 1, L, S)
-            elif attn_mask.shape[0] == N * h:
-                m = attn_mask.view(N, h, L, S)
+        fused = attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8)
+                                      and (attn_mask.dim() == 2 or attn_mask.shape[0] == N))
+        if fused:
+            # mask + softmax in one in-place pass (HIP operator): per-frame masks [N, L, S] shared by the heads,
+            # or one [L, S] mask for all batch entries
+            from . import ops
+            if attn_mask is not None and attn_mask.dim() == 2:
+                attn = ops.masked_softmax_(scores.view(1, N * h, L, S), attn_mask.view(1, L, S)).view(N, h, L, S)
             else:
-                m = attn_mask.view(N, 1, L, S)
-            if m.dtype == torch.bool:
-                scores = scores.masked_fill(m, float("-inf"))
-            else:
-                scores = scores + m
-        attn = torch.softmax(scores, dim=-1)
+                attn = ops.masked_softmax_(scores, attn_mask)
+        else:
+            m = attn_mask.view(N, h, L, S) if attn_mask.shape[0] == N * h else attn_mask.view(N, 1, L, S)
+            scores = scores.masked_fill(m, float("-inf")) if m.dtype == torch.bool else scores + m
+            attn = torch.softmax(scores, dim=-1)
         out = torch.matmul(attn, v)  # [N, h, L, d]
         out = out.permute(2, 0, 1, 3).reshape(L, N, E)
         out = self.out_proj(out)

@@ -241,7 +241,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             x = features[f].float()
             cur_fpn = self.lateral_convs[idx](x)
-            y_ = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+            y_ = ops.bilinear_resample(out[-1], cur_fpn.shape[-2:], addend=cur_fpn)
             out.append(self.output_convs[idx](y_))
         multi_scale_features = out[:self.maskformer_num_feature_levels]
         return self.mask_features(out[-1]), out[-1], out[0], multi_scale_features

@@ -184,19 +184,27 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
     return out
 
 
-def bilinear_resample(x, size):
-    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for contiguous float32
-    [..., Hin, Win] on the GPU (decoder attention-mask path, ...decoder_univs.py:555-558)."""
+def bilinear_resample(x, size, addend=None):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for float32 [..., Hin, Win] on the
+    GPU (decoder attention-mask path, ...decoder_univs.py:555-558); with `addend` [..., Hout, Wout] the FPN
+    top-down step `addend + interpolate(x)` (msdeformattn.py:350-351) in one pass."""
+    x = x.contiguous()
     _require_gpu("bilinear_resample", x)
     if x.dtype != torch.float32 or x.dim() < 2:
         raise RuntimeError("bilinear_resample: float32 [..., H, W] only")
-    x = x.contiguous()
     Hin, Win = x.shape[-2:]
     Hout, Wout = int(size[0]), int(size[1])
     planes = x.numel() // max(Hin * Win, 1)
-    out = torch.empty(tuple(x.shape[:-2]) + (Hout, Wout), dtype=torch.float32, device=x.device)
+    oshape = tuple(x.shape[:-2]) + (Hout, Wout)
+    if addend is not None:
+        addend = addend.contiguous()
+        _require_gpu("bilinear_resample", addend)
+        if tuple(addend.shape) != oshape or addend.dtype != torch.float32:
+            raise RuntimeError("bilinear_resample: addend must be float32 of the output shape")
+    out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(out), planes, Hin, Win, Hout, Wout, _stream_ptr(x))
+        rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(addend) if addend is not None else None, _ptr(out),
+                                                    planes, Hin, Win, Hout, Wout, _stream_ptr(x))
     _lib.check(rc, "bilinear_resample")
     return out
 
@@ -229,3 +237,44 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
                                              _ptr(s) if s is not None else None, _ptr(out), _stream_ptr(x))
     _lib.check(rc, "layer_norm")
     return (s, out) if return_sum else out
+
+
+def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
+    """F.group_norm(x, num_groups, weight, bias, eps) [+ relu] for contiguous float32 NCHW `x` on the GPU: the
+    Conv2d(norm=GN, activation=relu) epilogues of the pixel decoder (msdeformattn.py:214-232, :262-283)."""
+    x = x.contiguous()
+    _require_gpu("group_norm", x, weight, bias)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise RuntimeError("group_norm: float32 [N, C, ...] only")
+    N, C = x.shape[:2]
+    if C % int(num_groups) != 0 or tuple(weight.shape) != (C,) or tuple(bias.shape) != (C,):
+        raise RuntimeError("group_norm: bad channel / group / parameter shapes")
+    HW = x.numel() // max(N * C, 1)
+    out = torch.empty_like(x)
+    ws = torch.empty(N * C * 2 * max(1, (HW + 8191) // 8192), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_group_norm_f32(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), N, C, HW,
+                                             int(num_groups), float(eps), 1 if relu else 0, _ptr(ws), ws.numel(),
+                                             _ptr(out), _stream_ptr(x))
+    _lib.check(rc, "group_norm")
+    return out
+
+
+def masked_softmax_(scores, mask=None):
+    """In-place softmax over the last dimension of contiguous float32 attention scores [N, h, L, S] with an
+    optional boolean / uint8 mask [N, L, S] (True = masked out, shared by the heads): the masked softmax inside
+    nn.MultiheadAttention (transformer_layers.py:101-105).  Returns `scores`."""
+    _require_gpu("masked_softmax_", scores)
+    if scores.dtype != torch.float32 or scores.dim() != 4:
+        raise RuntimeError("masked_softmax_: float32 [N, h, L, S] only")
+    N, h, L, S = scores.shape
+    mptr = None
+    if mask is not None:
+        _require_gpu("masked_softmax_", mask)
+        if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8):
+            raise RuntimeError("masked_softmax_: mask must be bool / uint8 [N, L, S]")
+        mptr = _ptr(mask)
+    with torch.cuda.device(scores.device):
+        rc = _lib.load().univs_masked_softmax_f32(_ptr(scores), mptr, N, h, L, S, _stream_ptr(scores))
+    _lib.check(rc, "masked_softmax_")
+    return scores
