@@ -131,6 +131,19 @@ int univs_window_attention_f32(const float* qkv, const float* bias, const float*
                                int B_, int nW, int Ntok, int nH, int hd, float scale, float* out,
                                void* stream);
 
+/* Image-mode variant of the window attention core: qkv / out stay in TOKEN order and the kernel performs the
+ * reference's pad -> roll(-shift) -> window_partition before and window_reverse -> roll(+shift) -> crop after
+ * the attention (mask2former/modeling/backbone/swin.py:252-284) by index arithmetic.
+ *   qkv        [B, H*W, 3, nH, hd]   the qkv Linear applied to the (un-padded) tokens
+ *   qkv_bias   [3 * nH * hd] or NULL q/k/v of the zero-padded pixels (= the qkv Linear's bias)
+ *   bias       [nH, ws*ws, ws*ws]    relative position bias per head
+ *   shift_mask [nW, ws*ws, ws*ws] or NULL   (nW = ceil(H/ws) * ceil(W/ws), used when shift > 0)
+ *   out        [B, H*W, nH*hd]
+ * ------------------------------------------------------------------------------------------- */
+int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias,
+                                     const float* shift_mask, int B, int H, int W, int ws, int shift,
+                                     int nH, int hd, float scale, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bilinear resampling of image planes, align_corners = false (PyTorch semantics).
  * Replaces: F.interpolate(x, size=(Hout, Wout), mode="bilinear", align_corners=False) on the path of the

@@ -76,6 +76,30 @@ def masked_softmax_(scores, mask=None):
     return scores
 
 
+def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale):
+    """The reference's data movement around the core (swin.py:252-284): pad (padded pixels carry the qkv bias =
+    Linear(0)), roll, window_partition -> core -> window_reverse, roll back, crop."""
+    B, L, _, nH, hd = qkv.shape
+    ws, F = int(window_size), torch.nn.functional
+    x = qkv.reshape(B, H, W, 3 * nH * hd)
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    if pr or pb:
+        fill = qkv_bias.reshape(-1) if qkv_bias is not None else x.new_zeros(3 * nH * hd)
+        xp = fill.view(1, 1, 1, -1).expand(B, H + pb, W + pr, -1).clone()
+        xp[:, :H, :W] = x
+        x = xp
+    Hp, Wp = x.shape[1:3]
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = x.view(B, Hp // ws, ws, Wp // ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3, nH, hd)
+    nW = (Hp // ws) * (Wp // ws)
+    o = window_attention(xw, bias, shift_mask if shift else None, nW, scale)          # [B*nW, ws*ws, C]
+    o = o.view(B, Hp // ws, Wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, -1)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o[:, :H, :W].reshape(B, H * W, -1)
+
+
 def msda_set_impl(impl):
     return None
 
@@ -84,7 +108,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_", "window_attention_image")
 
 
 @contextlib.contextmanager

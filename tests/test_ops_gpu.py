@@ -294,3 +294,37 @@ def test_masked_softmax_matches_torch(cuda, N, h, L, S):
     assert (got2 - torch.softmax(x, dim=-1)).abs().max().item() < 4e-6
     got3 = ops.masked_softmax_(x.to(cuda), m.to(cuda).to(torch.uint8)).cpu()
     assert torch.equal(got3, got.cpu())
+
+
+@pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 0, 3), (2, 14, 21, 7, 3, 3), (1, 23, 40, 7, 3, 2), (1, 24, 36, 12, 6, 4),
+                                                (2, 9, 11, 12, 0, 1), (1, 7, 7, 7, 0, 2)], ids=lambda v: str(v))
+def test_window_attention_image_matches_reference_data_movement(cuda, B, H, W, ws, shift, nH):
+    """Image-mode window attention == pad -> roll -> window_partition -> core -> window_reverse -> roll -> crop
+    (the oracle's restatement of swin.py:252-284 around the already-pinned core), incl. padded pixels (qkv = bias),
+    shifted windows with the 0/-100 mask, windows larger than the image, and both window sizes."""
+    from oracle import cpu_path
+    hd, n = 32, ws * ws
+    tag = f"wai/{B}/{H}/{W}/{ws}/{shift}/{nH}"
+    qkv = synth.normal(tag + "/qkv", (B, H * W, 3, nH, hd))
+    qb = synth.normal(tag + "/qb", (3 * nH * hd,)) * 0.5
+    bias = synth.normal(tag + "/bias", (nH, n, n))
+    Hp, Wp = (H + ws - 1) // ws * ws, (W + ws - 1) // ws * ws
+    nW = (Hp // ws) * (Wp // ws)
+    mask = None
+    if shift:
+        # the reference's shift mask (swin.py:413-440): region ids on the padded canvas -> 0 / -100
+        img = torch.zeros(1, Hp, Wp, 1)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, Hp // ws, ws, Wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        mask = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+        assert mask.shape[0] == nW
+    ref = cpu_path.window_attention_image(qkv, qb, bias, mask, H, W, ws, shift, hd ** -0.5)
+    got = ops.window_attention_image(qkv.to(cuda), qb.to(cuda), bias.to(cuda), mask.to(cuda) if mask is not None else None,
+                                     H, W, ws, shift, hd ** -0.5).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-5

@@ -38,6 +38,8 @@ int layer_norm_f32(const float*, const float*, const float*, const float*, long 
 int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
                    float*, hipStream_t);
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
+int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
+                               int, float, float*, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -271,6 +273,24 @@ int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, i
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return masked_softmax_f32(scores, mask, N, h, L, S, static_cast<hipStream_t>(stream));
+}
+
+int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias,
+                                     const float* shift_mask, int B, int H, int W, int ws, int shift, int nH,
+                                     int hd, float scale, float* out, void* stream) {
+  clear_sticky_error();
+  if (B < 0 || H < 1 || W < 1 || ws < 1 || shift < 0 || shift >= ws || nH < 1 || hd < 1) {
+    set_error("univs_window_attention_image_f32: bad dimensions B=%d H=%d W=%d ws=%d shift=%d nH=%d hd=%d", B, H, W,
+              ws, shift, nH, hd);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return UNIVS_OK;
+  if (!qkv || !bias || !out) {
+    set_error("univs_window_attention_image_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out,
+                                    static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -26,13 +26,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WA_WAVES = 4;
 constexpr int WA_VSTRIDE = 36;  // floats per staged V row (32 + 4 pad): groups g, g+1 hit disjoint banks
 
-template <int NB>  // NB 16-token blocks: Ntok <= 16*NB
+// Image mode (IMG): qkv / out are in TOKEN order [B, H*W, ...] and the kernel does the reference's
+// pad -> roll(-shift) -> window_partition on the way in and window_reverse -> roll(+shift) -> crop on
+// the way out (swin.py:252-284) by index arithmetic: window b = (image, wy, wx), position j = (py, px)
+// maps to pixel ((wy*ws + py + shift) mod Hp, (wx*ws + px + shift) mod Wp); pixels beyond (H, W) are the
+// zero padding, whose q/k/v are the qkv Linear's bias (Linear(0) = bias) and which are not written back.
+struct WinImage {
+  int H, W, ws, shift, nWx, Hp, Wp;
+};
+
+template <bool IMG>
+__device__ __forceinline__ long long win_token(const WinImage& wi, long long b, int nW, int Ntok, int j) {
+  if (!IMG) return b * Ntok + j;
+  const int w = (int)(b % nW);
+  const long long img = b / nW;
+  const int wy = w / wi.nWx, wx = w - wy * wi.nWx;
+  const int py = j / wi.ws, px = j - py * wi.ws;
+  int y = wy * wi.ws + py + wi.shift, x = wx * wi.ws + px + wi.shift;
+  y -= (y >= wi.Hp) ? wi.Hp : 0;
+  x -= (x >= wi.Wp) ? wi.Wp : 0;
+  return (y < wi.H && x < wi.W) ? (img * wi.H + y) * wi.W + x : -1;
+}
+
+template <int NB, bool IMG>  // NB 16-token blocks: Ntok <= 16*NB
 __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ qkv_bias,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ shift_mask,
                                                                   int B_, int nW, int Ntok, int nH,
                                                                   float scale, float* __restrict__ out,
-                                                                  long long npairs) {
+                                                                  long long npairs, WinImage wi) {
   constexpr int HD = 32;
   constexpr int NP = 16 * NB;
   extern __shared__ __attribute__((aligned(16))) float vlds_all[];
@@ -45,9 +68,13 @@ __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __
   float* vlds = vlds_all + wave * (NP * WA_VSTRIDE);
 
   const long long tok_stride = 3LL * nH * HD;
-  const float* qb = qkv + (b * Ntok) * tok_stride + (long long)h * HD;  // q of token 0
-  const float* kb = qb + (long long)nH * HD;
-  const float* vb = kb + (long long)nH * HD;
+  const long long part = (long long)nH * HD;   // q | k | v parts of a token row
+  // row of (window b, position j): its q part for head h; padding pixels read the qkv bias (or zeros)
+  auto row = [&](int j) __attribute__((always_inline)) -> const float* {
+    const long long t = win_token<IMG>(wi, b, nW, Ntok, j);
+    if (t >= 0) return qkv + t * tok_stride + (long long)h * HD;
+    return qkv_bias ? qkv_bias + (long long)h * HD : nullptr;
+  };
 
   // ---- stage V[j][0..31] into LDS (8 lanes x 16 B per row, 8 rows per pass)
   {
@@ -55,7 +82,10 @@ __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __
     for (int j0 = 0; j0 < NP; j0 += 8) {
       const int j = j0 + r8;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < Ntok) v = *reinterpret_cast<const float4*>(vb + (long long)j * tok_stride + c4);
+      if (j < Ntok) {
+        const float* rp = row(j);
+        if (rp) v = *reinterpret_cast<const float4*>(rp + 2 * part + c4);
+      }
       *reinterpret_cast<float4*>(vlds + j * WA_VSTRIDE + c4) = v;
     }
   }
@@ -67,9 +97,12 @@ __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __
     const int j = jb * 16 + n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
     if (j < Ntok) {
-      const float4* p = reinterpret_cast<const float4*>(kb + (long long)j * tok_stride + 8 * g);
-      a = p[0];
-      c = p[1];
+      const float* rp = row(j);
+      if (rp) {
+        const float4* p = reinterpret_cast<const float4*>(rp + part + 8 * g);
+        a = p[0];
+        c = p[1];
+      }
     }
     kf[jb][0] = a.x; kf[jb][1] = a.y; kf[jb][2] = a.z; kf[jb][3] = a.w;
     kf[jb][4] = c.x; kf[jb][5] = c.y; kf[jb][6] = c.z; kf[jb][7] = c.w;
@@ -90,9 +123,12 @@ __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __
     {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
       if (i < Ntok) {
-        const float4* p = reinterpret_cast<const float4*>(qb + (long long)i * tok_stride + 8 * g);
-        a = p[0];
-        c = p[1];
+        const float* rp = row(i);
+        if (rp) {
+          const float4* p = reinterpret_cast<const float4*>(rp + 8 * g);
+          a = p[0];
+          c = p[1];
+        }
       }
       qf[0] = a.x * scale; qf[1] = a.y * scale; qf[2] = a.z * scale; qf[3] = a.w * scale;
       qf[4] = c.x * scale; qf[5] = c.y * scale; qf[6] = c.z * scale; qf[7] = c.w * scale;
@@ -159,16 +195,21 @@ __global__ __launch_bounds__(64 * WA_WAVES) void window_attn_f32(const float* __
     for (int r = 0; r < 4; ++r) {
       const int io = ib * 16 + 4 * g + r;
       if (io < Ntok) {
-        float* op = out + ((b * Ntok + io) * nH + h) * HD;
-        op[n] = o0[r];
-        op[16 + n] = o1[r];
+        const long long t = win_token<IMG>(wi, b, nW, Ntok, io);
+        if (t >= 0) {
+          float* op = out + (t * nH + h) * HD;
+          op[n] = o0[r];
+          op[16 + n] = o1[r];
+        }
       }
     }
   }
 }
 
-int window_attention_f32(const float* qkv, const float* bias, const float* shift_mask, int B_, int nW,
-                         int Ntok, int nH, int hd, float scale, float* out, hipStream_t st) {
+template <bool IMG>
+static int launch_window_attn(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask,
+                              int B_, int nW, int Ntok, int nH, int hd, float scale, float* out, const WinImage& wi,
+                              hipStream_t st) {
   if (hd != 32) {
     set_error("window_attention_f32: head_dim=%d (only 32, the Swin-T/B/L value)", hd);
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -178,19 +219,38 @@ int window_attention_f32(const float* qkv, const float* bias, const float* shift
   const unsigned nblocks = (unsigned)((npairs + WA_WAVES - 1) / WA_WAVES);
   if (Ntok <= 64) {
     const size_t lds = (size_t)WA_WAVES * 64 * WA_VSTRIDE * sizeof(float);
-    hipLaunchKernelGGL((window_attn_f32<4>), dim3(nblocks), dim3(64 * WA_WAVES), lds, st, qkv, bias,
-                       shift_mask, B_, nW, Ntok, nH, scale, out, npairs);
+    hipLaunchKernelGGL((window_attn_f32<4, IMG>), dim3(nblocks), dim3(64 * WA_WAVES), lds, st, qkv, qkv_bias, bias,
+                       shift_mask, B_, nW, Ntok, nH, scale, out, npairs, wi);
   } else if (Ntok <= 144) {
     const size_t lds = (size_t)WA_WAVES * 144 * WA_VSTRIDE * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_f32<9>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_f32<9, IMG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((window_attn_f32<9>), dim3(nblocks), dim3(64 * WA_WAVES), lds, st, qkv, bias,
-                       shift_mask, B_, nW, Ntok, nH, scale, out, npairs);
+    hipLaunchKernelGGL((window_attn_f32<9, IMG>), dim3(nblocks), dim3(64 * WA_WAVES), lds, st, qkv, qkv_bias, bias,
+                       shift_mask, B_, nW, Ntok, nH, scale, out, npairs, wi);
   } else {
     set_error("window_attention_f32: %d tokens per window (max 144 = 12x12)", Ntok);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return check_launch("window_attn_f32");
+}
+
+int window_attention_f32(const float* qkv, const float* bias, const float* shift_mask, int B_, int nW,
+                         int Ntok, int nH, int hd, float scale, float* out, hipStream_t st) {
+  WinImage wi{};
+  return launch_window_attn<false>(qkv, nullptr, bias, shift_mask, B_, nW, Ntok, nH, hd, scale, out, wi, st);
+}
+
+// qkv [B, H*W, 3, nH, hd] in token order; out [B, H*W, nH*hd]
+int window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask,
+                               int B, int H, int W, int ws, int shift, int nH, int hd, float scale, float* out,
+                               hipStream_t st) {
+  WinImage wi;
+  wi.H = H; wi.W = W; wi.ws = ws; wi.shift = shift;
+  wi.Hp = (H + ws - 1) / ws * ws;
+  wi.Wp = (W + ws - 1) / ws * ws;
+  wi.nWx = wi.Wp / ws;
+  const int nW = (wi.Hp / ws) * wi.nWx;
+  return launch_window_attn<true>(qkv, qkv_bias, bias, shift_mask, B * nW, nW, ws * ws, nH, hd, scale, out, wi, st);
 }
 
 }  // namespace univs

@@ -88,6 +88,17 @@ class WindowAttention(nn.Module):
             self._bias_cache = (key, b.detach())
         return self._bias_cache[1]
 
+    def forward_image(self, x, H, W, shift, mask=None):
+        """x: [B, H*W, C] tokens in image order.  Same result as pad -> roll -> window_partition -> forward ->
+        window_reverse -> roll -> crop (the reference block, swin.py:252-284), with all of that data movement
+        done by index arithmetic inside the attention kernel (the qkv / proj Linears are per token, so they
+        commute with the partition)."""
+        B, L, C = x.shape
+        qkv = self.qkv(x).view(B, L, 3, self.num_heads, C // self.num_heads)
+        out = ops.window_attention_image(qkv, self.qkv.bias, self._bias(), mask, H, W, self.window_size[0], shift,
+                                         self.scale)
+        return self.proj(out)
+
     def forward(self, x, mask=None):
         """x: [num_windows*B, N, C]; mask: [nW, N, N] (0 / -100) or None."""
         B_, N, C = x.shape
@@ -117,26 +128,8 @@ class SwinTransformerBlock(nn.Module):
         assert L == H * W, "input feature has wrong size"
         ws = self.window_size
         shortcut = x
-        x = layer_norm(self.norm1, x).view(B, H, W, C)
-        pad_r = (ws - W % ws) % ws
-        pad_b = (ws - H % ws) % ws
-        if pad_r or pad_b:
-            x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
-        _, Hp, Wp, _ = x.shape
-        if self.shift_size > 0:
-            shifted_x = torch.roll(x, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
-            attn_mask = mask_matrix
-        else:
-            shifted_x, attn_mask = x, None
-        x_windows = window_partition(shifted_x, ws).view(-1, ws * ws, C)
-        attn_windows = self.attn(x_windows, mask=attn_mask).view(-1, ws, ws, C)
-        shifted_x = window_reverse(attn_windows, ws, Hp, Wp)
-        if self.shift_size > 0:
-            x = torch.roll(shifted_x, shifts=(self.shift_size, self.shift_size), dims=(1, 2))
-        else:
-            x = shifted_x
-        if pad_r > 0 or pad_b > 0:
-            x = x[:, :H, :W, :].contiguous()
+        x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
+                                    mask_matrix if self.shift_size > 0 else None)
         # residual add and norm2 in one pass: x = shortcut + attn branch, h = norm2(x)
         x, h = layer_norm(self.norm2, x.reshape(B, H * W, C), residual=shortcut, return_sum=True)
         return x + self.mlp(h)

@@ -278,3 +278,39 @@ def masked_softmax_(scores, mask=None):
         rc = _lib.load().univs_masked_softmax_f32(_ptr(scores), mptr, N, h, L, S, _stream_ptr(scores))
     _lib.check(rc, "masked_softmax_")
     return scores
+
+
+def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale):
+    """Swin window attention on tokens in image order: qkv [B, H*W, 3, nH, hd] (the qkv Linear applied to the
+    un-padded tokens) -> [B, H*W, nH*hd]; pad / roll / window_partition / window_reverse / crop of
+    swin.py:252-284 happen inside the kernel.  `qkv_bias` [3*nH*hd] or None supplies q/k/v of the padded
+    pixels; `shift_mask` [nW, ws*ws, ws*ws] is required when shift > 0."""
+    _require_gpu("window_attention_image", qkv, bias)
+    if qkv.dtype != torch.float32 or qkv.dim() != 5:
+        raise RuntimeError("window_attention_image: float32 [B, H*W, 3, nH, hd] only")
+    B, L, three, nH, hd = qkv.shape
+    ws = int(window_size)
+    n = ws * ws
+    if three != 3 or L != H * W or tuple(bias.shape) != (nH, n, n):
+        raise RuntimeError("window_attention_image: bad shapes")
+    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    if shift:
+        if shift_mask is None:
+            raise RuntimeError("window_attention_image: shift > 0 needs the shift mask")
+        _require_gpu("window_attention_image", shift_mask)
+        if tuple(shift_mask.shape) != (nW, n, n):
+            raise RuntimeError("window_attention_image: bad shift_mask shape")
+    else:
+        shift_mask = None
+    if qkv_bias is not None:
+        _require_gpu("window_attention_image", qkv_bias)
+        if qkv_bias.numel() != 3 * nH * hd:
+            raise RuntimeError("window_attention_image: bad qkv_bias shape")
+    out = torch.empty((B, L, nH * hd), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = _lib.load().univs_window_attention_image_f32(
+            _ptr(qkv), _ptr(qkv_bias) if qkv_bias is not None else None, _ptr(bias),
+            _ptr(shift_mask) if shift_mask is not None else None, B, int(H), int(W), ws, int(shift), nH, hd,
+            float(scale), _ptr(out), _stream_ptr(qkv))
+    _lib.check(rc, "window_attention_image")
+    return out
