@@ -25,8 +25,9 @@ __device__ __forceinline__ float wg_reduce(float v, float* lds, bool is_max) {
   return is_max ? fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3])) : (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
-// scores [N, h, L, S]; mask [N, L, S] bytes (non-zero = masked out) or NULL
-template <int KMAX>
+// scores [N, h, L, S]; mask [N, L, S] bytes (non-zero = masked out) or NULL.
+// VEC = 4: S % 4 == 0, 16-B score loads and one 4-B mask load per 4 elements; VEC = 1: any S.
+template <int KMAX, int VEC>
 __global__ __launch_bounds__(256) void masked_softmax_f32_kernel(float* __restrict__ scores,
                                                                  const unsigned char* __restrict__ mask, int h, int L,
                                                                  int S) {
@@ -36,31 +37,47 @@ __global__ __launch_bounds__(256) void masked_softmax_f32_kernel(float* __restri
   float* p = scores + row * S;
   const unsigned char* m = mask ? mask + (n * L + l) * (long long)S : nullptr;
   const float NEG = -__builtin_inff();
-  float v[KMAX];
+  float v[KMAX][VEC];
   float mx = NEG;
+  const int nvec = S / VEC;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const int i = threadIdx.x + k * 256;
-    v[k] = NEG;
-    if (i < S) {
-      const float x = p[i];
-      v[k] = (m && m[i]) ? NEG : x;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[k][e] = NEG;
+    if (i < nvec) {
+      if (VEC == 4) {
+        const v4f x = reinterpret_cast<const v4f*>(p)[i];
+        const unsigned mm = m ? reinterpret_cast<const unsigned*>(m)[i] : 0u;
+        v[k][0] = (mm & 0x000000ffu) ? NEG : x.x;
+        v[k][1 % VEC] = (mm & 0x0000ff00u) ? NEG : x.y;
+        v[k][2 % VEC] = (mm & 0x00ff0000u) ? NEG : x.z;
+        v[k][3 % VEC] = (mm & 0xff000000u) ? NEG : x.w;
+      } else {
+        v[k][0] = (m && m[i]) ? NEG : p[i];
+      }
     }
-    mx = fmaxf(mx, v[k]);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, v[k][e]);
   }
   mx = wg_reduce(mx, red, true);
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    v[k] = expf(v[k] - mx);       // exp(-inf) = 0 for masked / out-of-range entries
-    sum += v[k];
-  }
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      v[k][e] = expf(v[k][e] - mx);       // exp(-inf) = 0 for masked / out-of-range entries
+      sum += v[k][e];
+    }
   sum = wg_reduce(sum, red, false);
   const float inv = 1.f / sum;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const int i = threadIdx.x + k * 256;
-    if (i < S) p[i] = v[k] * inv;
+    if (i < nvec) {
+      if (VEC == 4) reinterpret_cast<v4f*>(p)[i] = (v4f){v[k][0] * inv, v[k][1 % VEC] * inv, v[k][2 % VEC] * inv, v[k][3 % VEC] * inv};
+      else p[i] = v[k][0] * inv;
+    }
   }
 }
 
@@ -87,10 +104,17 @@ int masked_softmax_f32(float* scores, const unsigned char* mask, int N, int h, i
   const long long rows = (long long)N * h * L;
   if (rows > 0x7fffffffLL) return UNIVS_ERR_INVALID_ARGUMENT;
   const dim3 grid((unsigned)rows), block(256);
-  if (S <= 256 * 4) hipLaunchKernelGGL(masked_softmax_f32_kernel<4>, grid, block, 0, st, scores, mask, h, L, S);
-  else if (S <= 256 * 16) hipLaunchKernelGGL(masked_softmax_f32_kernel<16>, grid, block, 0, st, scores, mask, h, L, S);
-  else if (S <= 256 * 64) hipLaunchKernelGGL(masked_softmax_f32_kernel<64>, grid, block, 0, st, scores, mask, h, L, S);
+  // rows of S % 4 == 0 whose row starts (and mask rows) stay 16-B / 4-B aligned take the vector path
+  const bool vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) &&
+                   (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+#define UNIVS_SM(K, V) hipLaunchKernelGGL((masked_softmax_f32_kernel<K, V>), grid, block, 0, st, scores, mask, h, L, S)
+  if (vec && S <= 1024 * 4) UNIVS_SM(4, 4);
+  else if (vec && S <= 1024 * 16) UNIVS_SM(16, 4);
+  else if (!vec && S <= 256 * 4) UNIVS_SM(4, 1);
+  else if (!vec && S <= 256 * 16) UNIVS_SM(16, 1);
+  else if (!vec && S <= 256 * 64) UNIVS_SM(64, 1);
   else hipLaunchKernelGGL(masked_softmax_f32_stream_kernel, grid, block, 0, st, scores, mask, h, L, S);
+#undef UNIVS_SM
   return check_launch("masked_softmax_f32");
 }
 

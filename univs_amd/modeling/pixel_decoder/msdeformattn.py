@@ -41,6 +41,17 @@ class MSDeformAttn(nn.Module):
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
 
+    def _merged_query_proj(self):
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight.data_ptr(), so.weight._version, aw.weight.data_ptr(), aw.weight._version,
+               so.bias._version, aw.bias._version, so.weight.device)
+        c = getattr(self, "_qproj_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, torch.cat([so.weight, aw.weight]).contiguous(), torch.cat([so.bias, aw.bias]).contiguous())
+            self._qproj_cache = c
+        return c[1], c[2], so.weight.shape[0]
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None):
         """query [N,Lq,C]; reference_points [N|1,Lq,L,2]; input_flatten [N,S,C];
@@ -52,9 +63,12 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
-        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
-        attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
-        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
+        # one GEMM for the two Linears that read `query` (their weights concatenated once): 288 output columns
+        # instead of 192 + 96, `query` is read once
+        w, b, n_off = self._merged_query_proj()
+        qp = F.linear(query, w, b)
+        sampling_offsets = qp[..., :n_off].view(N, Len_q, M, L, P, 2)
+        attention_weights = F.softmax(qp[..., n_off:].reshape(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
         if reference_points.shape[-1] == 2:
             if isinstance(input_spatial_shapes, torch.Tensor):
                 normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(query)
