@@ -95,6 +95,8 @@ def main():
     from tests import cases
     from univs_amd import ops
 
+    from univs_amd import runtime
+    gemm_note = runtime.enable_tuned_gemms()      # hipBLASLt / rocBLAS algorithm table (fp32 unchanged)
     swin, head = build_model(dev)
     case = cases.CFG2
     frames = cases.cfg2_frames().to(dev)                      # [5,3,720,1280], 0..255
@@ -168,6 +170,7 @@ def main():
                    "parallelism": (f"frame-sharded x{world} (RCCL all-gather of query states per decoder layer)"
                                    if frames_mode else f"clip-replicas x{world}")},
     }
+    res["gemm_algorithms"] = gemm_note
     # parity of the timed path against the reference's own CPU run (tests/golden/g12)
     try:
         import numpy as np
