@@ -380,6 +380,37 @@ def g13_msda_backward():
          grad_attn_weight=a.grad.float())
 
 
+@gen
+def g14_cfg4_full_size():
+    """BASELINE config 4 (Swin-B, grounding with 4 expressions, 200 queries, T=5 @ 720p) through the real
+    reference on CPU: strided samples + checksums, as G12."""
+    import hashlib
+    R = rh.ref()
+    case = cases.CFG4
+    swin = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_B)
+    swin.eval()
+    synth.load_synthetic(swin, prefix="backbone.")
+    head = _ref_head(R, case, **cases.CFG4_DECODER)
+    x = cases.preprocess(cases.cfg2_frames())
+    feats = swin(x)
+    out = head(feats, targets=cases.cfg4_targets(case))
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k + "_s"] = v[:, ::16, ::4, ::4]
+    pm = out["pred_masks"]
+    d["pred_masks_s"] = pm[0, :, :, ::16, ::16]
+    d["pred_masks_abs_mean"] = pm.double().abs().mean()
+    d["pred_masks_pos_count"] = (pm > 0).sum()
+    d["pred_masks_near_zero_1e-3"] = (pm.abs() < 1e-3).sum()
+    d["pred_masks_sign_sha256"] = np.frombuffer(
+        hashlib.sha256(np.packbits((pm > 0).numpy()).tobytes()).digest(), dtype=np.uint8)
+    d["pred_logits"] = out["pred_logits"]
+    d["pred_embds"] = out["pred_embds"][:, :, :, ::4]
+    if out.get("pred_reid_logits") is not None and isinstance(out["pred_reid_logits"], torch.Tensor):
+        d["pred_reid_logits"] = out["pred_reid_logits"]
+    save("g14_cfg4_full_size", **d)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

@@ -358,3 +358,17 @@ class ScriptedHead:
                 "pred_masks": torch.stack([r[1] for r in rows])[None].to(dev),
                 "pred_embds": torch.stack([r[2] for r in rows])[None].to(dev),
                 "aux_outputs": []}
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 4: Swin-B (window 12), T=5 @ 720p, 200 learnable queries + 4 referring expressions
+# (grounding, 'sep-blocked' self-attention mask, text prompts fused into the image features)
+# ---------------------------------------------------------------------------------------------------
+SWINB_SHAPES = {"res2": (128, 4), "res3": (256, 8), "res4": (512, 16), "res5": (1024, 32)}
+CFG4 = dict(name="cfg4", T=5, H=720, W=1280, Q=200, shapes=SWINB_SHAPES, n_exp=4)
+CFG4_DECODER = dict(text_to_image=True, sa_mask="sep-blocked")
+
+
+def cfg4_targets(case=CFG4):
+    tv = targets_grounding(case, n_exp=case["n_exp"])[0]
+    return [tv]

@@ -174,3 +174,36 @@ def test_clip_loop_on_device_matches_reference(cuda, golden_dir):
     assert ops.msda_last_impl() in (1, 2)
     compare_states(got, g, tol=1e-3, mask_margin=1e-3)
     assert len(results) == 1 and results[0][0]["masks"].shape[-2:] == case["image_size"]
+
+
+def test_config4_full_size_against_reference(cuda, golden_dir):
+    """BASELINE config 4 (Swin-B window 12, grounding with 4 expressions 'sep-blocked', 200 queries, T=5 @ 720p):
+    every stage against strided samples / checksums of the reference's own CPU run (g14)."""
+    path = os.path.join(golden_dir, "g14_cfg4_full_size.npz")
+    if not os.path.exists(path):
+        pytest.skip("g14 golden not generated")
+    g = np.load(path)
+    case = cases.CFG4
+    swin = helpers.build_swin(cuda, variant=cases.SWIN_B)
+    head = helpers.build_head(case, cuda, return_aux=False, **cases.CFG4_DECODER)
+    x = cases.preprocess(cases.cfg2_frames()).to(cuda)
+    with torch.no_grad():
+        feats = swin(x)
+        out = head(feats, targets=_targets_to(cases.cfg4_targets(case), cuda))
+    for k, v in feats.items():
+        err = np.abs(v[:, ::16, ::4, ::4].cpu().numpy() - g["feat_" + k + "_s"]).max()
+        assert err < 3e-3, (k, err)
+    pm = out["pred_masks"]
+    assert pm.shape[1] == case["Q"] + case["n_exp"]
+    ref_s = g["pred_masks_s"]
+    got_s = pm[0, :, :, ::16, ::16].cpu().numpy()
+    err = np.abs(got_s - ref_s).max()
+    flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
+    print(f"cfg4 pred_masks: max-abs-err {err:.3e}, |ref| max {np.abs(ref_s).max():.2f}, sign flips {flips.sum()}")
+    assert err < 1e-3 * max(1.0, np.abs(ref_s).max() / 10.0), err
+    assert flips.sum() == 0
+    pos = int((pm > 0).sum())
+    assert abs(pos - int(g["pred_masks_pos_count"])) <= int(g["pred_masks_near_zero_1e-3"]) + 8
+    assert abs(float(pm.double().abs().mean()) - float(g["pred_masks_abs_mean"])) < 1e-4
+    assert np.abs(out["pred_logits"].cpu().numpy() - g["pred_logits"]).max() < 3e-3
+    assert np.abs(out["pred_embds"][:, :, :, ::4].cpu().numpy() - g["pred_embds"]).max() < 3e-3
