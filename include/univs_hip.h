@@ -77,6 +77,22 @@ int univs_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
                             int D, int L, int Lq, int P, float* grad_value, float* grad_sampling_loc,
                             float* grad_attn_weight, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MSDeformAttn input preparation: sampling locations and attention weights from the raw projections.
+ * Replaces: the elementwise tail of MSDeformAttn.forward (ops/modules/ms_deform_attn.py:100-113):
+ *           softmax over the L*P logits of each (query, head); reference point + offset / (W_l, H_l).
+ *   proj        [N*Lq, row_stride] rows; columns [0, M*L*P*2) = sampling offsets (m, l, p, xy),
+ *               columns [n_off, n_off + M*L*P) = attention logits (m, l, p)   (one merged projection,
+ *               or two tensors seen as one row with a stride)
+ *   ref_points  [N or 1, Lq, L, 2] normalised reference points (ref_batch_stride = 0 broadcasts over N)
+ *   spatial_shapes  HOST int64 [L, 2] as in univs_msda_forward_f32
+ *   loc   [N, Lq, M, L, P, 2],  attn  [N, Lq, M, L, P]     (the operands of univs_msda_forward_f32)
+ *   P == 4 and L <= 4, else UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const float* ref_points,
+                           long long ref_batch_stride, const int64_t* spatial_shapes, int N, int Lq, int M,
+                           int L, int P, float* loc, float* attn, void* stream);
+
 /* Selects the MSDA forward implementation: 0 = auto (default), 1 = generic direct-gather kernel,
  * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
  * Used by the parity tests and bench to exercise each path explicitly. */

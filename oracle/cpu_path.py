@@ -100,6 +100,18 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
     return o[:, :H, :W].reshape(B, H * W, -1)
 
 
+def msda_prepare(proj, n_off, reference_points, spatial_shapes, num_heads, num_levels, num_points):
+    """ms_deform_attn.py:100-113, the reference's own expressions."""
+    N, Lq, _ = proj.shape
+    M, L, P = num_heads, num_levels, num_points
+    off = proj[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
+    attn = torch.softmax(proj[..., n_off:n_off + M * L * P].reshape(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else spatial_shapes
+    normalizer = torch.tensor([[w, h] for (h, w) in shapes], dtype=proj.dtype)
+    loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    return loc, attn
+
+
 def msda_set_impl(impl):
     return None
 
@@ -108,7 +120,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_", "window_attention_image")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_", "window_attention_image", "msda_prepare")
 
 
 @contextlib.contextmanager

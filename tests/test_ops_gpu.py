@@ -328,3 +328,21 @@ def test_window_attention_image_matches_reference_data_movement(cuda, B, H, W, w
                                      H, W, ws, shift, hd ** -0.5).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("N,Lq,M,shapes,bcast", [(2, 37, 8, [(8, 14), (16, 28), (32, 56)], True), (1, 5, 2, [(3, 4)], False),
+                                                  (3, 11, 4, [(2, 2), (4, 4), (8, 8), (16, 16)], False)], ids=lambda v: str(v))
+def test_msda_prepare_matches_reference_expressions(cuda, N, Lq, M, shapes, bcast):
+    """ops.msda_prepare == softmax + reference + offset / normalizer (ms_deform_attn.py:100-113), merged or padded
+    projection rows, broadcast and per-batch reference points."""
+    from oracle import cpu_path
+    L, P = len(shapes), 4
+    n_off = M * L * P * 2
+    C = n_off + M * L * P + (8 if not bcast else 0)          # extra columns after the logits are ignored
+    proj = synth.normal(f"prep/{N}/{Lq}/{M}/{L}", (N, Lq, C)) * 2.0
+    ref = synth.uniform(f"prep/ref/{N}/{Lq}/{L}", (1 if bcast else N, Lq, L, 2), 0.0, 1.0)
+    loc_r, attn_r = cpu_path.msda_prepare(proj, n_off, ref, shapes, M, L, P)
+    loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+    assert (loc.cpu() - loc_r).abs().max().item() < 1e-6
+    assert (attn.cpu() - attn_r).abs().max().item() < 1e-6
+    assert loc.is_contiguous() and attn.is_contiguous()

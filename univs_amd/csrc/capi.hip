@@ -32,6 +32,8 @@ int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, u
 
 int msda_backward_f32(const float*, const LevelTable&, const float*, const float*, const float*, int, int, int, int,
                       int, int, int, float*, float*, float*, hipStream_t);
+int msda_prepare_f32(const float*, int, int, const float*, long long, const LevelTable&, int, int, int, int, int,
+                     float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*,
                    hipStream_t);
@@ -291,6 +293,37 @@ int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, co
   }
   return window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out,
                                     static_cast<hipStream_t>(stream));
+}
+
+int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const float* ref_points,
+                           long long ref_batch_stride, const int64_t* spatial_shapes, int N, int Lq, int M, int L,
+                           int P, float* loc, float* attn, void* stream) {
+  clear_sticky_error();
+  if (N < 0 || Lq < 0 || M < 1 || L < 1 || L > UNIVS_MAX_LEVELS || P < 1 || row_stride < M * L * P * 3 || n_off < M * L * P * 2 ||
+      n_off + M * L * P > row_stride || ref_batch_stride < 0) {
+    set_error("univs_msda_prepare_f32: bad dimensions N=%d Lq=%d M=%d L=%d P=%d row_stride=%d n_off=%d", N, Lq, M, L, P,
+              row_stride, n_off);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq == 0) return UNIVS_OK;
+  if (!proj || !ref_points || !spatial_shapes || !loc || !attn) {
+    set_error("univs_msda_prepare_f32: NULL pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  for (int l = 0; l < UNIVS_MAX_LEVELS; ++l) {
+    lv.H[l] = l < L ? (int)spatial_shapes[2 * l] : 0;
+    lv.W[l] = l < L ? (int)spatial_shapes[2 * l + 1] : 0;
+    lv.start[l] = 0;
+    if (l < L && (lv.H[l] < 1 || lv.W[l] < 1)) {
+      set_error("univs_msda_prepare_f32: level %d has an empty shape", l);
+      return UNIVS_ERR_INVALID_ARGUMENT;
+    }
+  }
+  const int rc = msda_prepare_f32(proj, row_stride, n_off, ref_points, ref_batch_stride, lv, N, Lq, M, L, P, loc, attn,
+                                  static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_msda_prepare_f32: (L=%d, P=%d) not instantiated (P == 4, L <= 4)", L, P);
+  return rc;
 }
 
 }  // extern "C"

@@ -29,6 +29,10 @@ from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
 
+def _shape_list(spatial_shapes):
+    return spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else list(spatial_shapes)
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
@@ -67,21 +71,23 @@ class MSDeformAttn(nn.Module):
         # instead of 192 + 96, `query` is read once
         w, b, n_off = self._merged_query_proj()
         qp = F.linear(query, w, b)
-        sampling_offsets = qp[..., :n_off].view(N, Len_q, M, L, P, 2)
-        attention_weights = F.softmax(qp[..., n_off:].reshape(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
-        if reference_points.shape[-1] == 2:
-            if isinstance(input_spatial_shapes, torch.Tensor):
-                normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(query)
-            else:
-                normalizer = torch.tensor([[w, h] for (h, w) in input_spatial_shapes], dtype=query.dtype,
-                                          device=query.device)
-            sampling_locations = reference_points[:, :, None, :, None, :] \
-                + sampling_offsets / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        if reference_points.shape[-1] == 2 and P == 4 and L <= 4:
+            # softmax over the L*P logits + reference point + offset / (W_l, H_l): one pass (HIP operator)
+            sampling_locations, attention_weights = ops.msda_prepare(qp, n_off, reference_points, input_spatial_shapes,
+                                                                     M, L, P)
         else:
-            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+            sampling_offsets = qp[..., :n_off].view(N, Len_q, M, L, P, 2)
+            attention_weights = F.softmax(qp[..., n_off:].reshape(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
+            if reference_points.shape[-1] == 2:
+                normalizer = torch.tensor([[w_, h_] for (h_, w_) in _shape_list(input_spatial_shapes)], dtype=query.dtype,
+                                          device=query.device)
+                sampling_locations = reference_points[:, :, None, :, None, :] \
+                    + sampling_offsets / normalizer[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                sampling_locations = reference_points[:, :, None, :, None, :2] \
+                    + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            else:
+                raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         output = ops.ms_deform_attn_forward(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights.contiguous(),
                                             self.im2col_step)

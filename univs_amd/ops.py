@@ -314,3 +314,30 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
             float(scale), _ptr(out), _stream_ptr(qkv))
     _lib.check(rc, "window_attention_image")
     return out
+
+
+def msda_prepare(proj, n_off, reference_points, spatial_shapes, num_heads, num_levels, num_points):
+    """Elementwise tail of MSDeformAttn.forward (ms_deform_attn.py:100-113) in one pass: `proj` [N, Lq, C]
+    holds the sampling offsets in columns [0, M*L*P*2) and the attention logits in columns [n_off, ...);
+    `reference_points` [N or 1, Lq, L, 2].  Returns (sampling_locations [N,Lq,M,L,P,2], attention_weights
+    [N,Lq,M,L,P]) -- the operands of `ms_deform_attn_forward`."""
+    proj = proj.contiguous()
+    reference_points = reference_points.contiguous()
+    _require_gpu("msda_prepare", proj, reference_points)
+    if proj.dtype != torch.float32 or proj.dim() != 3 or reference_points.dtype != torch.float32:
+        raise RuntimeError("msda_prepare: float32 proj [N, Lq, C] and reference_points only")
+    N, Lq, C = proj.shape
+    M, L, P = int(num_heads), int(num_levels), int(num_points)
+    if tuple(reference_points.shape[1:]) != (Lq, L, 2) or reference_points.shape[0] not in (1, N):
+        raise RuntimeError("msda_prepare: reference_points must be [N or 1, Lq, L, 2]")
+    sh, _, L2 = _host_shapes(spatial_shapes, [0] * L)
+    if L2 != L:
+        raise RuntimeError("msda_prepare: spatial_shapes / num_levels mismatch")
+    loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=proj.device)
+    attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=proj.device)
+    rbs = 0 if reference_points.shape[0] == 1 else Lq * L * 2
+    with torch.cuda.device(proj.device):
+        rc = _lib.load().univs_msda_prepare_f32(_ptr(proj), C, int(n_off), _ptr(reference_points), rbs, sh, N, Lq, M, L, P,
+                                               _ptr(loc), _ptr(attn), _stream_ptr(proj))
+    _lib.check(rc, "msda_prepare")
+    return loc, attn
