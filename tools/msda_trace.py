@@ -59,9 +59,10 @@ def main():
     torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     nblk = int(os.environ.get("UNIVS_MSDA_GRID", "256"))
+    gen2 = os.environ.get("UNIVS_MSDA_TILED", "2") != "1"
     buf = np.zeros((nblk, 16), dtype=np.uint64)
     lib = _lib.load()
-    fn = lib.univs_msda_trace_read
+    fn = lib.univs_msda_trace2_read if gen2 else lib.univs_msda_trace_read
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     rc = fn(buf.ctypes.data, nblk)
@@ -78,7 +79,13 @@ def main():
     print(f"steady-state item: mean {tot.mean():.0f}  p10 {np.percentile(tot, 10):.0f}  p90 {np.percentile(tot, 90):.0f} ticks")
     names = {3: "top (decode, acc=0, barrier)", 4: "L0 commit+sync", 5: "L0 loads+gathers", 6: "L1 barrier", 7: "L1 commit+sync",
              8: "L1 loads+gathers", 9: "L2 barrier", 10: "L2 commit(+qglob)+sync", 11: "L2 prefetch+gathers", 15: "reduce+stores"}
+    if gen2:   # one barrier per step: stamps are (step top, after the barrier, after the gathers)
+        names = {3: "top (item turnover)", 4: "step0 commit+barrier", 5: "step0 loads+gathers", 6: "-", 7: "step1 commit+barrier",
+                 8: "step1 loads+gathers", 9: "-", 10: "step2 commit(+qglob)+barrier", 11: "step2 prefetch+gathers", 15: "reduce+stores"}
     order = [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15]
+    if gen2:
+        print(f"  step1 detail: wait for staged loads {np.mean(t[:, 1] - t[:, 6]):.0f}, LDS writes + record {np.mean(t[:, 2] - t[:, 1]):.0f}, "
+              f"geometry + window loads + barrier {np.mean(t[:, 7] - t[:, 2]):.0f}")
     for i, j in zip(order[:-1], order[1:]):
         d = t[:, j] - t[:, i]
         print(f"  {names[j]:<30s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}  "

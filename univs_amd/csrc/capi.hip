@@ -24,6 +24,8 @@ int msda_forward_generic_f32(const float*, const LevelTable&, const float*, cons
 int msda_forward_generic_f64(const double*, const LevelTable&, const double*, const double*, int,
                              int, int, int, int, int, int, double*, hipStream_t);
 // returns 1 if the tiled kernel was launched, 0 if its preconditions do not hold, <0 on error
+int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
+                            int, float*, hipStream_t);
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
@@ -109,6 +111,14 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   if (rc != UNIVS_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g_msda_impl != 1) {
+    // LDS-tiled kernels for the encoder geometry: the double-buffered 16-wave generation first
+    // (UNIVS_MSDA_TILED=1 selects the single-buffer kernel), each returns 0 when its preconditions fail
+    static const int tiled_gen = [] { const char* e = getenv("UNIVS_MSDA_TILED"); return (e && *e) ? atoi(e) : 2; }();
+    rc = tiled_gen >= 2 ? msda_forward_tiled2_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
+    if (rc != 0) {
+      if (rc > 0) g_msda_last = 2;
+      return rc < 0 ? rc : UNIVS_OK;
+    }
     rc = msda_forward_tiled_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
     if (rc != 0) {
       if (rc > 0) g_msda_last = 2;

@@ -37,11 +37,7 @@
 // Block order: logical id = ((n * tiles + tile) * M + m), XCD-chunked, so the 8 head-workgroups
 // of a tile (which share the 128-B lines of sampling_loc / attn_weight) and neighbouring tiles
 // (which share halo rows) run on the same XCD L2.
-#include <algorithm>
-#include <mutex>
-#include <vector>
-
-#include "msda_common.h"
+#include "msda_geometry.h"
 
 #ifdef UNIVS_MSDA_TRACE
 // Debug builds only (tools/msda_trace.py): per-workgroup s_memtime stamps of the kernel's phases.
@@ -74,7 +70,7 @@ constexpr int TL_QMAX = TL_QCAP / TL_GROUPS;      // queries per gather group
 constexpr int TL_OCTETS = TL_THREADS / 8;         // 8-lane copy groups (one 128-B row each)
 constexpr int TL_WR = 15;                         // window float4 per lane: 960 pixels (a 30 x 30 window = 16 + 2 x 6 + 2)
 constexpr int TL_SR = TL_NSMP / TL_THREADS;       // samples per thread
-constexpr int TL_WIN_MAX = 64;                    // window edge limit (the product ww*wh is bounded by the LDS carve)
+
 
 __device__ __forceinline__ v4f fma4v(float s, v4f v, v4f a) {
   const v4f s4 = {s, s, s, s};
@@ -403,103 +399,6 @@ __global__ __launch_bounds__(TL_THREADS) void msda_fwd_tiled(const float* __rest
     par ^= 1;
   }
   TSTAMP(14);
-}
-
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
-static long long floor_div(long long a, long long b) {  // b > 0
-  return (a >= 0) ? a / b : -((-a + b - 1) / b);
-}
-static long long ceil_div(long long a, long long b) {  // b > 0
-  return -floor_div(-a, b);
-}
-
-// ---- host-side geometry: built once per (device, level shapes, tile parameters), kept for the
-// lifetime of the process (a few hundred bytes of device memory per distinct geometry).
-struct GeoKey {
-  int dev, L, TH, TW, R;
-  int H[UNIVS_MAX_LEVELS], W[UNIVS_MAX_LEVELS];
-  bool operator==(const GeoKey& o) const {
-    if (dev != o.dev || L != o.L || TH != o.TH || TW != o.TW || R != o.R) return false;
-    for (int l = 0; l < L; ++l)
-      if (H[l] != o.H[l] || W[l] != o.W[l]) return false;
-    return true;
-  }
-};
-struct GeoEntry {
-  GeoKey key;
-  int4* table;       // device
-  int tiles_y, tiles_x;
-  long long qmax;    // max queries of a tile
-  long long win_px;  // max window pixels of a (tile, level)
-};
-
-// one axis of one level: query interval and window interval of tile t
-static void axis_entry(int t, int ntile, int T, int Nq, int Nf, int R, int cap, int4& e) {
-  // queries: pixel centres (i + 0.5) / Nq inside [t*T/Nf, (t+1)*T/Nf)
-  long long lo = std::max<long long>(0, ceil_div(2LL * t * T * Nq - Nf, 2LL * Nf));
-  long long hi = (t + 1 == ntile) ? Nq : ceil_div(2LL * (t + 1) * T * Nq - Nf, 2LL * Nf);
-  hi = std::min<long long>(std::max(hi, lo), Nq);
-  // window: bilinear corners of samples within R pixels of the tile's box, clipped to the zero ring
-  const long long num1 = std::min<long long>((long long)(t + 1) * T, Nf);
-  long long w0 = std::max<long long>(-1, floor_div(2LL * t * T * Nq - (1 + 2LL * R) * Nf, 2LL * Nf));
-  long long w1 = std::min<long long>(Nq, floor_div(2LL * num1 * Nq - (1 - 2LL * R) * Nf, 2LL * Nf) + 1);
-  long long wn = std::max<long long>(w1 - w0 + 1, 2);
-  wn = std::min<long long>(wn, cap);
-  e.x = (int)lo; e.y = (int)(hi - lo); e.z = (int)w0; e.w = (int)wn;
-}
-
-static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, long long cap_px) {
-  static std::mutex mu;
-  static std::vector<GeoEntry*> cache;
-  GeoKey key{};
-  if (hipGetDevice(&key.dev) != hipSuccess) return nullptr;
-  key.L = L; key.TH = TH; key.TW = TW; key.R = R;
-  for (int l = 0; l < L; ++l) { key.H[l] = lv.H[l]; key.W[l] = lv.W[l]; }
-  std::lock_guard<std::mutex> lock(mu);
-  for (const GeoEntry* e : cache)
-    if (e->key == key) return e;
-
-  GeoEntry* ge = new GeoEntry();
-  ge->key = key;
-  ge->tiles_y = (lv.H[fine] + TH - 1) / TH;
-  ge->tiles_x = (lv.W[fine] + TW - 1) / TW;
-  std::vector<int4> tab((size_t)L * (ge->tiles_x + ge->tiles_y));
-  for (int l = 0; l < L; ++l) {
-    for (int tx = 0; tx < ge->tiles_x; ++tx)
-      axis_entry(tx, ge->tiles_x, TW, lv.W[l], lv.W[fine], R, TL_WIN_MAX, tab[(size_t)l * ge->tiles_x + tx]);
-    for (int ty = 0; ty < ge->tiles_y; ++ty)
-      axis_entry(ty, ge->tiles_y, TH, lv.H[l], lv.H[fine], R, TL_WIN_MAX,
-                 tab[(size_t)L * ge->tiles_x + (size_t)l * ge->tiles_y + ty]);
-  }
-  // windows must fit the LDS carve: shrink rows where a (tile, level) would not (samples beyond go
-  // through the global fallback, results unchanged)
-  ge->qmax = 0; ge->win_px = 4;
-  for (int l = 0; l < L; ++l) {
-    int mw = 2, mqx = 0, mqy = 0;
-    for (int tx = 0; tx < ge->tiles_x; ++tx) {
-      mw = std::max(mw, tab[(size_t)l * ge->tiles_x + tx].w);
-      mqx = std::max(mqx, tab[(size_t)l * ge->tiles_x + tx].y);
-    }
-    for (int ty = 0; ty < ge->tiles_y; ++ty) {
-      int4& e = tab[(size_t)L * ge->tiles_x + (size_t)l * ge->tiles_y + ty];
-      e.w = (int)std::max<long long>(2, std::min<long long>(e.w, cap_px / mw));
-      mqy = std::max(mqy, e.y);
-      ge->win_px = std::max<long long>(ge->win_px, (long long)mw * e.w);
-    }
-    ge->qmax += (long long)mqx * mqy;
-  }
-  if (hipMalloc(reinterpret_cast<void**>(&ge->table), tab.size() * sizeof(int4)) != hipSuccess ||
-      hipMemcpy(ge->table, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    delete ge;
-    return nullptr;
-  }
-  cache.push_back(ge);
-  return ge;
 }
 
 template <int L>
