@@ -80,12 +80,13 @@ def main():
     names = {3: "top (decode, acc=0, barrier)", 4: "L0 commit+sync", 5: "L0 loads+gathers", 6: "L1 barrier", 7: "L1 commit+sync",
              8: "L1 loads+gathers", 9: "L2 barrier", 10: "L2 commit(+qglob)+sync", 11: "L2 prefetch+gathers", 15: "reduce+stores"}
     if gen2:   # one barrier per step: stamps are (step top, after the barrier, after the gathers)
-        names = {3: "top (item turnover)", 4: "step0 commit+barrier", 5: "step0 loads+gathers", 6: "-", 7: "step1 commit+barrier",
-                 8: "step1 loads+gathers", 9: "-", 10: "step2 commit(+qglob)+barrier", 11: "step2 prefetch+gathers", 15: "reduce+stores"}
+        names = {3: "top (item turnover)", 4: "step0 commit + issue loads", 5: "step0 barrier wait", 6: "-", 7: "step1 commit + issue loads",
+                 8: "step1 barrier wait", 9: "-", 10: "step2 commit + issue loads", 11: "step2 barrier wait", 15: "end"}
     order = [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15]
     if gen2:
-        print(f"  step1 detail: wait for staged loads {np.mean(t[:, 1] - t[:, 6]):.0f}, LDS writes + record {np.mean(t[:, 2] - t[:, 1]):.0f}, "
-              f"geometry + window loads + barrier {np.mean(t[:, 7] - t[:, 2]):.0f}")
+        print(f"  consumers (wave 8): gathers step0 {np.mean(t[:, 2] - t[:, 1]):.0f}, barrier wait {np.mean(t[:, 6] - t[:, 2]):.0f}, "
+              f"gathers step1 {np.mean(t[:, 9] - t[:, 6]):.0f}, barrier wait {np.mean(t[:, 12] - t[:, 9]):.0f}")
+        print("  producers (wave 0):")
     for i, j in zip(order[:-1], order[1:]):
         d = t[:, j] - t[:, i]
         print(f"  {names[j]:<30s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f}  "

@@ -1,22 +1,24 @@
-// LDS-tiled MSDA forward, second generation (gfx950): double-buffered windows, 16 waves per workgroup.
+// LDS-tiled MSDA forward, second generation (gfx950): double-buffered windows + wave specialisation.
 //
 // Same decomposition, record format, zero-ring buffer loads and conflict-free 16-lane gather groups as
 // msda_tiled.hip (read that file's header first).  What changes is the schedule.  msda_tiled.hip spends
 // 45 % of an item outside the gathers because its single 115-KB window forces the sequence
 //     barrier -> commit (LDS writes, records) -> barrier -> gathers
-// on one workgroup per CU.  Here a tile is 16 x 8 pixels of the finest level (168 queries), so two windows
-// fit in LDS side by side (660 + 396 pixels at halo 6) and a step is
-//     commit(step s+1's window into the OTHER region, records into the other record buffer)
-//     -> ONE barrier -> issue the loads of step s+2 -> gathers(step s+1)
-// so a wave that finishes its gathers early goes straight on to committing the next window while other
-// waves still gather from the current one: LDS writes, record arithmetic and barrier skew overlap the
-// gathers instead of adding to them.  Half as many queries per item also shrink the register footprint
-// (3 accumulators + 6 staged 16-B window rows per lane), which is what lets 1024 threads (4 waves per SIMD)
-// fit in 128 VGPRs and hide LDS / memory latency.
+// with every wave in the same phase at the same time: the LDS pipe idles while the vector-memory pipe
+// issues the window loads and vice versa.  Here a tile is 16 x 8 pixels of the finest level (168 queries),
+// so two windows fit in LDS side by side (660 + 396 pixels at halo 6), and the 16 waves of a workgroup
+// are split into
+//     8 PRODUCER waves: wait for the staged loads of step s+1, write that window (into the region the
+//                       consumers are not reading) and its sample records, issue the loads of step s+2;
+//     8 CONSUMER waves: gathers of step s (LDS reads + packed FMAs), at the item's last level the
+//                       column reduction and the output stores;
+// with ONE workgroup barrier per step.  A step therefore costs max(producer, consumer) instead of their
+// sum, and the two pipes run side by side.
 //
 // Region plan (host, per geometry): step parity picks the region, A = the largest window, B = the second
 // largest.  With an odd number of levels the first step of every other item lands in B, so odd items visit
 // their levels in the order (1, 0, 2, ...) instead of (0, 1, 2, ...) -- the accumulators do not care.
+// Needs L >= 3 (the next item's query list is built two steps before its first sample loads).
 #include "msda_geometry.h"
 
 #ifdef UNIVS_MSDA_TRACE
@@ -26,11 +28,16 @@ __device__ unsigned long long g_msda_trace2[8192 * 16];
   do {                                                                                               \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_msda_trace2[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#define T2STAMPC(i)                                                                                  \
+  do {                                                                                               \
+    if (threadIdx.x == 512 && blockIdx.x < 8192) g_msda_trace2[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 extern "C" __attribute__((visibility("default"))) int univs_msda_trace2_read(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_msda_trace2), sizeof(unsigned long long) * 16 * n);
 }
 #else
 #define T2STAMP(i)
+#define T2STAMPC(i)
 #endif
 
 namespace univs {
@@ -38,13 +45,14 @@ namespace univs {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int T2_THREADS = 1024;
+constexpr int T2_HALF = T2_THREADS / 2;            // producer threads = consumer threads
 constexpr int T2_QCAP = 192;                       // max queries per tile
-constexpr int T2_NSMP = T2_QCAP * 4;               // sample records per level (<= T2_THREADS: one per thread)
-constexpr int T2_GROUPS = T2_THREADS / 16;         // 64 gather groups
-constexpr int T2_QMAX = T2_QCAP / T2_GROUPS;       // 3 queries per group
-constexpr int T2_OCTETS = T2_THREADS / 8;          // 128 copy octets
-constexpr int T2_WR = 6;                           // staged 16-B rows per lane: 768 window pixels
-static_assert(T2_NSMP <= T2_THREADS, "one sample record per thread");
+constexpr int T2_NSMP = T2_QCAP * 4;               // sample records per level
+constexpr int T2_GROUPS = T2_HALF / 16;            // 32 gather groups (consumers)
+constexpr int T2_QMAX = T2_QCAP / T2_GROUPS;       // 6 queries per group
+constexpr int T2_OCTETS = T2_HALF / 8;             // 64 copy octets (producers)
+constexpr int T2_WR = 11;                          // staged 16-B rows per producer lane: 704 window pixels
+constexpr int T2_SR = (T2_NSMP + T2_HALF - 1) / T2_HALF;   // 2 sample records per producer thread
 
 struct Tile2Geom {
   int tiles_y, tiles_x;
@@ -71,21 +79,11 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
   int* qgbuf = reinterpret_cast<int*>(lds + 2 * T2_NSMP);
   v4f* win_lds = lds + 2 * T2_NSMP + 2 * T2_QCAP / 4;
 
-  const int tid = threadIdx.x, lane8 = tid & 7, oct = tid >> 3;
+  const int tid = threadIdx.x;
+  const bool producer = tid < T2_HALF;             // waves 0..7 (wave-uniform)
+  const int ptid = tid & (T2_HALF - 1);            // index inside the role
+  const int lane8 = ptid & 7, oct = ptid >> 3;     // producers: 64 octets x 8 lanes
   const int ntiles = tg.tiles_y * tg.tiles_x;
-
-  // ---- 16-lane gather groups = the ds_read_b128 hardware lane groups (see msda_tiled.hip)
-  const int lane = tid & 63, hl = lane & 31;
-  const unsigned long long postab = hl < 16 ? 0x7654765432103210ull : 0xFEDCFEDCBA98BA98ull;
-  const int pos = (int)((postab >> ((hl & 15) * 4)) & 15);
-  const int g = (0xF00F0FF0u >> hl) & 1;
-  const int grp = (tid >> 6) * 4 + (lane >> 5) * 2 + g;        // 0 .. T2_GROUPS-1
-  const int side = pos >> 3, chunk = pos & 7;
-  const float xw_c0 = side ? 0.f : 1.f, xw_c1 = side ? 1.f : -1.f;
-  const int ppos = pos ^ 8;
-  const int phl = g ? (ppos < 8 ? ppos + 4 : ppos < 12 ? ppos + 8 : ppos + 16)
-                    : (ppos < 4 ? ppos : ppos < 8 ? ppos + 8 : ppos + 12);
-  const int partner = (lane & 32) | phl;
 
   // ---- this workgroup's items (XCD-chunked, fixed stride; see msda_tiled.hip)
   const unsigned nxcd = min(8u, gridDim.x);
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
   auto geo_y = [&](const Item& it, int l) __attribute__((always_inline)) {
     return geo[L * tg.tiles_x + l * tg.tiles_y + it.ty];
   };
-  auto fill_qglob = [&](const Item& it, int* qg) __attribute__((always_inline)) {
+  auto fill_qglob = [&](const Item& it, int* qg) __attribute__((always_inline)) {   // producers
     int pre[L + 1];
     int4 gxl[L], gyl[L];
     pre[0] = 0;
@@ -129,8 +127,8 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
       gyl[l] = geo_y(it, l);
       pre[l + 1] = pre[l] + gxl[l].y * gyl[l].y;
     }
-    if (tid < it.total) {
-      const int i = tid;
+    if (ptid < it.total) {
+      const int i = ptid;
       int li = i, qx0 = gxl[0].x, qnx = gxl[0].y, qy0 = gyl[0].x, Wq = lv.W[0], st = lv.start[0];
 #pragma unroll
       for (int j = 1; j < L; ++j)
@@ -156,190 +154,230 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
                                                (int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4), 0x00020000);
     return q;
   };
-  v4f wreg[T2_WR];
-  float2 sxy;
-  float sa;
-  auto load_windows = [&](const LevelGeo& q) __attribute__((always_inline)) {
-    if (tg.ablate & 1) return;
-    const unsigned pstride = (unsigned)(M * D * 4);
-    int ry = (int)(((float)oct + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));
-    int rx = oct - ry * q.ww;
-    unsigned off = (unsigned)((q.wy0 + ry) * q.W + q.wx0 + rx) * pstride + (unsigned)lane8 * 16u;
-    const unsigned step_n = (unsigned)(q.sy * q.W + q.sx) * pstride;
-    const unsigned step_c = (unsigned)((q.sy + 1) * q.W + q.sx - q.ww) * pstride;
-#pragma unroll
-    for (int u = 0; u < T2_WR; ++u) {
-      if (u * T2_OCTETS < q.npx) {   // uniform
-        const bool xin = (unsigned)(q.wx0 + rx) < (unsigned)q.W;
-        wreg[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(q.rsrc, xin ? off : 0x80000000u, 0, 0));
-        rx += q.sx;
-        const bool carry = rx >= q.ww;
-        rx -= carry ? q.ww : 0;
-        off += carry ? step_c : step_n;
-      }
-    }
-  };
-  auto load_sample = [&](const Item& it, const int* qg, int l) __attribute__((always_inline)) {
-    const int i = min(tid, it.total * 4 - 1);
-    const unsigned e = (unsigned)((qg[i >> 2] * M * L + l) * P + (i & 3));
-    sxy = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(loc + it.nm * (L * P * 2)) + e * 8u);
-    sa = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(attn + it.nm * (L * P)) + e * 4u);
-  };
-  auto commit = [&](const LevelGeo& q, int total, v4f* win, v4f* rec) __attribute__((always_inline)) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): explicit and unconditional, see msda_tiled.hip
-#pragma unroll
-    for (int u = 0; u < T2_WR; ++u) {
-      if (u * T2_OCTETS < q.npx) {   // uniform
-        const int j = oct + u * T2_OCTETS;
-        if (j < q.npx) win[j * 8 + lane8] = wreg[u];
-      }
-    }
-    const int wh = q.npx / max(q.ww, 1);
-    if (tid < total * 4) {
-      // reference: ms_deform_attn_cuda.cuh:285-293 (h_im, w_im, the (-1, H) x (-1, W) band)
-      const float him = sxy.y * (float)q.H - 0.5f, wim = sxy.x * (float)q.W - 0.5f;
-      const bool inimg = him > -1.f && wim > -1.f && him < (float)q.H && wim < (float)q.W;
-      const float hf = floorf(him), wf = floorf(wim);
-      const float lh = him - hf, lw = wim - wf;
-      const int r0 = (int)hf - q.wy0, c0 = (int)wf - q.wx0;
-      const bool inwin = (unsigned)r0 < (unsigned)(wh - 1) && (unsigned)c0 < (unsigned)(q.ww - 1);
-      const bool use = inimg && inwin;
-      const bool miss = inimg && !inwin && sa != 0.f;
-      const int slot = (use ? (r0 * q.ww + c0) * 8 : 0) | (miss ? (int)0x80000000 : 0);
-      rec[tid] = (v4f){__int_as_float(slot), use ? sa * (1.f - lh) : 0.f, use ? sa * lh : 0.f, use ? lw : 0.f};
-    }
-  };
-
-  // ---- prologue
-  Item cur = make_item(widx);
+  // ---- prologue: producers build step 0 completely and stage step 1
+  const Item first = make_item(widx);
   T2STAMP(13);
-  fill_qglob(cur, qgbuf);
+  if (producer) fill_qglob(first, qgbuf);
   __syncthreads();
-  LevelGeo geo_cur = level_geo(cur, tg.ord[0][0]);
-  load_windows(geo_cur);
-  load_sample(cur, qgbuf, geo_cur.l);
 
-  int par = 0;          // item parity: schedule row, query-id buffer
-  unsigned step = 0;    // global step counter: record buffer parity
-#pragma unroll 1
-  for (unsigned idx = widx, itn = 0;; idx += nw, ++itn) {
-    if (itn == 1) T2STAMP(0);
-    const bool has_next = idx + nw < csize;
-    const Item nxt_item = make_item(has_next ? idx + nw : idx);
-    const int* qg = qgbuf + par * T2_QCAP;
-    int* qg_next = qgbuf + (par ^ 1) * T2_QCAP;
-
-    v4f acc[T2_QMAX];
+  // Two separate loops (not one loop with a role branch inside): register allocation is per loop, so the
+  // producers' staging registers and the consumers' accumulators / gather temporaries do not add up.  Both
+  // loops execute exactly one barrier per step.
+  if (producer) {
+    // =========================== producers ===========================
+    v4f wreg[T2_WR];
+    float2 sxy[T2_SR];
+    float sa[T2_SR];
+    auto load_windows = [&](const LevelGeo& q) __attribute__((always_inline)) {
+      if (tg.ablate & 1) return;
+      const unsigned pstride = (unsigned)(M * D * 4);
+      int ry = (int)(((float)oct + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));
+      int rx = oct - ry * q.ww;
+      unsigned off = (unsigned)((q.wy0 + ry) * q.W + q.wx0 + rx) * pstride + (unsigned)lane8 * 16u;
+      const unsigned step_n = (unsigned)(q.sy * q.W + q.sx) * pstride;
+      const unsigned step_c = (unsigned)((q.sy + 1) * q.W + q.sx - q.ww) * pstride;
 #pragma unroll
-    for (int k = 0; k < T2_QMAX; ++k) acc[k] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int k = 0; k < L; ++k, ++step) {
-      const int l = geo_cur.l;
-      const int H = geo_cur.H, W = geo_cur.W;
-      const int rowstride = geo_cur.ww * 8;
-      v4f* win = win_lds + tg.reg[par][k];
-      v4f* rec = recbuf + (step & 1) * T2_NSMP;
-      const v4f* wl = win + pos;
-
-      if (itn == 1) T2STAMP(3 + 3 * k);
-#ifdef UNIVS_MSDA_TRACE
-      if (itn == 1 && k == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        T2STAMP(1);
+      for (int u = 0; u < T2_WR; ++u) {
+        if (u * T2_OCTETS < q.npx) {   // uniform
+          const bool xin = (unsigned)(q.wx0 + rx) < (unsigned)q.W;
+          wreg[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(q.rsrc, xin ? off : 0x80000000u, 0, 0));
+          rx += q.sx;
+          const bool carry = rx >= q.ww;
+          rx -= carry ? q.ww : 0;
+          off += carry ? step_c : step_n;
+        }
       }
-#endif
-      commit(geo_cur, cur.total, win, rec);
-#ifdef UNIVS_MSDA_TRACE
-      if (itn == 1 && k == 1) T2STAMP(2);
-#endif
-      if (k == L - 1 && has_next) fill_qglob(nxt_item, qg_next);
-      const bool do_loads = (k + 1 < L) || has_next;
-      // (k is a compile-time constant here: no run-time select between the two item structs, which would
-      // force both into scratch memory)
-      Item ld_item;
-      if (k + 1 < L) ld_item = cur; else ld_item = nxt_item;
-      const int ld_level = (k + 1 < L) ? tg.ord[par][(k + 1) % L] : tg.ord[par ^ 1][0];
-      const int* ld_qg = (k + 1 < L) ? qg : qg_next;
-      const LevelGeo geo_nxt = level_geo(ld_item, ld_level);   // (unused when nothing is left to load)
-      // the staging registers are free again: the next window's loads go out BEFORE the barrier, so that the
-      // barrier wait counts towards their latency (they do not depend on anything the barrier orders)
-      if (do_loads) load_windows(geo_nxt);
-      __syncthreads();   // the one barrier of the step: window + records of this step are complete
-      if (itn == 1) T2STAMP(4 + 3 * k);
-      if (do_loads) load_sample(ld_item, ld_qg, ld_level);   // (reads the query list filled above)
+    };
+    auto load_samples = [&](const Item& it, const int* qg, int l) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < T2_SR; ++s) {
+        const int i = min(ptid + s * T2_HALF, it.total * 4 - 1);
+        const unsigned e = (unsigned)((qg[i >> 2] * M * L + l) * P + (i & 3));
+        sxy[s] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(loc + it.nm * (L * P * 2)) + e * 8u);
+        sa[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(attn + it.nm * (L * P)) + e * 4u);
+      }
+    };
+    auto commit = [&](const LevelGeo& q, int total, v4f* win, v4f* rec) __attribute__((always_inline)) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): explicit and unconditional, see msda_tiled.hip
+#pragma unroll
+      for (int u = 0; u < T2_WR; ++u) {
+        if (u * T2_OCTETS < q.npx) {   // uniform
+          const int j = oct + u * T2_OCTETS;
+          if (j < q.npx) win[j * 8 + lane8] = wreg[u];
+        }
+      }
+      const int wh = q.npx / max(q.ww, 1);
+#pragma unroll
+      for (int s = 0; s < T2_SR; ++s) {
+        const int i = ptid + s * T2_HALF;
+        if (i < total * 4) {
+          // reference: ms_deform_attn_cuda.cuh:285-293 (h_im, w_im, the (-1, H) x (-1, W) band)
+          const float him = sxy[s].y * (float)q.H - 0.5f, wim = sxy[s].x * (float)q.W - 0.5f;
+          const bool inimg = him > -1.f && wim > -1.f && him < (float)q.H && wim < (float)q.W;
+          const float hf = floorf(him), wf = floorf(wim);
+          const float lh = him - hf, lw = wim - wf;
+          const int r0 = (int)hf - q.wy0, c0 = (int)wf - q.wx0;
+          const bool inwin = (unsigned)r0 < (unsigned)(wh - 1) && (unsigned)c0 < (unsigned)(q.ww - 1);
+          const bool use = inimg && inwin;
+          const bool miss = inimg && !inwin && sa[s] != 0.f;
+          const int slot = (use ? (r0 * q.ww + c0) * 8 : 0) | (miss ? (int)0x80000000 : 0);
+          rec[i] = (v4f){__int_as_float(slot), use ? sa[s] * (1.f - lh) : 0.f, use ? sa[s] * lh : 0.f, use ? lw : 0.f};
+        }
+      }
+    };
 
-      // ---- gathers: 16 lanes per query; per sample two 256-B spans (top pair, bottom pair)
+    Item cur = first;
+    {
+      const LevelGeo g0 = level_geo(cur, tg.ord[0][0]);
+      load_windows(g0);
+      load_samples(cur, qgbuf, g0.l);
+      commit(g0, cur.total, win_lds + tg.reg[0][0], recbuf);
+    }
+    LevelGeo geo_p = level_geo(cur, tg.ord[0][1]);          // the step held staged in registers
+    load_windows(geo_p);
+    load_samples(cur, qgbuf, geo_p.l);
+    __syncthreads();   // step 0 is ready for the consumers
+
+    int par = 0;
+    unsigned step = 0;
+#pragma unroll 1
+    for (unsigned idx = widx, itn = 0;; idx += nw, ++itn) {
+      if (itn == 1) T2STAMP(0);
+      const bool has_next = idx + nw < csize;
+      const Item nxt_item = make_item(has_next ? idx + nw : idx);
+      const int* qg = qgbuf + par * T2_QCAP;
+      int* qg_next = qgbuf + (par ^ 1) * T2_QCAP;
 #pragma unroll
-      for (int kq = 0; kq < T2_QMAX; ++kq) {
-        const int qi = grp + kq * T2_GROUPS;
-        if (qi < cur.total && !(tg.ablate & 4)) {
-          // two samples per batch: 6 LDS reads in flight per lane, 24 VGPRs (the 128-VGPR budget of 16 waves)
-          v4f a = acc[kq];
-          int sl[4];
+      for (int k = 0; k < L; ++k, ++step) {
+        // while the consumers gather step (cur, k): commit step + 1 (staged) and load step + 2
+        const bool valid1 = (k + 1 < L) || has_next, valid2 = (k + 2 < L) || has_next;
+        Item it1, it2;
+        if (k + 1 < L) it1 = cur; else it1 = nxt_item;
+        if (k + 2 < L) it2 = cur; else it2 = nxt_item;
+        const int par1 = (k + 1 < L) ? par : par ^ 1, k1 = (k + 1) % L;
+        const int par2 = (k + 2 < L) ? par : par ^ 1, k2 = (k + 2) % L;
+        const int* qg2 = (k + 2 < L) ? qg : qg_next;
+        const LevelGeo geo_n = level_geo(it2, tg.ord[par2][k2]);
+        if (itn == 1) T2STAMP(3 + 3 * k);
+        if (valid1) commit(geo_p, it1.total, win_lds + tg.reg[par1][k1], recbuf + ((step + 1) & 1) * T2_NSMP);
+        if (k == 0 && has_next) fill_qglob(nxt_item, qg_next);   // read two steps later (L >= 3)
+        if (valid2) {
+          load_windows(geo_n);
+          load_samples(it2, qg2, geo_n.l);
+        }
+        if (itn == 1) T2STAMP(4 + 3 * k);
+        __syncthreads();   // the one barrier of the step
+        if (itn == 1) T2STAMP(5 + 3 * k);
+        geo_p = geo_n;
+      }
+      if (itn == 1) T2STAMP(15);
+      if (!has_next) break;
+      cur = nxt_item;
+      par ^= 1;
+    }
+  } else {
+    // =========================== consumers ===========================
+    // 16-lane gather groups = the ds_read_b128 hardware lane groups (see msda_tiled.hip)
+    const int lane = tid & 63, hl = lane & 31;
+    const unsigned long long postab = hl < 16 ? 0x7654765432103210ull : 0xFEDCFEDCBA98BA98ull;
+    const int pos = (int)((postab >> ((hl & 15) * 4)) & 15);
+    const int g = (0xF00F0FF0u >> hl) & 1;
+    const int grp = (ptid >> 6) * 4 + (lane >> 5) * 2 + g;       // 0 .. T2_GROUPS-1
+    const int side = pos >> 3, chunk = pos & 7;
+    const float xw_c0 = side ? 0.f : 1.f, xw_c1 = side ? 1.f : -1.f;
+    const int ppos = pos ^ 8;
+    const int phl = g ? (ppos < 8 ? ppos + 4 : ppos < 12 ? ppos + 8 : ppos + 16)
+                      : (ppos < 4 ? ppos : ppos < 8 ? ppos + 8 : ppos + 12);
+    const int partner = (lane & 32) | phl;
+
+    Item cur = first;
+    __syncthreads();   // step 0 is ready
+    int par = 0;
+    unsigned step = 0;
+#pragma unroll 1
+    for (unsigned idx = widx, itn = 0;; idx += nw, ++itn) {
+      if (itn == 1) T2STAMPC(1);
+      const bool has_next = idx + nw < csize;
+      const int* qg = qgbuf + par * T2_QCAP;
+      v4f acc[T2_QMAX];
 #pragma unroll
-          for (int p0 = 0; p0 < 4; p0 += 2) {
-            v4f r[2], t[2], b[2];
+      for (int k = 0; k < T2_QMAX; ++k) acc[k] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < 2; ++p) r[p] = rec[qi * 4 + p0 + p];
+      for (int k = 0; k < L; ++k, ++step) {
+        // gathers of step (cur, k): 16 lanes per query, two 256-B spans per sample
+        const int l = tg.ord[par][k];
+        const int H = lv.H[l], W = lv.W[l];
+        const int rowstride = geo_x(cur, l).w * 8;
+        const v4f* rec = recbuf + (step & 1) * T2_NSMP;
+        const v4f* wl = win_lds + tg.reg[par][k] + pos;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              sl[p0 + p] = __float_as_int(r[p].x);
-              const v4f* base = wl + (sl[p0 + p] & 0x7fffffff);
+        for (int kq = 0; kq < T2_QMAX; ++kq) {
+          const int qi = grp + kq * T2_GROUPS;
+          if (qi < cur.total && !(tg.ablate & 4)) {
+            v4f r[4], t[4], b[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) r[p] = rec[qi * 4 + p];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const v4f* base = wl + (__float_as_int(r[p].x) & 0x7fffffff);
               t[p] = base[0];
               b[p] = base[rowstride];
             }
+            v4f a = acc[kq];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < 4; ++p) {
               const float xw = fmaf(xw_c1, r[p].w, xw_c0);
               a = fma4w(r[p].y * xw, t[p], a);
               a = fma4w(r[p].z * xw, b[p], a);
             }
-          }
-          const int s0 = sl[0], s1 = sl[1], s2 = sl[2], s3 = sl[3];
-          if ((s0 | s1 | s2 | s3) < 0 && !(tg.ablate & 8)) {
-            // rare: footprint(s) outside the staged window -> straight from global memory
-            const long long e = ((long long)qg[qi] * M * L + l) * P;
-            const v4f* vl = reinterpret_cast<const v4f*>(value + cur.nm * D) + (long long)lv.start[l] * (M * (D / 4)) + chunk;
+            const int s0 = __float_as_int(r[0].x), s1 = __float_as_int(r[1].x), s2 = __float_as_int(r[2].x),
+                      s3 = __float_as_int(r[3].x);
+            if ((s0 | s1 | s2 | s3) < 0 && !(tg.ablate & 8)) {
+              // rare: footprint(s) outside the staged window -> straight from global memory
+              const long long e = ((long long)qg[qi] * M * L + l) * P;
+              const v4f* vl = reinterpret_cast<const v4f*>(value + cur.nm * D) + (long long)lv.start[l] * (M * (D / 4)) + chunk;
 #pragma unroll 1
-            for (int p = 0; p < 4; ++p) {
-              const int slp = (p == 0) ? s0 : (p == 1) ? s1 : (p == 2) ? s2 : s3;
-              if (slp < 0) {
-                const float2 xy = reinterpret_cast<const float2*>(loc + cur.nm * (L * P * 2))[e + p];
-                const Footprint f = footprint(H, W, xy.x, xy.y, (attn + cur.nm * (L * P))[e + p]);
-                const int wc = side ? f.w1 : f.w0;
-                const v4f g0 = vl[(long long)(f.h0 * W + wc) * (M * (D / 4))];
-                const v4f g1 = vl[(long long)(f.h1 * W + wc) * (M * (D / 4))];
-                a = fma4w(side ? f.w01 : f.w00, g0, a);
-                a = fma4w(side ? f.w11 : f.w10, g1, a);
+              for (int p = 0; p < 4; ++p) {
+                const int slp = (p == 0) ? s0 : (p == 1) ? s1 : (p == 2) ? s2 : s3;
+                if (slp < 0) {
+                  const float2 xy = reinterpret_cast<const float2*>(loc + cur.nm * (L * P * 2))[e + p];
+                  const Footprint f = footprint(H, W, xy.x, xy.y, (attn + cur.nm * (L * P))[e + p]);
+                  const int wc = side ? f.w1 : f.w0;
+                  const v4f g0 = vl[(long long)(f.h0 * W + wc) * (M * (D / 4))];
+                  const v4f g1 = vl[(long long)(f.h1 * W + wc) * (M * (D / 4))];
+                  a = fma4w(side ? f.w01 : f.w00, g0, a);
+                  a = fma4w(side ? f.w11 : f.w10, g1, a);
+                }
               }
             }
+            acc[kq] = a;
           }
-          acc[kq] = a;
         }
-      }
-      geo_cur = geo_nxt;
-      if (itn == 1) T2STAMP(5 + 3 * k);
-    }
-
-    // ---- add the two corner columns (lane <-> partner lane) and store; the left lane writes the row
-    if (!(tg.ablate & 16))
+        if (k == L - 1 && !(tg.ablate & 16)) {
+          // add the two corner columns (lane <-> partner lane) and store; the left lane writes the row
 #pragma unroll
-    for (int kq = 0; kq < T2_QMAX; ++kq) {
-      v4f o = acc[kq];
-      o.x += __shfl(acc[kq].x, partner, 64);
-      o.y += __shfl(acc[kq].y, partner, 64);
-      o.z += __shfl(acc[kq].z, partner, 64);
-      o.w += __shfl(acc[kq].w, partner, 64);
-      const int qi = grp + kq * T2_GROUPS;
-      if (qi < cur.total && side == 0)
-        *reinterpret_cast<v4f*>(reinterpret_cast<char*>(out + cur.nm * D) +
-                                ((unsigned)(qg[qi] * M * D) * 4u + (unsigned)chunk * 16u)) = o;
+          for (int kq = 0; kq < T2_QMAX; ++kq) {
+            v4f o = acc[kq];
+            o.x += __shfl(acc[kq].x, partner, 64);
+            o.y += __shfl(acc[kq].y, partner, 64);
+            o.z += __shfl(acc[kq].z, partner, 64);
+            o.w += __shfl(acc[kq].w, partner, 64);
+            const int qi = grp + kq * T2_GROUPS;
+            if (qi < cur.total && side == 0)
+              *reinterpret_cast<v4f*>(reinterpret_cast<char*>(out + cur.nm * D) +
+                                      ((unsigned)(qg[qi] * M * D) * 4u + (unsigned)chunk * 16u)) = o;
+          }
+        }
+        if (itn == 1 && k == 0) T2STAMPC(2);
+        if (itn == 1 && k == 1) T2STAMPC(9);
+        __syncthreads();   // the one barrier of the step
+        if (itn == 1 && k == 0) T2STAMPC(6);
+        if (itn == 1 && k == 1) T2STAMPC(12);
+      }
+      if (!has_next) break;
+      cur = make_item(idx + nw);
+      par ^= 1;
     }
-    if (itn == 1) T2STAMP(15);
-    if (!has_next) break;
-    cur = nxt_item;
-    par ^= 1;
   }
   T2STAMP(14);
 }
@@ -356,7 +394,7 @@ static void launch_tiled2(unsigned grid, unsigned nitems, size_t lds, hipStream_
 // returns 1 if launched, 0 if preconditions do not hold (caller tries the next implementation), <0 on error
 int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const float* loc, const float* attn, int N,
                             int S, int M, int D, int L, int Lq, int P, float* out, hipStream_t st) {
-  if (D != 32 || P != 4 || L < 2 || L > 4 || Lq != S || M < 1) return 0;
+  if (D != 32 || P != 4 || L < 3 || L > 4 || Lq != S || M < 1) return 0;
   if ((long long)S * M * D * 4 >= (1LL << 31) || (long long)S * M * L * P * 8 >= (1LL << 31)) return 0;
   long long expect = 0;
   int fine = 0;
@@ -414,7 +452,6 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
   }
   const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", n_cu), 1));
   switch (L) {
-    case 2: launch_tiled2<2>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
     case 3: launch_tiled2<3>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
     default: launch_tiled2<4>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
   }
