@@ -191,7 +191,7 @@ def main():
                            "frac": alg / t_msda / HBM_PEAK, "traffic": None,
                            "avg_launch_us": t_msda * 1e6, "launches_per_step": len(msda_t.events) // args.steps,
                            "algorithmic_bytes_per_launch": alg}
-        res["roofline"]["kernel"] = "msda_fwd_tiled<3> (MSDeformAttn forward, LDS-tiled, persistent)"
+        res["roofline"]["kernel"] = "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)"
         # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
         # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
         try:
