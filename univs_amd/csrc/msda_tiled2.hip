@@ -8,9 +8,9 @@
 // issues the window loads and vice versa.  Here a tile is 16 x 8 pixels of the finest level (168 queries),
 // so two windows fit in LDS side by side (660 + 396 pixels at halo 6), and the 16 waves of a workgroup
 // are split into
-//     8 PRODUCER waves: wait for the staged loads of step s+1, write that window (into the region the
+//     6 PRODUCER waves: wait for the staged loads of step s+1, write that window (into the region the
 //                       consumers are not reading) and its sample records, issue the loads of step s+2;
-//     8 CONSUMER waves: gathers of step s (LDS reads + packed FMAs), at the item's last level the
+//     10 CONSUMER waves: gathers of step s (LDS reads + packed FMAs), at the item's last level the
 //                       column reduction and the output stores;
 // with ONE workgroup barrier per step.  A step therefore costs max(producer, consumer) instead of their
 // sum, and the two pipes run side by side.
@@ -30,7 +30,7 @@ __device__ unsigned long long g_msda_trace2[8192 * 16];
   } while (0)
 #define T2STAMPC(i)                                                                                  \
   do {                                                                                               \
-    if (threadIdx.x == 512 && blockIdx.x < 8192) g_msda_trace2[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 64 * UNIVS_MSDA_T2_PROD_WAVES && blockIdx.x < 8192) g_msda_trace2[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 extern "C" __attribute__((visibility("default"))) int univs_msda_trace2_read(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_msda_trace2), sizeof(unsigned long long) * 16 * n);
@@ -45,14 +45,20 @@ namespace univs {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int T2_THREADS = 1024;
-constexpr int T2_HALF = T2_THREADS / 2;            // producer threads = consumer threads
+#ifndef UNIVS_MSDA_T2_PROD_WAVES
+#define UNIVS_MSDA_T2_PROD_WAVES 6   // measured: 8 -> 175.6 us, 6 -> 169.7 us, 5 -> 194 us (spills)
+#endif
+constexpr int T2_PROD = 64 * UNIVS_MSDA_T2_PROD_WAVES;   // producer threads (waves 0 .. PROD_WAVES-1)
+constexpr int T2_CONS = T2_THREADS - T2_PROD;            // consumer threads
 constexpr int T2_QCAP = 192;                       // max queries per tile
 constexpr int T2_NSMP = T2_QCAP * 4;               // sample records per level
-constexpr int T2_GROUPS = T2_HALF / 16;            // 32 gather groups (consumers)
-constexpr int T2_QMAX = T2_QCAP / T2_GROUPS;       // 6 queries per group
-constexpr int T2_OCTETS = T2_HALF / 8;             // 64 copy octets (producers)
-constexpr int T2_WR = 11;                          // staged 16-B rows per producer lane: 704 window pixels
-constexpr int T2_SR = (T2_NSMP + T2_HALF - 1) / T2_HALF;   // 2 sample records per producer thread
+constexpr int T2_GROUPS = T2_CONS / 16;            // gather groups (consumers)
+constexpr int T2_QMAX = (T2_QCAP + T2_GROUPS - 1) / T2_GROUPS;   // queries per group
+constexpr int T2_OCTETS = T2_PROD / 8;             // copy octets (producers)
+constexpr int T2_WIN_PX = 704;                     // window capacity in pixels (a 30 x 22 window = 660)
+constexpr int T2_WR = (T2_WIN_PX + T2_OCTETS - 1) / T2_OCTETS;   // staged 16-B rows per producer lane
+constexpr int T2_SR = (T2_NSMP + T2_PROD - 1) / T2_PROD;         // sample records per producer thread
+static_assert(T2_QCAP <= T2_PROD, "one query id per producer thread");
 
 struct Tile2Geom {
   int tiles_y, tiles_x;
@@ -80,8 +86,8 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
   v4f* win_lds = lds + 2 * T2_NSMP + 2 * T2_QCAP / 4;
 
   const int tid = threadIdx.x;
-  const bool producer = tid < T2_HALF;             // waves 0..7 (wave-uniform)
-  const int ptid = tid & (T2_HALF - 1);            // index inside the role
+  const bool producer = tid < T2_PROD;             // the first waves (wave-uniform)
+  const int ptid = producer ? tid : tid - T2_PROD;   // index inside the role
   const int lane8 = ptid & 7, oct = ptid >> 3;     // producers: 64 octets x 8 lanes
   const int ntiles = tg.tiles_y * tg.tiles_x;
 
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
     auto load_samples = [&](const Item& it, const int* qg, int l) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < T2_SR; ++s) {
-        const int i = min(ptid + s * T2_HALF, it.total * 4 - 1);
+        const int i = min(ptid + s * T2_PROD, it.total * 4 - 1);
         const unsigned e = (unsigned)((qg[i >> 2] * M * L + l) * P + (i & 3));
         sxy[s] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(loc + it.nm * (L * P * 2)) + e * 8u);
         sa[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(attn + it.nm * (L * P)) + e * 4u);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(T2_THREADS) void msda_fwd_tiled2(const float* __res
       const int wh = q.npx / max(q.ww, 1);
 #pragma unroll
       for (int s = 0; s < T2_SR; ++s) {
-        const int i = ptid + s * T2_HALF;
+        const int i = ptid + s * T2_PROD;
         if (i < total * 4) {
           // reference: ms_deform_attn_cuda.cuh:285-293 (h_im, w_im, the (-1, H) x (-1, W) band)
           const float him = sxy[s].y * (float)q.H - 0.5f, wim = sxy[s].x * (float)q.W - 0.5f;
@@ -408,7 +414,7 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
   const int TH = env_int("UNIVS_MSDA_TILE2_H", 8), TW = env_int("UNIVS_MSDA_TILE2_W", 16);
   const int R = env_int("UNIVS_MSDA_HALO", 6);
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
-  const long long cap_px = (long long)T2_WR * T2_OCTETS;
+  const long long cap_px = std::min<long long>(T2_WIN_PX, (long long)T2_WR * T2_OCTETS);
   const GeoEntry* ge = geometry(lv, L, fine, TH, TW, R, cap_px);
   if (!ge || ge->qmax > T2_QCAP) return 0;
 
