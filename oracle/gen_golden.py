@@ -411,6 +411,73 @@ def g14_cfg4_full_size():
     save("g14_cfg4_full_size", **d)
 
 
+@gen
+def g11c_clip_loop_vss():
+    """semantic sub-task ('vss': non-overlapping clips, per-clip class x mask maps) on the scripted scene"""
+    RI = rh.ref_inference()
+    case = cases.SCRIPT_CASE
+    kw = cases.loop_kwargs(case)
+    kw.update(overlap_threshold=0.0, metadata=None, LSJ_aug_image_size=1024, LSJ_aug_enable_test=False,
+              sem_seg_postprocess_before_inference=False, num_classes=133, data_name="vspw_vss_video_dev",
+              prompt_as_queries=True, zero_shot_inference=False, semantic_on=True, instance_on=False,
+              panoptic_on=False, tracker_type="", window_inference=False, is_multi_cls=True, merge_on_cpu=False,
+              num_max_inst_test=50, output_dir="/tmp")
+    inf = RI.InferenceVideoEntity(**kw)
+    calls = []
+    head = cases.ScriptedHead()
+
+    def hooked(features, targets=None, **k):
+        calls.append(int(targets[0]["first_frame_idx"]))
+        return head(features, targets=targets, **k)
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(), sem_seg_head=hooked)
+    x = cases.preprocess(cases.loop_frames(case))
+    images = types.SimpleNamespace(tensor=x, image_sizes=[case["image_size"]] * case["n_frames"])
+    targets = cases.loop_targets(case)
+    targets[0]["sub_task"] = "vss"
+    targets[0]["dataset_name"] = "vspw_vss_video_dev"
+    res = inf.inference_video(model, cases.loop_batched_inputs(case), images, targets)
+    print("   clips at", calls, "sem map", tuple(res["pred_masks"].shape), "classes", res["pred_masks"].unique().tolist())
+    save("g11c_clip_loop_vss", pred_masks=res["pred_masks"], clip_first_frames=torch.tensor(calls))
+
+
+@gen
+def g11d_clip_loop_vps():
+    """panoptic sub-task ('vps') on the scripted scene: thing / stuff de-duplication, segment-id memory"""
+    RI = rh.ref_inference()
+    case = cases.SCRIPT_CASE
+    kw = cases.loop_kwargs(case)
+    meta = types.SimpleNamespace(thing_dataset_id_to_contiguous_id={c: i for i, c in enumerate(cases.SCRIPT_THING_IDS)})
+    kw.update(overlap_threshold=0.4, metadata=meta, LSJ_aug_image_size=1024, LSJ_aug_enable_test=False,
+              sem_seg_postprocess_before_inference=False, num_classes=133, data_name="vipseg_panoptic_val",
+              prompt_as_queries=True, zero_shot_inference=False, semantic_on=False, instance_on=False,
+              panoptic_on=True, tracker_type="", window_inference=False, is_multi_cls=True, merge_on_cpu=False,
+              num_max_inst_test=50, output_dir="/tmp")
+    inf = RI.InferenceVideoEntity(**kw)
+    dumps, calls = {}, []
+    head = cases.ScriptedHead()
+
+    def hooked(features, targets=None, **k):
+        tv = targets[0]
+        for key in LOOP_STATE_KEYS:
+            if key in tv:
+                v = tv[key].detach().clone()
+                dumps[f"clip{len(calls)}_in_{key}"] = v.float() if v.dtype == torch.bool else v
+        calls.append(int(tv["first_frame_idx"]))
+        return head(features, targets=targets, **k)
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(), sem_seg_head=hooked)
+    x = cases.preprocess(cases.loop_frames(case))
+    images = types.SimpleNamespace(tensor=x, image_sizes=[case["image_size"]] * case["n_frames"])
+    targets = cases.loop_targets(case)
+    targets[0].update(sub_task="vps", dataset_name="vipseg_panoptic_val")
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = inf.inference_video(model, cases.loop_batched_inputs(case), images, targets)
+    infos = sorted((d["id"], int(d["isthing"]), d["category_id"]) for d in res["segments_infos"])
+    print("   clips at", calls, "panoptic", tuple(res["pred_masks"].shape), "segments", infos)
+    save("g11d_clip_loop_vps", pred_masks=res["pred_masks"], segments_infos=np.array(infos, dtype=np.int64),
+         clip_first_frames=torch.tensor(calls), **dumps)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

@@ -372,3 +372,7 @@ CFG4_DECODER = dict(text_to_image=True, sa_mask="sep-blocked")
 def cfg4_targets(case=CFG4):
     tv = targets_grounding(case, n_exp=case["n_exp"])[0]
     return [tv]
+
+
+# panoptic sub-task on the scripted scene: categories (1-based) of objects 0, 3, 4 are "things", the others "stuff"
+SCRIPT_THING_IDS = (4, 10, 2)

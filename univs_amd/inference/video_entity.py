@@ -17,8 +17,8 @@ Everything stays on the device of the inputs; the only host round trip per clip 
 solve on the [entities x queries] similarity matrix (as in the reference, scipy).  The per-query
 Python loop of the reference's new-entity test (:640-645) is one batched mask-IoU here.
 
-Sub-tasks: 'vis' and 'entity_vis_*' (instance-style).  The panoptic / semantic variants ('vps', 'vss')
-are not part of this round's scope and raise NotImplementedError.
+Sub-tasks: 'vis' / 'entity_vis_*' (instance-style), 'vps' (panoptic: things + stuff, segment ids remembered in
+`targets[0]`) and 'vss' (semantic: per-clip class x mask maps, no entity bookkeeping).
 """
 import math
 from typing import Tuple
@@ -96,6 +96,8 @@ class InferenceVideoEntity(nn.Module):
         detect_newly_interval_frames: int = 1,
         custom_videos_enable: bool = False,
         dataset_category_info=None,
+        overlap_threshold: float = 0.0,
+        thing_dataset_ids=(),
     ):
         super().__init__()
         self.hidden_dim = hidden_dim
@@ -119,6 +121,9 @@ class InferenceVideoEntity(nn.Module):
         self.detect_newly_interval_frames = detect_newly_interval_frames
         self.num_prev_frames_memory = num_prev_frames_memory
         self.custom_videos_enable = custom_videos_enable
+        self.overlap_threshold = overlap_threshold
+        # category ids (1-based, as the reference's metadata.thing_dataset_id_to_contiguous_id keys) that are "things"
+        self.thing_dataset_ids = frozenset(int(c) for c in thing_dataset_ids)
         self.video_unified_inference_entities = video_unified_inference_entities
         # {dataset name: (num_classes, start index)} slices of the class-embedding table; None = no slicing
         self.dataset_category_info = COMBINED_DATASETS_CATEGORY_INFO if dataset_category_info is None else dataset_category_info
@@ -147,6 +152,7 @@ class InferenceVideoEntity(nn.Module):
             "detect_newly_interval_frames": test.DETECT_NEWLY_INTERVAL_FRAMES,
             "custom_videos_enable": test.CUSTOM_VIDEOS_ENABLE,
             "dataset_category_info": dataset_category_info,
+            "overlap_threshold": cfg.MODEL.MASK_FORMER.TEST.OVERLAP_THRESHOLD,
         }
 
     @property
@@ -188,15 +194,15 @@ class InferenceVideoEntity(nn.Module):
         x = images.tensor
         tv = targets[0]
         sub_task = tv["sub_task"]
-        if "vis" not in sub_task:
-            raise NotImplementedError(f"sub_task {sub_task!r}: only the instance-style ('vis') clip loop is built")
+        if not any(t in sub_task for t in ("vis", "vss", "vps")):
+            raise ValueError(f"Not support to eval the sub-task {sub_task!r} yet")
         n_total = len(x)
         video_len = int(batched_inputs[0]["video_len"])
         interim_size = tuple(x.shape[-2:])
         image_size = tuple(images.image_sizes[0])
         out_size = (batched_inputs[0].get("height", image_size[0]), batched_inputs[0].get("width", image_size[1]))
         T = self.num_frames
-        stride = min(self.clip_stride, T)
+        stride = min(T if "vss" in sub_task else self.clip_stride, T)   # semantic: non-overlapping clips (:299-300)
 
         results = []
         is_last = False
@@ -229,16 +235,24 @@ class InferenceVideoEntity(nn.Module):
             out_learn = {k: v[: self.num_queries] for k, v in out.items()}
             out_prompt = {k: v[self.num_queries:] for k, v in out.items()}
 
+            if "vss" in sub_task:
+                # semantic segmentation needs no entity bookkeeping: classes x masks of the learnable queries
+                results.append(self.save_results_vss(i, out_learn, interim_size, image_size, out_size, is_last, stride))
+                continue
             # 1. entities already in the pool: accumulate this clip's predictions of their prompt queries
             self.write_prompt_predictions_into_annotations_per_clip(i, out_prompt, targets, interim_size, image_size, stride)
             # 2. new entities from the learnable queries
             if i % self.detect_newly_interval_frames == 0 or tv["masks"].nelement() == 0:
-                self.detect_newly_entities_per_clip_instance(out_learn, targets, interim_size)
+                if "vis" in sub_task:
+                    self.detect_newly_entities_per_clip_instance(out_learn, targets, interim_size)
+                else:
+                    self.detect_newly_entities_per_clip_pixel(out_learn, targets, interim_size)
                 self.write_newly_entities_into_annotations_per_clip(i, out_learn, targets, interim_size)
             # 3. emit finished frames
             is_out = i > self.num_prev_frames_memory and i % self.num_frames_window_output == self.num_prev_frames_memory
             if is_out or is_last:
-                results.append(self.save_results_vis(i, targets, interim_size, image_size, out_size, is_last))
+                save = self.save_results_vis if "vis" in sub_task else self.save_results_vps
+                results.append(save(i, targets, interim_size, image_size, out_size, is_last))
                 w = self.num_frames_window_output
                 tv["mask_logits"] = tv["mask_logits"][:, w:]
                 tv["masks"] = tv["masks"][:, w:]
@@ -246,6 +260,10 @@ class InferenceVideoEntity(nn.Module):
             # 4. room for the next clip's new frames
             if not is_last and "masks" in tv:
                 self.pad_zero_annotations_for_next_clip(targets, min(stride, video_len - i - T))
+        if "vss" in sub_task:
+            return self.vss_output_results(targets, results, out_size)
+        if "vps" in sub_task:
+            return self.vps_output_results(targets, results, out_size)
         return results
 
     # ------------------------------------------------------------------------------------------
@@ -372,6 +390,78 @@ class InferenceVideoEntity(nn.Module):
                       ("mask_quality_scores", quality)):
             out_learn[k_] = v[new]
 
+    def detect_newly_entities_per_clip_pixel(self, out_learn, targets, interim_size):
+        """Panoptic variant (inference_video_entity.py:654-765): things are de-duplicated by box IoU, stuff by the
+        mask IoU of the first frame; matched entities always absorb the learnable queries' masks."""
+        tv = targets[0]
+        first = "masks" not in tv
+        logits = out_learn["pred_logits"].float()
+        masks = out_learn["pred_masks"].float()
+        embds = out_learn["pred_embds"].float()
+        h, w = masks.shape[-2:]
+        T = masks.shape[1]
+        boxes = convert_mask_to_box(masks > 0) / torch.as_tensor([w, h, w, h], device=masks.device)
+        quality = calculate_mask_quality_scores(masks)
+        logits = logits * quality.view(-1, 1)
+        scores, labels = logits.max(-1)
+
+        if first:
+            order = scores.sort(descending=True)[1][:100]
+            isthing = torch.as_tensor([int(c) + 1 in self.thing_dataset_ids for c in labels[order].tolist()],
+                                      dtype=torch.bool, device=order.device)
+            things, stuff = order[isthing], order[~isthing]
+            if len(things):
+                things = things[:70]
+                biou = video_box_iou(boxes[things], boxes[things])[0].max(-1)[0]
+                things = things[torch.triu(biou, diagonal=1).max(0)[0] < self.box_nms_thresh]
+            if len(stuff):
+                stuff = stuff[:30]
+                m0 = masks[stuff][:, 0].gt(0.0).float().unsqueeze(0)
+                miou = batched_mask_iou(m0, m0).max(0)[0]
+                stuff = stuff[torch.triu(miou, diagonal=1).max(0)[0] < 0.6]
+            new = torch.cat([things, stuff])
+            new = new[scores[new] > self.apply_cls_thres]
+        else:
+            gt_embds = tv["embds"]
+            tgt = gt_embds[:, -3:]
+            if self.use_quasi_track:
+                sim = torch.einsum("ntc,mfc->nmtf", tgt, embds).flatten(2)
+                sim = (sim.softmax(1) + sim.softmax(0)).mean(-1) / 2.0
+                sim = torch.where(sim < self.detect_newly_object_threshold, torch.zeros_like(sim), sim)
+                rows, cols = linear_sum_assignment((1 - sim).cpu())
+                rows = torch.as_tensor(rows, device=sim.device)
+                cols = torch.as_tensor(cols, device=sim.device)
+                msim = sim[rows, cols]
+            else:
+                (rows, cols), msim = match_from_learnable_embds(tgt, embds, return_similarity=True, return_src_indices=True,
+                                                                use_norm=False, thresh=self.detect_newly_object_threshold)
+                rows = torch.as_tensor(rows, device=msim.device)
+                cols = torch.as_tensor(cols, device=msim.device)
+            ok = msim > self.detect_newly_object_threshold
+            r, c = rows[ok], cols[ok]
+            m = _resize(masks[c], interim_size)
+            tv["mask_logits"][r, -T:] += m
+            tv["occurrence"][r, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
+            tv["logits"][r, -1] = 0.5 * (tv["logits"][r, -1] + logits[c])
+            last = gt_embds[r, -1]
+            gt_embds[r, -1] = (last + embds[c].mean(1)) / ((last != 0).any(-1)[..., None] + 1.0)
+            tv["mask_quality_scores"][r] += quality[c]
+            tv["masks"] = tv["mask_logits"].gt(0.0).float()
+
+            known = _resize(tv["mask_logits"][:, -T:], masks.shape[-2:]).transpose(0, 1).gt(0.0)   # [T, N, h, w]
+            cand = torch.ones(len(masks), dtype=torch.bool, device=masks.device)
+            cand[c] = False
+            cand &= scores > 2 * self.apply_cls_thres
+            if known.shape[1] > 0 and len(masks) > 0:
+                cand &= batched_mask_iou(masks.transpose(0, 1).gt(0.0), known).amax(dim=(0, 2)) < 0.5
+            else:
+                cand &= False
+            new = cand.nonzero(as_tuple=True)[0]
+
+        for k_, v in (("pred_logits", logits), ("pred_masks", masks), ("pred_embds", embds), ("pred_boxes", boxes),
+                      ("mask_quality_scores", quality)):
+            out_learn[k_] = v[new]
+
     def write_newly_entities_into_annotations_per_clip(self, first_frame_idx, out, targets, interim_size):
         tv = targets[0]
         dev = out["pred_masks"].device
@@ -436,6 +526,85 @@ class InferenceVideoEntity(nn.Module):
             "embds": torch.cat([tv["embds"], tv["embds"][:, -3:].mean(dim=1, keepdim=True)], dim=1),
             "occurrence": torch.cat([tv["occurrence"], torch.zeros((n, stride), device=dev)], dim=1),
         })
+
+    def save_results_vps(self, first_frame_idx, targets, interim_size, image_size, out_size, is_last):
+        """Panoptic map of the finished frames (inference_video_entity.py:962-1053): every pixel goes to the entity
+        with the highest score x logit, things keep an id per entity, stuff one id per class (both remembered in
+        `targets[0]` across calls).  The area tests run on the device for all entities at once; the segment-id
+        bookkeeping (a few dict updates per entity) stays on the host as in the reference."""
+        tv = targets[0]
+        masks, ids = tv["mask_logits"], tv["ids"]
+        if not is_last:
+            masks = masks[:, : self.num_frames_window_output]
+        masks = masks[:, :, : image_size[0], : image_size[1]]
+        masks = _resize(masks.float(), out_size) if masks.numel() else masks.new_zeros(masks.shape[:2] + tuple(out_size))
+        if "stuff_memory_list" not in tv:
+            tv["thing_memory_list"], tv["stuff_memory_list"] = {}, {}
+        things_mem, stuff_mem = tv["thing_memory_list"], tv["stuff_memory_list"]
+        known_ids = list(things_mem.values()) + list(stuff_mem.values())
+
+        scores, classes = tv["logits"].mean(1).max(-1)
+        classes = (classes + 1).tolist()                       # category labels start from 1
+        scores = scores * calculate_mask_quality_scores(masks)
+        is_thing = [c in self.thing_dataset_ids for c in classes]
+        demote = torch.tensor([0.75 if (k not in things_mem and not is_thing[k]) else 1.0 for k in range(len(classes))],
+                              device=scores.device, dtype=scores.dtype)
+        scores = scores * demote                               # things win ties against stuff
+        n, t = masks.shape[:2]
+        panoptic = torch.zeros((t, out_size[0], out_size[1]), dtype=torch.int32, device=masks.device)
+        if n == 0:
+            return panoptic.cpu()
+        assert int(ids.min()) == 0 and int(ids.max()) == len(ids) - 1
+        owner = (scores.view(-1, 1, 1, 1) * masks).argmax(0)   # [t, h, w]
+        prob = masks.sigmoid()
+        owner = torch.where((prob < 0.5).all(0), torch.full_like(owner, -1), owner)
+        onehot = owner[None] == torch.arange(n, device=owner.device).view(-1, 1, 1, 1)
+        fg = prob >= 0.5
+        area = onehot.flatten(1).sum(1).tolist()
+        orig = fg.flatten(1).sum(1).tolist()
+        inter = (onehot & fg).flatten(1).sum(1).tolist()
+        seg_of = [0] * n
+        nxt = max(known_ids) + 1 if known_ids else 0
+        for k in range(n):
+            if not (area[k] > 0 and orig[k] > 0 and inter[k] > 0):
+                continue
+            obj = int(ids[k])
+            thr = 0.5 * self.overlap_threshold if obj in things_mem else self.overlap_threshold
+            if is_thing[k] and area[k] / orig[k] < thr:
+                continue
+            mem, key = (things_mem, obj) if is_thing[k] else (stuff_mem, classes[k])
+            if key not in mem:
+                mem[key] = nxt + 1
+                nxt += 1
+            seg_of[k] = mem[key]
+        table = torch.tensor(seg_of + [0], dtype=torch.int32, device=masks.device)    # owner -1 -> 0
+        keep = torch.gather(fg, 0, owner.clamp(min=0)[None])[0] & (owner >= 0)
+        panoptic = torch.where(keep, table[owner], panoptic)
+        return panoptic.cpu()
+
+    def vps_output_results(self, targets, panoptic_seg_list, out_size):
+        tv = targets[0]
+        classes = (tv["logits"].mean(1).max(-1)[1] + 1).tolist()
+        infos = [{"id": seg, "isthing": classes[obj] in self.thing_dataset_ids, "category_id": int(classes[obj])}
+                 for obj, seg in tv["thing_memory_list"].items()]
+        infos += [{"id": seg, "isthing": False, "category_id": int(cls_)} for cls_, seg in tv["stuff_memory_list"].items()]
+        return {"image_size": out_size, "pred_masks": torch.cat(panoptic_seg_list, dim=0).cpu(), "segments_infos": infos,
+                "task": "vps"}
+
+    def save_results_vss(self, first_frame_idx, output, interim_size, image_size, out_size, is_last, stride):
+        """Per-clip semantic map (inference_video_entity.py:1086-1113): quality-weighted class probabilities
+        times mask probabilities, argmax over classes.  [T', H_out, W_out] int64 on the host."""
+        logits, masks = output["pred_logits"], output["pred_masks"]
+        if not is_last:
+            masks = masks[:, :stride]
+        masks = _resize(masks, interim_size)[:, :, : image_size[0], : image_size[1]]
+        masks = F.interpolate(masks.float(), size=out_size, mode="nearest")
+        logits = logits * calculate_mask_quality_scores(masks).view(-1, 1)
+        semseg = torch.einsum("qc,qthw->cthw", logits, masks.sigmoid())
+        return semseg.argmax(0).cpu()
+
+    def vss_output_results(self, targets, sem_mask_list, out_size):
+        return {"image_size": out_size, "pred_masks": torch.cat(sem_mask_list, dim=0).cpu(), "task": "vss"}
 
     def save_results_vis(self, first_frame_idx, targets, interim_size, image_size, out_size, is_last):
         tv = targets[0]
