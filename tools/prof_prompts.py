@@ -1,0 +1,30 @@
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from tests import cases
+dev = torch.device("cuda:0")
+swin, head = bench.build_model(dev)
+case = dict(cases.CFG2, H=736, W=1280)
+x = cases.preprocess(cases.cfg2_frames()).to(dev)
+tv0 = cases.targets_with_entities(case, first_frame_idx=1, n_ent=10)[0]
+mk = lambda: [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in tv0.items()}]
+from torch.profiler import ProfilerActivity, profile
+with torch.no_grad():
+    feats = swin(x)
+    for _ in range(2):
+        head(feats, targets=mk())
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+        t0 = time.perf_counter()
+        head(feats, targets=mk())
+        torch.cuda.synchronize()
+        print("wall ms", 1e3 * (time.perf_counter() - t0))
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    t = getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
+    if t > 150:
+        rows.append((t, e.key, e.count, str(e.input_shapes)[:100]))
+rows.sort(reverse=True)
+for t, k, c, sh in rows[:40]:
+    print(f"{t / 1e3:8.3f} ms  {k[:40]:40s} x{c:<4d} {sh}")

@@ -61,6 +61,30 @@ def convert_mask_to_box(masks):
     return out.reshape(*shape[:-2], 4) if len(shape) > 2 else out[0]
 
 
+def _kth_true(mask, ranks):
+    """mask [n, L] bool, ranks [n, R] int64 (0-based, < row count) -> flat index of the rank-th True of every
+    row, in raster order -- `nonzero(mask[k])[rank]` for all rows at once, without the host round trip of
+    `nonzero` (cumulative count + binary search)."""
+    cs = torch.cumsum(mask, dim=1, dtype=torch.int32)
+    return torch.searchsorted(cs, (ranks + 1).to(torch.int32), right=False).clamp(max=mask.shape[1] - 1)
+
+
+def _kth_true_2d(mask, ranks, rowcnt=None):
+    """Same for image-shaped masks [n, H, W] (full-resolution entity masks): first the image row that holds the
+    rank-th True (per-row counts, a scan over H), then the column inside that row (a scan over W) -- two short scans
+    instead of one over H*W elements per entity.  Returns flat indices y * W + x, [n, R]."""
+    n, H, W = mask.shape
+    rowcnt = mask.sum(2, dtype=torch.int32) if rowcnt is None else rowcnt
+    rc = torch.cumsum(rowcnt, dim=1, dtype=torch.int32)                                   # [n, H] inclusive
+    r1 = (ranks + 1).to(torch.int32)
+    y = torch.searchsorted(rc, r1, right=False).clamp(max=H - 1)                             # [n, R]
+    before = torch.where(y > 0, torch.gather(rc, 1, (y - 1).clamp(min=0)), torch.zeros_like(y, dtype=torch.int32))
+    rows = torch.gather(mask, 1, y[:, :, None].expand(-1, -1, W))                           # [n, R, W]
+    cs = torch.cumsum(rows, dim=2, dtype=torch.int32)
+    x = torch.searchsorted(cs, (r1 - before)[:, :, None].contiguous(), right=False).squeeze(-1).clamp(max=W - 1)
+    return y * W + x
+
+
 class VisualPromptEncoder:
     def __init__(self, pretrain_img_size=1024, hidden_dim=256, num_frames=1, num_dense_points=32,
                  position_embedding_sin3d_type="FixedT"):
@@ -125,15 +149,22 @@ class VisualPromptEncoder:
         h_img, w_img = img_features.shape[-2:]
         device = img_features.device
         assert masks.dim() == 3, f"Mask shape shoule be num_instsxHxW, but get {masks.shape}"
-        valid = masks.gt(mask_thresh).flatten(1).sum(-1) > 0
+        valid = masks.amax(2).amax(1) > mask_thresh          # some pixel above the threshold (two short reductions)
         n, h, w = masks.shape
-        point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes)
-        query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
         s = self.img_feats_scale
         img_masks = torch.zeros((n, h_img * s, w_img * s), device=masks.device)
         img_masks[:, :h, :w] = masks.float()
         feat_masks = F.interpolate(img_masks.unsqueeze(1), (h_img, w_img), mode="nearest").squeeze(1)
-        feat_masks_binary = feat_masks >= min(mask_thresh, feat_masks.max())
+        feat_masks_binary = feat_masks >= feat_masks.max().clamp(max=mask_thresh)
+        # ONE host round trip per call: the pixel counts that size the reference's randperm calls (point selection,
+        # then dense tokens -- generated on the host in exactly that order)
+        assert (h_img * s == h) and (w_img * s == w), \
+            f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
+        sel, rowcnt = self._select_candidates(masks, boxes)
+        counts = torch.cat([rowcnt.sum(1), feat_masks_binary.flatten(1).sum(1).to(torch.int32)]).tolist()
+        point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
+                                                        _prepared=(sel, rowcnt, counts[:n]))
+        query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
         fw = feat_masks * feat_masks_binary
         pf = torch.einsum("qn,nc->qc", fw.flatten(-2).float(), img_features.flatten(-2).t())
         pf = pf / fw.sum((-2, -1)).clamp(min=mask_thresh)[:, None]
@@ -146,11 +177,11 @@ class VisualPromptEncoder:
         fd, pd = query_feats[:, None], query_pe[:, None]
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
-                                             prompt_type="masks", is_train=is_train)
-        if (~valid).any():
-            pd = pd * valid.view(-1, 1, 1, 1).float()
-            fd = fd * valid.view(-1, 1, 1, 1).float()
-            attn[:, :, ~valid] = False
+                                             prompt_type="masks", is_train=is_train, _counts=counts[n:])
+        # invalid (empty) entities: zero tokens, nothing masked (unconditional: no host round trip for `.any()`)
+        pd = pd * valid.view(-1, 1, 1, 1).float()
+        fd = fd * valid.view(-1, 1, 1, 1).float()
+        attn = attn & valid.view(1, 1, -1, 1)
         return point_coords, pd, fd, attn
 
     @torch.no_grad()
@@ -184,8 +215,31 @@ class VisualPromptEncoder:
         return point_coords, pd, fd, attn
 
     @torch.no_grad()
+    def _select_candidates(self, masks, boxes, mask_thresh=0.75):
+        """Device part of the mask branch of `select_points_from_box_mask`: the candidate pixels of every entity
+        ([n, h, w] bool) and their per-row counts ([n, h] int32)."""
+        n, h, w = masks.shape
+        device = masks.device
+        masks = masks.float()
+        if boxes is None:
+            boxes = convert_mask_to_box(masks > mask_thresh) / torch.as_tensor([w, h, w, h], device=device).view(1, -1)
+        bc = box_xyxy_to_cxcywh(boxes).to(device)
+        mx = masks.amax(2).amax(1)                            # two-stage: rows of H*W elements reduce slowly
+        masks_binary = masks >= mx.clamp(max=mask_thresh).view(-1, 1, 1)
+        # pixel centres within the central half of the box (|c - centre| < w/4, h/4), separably
+        xs = (torch.arange(w, device=device, dtype=torch.float32) + 0.5) / w
+        ys = (torch.arange(h, device=device, dtype=torch.float32) + 0.5) / h
+        in_x = torch.abs(xs[None] - bc[:, None, 0]) < 0.25 * bc[:, None, 2]
+        in_y = torch.abs(ys[None] - bc[:, None, 1]) < 0.25 * bc[:, None, 3]
+        in_ctr = in_y[:, :, None] & in_x[:, None, :] & masks_binary
+        # entities without a central pixel fall back to their most confident pixels
+        hi = masks >= mx.clamp(max=0.95).view(-1, 1, 1)
+        sel = torch.where(in_ctr.any(2).any(1).view(-1, 1, 1), in_ctr, hi)
+        return sel, sel.sum(2, dtype=torch.int32)
+
+    @torch.no_grad()
     def select_points_from_box_mask(self, h_img, w_img, boxes=None, masks=None, is_train=False, mask_thresh=0.75,
-                                    num_points=1):
+                                    num_points=1, _prepared=None):
         assert (boxes is not None) or (masks is not None)
         assert not is_train
         if masks is not None:
@@ -195,27 +249,15 @@ class VisualPromptEncoder:
             s = self.img_feats_scale
             assert (h_img * s == h) and (w_img * s == w), \
                 f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
-            i, j = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
-            coords = (torch.stack([j, i], dim=-1) + 0.5) / torch.as_tensor([w, h]).view(1, 1, -1)
-            if boxes is None:
-                boxes = convert_mask_to_box(masks > mask_thresh) / torch.as_tensor([w, h, w, h]).view(1, 1, -1)
-            bc = box_xyxy_to_cxcywh(boxes)
-            thr = masks.flatten(1).max(1)[0].clamp(max=mask_thresh).reshape(-1, 1)
-            masks_binary = masks.flatten(-2, -1) >= thr
-            coords = coords[:h, :w].flatten(0, 1).to(device)
-            rel = torch.abs(coords[None] - bc[:, None, :2])
-            in_ctr = (rel < 0.25 * bc[:, None, 2:]).all(-1) & masks_binary
-            pts = []
-            for k, c in enumerate(in_ctr):
-                if c.any():
-                    idxs = torch.randperm(int(c.sum())).repeat(num_points)[:num_points]
-                    pts.append(coords[c][idxs.to(device)])
-                else:
-                    hi = masks[k].flatten() >= min(0.95, masks[k].max())
-                    idxs = torch.randperm(int(hi.sum())).repeat(num_points)[:num_points]
-                    pts.append(coords[hi][idxs.to(device)])
-            point_coords = torch.stack(pts)
-            assert (point_coords <= 1).all(), "Point coordinates should be smaller than 1"
+            if _prepared is None:
+                sel, rowcnt = self._select_candidates(masks, boxes, mask_thresh)
+                counts = rowcnt.sum(1).tolist()                   # the one host round trip of this call
+            else:
+                sel, rowcnt, counts = _prepared                   # get_mask_prompt shares one round trip
+            # same generator calls, in the same order, as the reference's per-entity loop (prompt_encoder.py:463-474)
+            ranks = torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]).to(device)
+            idx = _kth_true_2d(sel, ranks, rowcnt)                 # [n, num_points] flat pixel indices
+            point_coords = torch.stack([((idx % w).float() + 0.5) / w, ((idx // w).float() + 0.5) / h], dim=-1)
         else:
             device = boxes.device
             bc = box_xyxy_to_cxcywh(boxes)
@@ -227,27 +269,29 @@ class VisualPromptEncoder:
 
     @torch.no_grad()
     def get_dense_features(self, img_features, img_pos, masks_binary, query_pe, query_feats, prompt_type="masks",
-                           is_train=True):
+                           is_train=True, _counts=None):
         assert img_features.shape[-2:] == masks_binary.shape[-2:]
         feats = img_features.flatten(-2).t()
         pos = img_pos.flatten(-2).t()
         R = self.num_dense_points
-        fd, pd = [], []
-        for i, m in enumerate(masks_binary):
-            idx = torch.nonzero(m.flatten()).reshape(-1)
-            if len(idx) == 0:
-                fd.append(query_feats[i, 0].reshape(1, -1).repeat(R, 1))
-                pd.append(query_pe[i, 0].reshape(1, -1).repeat(R, 1))
-                continue
-            if len(idx) < R:
-                idx = idx.repeat(int(R / len(idx)) + 1)[:R]
+        m = masks_binary.flatten(1)
+        counts = m.sum(1).tolist() if _counts is None else _counts   # the one host round trip of this call
+        rows = []
+        for c in counts:                                          # generator calls as in the reference (:236-251)
+            c = int(c)
+            if c == 0:
+                rows.append(torch.zeros(R, dtype=torch.int64))
+            elif c < R:
+                rows.append(torch.arange(c).repeat(int(R / c) + 1)[:R])
             else:
-                idx = idx[torch.randperm(len(idx))[:R].to(idx.device)]
                 assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
-            fd.append(feats[idx])
-            pd.append(pos[idx])
-        fd = torch.stack(fd)[:, :, None].repeat(1, 1, self.num_frames, 1)
-        pd = torch.stack(pd)[:, :, None].repeat(1, 1, self.num_frames, 1)
+                rows.append(torch.randperm(c)[:R])
+        idx = _kth_true(m, torch.stack(rows).to(m.device))        # [n, R] flat feature-map indices
+        empty = torch.as_tensor([int(c) == 0 for c in counts], device=m.device).view(-1, 1, 1)
+        fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
+        pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
+        fd = fd[:, :, None].repeat(1, 1, self.num_frames, 1)
+        pd = pd[:, :, None].repeat(1, 1, self.num_frames, 1)
         return fd, pd
 
 
@@ -335,9 +379,11 @@ class VisualPromptSampler:
                 tv["prompt_pe"], tv["prompt_feats"], tv["prompt_attn_masks"] = pe_d, f_d, m_d
             else:
                 s_idx = -num_frames + key_fid
-                valid = gt_masks[:, key_fid].flatten(1).sum(1) > 0
-                tv["prompt_pe"][valid, :, s_idx:] = pe_d[valid, :, key_fid:]
-                tv["prompt_feats"][valid, :, s_idx:] = f_d[valid, :, key_fid:]
+                # entities visible in this frame overwrite their pool rows (select, not boolean-mask indexing:
+                # that would cost a host round trip per frame)
+                valid = (gt_masks[:, key_fid].amax(2).amax(1) > 0).view(-1, 1, 1, 1)
+                tv["prompt_pe"][:, :, s_idx:] = torch.where(valid, pe_d[:, :, key_fid:], tv["prompt_pe"][:, :, s_idx:])
+                tv["prompt_feats"][:, :, s_idx:] = torch.where(valid, f_d[:, :, key_fid:], tv["prompt_feats"][:, :, s_idx:])
                 tv["prompt_attn_masks"][s_idx:] = m_d[key_fid:]
         if "prompt_pe" not in tv:
             return None, None, None
