@@ -31,9 +31,9 @@ def convert_box_to_mask(outputs_box, h, w):
     """normalised xyxy boxes [..., 4] -> bool masks [..., h, w] (comm.py:6-39)."""
     box_shape = outputs_box.shape
     dev = outputs_box.device
-    norm = torch.as_tensor([w, h, w, h], dtype=outputs_box.dtype, device=dev).reshape(1, -1)
-    b = outputs_box.flatten(0, -2) * norm
-    b = torch.cat([b[..., :2].floor(), b[..., 2:].ceil()], dim=-1)
+    bx = outputs_box.flatten(0, -2)
+    # (x * w, y * h) without materialising [w, h, w, h] on the host: a pageable H2D copy is a full stream sync
+    b = torch.stack([(bx[..., 0] * w).floor(), (bx[..., 1] * h).floor(), (bx[..., 2] * w).ceil(), (bx[..., 3] * h).ceil()], dim=-1)
     gy, gx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
     gy, gx = gy.reshape(1, h, w), gx.reshape(1, h, w)
     m = (gx > b[..., 0, None, None]) & (gx <= b[..., 2, None, None]) & \
@@ -59,6 +59,13 @@ def convert_mask_to_box(masks):
     empty = (right < left) | (bottom < top)
     out = torch.stack([left, top, right, bottom], dim=-1) * (~empty).unsqueeze(-1)
     return out.reshape(*shape[:-2], 4) if len(shape) > 2 else out[0]
+
+
+def _to_device_async(t, device):
+    """Host tensor -> device without blocking the host on the stream (pinned staging + non_blocking copy)."""
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def _kth_true(mask, ranks):
@@ -255,7 +262,7 @@ class VisualPromptEncoder:
             else:
                 sel, rowcnt, counts = _prepared                   # get_mask_prompt shares one round trip
             # same generator calls, in the same order, as the reference's per-entity loop (prompt_encoder.py:463-474)
-            ranks = torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]).to(device)
+            ranks = _to_device_async(torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]), device)
             idx = _kth_true_2d(sel, ranks, rowcnt)                 # [n, num_points] flat pixel indices
             point_coords = torch.stack([((idx % w).float() + 0.5) / w, ((idx // w).float() + 0.5) / h], dim=-1)
         else:
@@ -286,8 +293,11 @@ class VisualPromptEncoder:
             else:
                 assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
                 rows.append(torch.randperm(c)[:R])
-        idx = _kth_true(m, torch.stack(rows).to(m.device))        # [n, R] flat feature-map indices
-        empty = torch.as_tensor([int(c) == 0 for c in counts], device=m.device).view(-1, 1, 1)
+        # one async transfer: the rank table plus a column flagging empty entities
+        host = torch.cat([torch.stack(rows), torch.tensor([[int(int(c) == 0)] for c in counts], dtype=torch.int64)], dim=1)
+        dev_tab = _to_device_async(host, m.device)
+        idx = _kth_true(m, dev_tab[:, :R])                        # [n, R] flat feature-map indices
+        empty = (dev_tab[:, R] != 0).view(-1, 1, 1)
         fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
         pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
         fd = fd[:, :, None].repeat(1, 1, self.num_frames, 1)
@@ -344,7 +354,7 @@ class VisualPromptSampler:
         mean = (prompt_feats_dense * isblank.unsqueeze(-1)).flatten(1, 2).sum(1)
         mean = mean / isblank.flatten(1, 2).sum(1).unsqueeze(-1).clamp(min=1)
         mean = mean[:, None, None].repeat(1, prompt_feats_dense.shape[1], prompt_feats_dense.shape[2], 1)
-        prompt_feats_dense[isblank] = mean[isblank].clone().detach()
+        prompt_feats_dense = torch.where(isblank.unsqueeze(-1), mean, prompt_feats_dense)
         return prompt_pe_dense, prompt_feats_dense, prompt_attn_masks
 
     @torch.no_grad()
@@ -399,12 +409,15 @@ class VisualPromptSampler:
         fa = tv["first_appear_frame_idxs"]
         has_appeared = (fa <= prev_frame_idx) & (fa != -1)
         update_prev_frame = (self.num_frames == 1) or ("prompt_feats" not in tv)
-        if has_appeared.sum() == 0 or not update_prev_frame:
+        if not update_prev_frame:
+            return
+        ha = torch.nonzero(has_appeared).flatten()      # the one host round trip of this function
+        if ha.numel() == 0:
             return
         cs = self.clip_stride
         for key_fid in range(cs):
-            gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[has_appeared]
-            gt_masks = tv["masks"][:, -(num_frames + cs) + key_fid].to(device)[has_appeared]
+            gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[ha]
+            gt_masks = tv["masks"][:, -(num_frames + cs) + key_fid].to(device)[ha]
             kfo = tv["frame_indices"][0] - (cs - key_fid)
             x_key, x_pos = tv["img_emb_per_video"][key_fid], tv["pos_emb_per_video"][key_fid]
             assert prompt_type == "masks"
@@ -417,9 +430,9 @@ class VisualPromptSampler:
                 tv["prompt_feats"] = torch.zeros([n_inst, R, T + cs, C], device=device)
                 tv["prompt_attn_masks"] = torch.zeros([T + cs, m_d.shape[1], n_inst, m_d.shape[-1]], device=device).bool()
             col = -(num_frames + cs) + key_fid
-            tv["prompt_pe"][has_appeared, :, col] = pe_d[:, :, key_fid]
-            tv["prompt_feats"][has_appeared, :, col] = f_d[:, :, key_fid]
-            tv["prompt_attn_masks"][col, :, has_appeared] = m_d[key_fid]
+            tv["prompt_pe"][ha, :, col] = pe_d[:, :, key_fid]
+            tv["prompt_feats"][ha, :, col] = f_d[:, :, key_fid]
+            tv["prompt_attn_masks"][col, :, ha] = m_d[key_fid]
 
     @torch.no_grad()
     def zero_pad_prompt(self, tv):
