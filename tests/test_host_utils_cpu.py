@@ -1,0 +1,57 @@
+"""Host-side helpers: rank -> pixel search of the prompt sampler, mask / box utilities of the clip loop, runtime."""
+import torch
+
+from univs_amd import runtime, synth
+from univs_amd.modeling.prompt_encoder import _kth_true, _kth_true_2d
+from univs_amd.utils import comm
+
+
+def test_kth_true_equals_nonzero_indexing():
+    """`nonzero(mask[k])[rank]` for all rows at once (1-D scan and the two-level image version), incl. single-pixel
+    rows, full rows and ranks at both ends."""
+    m = synth.uniform("kth/m", (6, 23, 31)) > 0.4
+    m[1] = False
+    m[1, 22, 30] = True            # one pixel, the last one
+    m[2] = True                    # every pixel
+    m[3] = False
+    m[3, 0, 0] = True              # the first one
+    cnt = m.flatten(1).sum(1)
+    g = torch.Generator().manual_seed(3)
+    ranks = torch.stack([torch.cat([torch.tensor([0, int(c) - 1]), torch.randint(0, int(c), (5,), generator=g)]) for c in cnt])
+    ref = torch.stack([torch.nonzero(m[k].flatten()).reshape(-1)[ranks[k]] for k in range(len(m))])
+    assert torch.equal(_kth_true(m.flatten(1), ranks), ref)
+    assert torch.equal(_kth_true_2d(m, ranks), ref)
+    assert torch.equal(_kth_true_2d(m, ranks, m.sum(2, dtype=torch.int32)), ref)
+
+
+def test_convert_mask_to_box_and_quality():
+    m = torch.zeros(2, 3, 8, 10, dtype=torch.bool)
+    m[0, 0, 2:5, 3:9] = True
+    m[1, 2, 7, 0] = True
+    b = comm.convert_mask_to_box(m)
+    assert b[0, 0].tolist() == [3, 2, 8, 4] and b[1, 2].tolist() == [0, 7, 0, 7]
+    assert b[0, 1].tolist() == [0, 0, 0, 0]                       # empty mask -> zeros
+    assert tuple(comm.convert_mask_to_box(torch.zeros(0, 2, 4, 4, dtype=torch.bool)).shape) == (0, 2, 4)
+    logit = torch.full((1, 2, 4, 4), -3.0)
+    logit[0, :, :2] = 2.0           # 16 pixels above +1
+    logit[0, :, 2, :2] = 0.0        # 4 pixels in the uncertain band
+    assert abs(float(comm.calculate_mask_quality_scores(logit)) - 16.0 / 20.0) < 1e-6
+
+
+def test_mask_and_box_iou():
+    a = torch.zeros(1, 2, 4, 4)
+    a[0, 0, :2] = 1
+    a[0, 1, :, :2] = 1
+    iou = comm.batched_mask_iou(a, a)
+    assert torch.allclose(iou[0], torch.tensor([[1.0, 4.0 / 12.0], [4.0 / 12.0, 1.0]]))
+    assert float(comm.batched_mask_iou(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))) == 0.0   # union clamped to 1
+    b1 = torch.tensor([[[0.0, 0.0, 2.0, 2.0]]])
+    b2 = torch.tensor([[[1.0, 1.0, 3.0, 3.0]], [[5.0, 5.0, 6.0, 6.0]]])
+    iou, inter, union = comm.video_box_iou(b1, b2)
+    assert torch.allclose(iou[0, :, 0], torch.tensor([1.0 / 7.0, 0.0]))
+
+
+def test_runtime_gemm_table_is_inert_without_gpu():
+    assert runtime.default_table() is not None and runtime.default_table().endswith(".csv")
+    if not torch.cuda.is_available():
+        assert runtime.enable_tuned_gemms() == "tunableop: no GPU"
