@@ -478,6 +478,103 @@ def g11d_clip_loop_vps():
          clip_first_frames=torch.tensor(calls), **dumps)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G15: the VOS / RefVOS drivers (univs/inference/inference_video_vos.py) on the scripted scene
+# ---------------------------------------------------------------------------------------------------
+VOS_STATE_KEYS = ("masks", "mask_logits", "boxes", "embds", "labels", "first_appear_frame_idxs", "frame_indices")
+
+
+class _RefAnn:
+    """stand-in for detectron2 Instances as the reference's VOS driver uses it (:586-607)"""
+
+    def __init__(self, image_size, ori_ids, gt_masks, gt_boxes, gt_classes):
+        self.image_size, self.ori_ids, self.gt_masks, self.gt_classes = tuple(image_size), list(ori_ids), gt_masks, gt_classes
+        self.gt_boxes = types.SimpleNamespace(tensor=gt_boxes)
+
+    def __len__(self):
+        return len(self.ori_ids)
+
+    def to(self, device):
+        return self
+
+
+def _ref_vos(mode, targets, tag):
+    import glob
+    import shutil
+    from PIL import Image
+    RV = rh.ref_inference_vos()
+    case = cases.SCRIPT_CASE
+    out_dir = f"/tmp/univs_vos_{tag}"
+    shutil.rmtree(out_dir, ignore_errors=True)
+    kw = cases.vos_kwargs(case, video_unified_inference_queries=mode)
+    kw.update(object_mask_threshold=0.8, overlap_threshold=0.8, overlap_threshold_entity=0.5, stability_score_thresh=0.0,
+              metadata=None, LSJ_aug_image_size=1024, LSJ_aug_enable_test=False, sem_seg_postprocess_before_inference=False,
+              num_classes=133, data_name="ytbvos18_val", zero_shot_inference=False, semantic_on=False, instance_on=True,
+              panoptic_on=False, test_topk_per_image=100, tracker_type="", window_inference=False, output_dir=out_dir)
+    inf = RV.InferenceVideoVOS(**kw)
+    dumps, calls = {}, []
+    head = cases.ScriptedHead()
+
+    def hooked(features, targets=None, **k):
+        calls.append(int(targets[0]["first_frame_idx"]))
+        return head(features, targets=targets, **k)
+    orig_write = inf.write_predictions_into_annotations_per_clip
+
+    def write_and_dump(out, image_size, tg, first_frame_idx, stride):
+        orig_write(out, image_size, tg, first_frame_idx, stride)
+        for key in VOS_STATE_KEYS:
+            v = tg[0][key].detach().clone()
+            dumps[f"clip{len(calls) - 1}_out_{key}"] = v.float() if v.dtype == torch.bool else v
+    inf.write_predictions_into_annotations_per_clip = write_and_dump
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(), sem_seg_head=hooked)
+    x = cases.preprocess(cases.loop_frames(case))
+    images = types.SimpleNamespace(tensor=x, image_sizes=[case["image_size"]] * case["n_frames"])
+    inf.inference_video_vos(model, cases.loop_batched_inputs(case), images, targets, case["image_size"], case["image_size"])
+    dumps["clip_first_frames"] = torch.tensor(calls)
+    # read the PNG results back
+    ann = os.path.join(out_dir, "inference/Annotations", "clip0")
+    if targets[0]["task"] == "sot":
+        files = sorted(glob.glob(ann + "/*.png"))
+        dumps["result_idmaps"] = torch.from_numpy(np.stack([np.array(Image.open(f)) for f in files]))
+        dumps["result_frames"] = torch.tensor([int(os.path.basename(f)[:5]) for f in files])
+    else:
+        for eid in sorted(os.listdir(ann)):
+            files = sorted(glob.glob(os.path.join(ann, eid, "*.png")))
+            dumps[f"result_exp{eid}"] = torch.from_numpy(np.stack([np.array(Image.open(f)) for f in files]))
+            dumps[f"result_exp{eid}_frames"] = torch.tensor([int(os.path.basename(f)[:5]) for f in files])
+    shutil.rmtree(out_dir, ignore_errors=True)
+    return dumps
+
+
+@gen
+def g15a_vos_prompt():
+    d = _ref_vos("prompt", cases.vos_targets_sot(_RefAnn), "a")
+    print("   clips", d["clip_first_frames"].tolist(), "frames written", d["result_frames"].tolist(),
+          "ids", d["result_idmaps"].unique().tolist())
+    save("g15a_vos_prompt", **d)
+
+
+@gen
+def g15b_vos_prompt_learn():
+    d = _ref_vos("prompt+learn", cases.vos_targets_sot(_RefAnn), "b")
+    print("   clips", d["clip_first_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
+    save("g15b_vos_prompt_learn", **d)
+
+
+@gen
+def g15d_vos_learn():
+    d = _ref_vos("learn", cases.vos_targets_sot(_RefAnn), "d")
+    print("   clips", d["clip_first_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
+    save("g15d_vos_learn", **d)
+
+
+@gen
+def g15c_rvos_grounding():
+    d = _ref_vos("prompt", cases.vos_targets_grounding(), "c")
+    print("   clips", d["clip_first_frames"].tolist(), [k for k in d if k.startswith("result_exp") and not k.endswith("frames")])
+    save("g15c_rvos_grounding", **d)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

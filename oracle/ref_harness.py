@@ -296,7 +296,7 @@ def _install_inference_stubs():
     _pkg("mask2former.utils", f"{R}/mask2former/utils")
     u = sys.modules["univs"]
     for n in ("VideoSetCriterionUni", "VideoHungarianMatcherUni", "BoxVISTeacherSetPseudoMask", "TextPromptEncoder",
-              "build_clip_language_encoder", "Clips", "FastOverTracker_DET"):
+              "build_clip_language_encoder", "Clips", "FastOverTracker_DET", "MDQE_OverTrackerEfficient"):
         setattr(u, n, _Inert)
     _pkg("univs.data")
     dd = _pkg("univs.data.datasets")
@@ -315,5 +315,17 @@ def ref_inference():
     ns.comm = importlib.import_module("univs.inference.comm")
     m = importlib.import_module("univs.inference.inference_video_entity")
     ns.InferenceVideoEntity = m.InferenceVideoEntity
+    ns.module = m
+    return ns
+
+
+def ref_inference_vos():
+    """The reference's `InferenceVideoVOS` (univs/inference/inference_video_vos.py); same inert stand-ins as for the
+    entity loop (PIL is real: the reference writes its results as PNG files, which the golden generator reads back)."""
+    install()
+    _install_inference_stubs()
+    ns = types.SimpleNamespace()
+    m = importlib.import_module("univs.inference.inference_video_vos")
+    ns.InferenceVideoVOS = m.InferenceVideoVOS
     ns.module = m
     return ns

@@ -318,15 +318,17 @@ class ScriptedHead:
         d = torch.maximum(torch.maximum(r[0] - xs, xs - r[2]), torch.maximum(r[1] - ys, ys - r[3]))
         return (-0.75 * d).clamp(-6.0, 6.0)
 
-    def followed_object(self, masks):
-        """masks [t_hist, H, W] of one entity -> index of the object it overlaps most (None if none)."""
+    def followed_object(self, masks, frame0=0):
+        """masks [t_hist, H, W] of one entity (masks[0] = absolute frame `frame0`) -> index of the object it overlaps
+        most (None if none)."""
         best, best_j = 0.0, None
         for j in range(len(self.objects)):
             ov = 0.0
-            for f in range(masks.shape[0]):
+            for f0 in range(masks.shape[0]):
+                f = f0 + frame0
                 r = self.rect(j, f)
                 if r is not None:
-                    ov += float(masks[f, max(r[1], 0):max(r[3], 0), max(r[0], 0):max(r[2], 0)].float().sum())
+                    ov += float(masks[f0, max(r[1], 0):max(r[3], 0), max(r[0], 0):max(r[2], 0)].float().sum())
             if ov > best:
                 best, best_j = ov, j
         return best_j
@@ -352,8 +354,13 @@ class ScriptedHead:
         dev = features["res2"].device
         rows = [self.row(j if j < len(self.objects) else None, frames, "l") for j in range(self.case["Q"])]
         if "masks" in tv:
+            frame0 = frames[-1] + 1 - tv["masks"].shape[1]       # absolute frame of masks[:, 0]
             for e in range(tv["masks"].shape[0]):
-                rows.append(self.row(self.followed_object(tv["masks"][e].cpu()), frames, "p"))
+                if tv.get("task") == "grounding":                # expression e refers to object exp_obj_ids[e]
+                    j = int(tv["exp_obj_ids"][e])
+                else:
+                    j = self.followed_object(tv["masks"][e].cpu(), frame0)
+                rows.append(self.row(j, frames, "p"))
         return {"pred_logits": torch.stack([r[0] for r in rows])[None].to(dev),
                 "pred_masks": torch.stack([r[1] for r in rows])[None].to(dev),
                 "pred_embds": torch.stack([r[2] for r in rows])[None].to(dev),
@@ -376,3 +383,48 @@ def cfg4_targets(case=CFG4):
 
 # panoptic sub-task on the scripted scene: categories (1-based) of objects 0, 3, 4 are "things", the others "stuff"
 SCRIPT_THING_IDS = (4, 10, 2)
+
+
+# (c) VOS / RefVOS drivers (univs_amd/inference/video_vos.py <-> univs/inference/inference_video_vos.py) on the scripted
+# scene: objects 0 and 1 are annotated in frame 0, object 3 enters (and is annotated) in frame 3
+VOS_OBJECTS = {11: (0, 0), 22: (1, 0), 33: (3, 3)}      # original id -> (scripted object, annotated frame)
+
+
+def vos_kwargs(case=SCRIPT_CASE, **over):
+    kw = dict(hidden_dim=256, num_queries=case["Q"], size_divisibility=32, pixel_mean=synth.PIXEL_MEAN,
+              pixel_std=synth.PIXEL_STD, num_frames=case["T"], prompt_as_queries=True, num_frames_window_test=5,
+              clip_stride=2, video_unified_inference_queries="prompt", num_prev_frames_memory=5)
+    kw.update(over)
+    return kw
+
+
+def vos_targets_sot(make_annotations, case=SCRIPT_CASE):
+    """`make_annotations(image_size, ori_ids, gt_masks, gt_boxes, gt_classes)` builds one frame's annotation object
+    (our FrameAnnotations or a stand-in for detectron2 Instances in the golden generator)."""
+    head = ScriptedHead(case)
+    h, w = case["image_size"]
+    per_frame = []
+    for f in range(case["n_frames"]):
+        ids, masks, boxes, classes = [], [], [], []
+        for oid, (j, f_ann) in VOS_OBJECTS.items():
+            if f_ann == f:
+                x0, y0, x1, y1 = head.rect(j, f)
+                m = torch.zeros(h, w)
+                m[y0:y1, x0:x1] = 1.0
+                ids.append(oid); masks.append(m); boxes.append(torch.tensor([x0, y0, x1, y1], dtype=torch.float32))
+                classes.append(SCRIPT_OBJECTS[j][0])
+        per_frame.append(make_annotations((h, w), ids, torch.stack(masks) if masks else torch.zeros(0, h, w),
+                                          torch.stack(boxes) if boxes else torch.zeros(0, 4),
+                                          torch.tensor(classes, dtype=torch.long)))
+    names = [f"videos/clip0/{f:05d}.jpg" for f in range(case["n_frames"])]
+    return [{"task": "sot", "dataset_name": "ytbvos18_val", "prompt_type": "visual", "num_frames": case["T"],
+             "video_len": case["n_frames"], "inter_image_size": (case["H"], case["W"]), "image_size": (h, w),
+             "instances": per_frame, "file_names": names, "mask_palette": [0] * 768}]
+
+
+def vos_targets_grounding(case=SCRIPT_CASE):
+    h, w = case["image_size"]
+    names = [f"videos/clip0/{f:05d}.jpg" for f in range(case["n_frames"])]
+    return [{"task": "grounding", "dataset_name": "rvos-refytb-val", "prompt_type": "text", "num_frames": case["T"],
+             "video_len": case["n_frames"], "inter_image_size": (case["H"], case["W"]), "image_size": (h, w),
+             "exp_obj_ids": [0, 3, 4], "file_names": names}]

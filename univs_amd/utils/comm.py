@@ -6,6 +6,7 @@ conventions) used by `univs_amd.inference.video_entity`:
   calculate_mask_quality_scores  univs/utils/comm.py:88-91   SAM-style stability of a logit mask
   video_box_iou                  univs/utils/comm.py:141-163
   batched_mask_iou               univs/utils/comm.py:199-214
+  batched_pair_mask_iou          univs/utils/comm.py:216-231
 The IoUs of binary masks are computed as matrix products of the flattened masks (inter = A B^T,
 union = |A| + |B| - inter) instead of materialising the [B, N, M, HW] pairwise sums.
 """
@@ -60,4 +61,14 @@ def batched_mask_iou(masks1: torch.Tensor, masks2: torch.Tensor) -> torch.Tensor
     b = masks2.flatten(-2).float()
     inter = torch.bmm(a, b.transpose(1, 2))
     union = (a.sum(-1)[:, :, None] + b.sum(-1)[:, None, :] - inter).clamp(min=1)
+    return inter / union
+
+
+def batched_pair_mask_iou(masks1: torch.Tensor, masks2: torch.Tensor) -> torch.Tensor:
+    """masks1, masks2 [B, N, H, W] (binary) -> IoU of corresponding pairs [B, N]; union clamped to >= 1
+    (univs/utils/comm.py:216-231)."""
+    a = masks1.flatten(-2).float()
+    b = masks2.flatten(-2).float()
+    inter = (a * b).sum(-1)
+    union = (a.sum(-1) + b.sum(-1) - inter).clamp(min=1)
     return inter / union
