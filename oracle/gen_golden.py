@@ -575,6 +575,65 @@ def g15c_rvos_grounding():
     save("g15c_rvos_grounding", **d)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G16: the CLIP text encoder + tokenizer that feed the grounding prompts (univs/modeling/language/)
+# ---------------------------------------------------------------------------------------------------
+TEXT_EXPRESSIONS = ["a dog running", "The person in a red-and-white jacket, skiing downhill!", "two zebras' heads (left)",
+                    "naive cafe - 3 cats & 12 dogs", "it's the giraffe that's eating leaves",
+                    "antidisestablishmentarianism supercalifragilistic", "a " * 100]
+TEXT_SMALL, TEXT_FULL = cases.TEXT_SMALL, cases.TEXT_FULL      # TEXT_FULL: RN50x4 text tower (TextEncoder.py:157-174)
+
+
+def _ref_text_encoder(L, cfg):
+    m = L.TextEncoder.CLIPLangEncoder(out_features=["res5"], freeze_at=0, **cfg)
+    return synth.load_synthetic(m, "lang_encoder.").eval()
+
+
+@gen
+def g16a_tokenizer():
+    L = rh.ref_language()
+    U = L.clip_prompt_utils
+    ids = U.pre_tokenize_expression(TEXT_EXPRESSIONS)
+    cls = U.pre_tokenize(["person", "traffic light", ["tv", "television"]][:2])
+    tok = U.SimpleTokenizer()
+    plain = U.tokenize(TEXT_EXPRESSIONS[:6])
+    cleaned = U.clean_strings(["Traffic_light(1)", "a man's hat - red/blue!"])
+    save("g16a_tokenizer", expressions=np.array(TEXT_EXPRESSIONS), ids=ids.to(torch.int32), class_ids=cls.to(torch.int32),
+         plain=plain.to(torch.int32), cleaned=np.array(cleaned),
+         decoded=np.array([tok.decode(tok.encode(e)) for e in TEXT_EXPRESSIONS[:6]]))
+
+
+def _text_case(L, cfg, n_exp):
+    enc = _ref_text_encoder(L, cfg)
+    tokens = L.clip_prompt_utils.pre_tokenize_expression(TEXT_EXPRESSIONS[:n_exp])       # [E, 81, 77]
+    sample = tokens[:, :3].reshape(-1, 77)                                                  # a few texts
+    with torch.no_grad():
+        x_word, x_eot = enc.encode_text(sample, only_eot=False)
+        only = enc.encode_text(sample, only_eot=True)
+    assert torch.equal(only, x_eot)
+    tpe = L.TextPromptEncoder(enc, num_frames=2)
+    with torch.no_grad():
+        w, s_, n = tpe.get_expression_prompt(TEXT_EXPRESSIONS[:n_exp], torch.device("cpu"))
+    return dict(tokens=tokens.to(torch.int32), sample=sample.to(torch.int32), x_word=x_word, x_eot=x_eot,
+                exp_word_feats=w[:, :, 0], exp_sentence_feats=s_[:, 0], exp_word_len=np.array(n))
+
+
+@gen
+def g16b_text_encoder_small():
+    d = _text_case(rh.ref_language(), TEXT_SMALL, 4)
+    print("   x_eot", tuple(d["x_eot"].shape), float(d["x_eot"].abs().max()), "word feats", tuple(d["exp_word_feats"].shape))
+    save("g16b_text_encoder_small", **d)
+
+
+@gen
+def g16c_text_encoder_full():
+    d = _text_case(rh.ref_language(), TEXT_FULL, 2)
+    d["x_word"] = d["x_word"][:, ::4]                 # keep the fixture small: every 4th token
+    d["exp_word_feats"] = d["exp_word_feats"][:, ::4]
+    print("   x_eot", tuple(d["x_eot"].shape), float(d["x_eot"].abs().max()))
+    save("g16c_text_encoder_full", **d)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

@@ -329,3 +329,30 @@ def ref_inference_vos():
     ns.InferenceVideoVOS = m.InferenceVideoVOS
     ns.module = m
     return ns
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's CLIP text encoder + tokenizer (univs/modeling/language/) -- dev container only.
+def ref_language():
+    """Namespace with the reference's `TextEncoder` module, `clip_prompt_utils` module and `TextPromptEncoder`.
+    `ftfy` is not installed here: it is replaced by an identity `fix_text` (the expressions used are plain ASCII)."""
+    import importlib.util
+    install()
+    if "ftfy" not in sys.modules:
+        f = types.ModuleType("ftfy")
+        f.fix_text = lambda t: t
+        sys.modules["ftfy"] = f
+    ns = types.SimpleNamespace()
+    for attr, fname in (("TextEncoder", "TextEncoder.py"), ("clip_prompt_utils", "clip_prompt_utils.py")):
+        name = f"_ref_language_{attr}"
+        if name not in sys.modules:
+            spec = importlib.util.spec_from_file_location(name, f"{REF_ROOT}/univs/modeling/language/{fname}")
+            m = importlib.util.module_from_spec(spec)
+            sys.modules[name] = m
+            spec.loader.exec_module(m)
+        setattr(ns, attr, sys.modules[name])
+    pe_leaf = importlib.import_module("univs.modeling.prompt_encoder.prompt_encoder")
+    pe_leaf.pre_tokenize_expression = ns.clip_prompt_utils.pre_tokenize_expression
+    ns.TextPromptEncoder = pe_leaf.TextPromptEncoder
+    ns.bpe_path = f"{REF_ROOT}/univs/modeling/language/bpe_simple_vocab_16e6.txt.gz"
+    return ns

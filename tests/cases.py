@@ -428,3 +428,15 @@ def vos_targets_grounding(case=SCRIPT_CASE):
     return [{"task": "grounding", "dataset_name": "rvos-refytb-val", "prompt_type": "text", "num_frames": case["T"],
              "video_len": case["n_frames"], "inter_image_size": (case["H"], case["W"]), "image_size": (h, w),
              "exp_obj_ids": [0, 3, 4], "file_names": names}]
+
+
+# (d) CLIP text tower (univs_amd/modeling/language <-> univs/modeling/language): a tiny geometry and the RN50x4 one
+TEXT_SMALL = dict(embed_dim=48, context_length=77, vocab_size=49408, transformer_width=64, transformer_heads=4,
+                  transformer_layers=3)
+TEXT_FULL = dict(embed_dim=640, context_length=77, vocab_size=49408, transformer_width=640, transformer_heads=10,
+                 transformer_layers=12)
+
+
+def build_text_encoder(cfg, device="cpu"):
+    from univs_amd.modeling.language import CLIPLangEncoder
+    return synth.load_synthetic(CLIPLangEncoder(**cfg), "lang_encoder.").eval().to(device)

@@ -207,3 +207,14 @@ def test_config4_full_size_against_reference(cuda, golden_dir):
     assert abs(float(pm.double().abs().mean()) - float(g["pred_masks_abs_mean"])) < 1e-4
     assert np.abs(out["pred_logits"].cpu().numpy() - g["pred_logits"]).max() < 3e-3
     assert np.abs(out["pred_embds"][:, :, :, ::4].cpu().numpy() - g["pred_embds"]).max() < 3e-3
+
+
+@pytest.mark.parametrize("name,cfg,tol,stride", [("g16b_text_encoder_small", cases.TEXT_SMALL, 1e-4, 1),
+                                                 ("g16c_text_encoder_full", cases.TEXT_FULL, 5e-4, 4)],
+                         ids=["small", "rn50x4"])
+def test_text_encoder_matches_reference(cuda, golden_dir, name, cfg, tol, stride):
+    """CLIP text tower + TextPromptEncoder.get_expression_prompt on the device (HIP LayerNorm / masked softmax) against
+    the reference's outputs (oracle/gen_golden.py: g16b / g16c)."""
+    from tests.test_language_cpu import check_text_encoder
+    err = check_text_encoder(_g(golden_dir, name), cfg, cuda, tol, stride)
+    print(f"text encoder {name}: max abs err {err:.2e}")

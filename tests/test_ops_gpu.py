@@ -204,7 +204,7 @@ def test_bilinear_resample_matches_torch(cuda, shape, size):
         ops.bilinear_resample(x, size)          # CPU tensors are refused (no fallback)
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 96), (513, 192), (300, 256), (257, 384), (129, 768), (65, 1536), (33, 3072), (7, 8), (0, 96)],
+@pytest.mark.parametrize("rows,C", [(1000, 96), (513, 192), (300, 256), (257, 384), (129, 768), (65, 1536), (33, 3072), (7, 8), (0, 96), (77, 640), (50, 64)],
                          ids=lambda v: str(v))
 def test_layer_norm_matches_torch(cuda, rows, C):
     """ops.layer_norm == F.layer_norm(x [+ residual]) for every row length of the path (Swin 96..768, patch merging
@@ -278,7 +278,7 @@ def test_group_norm_matches_torch(cuda, shape, groups, relu):
         ops.group_norm(x, groups, w, b)
 
 
-@pytest.mark.parametrize("N,h,L,S", [(2, 8, 13, 920), (1, 8, 100, 3680), (1, 2, 5, 14720), (1, 1, 3, 20000), (3, 4, 7, 33)],
+@pytest.mark.parametrize("N,h,L,S", [(2, 8, 13, 920), (1, 8, 100, 3680), (1, 2, 5, 14720), (1, 1, 3, 20000), (3, 4, 7, 33), (1, 30, 77, 77)],
                          ids=lambda v: str(v))
 def test_masked_softmax_matches_torch(cuda, N, h, L, S):
     """ops.masked_softmax_ == masked_fill(-inf) + softmax, every register-resident size class and the streaming one."""

@@ -1,6 +1,7 @@
-"""Visual prompt encoder and the per-video prompt memory pool (inference).
+"""Text / visual prompt encoders and the per-video prompt memory pool (inference).
 
 Restates the inference branches of univs/modeling/prompt_encoder/prompt_encoder.py:
+  TextPromptEncoder.get_expression_prompt (:28-55);
   VisualPromptEncoder.get_mask_prompt (:168-263), get_point_prompt (:82-165), get_box_prompt (:266-359),
   select_points_from_box_mask (:362-442), get_dense_features (:445-497);
   VisualPromptSampler.process_per_batch_inference (:782-842), process_per_video_inference (:845-960),
@@ -90,6 +91,44 @@ def _kth_true_2d(mask, ranks, rowcnt=None):
     cs = torch.cumsum(rows, dim=2, dtype=torch.int32)
     x = torch.searchsorted(cs, (r1 - before)[:, :, None].contiguous(), right=False).squeeze(-1).clamp(max=W - 1)
     return y * W + x
+
+
+class TextPromptEncoder:
+    """Referring expressions -> the text prompts of the hot path (prompt_encoder.py:16-55):
+    `exp_word_feats [E, 77, T, 640]` = per-token features of the bare expression ('{}.' template),
+    `exp_sentence_feats [E, T, 640]` = end-of-text feature averaged over the 81 prompt templates, both replicated over the
+    clip's frames, and `len_word_expressions` = words + 5.  The reference encodes one expression (81 x 77 tokens) per
+    call; here all E x 81 texts go through the text transformer as one batch."""
+
+    def __init__(self, lang_encoder, num_frames, device=None):
+        self.lang_encoder = lang_encoder
+        if lang_encoder is not None:
+            self.lang_encoder = lang_encoder.to(device or torch.device("cuda" if torch.cuda.is_available() else "cpu"))
+        self.num_frames = num_frames
+
+    @torch.no_grad()
+    def get_expression_prompt(self, expressions, device, tokens=None, max_batch=4096):
+        """`tokens` (optional): pre-tokenized `[E, n_templates, 77]` ids, e.g. cached per video."""
+        assert self.lang_encoder is not None, "No language encoder is assigned!!"
+        from .language import pre_tokenize_expression
+        len_word_expressions = [len(exp.split(" ")) + 5 for exp in expressions]
+        if tokens is None:
+            tokens = pre_tokenize_expression(expressions)
+        tokens = tokens.to(device)
+        E, P, L = tokens.shape
+        flat = tokens.reshape(E * P, L)
+        words, eots = [], []
+        for lo in range(0, E * P, max_batch):            # bounded activation memory for long expression lists
+            w, e = self.lang_encoder.encode_text(flat[lo:lo + max_batch], only_eot=False)
+            first = [i - lo for i in range(lo, min(lo + max_batch, E * P)) if i % P == 0]
+            if first:                                    # only the bare-expression rows are consumed per token
+                words.append(w[torch.as_tensor(first, device=w.device)])
+            eots.append(e)
+        exp_word_feats = torch.cat(words)                                   # [E, 77, C]
+        exp_sentence_feats = torch.cat(eots).view(E, P, -1).mean(1)         # [E, C]
+        exp_word_feats = exp_word_feats[:, :, None].repeat(1, 1, self.num_frames, 1)
+        exp_sentence_feats = exp_sentence_feats[:, None].repeat(1, self.num_frames, 1)
+        return exp_word_feats, exp_sentence_feats, len_word_expressions
 
 
 class VisualPromptEncoder:
