@@ -634,6 +634,38 @@ def g16c_text_encoder_full():
     save("g16c_text_encoder_full", **d)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G17: result merging of the VIS loop (univs/inference/comm.py:97-207).  pycocotools is absent: its `encode` is
+# backed by OUR run-length coder here, so this golden pins the score / merge / top-k logic, not the RLE strings.
+# ---------------------------------------------------------------------------------------------------
+@gen
+def g17_vis_results():
+    from univs_amd.inference import results as ours
+    RI = rh.ref_inference()
+    mu = sys.modules["pycocotools.mask"]
+
+    def encode(arr):            # [H, W, 1] Fortran uint8 -> list of RLE dicts with bytes counts, as pycocotools returns
+        r = ours.rle_encode_masks(torch.from_numpy(np.ascontiguousarray(arr[:, :, 0])).bool())[0]
+        return [{"size": r["size"], "counts": r["counts"].encode("ascii")}]
+    mu.encode = encode
+    out = {}
+    for tag, kw in (("default", {}), ("tight", dict(apply_cls_thresh=0.5, test_topk_per_video=2))):
+        info, clips = cases.vis_result_records()
+        for clip in clips:
+            for r in clip:
+                m = r.pop("masks")
+                r["segmentations"] = [dict(x) for x in ours.rle_encode_masks(m)]
+        res = RI.comm.vis_clip_instances_to_coco_json_video(info, clips, **kw)
+        out[f"{tag}_score"] = np.array([r["score"] for r in res])
+        out[f"{tag}_category"] = np.array([r["category_id"] for r in res])
+        out[f"{tag}_areas"] = np.array([[ours.rle_area(s) for s in r["segmentations"]] for r in res])
+        out[f"{tag}_video_id"] = np.array([r["video_id"] for r in res])
+        print("  ", tag, len(res), "records")
+    sc = torch.stack([cases.vis_result_records()[1][c][1]["score"] for c in range(3)]).clone()
+    out["consistency"] = RI.comm.calculate_mask_temporal_consistency_scores(sc.clone())
+    save("g17_vis_results", **out)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

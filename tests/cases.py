@@ -440,3 +440,23 @@ TEXT_FULL = dict(embed_dim=640, context_length=77, vocab_size=49408, transformer
 def build_text_encoder(cfg, device="cpu"):
     from univs_amd.modeling.language import CLIPLangEncoder
     return synth.load_synthetic(CLIPLangEncoder(**cfg), "lang_encoder.").eval().to(device)
+
+
+# (e) result formats: per-clip records of three entities over a 9-frame video (clips of 3 frames, 5 classes); entity 7 is
+# blank in the middle clip, entity 9 only exists in the last clip, entity 3 carries mask-quality scores
+def vis_result_records(height=12, width=10):
+    def masks(tag, t):
+        return synth.uniform(f"results/{tag}", (t, height, width)) > 0.2
+    def score(tag, scale=1.0):
+        return (synth.uniform(f"results/score/{tag}", (5,)) * 0.5 + 0.5) * scale
+    clips = [
+        [dict(obj_id=3, score=score("3a"), masks=masks("3a", 3), frame_id_start=0),
+         dict(obj_id=7, score=score("7a", 0.04), masks=masks("7a", 3), frame_id_start=0)],
+        [dict(obj_id=3, score=score("3b"), masks=masks("3b", 3), frame_id_start=3),
+         dict(obj_id=7, score=torch.zeros(5), masks=torch.zeros(3, height, width, dtype=torch.bool), frame_id_start=3)],
+        [dict(obj_id=3, score=score("3c"), masks=masks("3c", 3), frame_id_start=6, mask_quality_score=torch.tensor(0.8)),
+         dict(obj_id=7, score=score("7c", 0.04), masks=masks("7c", 3), frame_id_start=6, mask_quality_score=torch.tensor(0.5)),
+         dict(obj_id=9, score=score("9c", 0.3), masks=masks("9c", 2), frame_id_start=7)],
+    ]
+    info = [{"video_id": "17", "video_len": 9, "height": height, "width": width}]
+    return info, clips

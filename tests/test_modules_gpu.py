@@ -218,3 +218,19 @@ def test_text_encoder_matches_reference(cuda, golden_dir, name, cfg, tol, stride
     from tests.test_language_cpu import check_text_encoder
     err = check_text_encoder(_g(golden_dir, name), cfg, cuda, tol, stride)
     print(f"text encoder {name}: max abs err {err:.2e}")
+
+
+def test_rle_boundaries_on_device_match_host(cuda):
+    """results.rle_encode_masks finds the run boundaries on the device: same strings as from host tensors, decode == mask."""
+    from univs_amd.inference import results as R
+    m = (torch.rand(6, 736, 1280, generator=torch.Generator().manual_seed(0)) > 0.5)
+    m[0] = False
+    m[1] = True
+    m[2, 100:300, 200:900] = True
+    m[2, :100] = False
+    host = R.rle_encode_masks(m[:3])
+    dev = R.rle_encode_masks(m[:3].to(cuda))
+    assert host == dev and host[0]["counts"] == R.rle_encode_masks(torch.zeros(1, 736, 1280, dtype=torch.bool))[0]["counts"]
+    assert np.array_equal(R.rle_decode(dev[2]), m[2].numpy().astype(np.uint8))
+    noisy = R.rle_encode_masks(m[3:].to(cuda))
+    assert all(np.array_equal(R.rle_decode(r), m[3 + i].numpy().astype(np.uint8)) for i, r in enumerate(noisy))

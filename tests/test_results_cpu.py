@@ -1,0 +1,126 @@
+"""CPU: result formats (univs_amd/inference/results.py): COCO RLE coding, the per-video VIS records against the
+reference's merge logic (g17), the VOS / RefVOS png writers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from univs_amd import synth
+from univs_amd.inference import results as R
+
+
+def scalar_rle(mask):
+    """Independent restatement, one run and one character at a time (maskApi.c: rleEncode + rleToString)."""
+    flat = np.asarray(mask, dtype=np.uint8).T.reshape(-1)
+    counts, cur, run = [], 0, 0
+    for v in flat:
+        if v != cur:
+            counts.append(run)
+            run, cur = 0, v
+        run += 1
+    counts.append(run)
+    s = ""
+    for i, x in enumerate(counts):
+        if i > 2:
+            x -= counts[i - 2]
+        more = True
+        while more:
+            c = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            s += chr(c + 48)
+    return counts, s
+
+
+def test_blank_720p_known_answer():
+    # the string every YouTube-VIS result file holds for an empty 720 x 1280 frame
+    r = R.rle_encode_masks(torch.zeros(1, 720, 1280, dtype=torch.bool))[0]
+    assert r == {"size": [720, 1280], "counts": "PPTl0"}
+    assert R.rle_area(r) == 0 and R.rle_decode(r).sum() == 0
+
+
+def test_hand_derived_known_answers():
+    # 2 x 3 mask, column-major pixels 0 1 | 1 1 | 0 0 -> runs [1, 3, 2] -> '1' '3' '2'
+    m = torch.tensor([[0, 1, 0], [1, 1, 0]], dtype=torch.bool)
+    assert R.rle_encode_masks(m)[0]["counts"] == "132"
+    # leading foreground: an empty first run; 4th run stored as difference to the 2nd: runs [0, 2, 1, 1] -> 0, 2, 1, (1 - 2 = -1)
+    m = torch.tensor([[1, 0], [1, 1]], dtype=torch.bool)
+    assert list(R.rle_counts(R.rle_encode_masks(m)[0])) == [0, 2, 1, 1]
+    assert R.rle_encode_masks(m)[0]["counts"] == "021O"            # -1 -> 0b11111 with sign bit, no continuation: 31 + 48 = 'O'
+    # a run of 40 = 0b01000 + (1 << 5): low group 8 with continuation (8 | 32 + 48 = 'X'), then 1 ('1')
+    m = torch.zeros(1, 50, dtype=torch.bool)
+    m[0, 40:] = True
+    assert R.rle_encode_masks(m)[0]["counts"] == "X1:"             # 40 -> 'X1', 10 -> ':'
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 7, 5), (4, 60, 90), (2, 1, 33), (2, 33, 1), (5, 16, 16)], ids=str)
+def test_round_trip_and_scalar_restatement(shape):
+    m = synth.uniform("rle/" + "x".join(map(str, shape)), shape) > 0.1
+    m[0] = True                                                     # full foreground: leading empty run
+    if shape[0] > 1:
+        m[1] = False
+    if shape[0] > 2:                                                # vertical stripes: many short runs
+        m[2] = (torch.arange(shape[2]) % 2 == 0)[None, :].expand(shape[1], shape[2])
+    rles = R.rle_encode_masks(m)
+    assert len(rles) == shape[0]
+    for i, r in enumerate(rles):
+        counts, s = scalar_rle(m[i].numpy())
+        assert r["counts"] == s and r["size"] == list(shape[1:])
+        assert list(R.rle_counts(r)) == counts
+        assert np.array_equal(R.rle_decode(r), m[i].numpy().astype(np.uint8))
+        assert R.rle_area(r) == int(m[i].sum())
+    assert R.rle_encode_masks(m[:0]) == []
+
+
+def test_large_masks_need_long_codes():
+    m = torch.zeros(2, 1088, 1920, dtype=torch.bool)
+    m[0, 100:900, 300:1500] = True
+    m[1, :, 1919] = True
+    for i, r in enumerate(R.rle_encode_masks(m)):
+        assert np.array_equal(R.rle_decode(r), m[i].numpy().astype(np.uint8))
+    with pytest.raises(ValueError):
+        R.rle_decode({"size": [3, 3], "counts": "132"})
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("tight", dict(apply_cls_thresh=0.5, test_topk_per_video=2))])
+def test_vis_records_match_reference(golden_dir, tag, kw):
+    g = np.load(os.path.join(golden_dir, "g17_vis_results.npz"))
+    info, clips = cases.vis_result_records()
+    res = R.vis_clip_instances_to_coco_json_video(info, clips, **kw)
+    assert len(res) == len(g[f"{tag}_score"])
+    assert [r["category_id"] for r in res] == g[f"{tag}_category"].tolist()
+    assert np.allclose([r["score"] for r in res], g[f"{tag}_score"], rtol=1e-6, atol=1e-7)
+    areas = np.array([[R.rle_area(s) for s in r["segmentations"]] for r in res])
+    assert np.array_equal(areas, g[f"{tag}_areas"])
+    assert all(r["video_id"] == 17 and r["height"] == 12 and r["width"] == 10 and len(r["segmentations"]) == 9 for r in res)
+    assert all(isinstance(s["counts"], str) for r in res for s in r["segmentations"])       # json-serialisable
+
+
+def test_temporal_consistency_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g17_vis_results.npz"))
+    sc = torch.stack([cases.vis_result_records()[1][c][1]["score"] for c in range(3)]).clone()
+    got = R.calculate_mask_temporal_consistency_scores(sc)
+    assert got is sc and np.allclose(got.numpy(), g["consistency"], atol=1e-7)
+
+
+def test_vos_png_writers(tmp_path):
+    from PIL import Image
+    names = [f"videos/clipA/{f:05d}.jpg" for f in range(5)]
+    idmaps = (synth.uniform("png/ids", (2, 6, 8)) * 2 + 2).to(torch.uint8)
+    palette = [v % 256 for v in range(768)]
+    paths = R.write_vos_pngs(str(tmp_path), names, 3, idmaps, palette)
+    assert [os.path.relpath(p, tmp_path) for p in paths] == ["inference/Annotations/clipA/00003.png",
+                                                             "inference/Annotations/clipA/00004.png"]
+    for p, want in zip(paths, idmaps):
+        img = Image.open(p)
+        assert img.mode == "P" and np.array_equal(np.array(img), want.numpy())
+    res = {"ids": [0, 4], "masks": ((synth.uniform("png/rv", (2, 2, 6, 8)) > 0).to(torch.uint8) * 255)}
+    paths = R.write_rvos_pngs(str(tmp_path), names, 1, res)
+    assert [os.path.relpath(p, tmp_path) for p in paths] == [
+        "inference/Annotations/clipA/0/00001.png", "inference/Annotations/clipA/0/00002.png",
+        "inference/Annotations/clipA/4/00001.png", "inference/Annotations/clipA/4/00002.png"]
+    assert np.array_equal(np.array(Image.open(paths[3])), res["masks"][1, 1].numpy())
