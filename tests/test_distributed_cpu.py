@@ -32,6 +32,8 @@ def _worker(rank, world, port, scenario):
 
         case = dict(cases.HEAD_CASE, name="head_dist", T=4)
         feats = cases.backbone_features(case)
+        if scenario == "visual_prompts":
+            return _visual_prompt_clips(case, feats, world)
         if scenario == "first_clip":
             dec_over, targets_fn = {}, lambda: cases.targets_first_clip(case)
         else:
@@ -59,7 +61,58 @@ def _worker(rank, world, port, scenario):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["first_clip", "grounding"])
+def _visual_prompt_clips(case, feats, world):
+    """Second and third clip of a video with three tracked entities: prompt sampler + memory pool + ProCA, frames sharded
+    over the ranks (sampler replicated, token features summed over ranks) == the single-process result, pool included."""
+    from oracle.cpu_path import cpu_ops
+    from tests import cases, helpers
+    from univs_amd.distributed import FrameShard, shard_frames
+    T = case["T"]
+
+    def advance(tv):             # what the clip loop does between two clips at stride 1 (cf. helpers.advance_to_third_clip)
+        tv["first_frame_idx"] = 2
+        tv["frame_indices"] = torch.arange(2, 2 + T)
+        for k in ("masks", "boxes"):
+            tv[k] = torch.cat([tv[k], torch.zeros_like(tv[k][:, :1])], 1)
+            tv[k][:, -2] = tv[k][:, -3]
+        tv["ids"] = torch.cat([tv["ids"], tv["ids"][:, :1]], 1)
+
+    def two_clips(head, f):
+        targets = cases.targets_with_entities(case, first_frame_idx=1, n_ent=3)
+        outs = []
+        for clip in range(2):
+            torch.manual_seed(clip)          # the sampler draws from the CPU generator: same state on every rank
+            outs.append(head(f, targets=targets))
+            if clip == 0:
+                advance(targets[0])
+        return outs, targets[0]
+
+    head = helpers.build_head(case, "cpu", return_aux=False)
+    with cpu_ops(), torch.no_grad():
+        ref, tv_ref = two_clips(head, feats)
+        shard = FrameShard()
+        head.predictor.frame_shard = shard
+        out, tv = two_clips(head, shard_frames(feats, shard, T))
+    sl = shard.local_slice(T // world)
+    assert ref[0]["pred_masks"].shape[1] == case["Q"] + 3          # learnable + one prompt query per entity
+    for c in range(2):
+        assert out[c]["pred_masks"].shape == ref[c]["pred_masks"][:, :, sl].shape
+        err_m = (out[c]["pred_masks"] - ref[c]["pred_masks"][:, :, sl]).abs().max().item()
+        err_l = (out[c]["pred_logits"] - ref[c]["pred_logits"]).abs().max().item()
+        err_e = (out[c]["pred_embds"] - ref[c]["pred_embds"][:, :, sl]).abs().max().item()
+        assert err_m < 2e-4 and err_l < 2e-4 and err_e < 2e-4, (c, err_m, err_l, err_e)
+    # the memory pool is replicated: every rank ends up with the single-process pool
+    for k in ("prompt_feats", "prompt_pe"):
+        assert tv[k].shape == tv_ref[k].shape and (tv[k] - tv_ref[k]).abs().max().item() < 1e-5, k
+        assert tv[k].abs().max().item() > 0
+    assert torch.equal(tv["prompt_attn_masks"], tv_ref["prompt_attn_masks"])
+    # only this rank's frames of the stored features are real, the rest are zeros (they never cross the fabric)
+    other = [t for t in range(T) if not (sl.start <= t < sl.stop)]
+    assert tv["img_emb_per_video"][other].abs().max().item() == 0
+    assert torch.equal(tv["img_emb_per_video"][sl], tv_ref["img_emb_per_video"][sl])
+
+
+@pytest.mark.parametrize("scenario", ["first_clip", "grounding", "visual_prompts"])
 def test_frame_sharded_decoder_matches_single_process(scenario):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), scenario), nprocs=world, join=True)

@@ -145,6 +145,11 @@ class VisualPromptEncoder:
         self.position_embedding_sin3d_type = position_embedding_sin3d_type
         self.key_fid = int((num_frames - 1) / 2)
         self.img_feats_scale = 8  # prompts are read from the 1/8-resolution level
+        # frame-sharded clips (univs_amd/distributed.py): a sum over the ranks.  Only the rank that owns a key frame
+        # holds its features, the others pass zeros; token features are linear in them, so the sum hands every rank
+        # the owner's values (x + 0 is exact).  Everything else (candidate pixels, random ranks, position tokens,
+        # attention masks) depends on the replicated annotations only and is evaluated identically on every rank.
+        self.feature_reduce = None
 
     def _point_pe(self, h_img, w_img, point_coords, key_fid, key_fid_original):
         size = (self.num_frames, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
@@ -156,6 +161,8 @@ class VisualPromptEncoder:
     @torch.no_grad()
     def get_point_prompt(self, img_features, img_pos, point_coords=None, boxes=None, masks=None, key_fid=None,
                          key_fid_original=None, is_train=False, enable_dense_prompt=True):
+        if self.feature_reduce is not None:
+            raise NotImplementedError("point prompts are not covered by the frame-sharded mode (mask prompts are)")
         key_fid = self.key_fid if key_fid is None else key_fid
         key_fid_original = key_fid if key_fid_original is None else key_fid_original
         h_img, w_img = img_features.shape[-2:]
@@ -224,6 +231,8 @@ class VisualPromptEncoder:
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
                                              prompt_type="masks", is_train=is_train, _counts=counts[n:])
+        if self.feature_reduce is not None:
+            fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
         # invalid (empty) entities: zero tokens, nothing masked (unconditional: no host round trip for `.any()`)
         pd = pd * valid.view(-1, 1, 1, 1).float()
         fd = fd * valid.view(-1, 1, 1, 1).float()
@@ -233,6 +242,8 @@ class VisualPromptEncoder:
     @torch.no_grad()
     def get_box_prompt(self, img_features, img_pos, boxes, key_fid=None, key_fid_original=None, is_train=False,
                        enable_dense_prompt=True):
+        if self.feature_reduce is not None:
+            raise NotImplementedError("box prompts are not covered by the frame-sharded mode (mask prompts are)")
         key_fid = self.key_fid if key_fid is None else key_fid
         key_fid_original = key_fid if key_fid_original is None else key_fid_original
         h_img, w_img = img_features.shape[-2:]

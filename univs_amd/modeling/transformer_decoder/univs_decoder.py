@@ -203,9 +203,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             frame_indices = torch.arange(t_total, device=dev)[None].repeat(bs, 1)
         if fs is not None:
             assert frame_indices.shape[1] == t_total, "targets['frame_indices'] must list the frames of ALL ranks"
+            self._frame_indices_all = frame_indices
             frame_indices = frame_indices[:, fs.local_slice(t)]
-            if targets[0].get("prompt_type") == "visual" and "masks" in targets[0] and targets[0]["masks"].nelement():
-                raise NotImplementedError("frame-sharded mode does not cover visual prompts / the memory pool yet")
         for i in range(self.num_feature_levels):
             size_list.append(tuple(int(s) for s in x[i].shape[-2:]))
             xi = x[i].view(bs, t, -1, size_list[-1][0], size_list[-1][1])
@@ -389,7 +388,16 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         assert all(tk == tasks[0] for tk in tasks)
         prompt_feats_dense, prompt_pe_dense, l2v = None, None, None
 
+        fs = self.frame_shard
         if tasks[0] == "sot" or targets[0]["prompt_type"] == "visual" or prompt_type == "visual":
+            enc = self.visual_prompt_sampler.visual_prompt_encoder
+            if fs is not None:
+                # the sampler runs replicated over the whole clip: position tokens are recomputed for all frames, the
+                # features of the other ranks' frames are zeros and `feature_reduce` sums the token features over ranks
+                src, pos = self._prompt_level_of_whole_clip(src, pos, size_list, num_frames)
+                enc.feature_reduce = fs.all_reduce_sum
+            else:
+                enc.feature_reduce = None
             prompt_tuple = self.visual_prompt_sampler.process_per_batch(
                 src, pos, size_list, targets, False, use_all_prev_frames=use_all_prev_frames)
             prompt_pe_dense, prompt_feats_dense = prompt_tuple[:2]
@@ -406,6 +414,10 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 assert len(targets) == 1, "Only support batch size is 1 now"
                 prompt_pe_dense, prompt_feats_dense = self.extract_prompt_features_from_memoey_pool(
                     targets, prompt_pe_dense, prompt_feats_dense)
+            if fs is not None:      # back to this rank's frames
+                sl = fs.local_slice(num_frames)
+                output_prompt, query_embed_prompt = output_prompt[:, sl], query_embed_prompt[:, sl]
+                prompt_feats_dense, prompt_pe_dense = prompt_feats_dense[:, :, sl], prompt_pe_dense[:, :, sl]
             return output_prompt, query_embed_prompt, prompt_feats_dense, prompt_pe_dense, l2v
 
         if tasks[0] == "detection":
@@ -447,6 +459,26 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                     prompt_feats_dense = torch.cat([vis_feats, prompt_feats_dense], dim=1)
             return output_prompt, sentence, prompt_feats_dense, None, l2v
         raise ValueError(tasks[0])
+
+    def _prompt_level_of_whole_clip(self, src, pos, size_list, t_local):
+        """Frame-sharded clip: the sampler's feature level as `[HW, T_total, C]` lists -- this rank's frames in place, zeros
+        elsewhere -- and its position embedding for ALL frames (a function of shape and frame indices only)."""
+        fs = self.frame_shard
+        li = self.visual_prompt_sampler.prompt_feature_level_index
+        h, w = size_list[li]
+        t_total = fs.total(t_local)
+        s_loc = src[li]
+        s_full = s_loc.new_zeros(s_loc.shape[0], t_total, s_loc.shape[2])
+        s_full[:, fs.local_slice(t_local)] = s_loc
+        shape_only = s_loc.new_empty(1).expand(1, t_total, 1, h, w)
+        if self.position_embedding_sin3d_type == "FixedT":
+            p = self.pe_layer(shape_only)
+        else:
+            p = self.pe_layer(shape_only, self._frame_indices_all)
+        p_full = p.flatten(3).flatten(0, 1).permute(2, 0, 1)
+        src, pos = list(src), list(pos)
+        src[li], pos[li] = s_full, p_full
+        return src, pos
 
     def forward_lang_to_vision(self, prompt_feats, src, size_list, num_frames, task_type):
         """:760-793: one cross-attention of all text tokens against the concatenation of the 3 levels."""
