@@ -207,10 +207,19 @@ def main():
         H, W, C = 184, 320, 256
         algb = 4.0 * (C * H * W + Q * C + Q * H * W) * T
         flops = 2.0 * Q * C * H * W * T
-        res["roofline_mask_decode"] = {"kernel": "skinny_gemm_f32<4,StoreLogits> (mask decode, f32 MFMA)",
-                                       "bound": "mfma", "achieved": flops / t_md / 1e12, "peak": F32_MFMA_PEAK / 1e12,
-                                       "unit": "TFLOP/s", "frac": flops / t_md / F32_MFMA_PEAK,
-                                       "hbm_GBps": algb / t_md / 1e9, "avg_launch_us": t_md * 1e6}
+        if ops.mask_decode_last_impl() == 2:
+            # fp32 emulated on the bf16 matrix cores (6 bf16 products per fp32 product): HBM-bound, as SURVEY 8d prices it
+            res["roofline_mask_decode"] = {"kernel": "skinny_gemm_bf16x6<7,StoreLogits> (mask decode, split-bf16 MFMA)",
+                                           "bound": "hbm", "achieved": algb / t_md / 1e9, "peak": HBM_PEAK / 1e9,
+                                           "unit": "GB/s", "frac": algb / t_md / HBM_PEAK,
+                                           "algorithmic_bytes_per_launch": algb, "fp32_equivalent_TFLOPs": flops / t_md / 1e12,
+                                           "bf16_mfma_TFLOPs": 6.0 * flops * (112.0 / Q) / t_md / 1e12,
+                                           "avg_launch_us": t_md * 1e6}
+        else:
+            res["roofline_mask_decode"] = {"kernel": "skinny_gemm_f32<4,StoreLogits> (mask decode, f32 MFMA)",
+                                           "bound": "mfma", "achieved": flops / t_md / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+                                           "unit": "TFLOP/s", "frac": flops / t_md / F32_MFMA_PEAK,
+                                           "hbm_GBps": algb / t_md / 1e9, "avg_launch_us": t_md * 1e6}
 
     if world == 1 and not frames_mode:
         # informational: a steady-state clip of the same video (second clip, 10 visual-prompt entities in the memory

@@ -101,6 +101,15 @@ int univs_msda_set_impl(int impl);
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
 int univs_msda_last_impl(void);
 
+/* Selects the mask-decode contraction kernel (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
+ * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel
+ * (v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fp32 fmaf chain), 2 = fp32 emulated on the bf16 matrix
+ * cores from an exact 3-way split of both operands ("bf16 x 6", error <= 3 * 2^-24 per product) wherever its
+ * preconditions hold (C % 64 == 0, HW % 4 == 0, 16-byte aligned pointers), the f32 kernel elsewhere. */
+int univs_mask_decode_set_impl(int impl);
+/* 1 / 2: which of the two kernels the last mask-decode call on this thread launched (0: none yet). */
+int univs_mask_decode_last_impl(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Mask decode: per-frame contraction of mask embeddings with per-pixel features.
  * Replaces: torch.einsum("btqc,btchw->btqhw", mask_embed, mask_features).transpose(1, 2)

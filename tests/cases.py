@@ -113,6 +113,18 @@ MASKDEC_CASES = [
 ]
 
 
+# shapes that exercise the split-bf16 kernel's corners: a ragged last 64-column tile, one / several row blocks with a
+# partial last block, 100 rows (the headline query count), two row passes, a single k-step pair
+MASKDEC_SPLIT_CASES = [
+    dict(name="maskdec/split_q100", T=2, Q=100, C=256, H=31, W=36),    # 1116 columns = 17.4 tiles; 7 row blocks
+    dict(name="maskdec/split_q106", T=1, Q=106, C=256, H=8, W=20),     # the largest single pass
+    dict(name="maskdec/split_q107", T=1, Q=107, C=256, H=8, W=20),     # two passes of 54 rows
+    dict(name="maskdec/split_q17", T=3, Q=17, C=128, H=10, W=14),      # 2 row blocks, the second with one row
+    dict(name="maskdec/split_tiny", T=1, Q=1, C=64, H=2, W=2),         # one 4-column group
+    dict(name="maskdec/split_q204", T=1, Q=204, C=256, H=46, W=80),    # config 4: 200 + 4 queries, 1/16 level
+]
+
+
 def maskdec_inputs(case):
     e = synth.normal(case["name"] + "/embed", (case["T"], case["Q"], case["C"]), std=0.5)
     f = synth.normal(case["name"] + "/feat", (case["T"], case["C"], case["H"], case["W"]), std=0.5)

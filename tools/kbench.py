@@ -55,16 +55,22 @@ def main():
         Q, C, H, W = 100, 256, 184, 320
         e = synth.normal("kb/e", (T, Q, C)).to(dev)
         f = synth.normal("kb/f", (T, C, H, W)).to(dev)
-        t = timeit(lambda: ops.mask_decode(e, f))
         algm = 4.0 * (C * H * W + Q * C + Q * H * W) * T
-        res["mask_decode"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=algm / t / 1e9, frac_hbm=algm / t / HBM_PEAK,
-                                  TFLOPs=2.0 * Q * C * H * W * T / t / 1e12)
+        for impl, nm in ((1, "mask_decode_f32"), (2, "mask_decode_bf16x6")):
+            ops.mask_decode_set_impl(impl)
+            t = timeit(lambda: ops.mask_decode(e, f))
+            res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=algm / t / 1e9, frac_hbm=algm / t / HBM_PEAK,
+                           TFLOPs=2.0 * Q * C * H * W * T / t / 1e12, impl=ops.mask_decode_last_impl())
+            for (h, w) in shapes:
+                fl = torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+                t = timeit(lambda: ops.mask_decode_attn(e, fl))
+                res[f"{nm}_attn_{h}x{w}"] = dict(ms=t * 1e3, impl=ops.mask_decode_last_impl())
+        e110 = synth.normal("kb/e110", (T, 110, C)).to(dev)
+        t = timeit(lambda: ops.mask_decode(e110, f))
+        res["mask_decode_bf16x6_q110"] = dict(ms=t * 1e3, impl=ops.mask_decode_last_impl())
+        ops.mask_decode_set_impl(0)
         t = timeit(lambda: torch.einsum("tqc,tchw->tqhw", e, f))
         res["mask_decode_torch_einsum"] = dict(ms=t * 1e3, TFLOPs=2.0 * Q * C * H * W * T / t / 1e12)
-        for (h, w) in shapes:
-            fl = torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False).contiguous()
-            t = timeit(lambda: ops.mask_decode_attn(e, fl))
-            res[f"mask_decode_attn_{h}x{w}"] = dict(ms=t * 1e3)
     if not args.only or "win" in args.only:
         # Swin-T stage 1 at 720p: 27x46 windows of 49 tokens, 3 heads, per frame
         nW, nH, ntok, hd = 27 * 46, 3, 49, 32

@@ -29,6 +29,8 @@ int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
+void mask_decode_set_impl(int);
+int mask_decode_last_impl();
 int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
                          hipStream_t);
 
@@ -91,6 +93,18 @@ int univs_msda_set_impl(int impl) {
 }
 
 int univs_msda_last_impl(void) { return g_msda_last; }
+
+int univs_mask_decode_set_impl(int impl) {
+  clear_sticky_error();
+  if (impl < 0 || impl > 2) {
+    set_error("univs_mask_decode_set_impl: impl=%d not in {0,1,2}", impl);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  univs::mask_decode_set_impl(impl);
+  return UNIVS_OK;
+}
+
+int univs_mask_decode_last_impl(void) { return univs::mask_decode_last_impl(); }
 
 int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* sampling_loc,

@@ -123,6 +123,15 @@ def msda_last_impl() -> int:
     return int(_lib.load().univs_msda_last_impl())
 
 
+def mask_decode_set_impl(impl: int):
+    """0 = by size (default), 1 = exact-f32 MFMA kernel, 2 = split-bf16 ("bf16 x 6") kernel where eligible."""
+    _lib.check(_lib.load().univs_mask_decode_set_impl(int(impl)), "mask_decode_set_impl")
+
+
+def mask_decode_last_impl() -> int:
+    return int(_lib.load().univs_mask_decode_last_impl())
+
+
 def mask_decode(mask_embed, mask_features):
     """einsum('tqc,tchw->qthw'): mask_embed [T,Q,C], mask_features [T,C,H,W] -> logits [Q,T,H,W]
     (== ...decoder_univs.py:527-528 for batch 1)."""
