@@ -45,9 +45,10 @@ class KernelTimer:
     """HIP events (torch.cuda.Event on the launch stream == torch's current stream, which is the stream
     the C ABI is handed) around every launch of one operator during the timed region."""
 
-    def __init__(self, module, name):
+    def __init__(self, module, name, after=None):
         self.module, self.name, self.orig = module, name, getattr(module, name)
         self.events, self.enabled = [], False
+        self.after, self.notes = after, []      # optional probe evaluated right after each timed launch
 
         def wrapped(*a, **k):
             if not self.enabled:
@@ -57,6 +58,8 @@ class KernelTimer:
             out = self.orig(*a, **k)
             e.record()
             self.events.append((s, e))
+            if self.after is not None:
+                self.notes.append(self.after())
             return out
         setattr(module, name, wrapped)
 
@@ -122,7 +125,7 @@ def main():
         return head(swin(x), targets=targets())
 
     msda_t = KernelTimer(ops, "ms_deform_attn_forward")
-    mdec_t = KernelTimer(ops, "mask_decode")
+    mdec_t = KernelTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)   # which kernel ran (1 f32, 2 split-bf16)
 
     out = None
     for _ in range(args.warmup):
@@ -207,9 +210,9 @@ def main():
         H, W, C = 184, 320, 256
         algb = 4.0 * (C * H * W + Q * C + Q * H * W) * T
         flops = 2.0 * Q * C * H * W * T
-        if ops.mask_decode_last_impl() == 2:
+        if mdec_t.notes and all(n == 2 for n in mdec_t.notes):
             # fp32 emulated on the bf16 matrix cores (6 bf16 products per fp32 product): HBM-bound, as SURVEY 8d prices it
-            res["roofline_mask_decode"] = {"kernel": "skinny_gemm_bf16x6<7,StoreLogits> (mask decode, split-bf16 MFMA)",
+            res["roofline_mask_decode"] = {"kernel": "skinny_gemm_bf16x6_n32<7,8,Store2Logits> (mask decode: fp32 from an exact 3-way bf16 split, bf16 MFMA)",
                                            "bound": "hbm", "achieved": algb / t_md / 1e9, "peak": HBM_PEAK / 1e9,
                                            "unit": "GB/s", "frac": algb / t_md / HBM_PEAK,
                                            "algorithmic_bytes_per_launch": algb, "fp32_equivalent_TFLOPs": flops / t_md / 1e12,
