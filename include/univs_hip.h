@@ -101,6 +101,15 @@ int univs_msda_set_impl(int impl);
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
 int univs_msda_last_impl(void);
 
+/* y[M, N] = x[M, K] * W[N, K]^T + bias[N] (+ ReLU): torch.nn.functional.linear for contiguous float32 operands, as the
+ * token projections of MSDeformAttn use it (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113:
+ * value_proj, sampling_offsets + attention_weights, output_proj).  fp32 emulated on the bf16 matrix cores from an exact
+ * 3-way split of both operands (error <= 3 * 2^-24 per product, i.e. fp32 rounding level).
+ * Covered: K % 128 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31; anything else returns
+ * UNIVS_ERR_NOT_IMPLEMENTED without touching y (the caller keeps its library GEMM).  bias may be NULL. */
+int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
+                           int relu, float* y, void* stream);
+
 /* Selects the mask-decode contraction kernel (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel
  * (v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fp32 fmaf chain), 2 = fp32 emulated on the bf16 matrix

@@ -394,3 +394,41 @@ def test_msda_prepare_matches_reference_expressions(cuda, N, Lq, M, shapes, bcas
     assert (loc.cpu() - loc_r).abs().max().item() < 1e-6
     assert (attn.cpu() - attn_r).abs().max().item() < 1e-6
     assert loc.is_contiguous() and attn.is_contiguous()
+
+
+@pytest.mark.parametrize("M,K,N,relu,bias", [(96600, 256, 256, False, True), (96600, 256, 288, False, True),
+                                             (5000, 256, 1024, True, True), (4099, 128, 100, False, False),
+                                             (2048, 384, 4, False, True), (3000, 256, 108, True, True)],
+                         ids=lambda v: str(v))
+def test_linear_split_matches_torch(cuda, M, K, N, relu, bias):
+    """ops.linear_split (fp32 from an exact 3-way bf16 split on the bf16 matrix cores) == F.linear to fp32 rounding:
+    within a few ulp, same order as the error of ATen's own fp32 GEMM against the fp64 result."""
+    F = torch.nn.functional
+    x = synth.normal(f"ls/x/{M}x{K}", (M, K), std=1.0)
+    w = synth.normal(f"ls/w/{N}x{K}", (N, K), std=K ** -0.5)
+    b = synth.normal(f"ls/b/{N}", (N,), std=0.5) if bias else None
+    xd, wd, bd = x.to(cuda), w.to(cuda), (b.to(cuda) if bias else None)
+    y = ops.linear_split(xd.view(4 if M % 4 == 0 else 1, -1, K), wd, bd, relu=relu)
+    assert y is not None and tuple(y.shape) == (4 if M % 4 == 0 else 1, M // (4 if M % 4 == 0 else 1), N)
+    ref64 = F.linear(xd.double(), wd.double(), bd.double() if bias else None)
+    ref32 = F.linear(xd, wd, bd)
+    if relu:
+        ref64, ref32 = ref64.relu(), ref32.relu()
+    err = (y.view(M, N).double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)        # a few ulp of the result, like any fp32 GEMM
+    # scaling by a power of two is exact in the split as in fp32
+    y2 = ops.linear_split(2.0 * xd, wd, None)
+    y1 = ops.linear_split(xd, wd, None)
+    assert torch.equal(y2, 2.0 * y1)
+
+
+def test_linear_split_uncovered_shapes_return_none(cuda):
+    x = torch.zeros(4096, 96, device=cuda)
+    assert ops.linear_split(x, torch.zeros(96, 96, device=cuda)) is None                      # K % 128
+    assert ops.linear_split(torch.zeros(4096, 256, device=cuda), torch.zeros(6, 256, device=cuda)) is None     # N % 4
+    assert ops.linear_split(torch.zeros(100, 256, device=cuda), torch.zeros(8, 256, device=cuda)) is None      # few rows
+    assert ops.linear_split(torch.zeros(4096, 256), torch.zeros(8, 256)) is None                               # CPU tensors
+    from univs_amd import layers
+    y = layers.linear(x, torch.ones(96, 96, device=cuda), None)                                # falls through to ATen
+    assert tuple(y.shape) == (4096, 96)

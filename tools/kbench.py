@@ -71,6 +71,21 @@ def main():
         ops.mask_decode_set_impl(0)
         t = timeit(lambda: torch.einsum("tqc,tchw->tqhw", e, f))
         res["mask_decode_torch_einsum"] = dict(ms=t * 1e3, TFLOPs=2.0 * Q * C * H * W * T / t / 1e12)
+    if not args.only or "linear" in args.only:
+        # the encoder's token projections: 96 600 rows x 256 -> 256 / 288 (/ 1024 with ReLU)
+        Mr = T * 19320
+        xs = synth.normal("kb/lin/x", (Mr, 256)).to(dev)
+        for N_, relu in ((256, False), (288, False), (1024, True)):
+            w_ = synth.normal(f"kb/lin/w{N_}", (N_, 256), std=1 / 16).to(dev)
+            b_ = synth.normal(f"kb/lin/b{N_}", (N_,)).to(dev)
+            t = timeit(lambda: ops.linear_split(xs, w_, b_, relu=relu))
+            fl = 2.0 * Mr * 256 * N_
+            res[f"linear_split_{N_}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, GBps=(Mr * (256 + N_) * 4.0) / t / 1e9)
+            if relu:
+                t = timeit(lambda: torch._addmm_activation(b_, xs, w_.t(), use_gelu=False))
+            else:
+                t = timeit(lambda: torch.nn.functional.linear(xs, w_, b_))
+            res[f"linear_aten_{N_}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12)
     if not args.only or "win" in args.only:
         # Swin-T stage 1 at 720p: 27x46 windows of 49 tokens, 3 heads, per frame
         nW, nH, ntok, hd = 27 * 46, 3, 49, 32

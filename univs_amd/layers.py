@@ -3,6 +3,7 @@
 conv / norm work goes to ATen (hipBLASLt / MIOpen) -- host glue around the HIP kernels.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -141,11 +142,30 @@ def layer_norm(norm, x, residual=None, return_sum=False):
     return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, residual=residual, return_sum=return_sum)
 
 
+_SPLIT_LINEAR = os.environ.get("UNIVS_SPLIT_LINEAR", "1") != "0"
+
+
+def linear(x, weight, bias=None):
+    """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 (the MSDeformAttn token projections: 96 600 rows x
+    256 -> 256 / 288) take the split-bf16 kernel (fp32-accurate, ~2x hipBLASLt's fp32 rate), everything else ATen."""
+    if _SPLIT_LINEAR and x.is_cuda:
+        from . import ops
+        y = ops.linear_split(x, weight, bias)
+        if y is not None:
+            return y
+    return F.linear(x, weight, bias)
+
+
 def linear_act(x, linear, activation):
     """activation(linear(x)).  For ReLU on the GPU the activation rides in the GEMM epilogue (hipBLASLt via
     ATen's `_addmm_activation`: bit-identical to relu(linear(x)), one pass over the [tokens, d_ffn]
     activations less -- 0.17 ms per encoder layer at 720p)."""
     if activation is F.relu and x.is_cuda and x.dtype == torch.float32 and linear.bias is not None:
+        if _SPLIT_LINEAR:
+            from . import ops
+            y = ops.linear_split(x, linear.weight, linear.bias, relu=True)
+            if y is not None:
+                return y
         y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], -1)
     return activation(linear(x))

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from ...layers import Conv2d, get_activation_fn, get_norm, layer_norm, linear_act
+from ...layers import Conv2d, get_activation_fn, get_norm, layer_norm, linear, linear_act
 from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
@@ -63,14 +63,14 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
         # one GEMM for the two Linears that read `query` (their weights concatenated once): 288 output columns
         # instead of 192 + 96, `query` is read once
         w, b, n_off = self._merged_query_proj()
-        qp = F.linear(query, w, b)
+        qp = linear(query, w, b)
         if reference_points.shape[-1] == 2 and P == 4 and L <= 4:
             # softmax over the L*P logits + reference point + offset / (W_l, H_l): one pass (HIP operator)
             sampling_locations, attention_weights = ops.msda_prepare(qp, n_off, reference_points, input_spatial_shapes,
@@ -91,7 +91,7 @@ class MSDeformAttn(nn.Module):
         output = ops.ms_deform_attn_forward(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights.contiguous(),
                                             self.im2col_step)
-        return self.output_proj(output)
+        return linear(output, self.output_proj.weight, self.output_proj.bias)
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):

@@ -123,6 +123,33 @@ def msda_last_impl() -> int:
     return int(_lib.load().univs_msda_last_impl())
 
 
+def linear_split(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) [+ relu] for float32 on the GPU through the split-bf16 kernel (fp32-accurate: an exact
+    3-way bf16 split of both operands, six MFMA terms) -- the K = 256 token projections of MSDeformAttn
+    (ms_deform_attn.py:95-113).  Returns None when the shape is not covered (K % 128, N % 4, fewer than 2048 rows,
+    ranges beyond 2^31 bytes): the caller then keeps the library GEMM."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    M = x.numel() // max(K, 1)
+    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.shape[1] != K
+            or K % 128 != 0 or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1):
+        return None
+    x2 = x.contiguous().view(M, K)
+    w = weight.contiguous()
+    b = bias.contiguous() if bias is not None else None
+    _require_gpu("linear_split", x2, w)
+    if b is not None and (b.dtype != torch.float32 or tuple(b.shape) != (N,) or not b.is_cuda):
+        raise RuntimeError("linear_split: bias must be float32 [N] on the GPU")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_linear_split_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, M, N, K,
+                                                int(bool(relu)), _ptr(y), _stream_ptr(x2))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "linear_split")
+    return y.view(*x.shape[:-1], N)
+
+
 def mask_decode_set_impl(impl: int):
     """0 = by size (default), 1 = exact-f32 MFMA kernel, 2 = split-bf16 ("bf16 x 6") kernel where eligible."""
     _lib.check(_lib.load().univs_mask_decode_set_impl(int(impl)), "mask_decode_set_impl")
