@@ -363,6 +363,39 @@ def g11b_clip_loop_scripted():
     save("g11b_clip_loop_scripted", **d)
 
 
+# edge cases of the clip schedule on the scripted scene: a video shorter than a clip, exactly one clip, stride 1 with the
+# backbone window equal to the clip length
+LOOP_EDGE_CASES = {
+    "g11e_loop_short_video": (dict(n_frames=2), {}),
+    "g11f_loop_one_clip": (dict(n_frames=3), dict(clip_stride=1)),
+    "g11g_loop_stride1_window3": (dict(n_frames=5), dict(clip_stride=1, num_frames_window_test=3)),
+}
+
+
+def _loop_edge(name):
+    case_over, kw_over = LOOP_EDGE_CASES[name]
+    case = dict(cases.SCRIPT_CASE, **case_over)
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(), sem_seg_head=cases.ScriptedHead(case))
+    d = _ref_loop(case, model, **kw_over)
+    print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist() if "final_ids" in d else None)
+    save(name, **d)
+
+
+@gen
+def g11e_loop_short_video():
+    _loop_edge("g11e_loop_short_video")
+
+
+@gen
+def g11f_loop_one_clip():
+    _loop_edge("g11f_loop_one_clip")
+
+
+@gen
+def g11g_loop_stride1_window3():
+    _loop_edge("g11g_loop_stride1_window3")
+
+
 @gen
 def g13_msda_backward():
     """gradients of the REFERENCE's ms_deform_attn_core_pytorch by autograd (float64 -> stored as float32)"""
@@ -424,7 +457,7 @@ def g11c_clip_loop_vss():
               num_max_inst_test=50, output_dir="/tmp")
     inf = RI.InferenceVideoEntity(**kw)
     calls = []
-    head = cases.ScriptedHead()
+    head = cases.ScriptedHead(case)
 
     def hooked(features, targets=None, **k):
         calls.append(int(targets[0]["first_frame_idx"]))
@@ -498,12 +531,12 @@ class _RefAnn:
         return self
 
 
-def _ref_vos(mode, targets, tag):
+def _ref_vos(mode, targets, tag, case=None, **kw_over):
     import glob
     import shutil
     from PIL import Image
     RV = rh.ref_inference_vos()
-    case = cases.SCRIPT_CASE
+    case = case or cases.SCRIPT_CASE
     out_dir = f"/tmp/univs_vos_{tag}"
     shutil.rmtree(out_dir, ignore_errors=True)
     kw = cases.vos_kwargs(case, video_unified_inference_queries=mode)
@@ -511,6 +544,7 @@ def _ref_vos(mode, targets, tag):
               metadata=None, LSJ_aug_image_size=1024, LSJ_aug_enable_test=False, sem_seg_postprocess_before_inference=False,
               num_classes=133, data_name="ytbvos18_val", zero_shot_inference=False, semantic_on=False, instance_on=True,
               panoptic_on=False, test_topk_per_image=100, tracker_type="", window_inference=False, output_dir=out_dir)
+    kw.update(kw_over)
     inf = RV.InferenceVideoVOS(**kw)
     dumps, calls = {}, []
     head = cases.ScriptedHead()
@@ -566,6 +600,24 @@ def g15d_vos_learn():
     d = _ref_vos("learn", cases.vos_targets_sot(_RefAnn), "d")
     print("   clips", d["clip_first_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
     save("g15d_vos_learn", **d)
+
+
+@gen
+def g15e_vos_short_tail():
+    """4-frame video, stride 2: the second clip is the 2-frame tail; object 33 is annotated in the LAST frame"""
+    case = dict(cases.SCRIPT_CASE, n_frames=4)
+    d = _ref_vos("prompt", cases.vos_targets_sot(_RefAnn, case), "e", case=case)
+    print("   clips", d["clip_first_frames"].tolist(), "frames", d["result_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
+    save("g15e_vos_short_tail", **d)
+
+
+@gen
+def g15f_vos_stride1():
+    """5-frame video, stride 1 (every clip finishes one frame), prompt + learnable queries"""
+    case = dict(cases.SCRIPT_CASE, n_frames=5)
+    d = _ref_vos("prompt+learn", cases.vos_targets_sot(_RefAnn, case), "f", case=case, clip_stride=1)
+    print("   clips", d["clip_first_frames"].tolist(), "frames", d["result_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
+    save("g15f_vos_stride1", **d)
 
 
 @gen
