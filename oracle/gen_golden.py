@@ -396,6 +396,31 @@ def g11g_loop_stride1_window3():
     _loop_edge("g11g_loop_stride1_window3")
 
 
+def _loop_scene(scene):
+    case = cases.SCRIPT_CASE
+    model = types.SimpleNamespace(backbone=cases.ScriptedBackbone(),
+                                  sem_seg_head=cases.ScriptedHead(case, cases.SCRIPT_SCENES[scene]))
+    d = _ref_loop(case, model)
+    print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist() if "final_ids" in d else None,
+          "keys", len(d))
+    save(f"g11_scene_{scene}", **d)
+
+
+@gen
+def g11h_scene_empty():
+    _loop_scene("empty")
+
+
+@gen
+def g11i_scene_late():
+    _loop_scene("late")
+
+
+@gen
+def g11j_scene_leavers():
+    _loop_scene("leavers")
+
+
 @gen
 def g13_msda_backward():
     """gradients of the REFERENCE's ms_deform_attn_core_pytorch by autograd (float64 -> stored as float32)"""

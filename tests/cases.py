@@ -297,6 +297,14 @@ SCRIPT_OBJECTS = [
 ]
 
 
+# edge scenes: nothing is ever confident / the first entity shows up only in the third clip and everything else is gone
+SCRIPT_SCENES = {
+    "empty": [(7, -1.2, 40, 2, 20, 14, 1, 0, 0, 6), (2, -2.0, 10, 30, 20, 14, 0, 0, 0, 6)],
+    "late": [(3, 3.0, 4, 6, 30, 24, 3, 1, 4, 6), (1, 2.8, 60, 30, 18, 20, 0, 0, 5, 6)],
+    "leavers": [(3, 3.0, 4, 6, 30, 24, 3, 1, 0, 1), (5, 2.5, 50, 30, 28, 22, 0, 0, 0, 2)],
+}
+
+
 class ScriptedBackbone:
     def __call__(self, x):
         return {"res2": x.new_zeros((x.shape[0], 1, 1, 1))}
