@@ -743,6 +743,46 @@ def g17_vis_results():
     save("g17_vis_results", **out)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G18: caller-side target preparation (univs/prepare_targets.py: process_inference)
+# ---------------------------------------------------------------------------------------------------
+def _describe_targets(out, prefix):
+    """dict list -> flat {name: array}: tensors as they are, everything else as one json string per video"""
+    d = {}
+    for i, tv in enumerate(out):
+        plain = {}
+        for k, v in tv.items():
+            if isinstance(v, torch.Tensor) and v.numel() > 100_000:      # e.g. the class-embedding table: sample + checksum
+                d[f"{prefix}_{i}_{k}_shape"] = np.array(v.shape)
+                d[f"{prefix}_{i}_{k}_sample"] = v[::97, ::16]
+                d[f"{prefix}_{i}_{k}_sum"] = v.double().sum()
+            elif isinstance(v, torch.Tensor):
+                d[f"{prefix}_{i}_{k}"] = v
+            else:
+                plain[k] = v
+        d[f"{prefix}_{i}_plain"] = np.array(json.dumps(plain, sort_keys=True, default=list))
+    return d
+
+
+@gen
+def g18_prepare_targets():
+    PT = rh.ref_prepare_targets()
+    L = rh.ref_language()
+    table_path = "/tmp/univs_clip_table.pth"
+    torch.save(cases.clip_table(), table_path)
+    enc = _ref_text_encoder(L, TEXT_SMALL)
+    tpe = L.TextPromptEncoder(enc, num_frames=3)
+    d = {}
+    for name, (over, batched) in cases.prepare_targets_inputs().items():
+        pt = PT(num_frames=3, clip_class_embed_path=table_path, **over)
+        with torch.no_grad():
+            out = pt.process_inference(batched, (64, 96), torch.device("cpu"), tpe, (60, 90))
+        d.update(_describe_targets(out, name))
+        d[f"{name}_input_prompt_type"] = np.array(batched[0]["prompt_type"])
+        print("  ", name, sorted(out[0].keys()))
+    save("g18_prepare_targets", **d)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

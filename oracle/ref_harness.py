@@ -356,3 +356,18 @@ def ref_language():
     ns.TextPromptEncoder = pe_leaf.TextPromptEncoder
     ns.bpe_path = f"{REF_ROOT}/univs/modeling/language/bpe_simple_vocab_16e6.txt.gz"
     return ns
+
+
+def ref_prepare_targets():
+    """The reference's `PrepareTargets` class (univs/prepare_targets.py), loaded from its file under a private module name
+    (the `univs.prepare_targets` entry of sys.modules is an inert stand-in for the inference-loop imports)."""
+    import importlib.util
+    install()
+    _install_inference_stubs()
+    name = "_ref_prepare_targets"
+    if name not in sys.modules:
+        spec = importlib.util.spec_from_file_location(name, f"{REF_ROOT}/univs/prepare_targets.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+    return sys.modules[name].PrepareTargets

@@ -480,3 +480,23 @@ def vis_result_records(height=12, width=10):
     ]
     info = [{"video_id": "17", "video_len": 9, "height": height, "width": width}]
     return info, clips
+
+
+# (f) caller-side target preparation (univs_amd/prepare_targets.py <-> univs/prepare_targets.py: process_inference)
+def prepare_targets_inputs():
+    """scenario -> (constructor overrides, batched_inputs as the dataset mapper hands them over)"""
+    names = [f"videos/clipA/{f:05d}.jpg" for f in range(4)]
+    base = dict(video_len=4, file_names=names)
+    return {
+        "detection_known": ({}, [dict(base, task="detection", dataset_name="ytvis_2021", video_id=17, is_raw_video=False)]),
+        "detection_raw": ({}, [dict(base, task="detection", dataset_name="my_videos", is_raw_video=True)]),
+        "detection_semantic": (dict(semantic_on=True), [dict(base, task="detection", dataset_name="vipseg", is_raw_video=False)]),
+        "detection_vspw": ({}, [dict(base, task="detection", dataset_name="vspw_vss_video_val", is_raw_video=False)]),
+        "grounding": ({}, [dict(base, task="grounding", dataset_name="rvos-refytb-val", expressions=["a dog running", "the person on the left"],
+                                exp_obj_ids=[3, 7])]),
+        "grounding_empty": ({}, [dict(base, task="grounding", dataset_name="rvos-refytb-val", expressions=[], exp_obj_ids=[])]),
+        "sot": ({}, [dict(base, task="sot", dataset_name="ytbvos18_val", instances=["f0", "f1", "f2", "f3"], mask_palette=[1, 2, 3],
+                          video_id="ab12")]),
+        "custom_text": (dict(custom_videos_text=[["two zebras", "a red car"]]),
+                        [dict(base, task="detection", dataset_name="my_videos", is_raw_video=True)]),
+    }

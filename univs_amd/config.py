@@ -114,9 +114,14 @@ def get_cfg():
                        PRE_NORM=False, HIDDEN_DIM=256, NUM_OBJECT_QUERIES=200,
                        TRANSFORMER_IN_FEATURE="multi_scale_pixel_decoder", ENFORCE_INPUT_PROJ=False,
                        SIZE_DIVISIBILITY=32,
-                       TRANSFORMER_DECODER_NAME="VideoMultiScaleMaskedTransformerDecoderUniVS")
+                       TRANSFORMER_DECODER_NAME="VideoMultiScaleMaskedTransformerDecoderUniVS",
+                       # mask2former/config.py:60-65, univs/config.py:90-91
+                       TEST=CN(SEMANTIC_ON=True, INSTANCE_ON=False, PANOPTIC_ON=False, OBJECT_MASK_THRESHOLD=0.0,
+                               OVERLAP_THRESHOLD=0.0, STABILITY_SCORE_THRESH=0.0, OVERLAP_THRESHOLD_ENTITY=0.5))
     m.BoxVIS = CN(TEST=CN(NUM_FRAMES=3, NUM_FRAMES_WINDOW=5, NUM_MAX_INST=50, CLIP_STRIDE=1,
-                          LSJ_AUG_ENABLED=True))
+                          LSJ_AUG_ENABLED=True, APPLY_CLS_THRES=0.05, MULTI_CLS_ON=True))   # univs/config.py:101-113
+    # text tower of CLIP RN50x4 (TextEncoder.py:152-174 reads these; the reference sets them in its yaml recipes)
+    m.CLIP = CN(RESNETS_DEPTH=200, BACKBONE_FREEZE_AT=0, WEIGHTS="")
     m.UniVS = CN(PROMPT_TYPE="category",
                  CLIP_CLASS_EMBED_PATH="datasets/concept_emb/combined_datasets_cls_emb_rn50x4.pth",
                  NUM_POS_QUERIES=30, VISUAL_PROMPT_ENCODER=True, TEXT_PROMPT_ENCODER=True,
@@ -128,6 +133,10 @@ def get_cfg():
     m.UniVS.TEST = CN(VIDEO_UNIFIED_INFERENCE_ENABLE=False, CLIP_STRIDE=1, NUM_PREV_FRAMES_MEMORY=5,
                       ENABLED_PREV_FRAMES_MEMORY=True, ENABLED_PREV_VISUAL_PROMPTS_FOR_GROUNDING=False,
                       DETECT_NEWLY_INTERVAL_FRAMES=1,
+                      # univs/config.py:138-153
+                      VIDEO_UNIFIED_INFERENCE_QUERIES="prompt", VIDEO_UNIFIED_INFERENCE_ENTITIES="",
+                      BOX_NMS_THRESH=0.75, TEMPORAL_CONSISTENCY_THRESHOLD=0.05, DETECT_NEWLY_OBJECT_THRESHOLD=0.05,
+                      CUSTOM_VIDEOS_ENABLE=False, CUSTOM_VIDEOS_TEXT=[],
                       SEMANTIC_EXTRACTION=CN(ENABLE=False))
     c.INPUT = CN(FORMAT="RGB", SAMPLING_FRAME_NUM=2, MIN_SIZE_TEST=800, MAX_SIZE_TEST=1333,
                  LSJ_AUG=CN(ENABLED=True, SQUARE_ENABLED=True, IMAGE_SIZE=1024, MIN_SCALE=0.25, MAX_SCALE=4.0))

@@ -162,12 +162,16 @@ class InferenceVideoEntity(nn.Module):
     # ------------------------------------------------------------------------------------------
     # entry points
     # ------------------------------------------------------------------------------------------
-    def eval(self, model, batched_inputs, targets):
-        """batched_inputs: [{"image": [frame tensors CHW, 0..255], "video_len", "height", "width"}];
-        targets: the per-video dict list the reference's `PrepareTargets.process_inference` produces
-        (task / dataset_name / prompt_type / num_frames / video_len)."""
+    def eval(self, model, batched_inputs, targets=None):
+        """The reference's entry point (:237-281): batched_inputs = [{"image": [frame tensors CHW, 0..255], "video_len",
+        "height", "width", "task", "dataset_name", "file_names", ...}].  `targets` defaults to what
+        `model.prepare_targets.process_inference` builds (the reference's only mode); a prepared list may be passed."""
         frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
         images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        if targets is None:
+            targets = model.prepare_targets.process_inference(batched_inputs, tuple(images.tensor.shape[-2:]), self.device,
+                                                              getattr(model, "text_prompt_encoder", None),
+                                                              images.image_sizes[0])
         if self.video_unified_inference_entities:
             targets[0]["sub_task"] = self.video_unified_inference_entities
         else:
@@ -190,7 +194,7 @@ class InferenceVideoEntity(nn.Module):
             return self.dataset_category_info[dataset_name]
         return self.dataset_category_info.get(dataset_name)
 
-    def inference_video(self, model, batched_inputs, images, targets):
+    def inference_video(self, model, batched_inputs, images, targets, merge_results=True):
         x = images.tensor
         tv = targets[0]
         sub_task = tv["sub_task"]
@@ -264,7 +268,14 @@ class InferenceVideoEntity(nn.Module):
             return self.vss_output_results(targets, results, out_size)
         if "vps" in sub_task:
             return self.vps_output_results(targets, results, out_size)
-        return results
+        if not merge_results:
+            return results            # per clip: [{"obj_id", "score", "masks" bool [T', H, W], "frame_id_start", ...}]
+        # the reference's return value (:405-409): one YouTube-VIS record per (entity, class), COCO-RLE segmentations
+        from .results import vis_clip_instances_to_coco_json_video
+        if not ("video_id" in batched_inputs[0] and "height" in batched_inputs[0] and "width" in batched_inputs[0]):
+            batched_inputs = [dict(batched_inputs[0], video_id=batched_inputs[0].get("video_id", 0), height=out_size[0],
+                                   width=out_size[1])]
+        return vis_clip_instances_to_coco_json_video(batched_inputs, results, test_topk_per_video=self.test_topk_per_image)
 
     # ------------------------------------------------------------------------------------------
     # step 1: prompt-specified entities

@@ -108,6 +108,20 @@ class InferenceVideoVOS(nn.Module):
         return self.pixel_mean.device
 
     # ------------------------------------------------------------------------------------------
+    def eval(self, model, batched_inputs, targets=None):
+        """The reference's entry point (:203-241): normalise and pad the frames, build `targets` through
+        `model.prepare_targets.process_inference` (unless a prepared list is passed), run the loop."""
+        from .video_entity import ImageList
+        frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
+        images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        image_size = images.image_sizes[0]
+        out_size = (batched_inputs[0].get("height", image_size[0]), batched_inputs[0].get("width", image_size[1]))
+        if targets is None:
+            targets = model.prepare_targets.process_inference(batched_inputs, tuple(images.tensor.shape[-2:]), self.device,
+                                                              getattr(model, "text_prompt_encoder", None))
+        targets[0]["video_len"] = len(frames)
+        return self.inference_video_vos(model, batched_inputs, images, targets, image_size, out_size)
+
     def inference_video_vos(self, model, batched_inputs, images, targets, image_size=None, out_size=None):
         x = images.tensor
         image_size = tuple(images.image_sizes[0])

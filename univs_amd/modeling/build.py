@@ -12,6 +12,13 @@ from .pixel_decoder import msdeformattn as _pd  # noqa: F401
 from .transformer_decoder import univs_decoder as _dec  # noqa: F401
 
 
+def build_model(cfg):
+    """detectron2's `build_model`: resolves cfg.MODEL.META_ARCHITECTURE ('UniVS_Prompt')."""
+    from ..registry import META_ARCH_REGISTRY
+    from .meta_arch import univs_prompt as _meta  # noqa: F401  (registers the class)
+    return META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+
+
 def build_backbone(cfg, input_shape=None):
     if input_shape is None:
         input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
