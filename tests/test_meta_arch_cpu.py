@@ -95,3 +95,27 @@ def test_unbuilt_branches_are_loud():
     model.train()
     with pytest.raises(NotImplementedError):
         model(video("detection", "ytvis_2021"))
+
+
+def test_longvideo_shell_shares_the_inference_dispatch():
+    from univs_amd.registry import META_ARCH_REGISTRY
+    from univs_amd.modeling.meta_arch.univs_prompt import UniVS_Prompt, UniVS_Prompt_LongVideo
+    assert META_ARCH_REGISTRY.get("UniVS_Prompt") is UniVS_Prompt
+    assert META_ARCH_REGISTRY.get("UniVS_Prompt_LongVideo") is UniVS_Prompt_LongVideo
+    cfg = get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "UniVS_Prompt_LongVideo"
+    cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES = 20
+    cfg.INPUT.SAMPLING_FRAME_NUM = 3
+    cfg.MODEL.UniVS.CLIP_CLASS_EMBED_PATH = cases.clip_table()
+    cfg.MODEL.UniVS.TEST.VIDEO_UNIFIED_INFERENCE_ENABLE = True
+    model = build_model(cfg).eval()
+    assert isinstance(model, UniVS_Prompt_LongVideo)
+    seen = []
+    model.inference_video_entity.eval = lambda m, b: seen.append("entity") or []
+    model.inference_video_vos.eval = lambda m, b: seen.append("vos") or []
+    model(video("detection", "ovis"))
+    with pytest.raises(ValueError):
+        model(video("detection", "my_dataset"))
+    model.video_unified_inference_enable = False
+    model(video("sot", "sot_ytbvos18_val"))
+    assert seen == ["entity", "vos"]

@@ -86,3 +86,24 @@ class UniVS_Prompt(nn.Module):
             raise ValueError(f"Not support to eval the dataset {name} yet")
         raise NotImplementedError("the non-unified trackers (MinVIS / MDQE style association) are not built: set "
                                   "MODEL.UniVS.TEST.VIDEO_UNIFIED_INFERENCE_ENABLE True")
+
+
+@META_ARCH_REGISTRY.register()
+class UniVS_Prompt_LongVideo(UniVS_Prompt):
+    """`univs/univs_prompt_longvideo.py`: the long-video recipe differs from `UniVS_Prompt` in TRAINING only (several clips
+    of one video per step, inter-clip re-identification loss, :347-438 / :469-589); its inference dispatch (:440-467) sends
+    category-specified videos to the same unified entity loop and 'sot*' datasets to the VOS loop."""
+
+    @torch.no_grad()
+    def forward_inference(self, batched_inputs):
+        name = batched_inputs[0]["dataset_name"]
+        if name.startswith("coco") or name.startswith("ade20k"):
+            raise ValueError(f"Not support to eval the image datasets {name} here")
+        if self.video_unified_inference_enable:
+            if name.startswith(("ytvis", "ovis", "vipseg", "vpsw")):      # ('vpsw': the reference's spelling, :451)
+                return self.inference_video_entity.eval(self, batched_inputs)
+            raise ValueError(f"Not support to eval the dataset {name} yet")
+        if name.startswith("sot"):
+            return self.inference_video_vos.eval(self, batched_inputs)
+        raise NotImplementedError("the non-unified trackers (MinVIS / MDQE style association) are not built: set "
+                                  "MODEL.UniVS.TEST.VIDEO_UNIFIED_INFERENCE_ENABLE True")
