@@ -10,7 +10,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if pat and pat not in k:
+        if pat and not any(p_ in k for p_ in pat.split(",")):
             continue
         acc[k[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
