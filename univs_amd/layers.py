@@ -84,15 +84,16 @@ class MultiheadAttention(nn.Module):
         S = key.shape[0]
         h, d = self.num_heads, self.head_dim
         w, b = self.in_proj_weight, self.in_proj_bias
+        lin = linear if _SPLIT_LINEAR_LEVEL >= 2 else F.linear
         if query is key and key is value:
-            q, k, v = F.linear(query, w, b).chunk(3, dim=-1)
+            q, k, v = lin(query, w, b).chunk(3, dim=-1)
         else:
-            q = F.linear(query, w[:E], b[:E])
+            q = lin(query, w[:E], b[:E])
             if key is value:
-                k, v = F.linear(key, w[E:], b[E:]).chunk(2, dim=-1)
+                k, v = lin(key, w[E:], b[E:]).chunk(2, dim=-1)
             else:
-                k = F.linear(key, w[E:2 * E], b[E:2 * E])
-                v = F.linear(value, w[2 * E:], b[2 * E:])
+                k = lin(key, w[E:2 * E], b[E:2 * E])
+                v = lin(value, w[2 * E:], b[2 * E:])
         # [L, N, h, d] -> [N, h, L, d]
         q = q.reshape(L, N, h, d).permute(1, 2, 0, 3)
         k = k.reshape(S, N, h, d).permute(1, 2, 0, 3)
@@ -142,7 +143,11 @@ def layer_norm(norm, x, residual=None, return_sum=False):
     return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, residual=residual, return_sum=return_sum)
 
 
-_SPLIT_LINEAR = os.environ.get("UNIVS_SPLIT_LINEAR", "1") != "0"
+# UNIVS_SPLIT_LINEAR: 0 = library GEMMs only, 1 (default) = the MSDeformAttn token projections + encoder FFN through the
+# split-bf16 kernel (measured), 2 = additionally the attention in-projections of tall memories
+# (decoder cross-attention K / V: covered shapes, routing not yet measured on the GPU -- opt-in until it is)
+_SPLIT_LINEAR_LEVEL = int(os.environ.get("UNIVS_SPLIT_LINEAR", "1") or 0)
+_SPLIT_LINEAR = _SPLIT_LINEAR_LEVEL != 0
 
 
 def linear(x, weight, bias=None):
