@@ -15,6 +15,8 @@ same call order as the reference, so a seeded run reproduces the reference's sam
 Known quirk kept on purpose: the "avoid NaN" block multiplies by `isblank` instead of `~isblank`
 (:836-840), so blank prompt tokens are filled with zeros.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -150,6 +152,24 @@ class VisualPromptEncoder:
         # the owner's values (x + 0 is exact).  Everything else (candidate pixels, random ranks, position tokens,
         # attention masks) depends on the replicated annotations only and is evaluated identically on every rank.
         self.feature_reduce = None
+        # "reference" (default): the reference's own `torch.randperm` draws on the CPU generator, in its call order --
+        # bit-identical sampling, at the price of one host round trip per key frame (the draw sizes are pixel counts that
+        # live on the device).  "device" (UNIVS_SAMPLER=device): the same distributions drawn on the device (uniform
+        # rank per point; uniform R-subset in random order via top-R of random keys), no host round trip; the random
+        # stream differs from the reference's, everything that is not random (cyclic fill of small masks, fallbacks of
+        # empty ones) is identical.
+        self.sampler_rng = os.environ.get("UNIVS_SAMPLER", "reference")
+        if self.sampler_rng not in ("reference", "device"):
+            raise ValueError(f"UNIVS_SAMPLER={self.sampler_rng!r} (expected 'reference' or 'device')")
+        self._dev_gen = {}
+
+    def _generator(self, device):
+        g = self._dev_gen.get(str(device))
+        if g is None:
+            g = torch.Generator(device=device)
+            g.manual_seed(torch.initial_seed() % (2 ** 63))
+            self._dev_gen[str(device)] = g
+        return g
 
     def _point_pe(self, h_img, w_img, point_coords, key_fid, key_fid_original):
         size = (self.num_frames, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
@@ -214,9 +234,14 @@ class VisualPromptEncoder:
         assert (h_img * s == h) and (w_img * s == w), \
             f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
         sel, rowcnt = self._select_candidates(masks, boxes)
-        counts = torch.cat([rowcnt.sum(1), feat_masks_binary.flatten(1).sum(1).to(torch.int32)]).tolist()
-        point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
-                                                        _prepared=(sel, rowcnt, counts[:n]))
+        if self.sampler_rng == "device":
+            counts = [None] * (2 * n)                        # sizes stay on the device
+            point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
+                                                            _prepared=(sel, rowcnt, None))
+        else:
+            counts = torch.cat([rowcnt.sum(1), feat_masks_binary.flatten(1).sum(1).to(torch.int32)]).tolist()
+            point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
+                                                            _prepared=(sel, rowcnt, counts[:n]))
         query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
         fw = feat_masks * feat_masks_binary
         pf = torch.einsum("qn,nc->qc", fw.flatten(-2).float(), img_features.flatten(-2).t())
@@ -230,7 +255,8 @@ class VisualPromptEncoder:
         fd, pd = query_feats[:, None], query_pe[:, None]
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
-                                             prompt_type="masks", is_train=is_train, _counts=counts[n:])
+                                             prompt_type="masks", is_train=is_train,
+                                             _counts=None if self.sampler_rng == "device" else counts[n:])
         if self.feature_reduce is not None:
             fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
         # invalid (empty) entities: zero tokens, nothing masked (unconditional: no host round trip for `.any()`)
@@ -308,11 +334,17 @@ class VisualPromptEncoder:
                 f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
             if _prepared is None:
                 sel, rowcnt = self._select_candidates(masks, boxes, mask_thresh)
-                counts = rowcnt.sum(1).tolist()                   # the one host round trip of this call
+                counts = None if self.sampler_rng == "device" else rowcnt.sum(1).tolist()   # the one host round trip
             else:
                 sel, rowcnt, counts = _prepared                   # get_mask_prompt shares one round trip
-            # same generator calls, in the same order, as the reference's per-entity loop (prompt_encoder.py:463-474)
-            ranks = _to_device_async(torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]), device)
+            if self.sampler_rng == "device":
+                # a uniform candidate per point: rank = floor(u * count), count >= 1 by construction of `sel`
+                cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
+                u = torch.rand((n, num_points), device=device, generator=self._generator(device))
+                ranks = (u * cnt[:, None]).long().clamp(max=cnt[:, None] - 1)
+            else:
+                # same generator calls, in the same order, as the reference's per-entity loop (prompt_encoder.py:463-474)
+                ranks = _to_device_async(torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]), device)
             idx = _kth_true_2d(sel, ranks, rowcnt)                 # [n, num_points] flat pixel indices
             point_coords = torch.stack([((idx % w).float() + 0.5) / w, ((idx // w).float() + 0.5) / h], dim=-1)
         else:
@@ -332,6 +364,22 @@ class VisualPromptEncoder:
         pos = img_pos.flatten(-2).t()
         R = self.num_dense_points
         m = masks_binary.flatten(1)
+        if self.sampler_rng == "device":
+            assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
+            cnt = m.sum(1)                                                        # [n] on the device
+            # masks with fewer than R pixels: all of them, cyclically, in pixel order (the reference's rule, :240-246)
+            cyc = torch.arange(R, device=m.device)[None] % cnt.clamp(min=1)[:, None]
+            idx_small = _kth_true(m, cyc)
+            # larger masks: a uniform R-subset in random order = the R largest of i.i.d. keys on the mask's pixels
+            keys = torch.rand(m.shape, device=m.device, generator=self._generator(m.device)).masked_fill(~m.bool(), -1.0)
+            idx_big = keys.topk(min(R, m.shape[1]), dim=1).indices
+            if idx_big.shape[1] < R:
+                idx_big = torch.cat([idx_big, idx_big[:, :1].expand(-1, R - idx_big.shape[1])], dim=1)
+            idx = torch.where((cnt >= R)[:, None], idx_big, idx_small)
+            empty = (cnt == 0).view(-1, 1, 1)
+            fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
+            pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
+            return (fd[:, :, None].repeat(1, 1, self.num_frames, 1), pd[:, :, None].repeat(1, 1, self.num_frames, 1))
         counts = m.sum(1).tolist() if _counts is None else _counts   # the one host round trip of this call
         rows = []
         for c in counts:                                          # generator calls as in the reference (:236-251)
