@@ -85,6 +85,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        # one process per GPU on one node: share the host cores instead of N x all-cores thread pools
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension is the only implementation)"
