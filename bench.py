@@ -269,6 +269,7 @@ def main():
         res["cpu_baseline"] = {"value": T / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
                                "sample": "one config-2 clip (5 frames) through the CPU oracle path "
                                          "(oracle/cpu_path.py: ATen CPU + plain-C MSDA), cold, single run"}
+        res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]   # reported, not a quality measure
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
