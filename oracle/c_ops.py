@@ -80,3 +80,16 @@ def window_attention(qkv, bias, shift_mask, scale):
     out = np.empty((B_, Ntok, nH * hd), dtype=np.float32)
     lib().oracle_window_attention_f32(_p(qkv), _p(bias), mp, B_, nW, Ntok, nH, hd, ctypes.c_float(scale), _p(out))
     return out
+
+
+def rle_encode(mask):
+    """mask [H, W] (bool / 0-1) -> (counts int64 array, compressed COCO RLE string) by the C restatement of maskApi.c."""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = m.shape
+    out = ctypes.create_string_buffer(7 * (h * w + 1) + 1)
+    counts = np.empty(h * w + 1, dtype=np.int64)
+    n = ctypes.c_longlong(0)
+    fn = lib().oracle_rle_encode
+    fn.restype = ctypes.c_longlong
+    fn(_p(m), h, w, out, _p(counts), ctypes.byref(n))
+    return counts[: n.value].copy(), out.value.decode("ascii")

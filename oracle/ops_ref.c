@@ -138,3 +138,45 @@ void oracle_window_attention_f32(const float* qkv, const float* bias, const floa
       }
   free(s);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * COCO run-length coding of a binary mask (result format of the VIS loop: the reference calls pycocotools'
+ * mask.encode per object and frame, univs/inference/inference_video_entity.py:944-948).  pycocotools (third party, version
+ * un-pinned by INSTALL.md) is absent from this image; this restates its published algorithm, maskApi.c:
+ *   rleEncode:   column-major runs, the first run counts zeros (possibly 0 of them);
+ *   rleToString: each count (from the 4th on: minus the count two places back) as 5-bit groups, low group first, bit 5 =
+ *                "more groups follow", sign-extended from bit 4 of the last group, each group + 48 as a character.
+ * Returns the string length (without the terminator); `out` must hold 7 * (h * w + 1) + 1 bytes.
+ * ------------------------------------------------------------------------------------------------------------------- */
+long long oracle_rle_encode(const uint8_t* mask, int h, int w, char* out, long long* counts_out, long long* n_counts) {
+  const long long n = (long long)h * w;
+  long long m = 0, run = 0, p = 0;
+  uint8_t cur = 0;
+  long long* cnts = counts_out;
+  for (long long i = 0; i < n; ++i) {
+    const long long col = i / h, row = i - col * h;      /* column-major walk over a row-major array */
+    const uint8_t v = mask[row * w + col] ? 1 : 0;
+    if (v != cur) {
+      cnts[m++] = run;
+      run = 0;
+      cur = v;
+    }
+    ++run;
+  }
+  cnts[m++] = run;
+  *n_counts = m;
+  for (long long i = 0; i < m; ++i) {
+    long long x = cnts[i];
+    if (i > 2) x -= cnts[i - 2];
+    int more = 1;
+    while (more) {
+      char c = (char)(x & 0x1f);
+      x >>= 5;
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      out[p++] = (char)(c + 48);
+    }
+  }
+  out[p] = 0;
+  return p;
+}
