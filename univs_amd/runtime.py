@@ -39,6 +39,8 @@ def enable_tuned_gemms(path=None, tune=None):
         return "tunableop: no table"
     tn.enable(True)
     tn.tuning_enable(False)
+    if hasattr(tn, "write_file_on_exit"):
+        tn.write_file_on_exit(False)          # read-only use: no per-rank result files in the working directory
     ok = tn.read_file(path)
     if not ok:
         tn.enable(False)
