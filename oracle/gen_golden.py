@@ -556,7 +556,7 @@ class _RefAnn:
         return self
 
 
-def _ref_vos(mode, targets, tag, case=None, **kw_over):
+def _ref_vos(mode, targets, tag, case=None, objects=None, **kw_over):
     import glob
     import shutil
     from PIL import Image
@@ -572,7 +572,7 @@ def _ref_vos(mode, targets, tag, case=None, **kw_over):
     kw.update(kw_over)
     inf = RV.InferenceVideoVOS(**kw)
     dumps, calls = {}, []
-    head = cases.ScriptedHead()
+    head = cases.ScriptedHead(case, objects) if objects is not None else cases.ScriptedHead(case)
 
     def hooked(features, targets=None, **k):
         calls.append(int(targets[0]["first_frame_idx"]))
@@ -643,6 +643,26 @@ def g15f_vos_stride1():
     d = _ref_vos("prompt+learn", cases.vos_targets_sot(_RefAnn, case), "f", case=case, clip_stride=1)
     print("   clips", d["clip_first_frames"].tolist(), "frames", d["result_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
     save("g15f_vos_stride1", **d)
+
+
+def _viposeg(mode, tag):
+    case = cases.VIPOSEG_CASE
+    targets = cases.vos_targets_sot(_RefAnn, case, objects=cases.VIPOSEG_OBJECTS, class_offset=cases.VIPOSEG_CLASS_START,
+                                    dataset="viposeg_val")
+    meta = types.SimpleNamespace(stuff_dataset_id_to_contiguous_id={i: i - 1 for i in cases.VIPOSEG_STUFF_IDS})
+    d = _ref_vos(mode, targets, tag, case=case, objects=cases.VIPOSEG_OBJECTS, metadata=meta, data_name="viposeg_val")
+    print("   clips", d["clip_first_frames"].tolist(), "ids", d["result_idmaps"].unique().tolist())
+    return d
+
+
+@gen
+def g15g_viposeg_prompt():
+    save("g15g_viposeg_prompt", **_viposeg("prompt", "g"))
+
+
+@gen
+def g15h_viposeg_prompt_learn():
+    save("g15h_viposeg_prompt_learn", **_viposeg("prompt+learn", "h"))
 
 
 @gen

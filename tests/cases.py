@@ -418,10 +418,11 @@ def vos_kwargs(case=SCRIPT_CASE, **over):
     return kw
 
 
-def vos_targets_sot(make_annotations, case=SCRIPT_CASE):
+def vos_targets_sot(make_annotations, case=SCRIPT_CASE, objects=None, class_offset=0, dataset="ytbvos18_val"):
     """`make_annotations(image_size, ori_ids, gt_masks, gt_boxes, gt_classes)` builds one frame's annotation object
     (our FrameAnnotations or a stand-in for detectron2 Instances in the golden generator)."""
-    head = ScriptedHead(case)
+    objects = SCRIPT_OBJECTS if objects is None else objects
+    head = ScriptedHead(case, objects)
     h, w = case["image_size"]
     per_frame = []
     for f in range(case["n_frames"]):
@@ -432,12 +433,12 @@ def vos_targets_sot(make_annotations, case=SCRIPT_CASE):
                 m = torch.zeros(h, w)
                 m[y0:y1, x0:x1] = 1.0
                 ids.append(oid); masks.append(m); boxes.append(torch.tensor([x0, y0, x1, y1], dtype=torch.float32))
-                classes.append(SCRIPT_OBJECTS[j][0])
+                classes.append(objects[j][0] - class_offset)
         per_frame.append(make_annotations((h, w), ids, torch.stack(masks) if masks else torch.zeros(0, h, w),
                                           torch.stack(boxes) if boxes else torch.zeros(0, 4),
                                           torch.tensor(classes, dtype=torch.long)))
     names = [f"videos/clip0/{f:05d}.jpg" for f in range(case["n_frames"])]
-    return [{"task": "sot", "dataset_name": "ytbvos18_val", "prompt_type": "visual", "num_frames": case["T"],
+    return [{"task": "sot", "dataset_name": dataset, "prompt_type": "visual", "num_frames": case["T"],
              "video_len": case["n_frames"], "inter_image_size": (case["H"], case["W"]), "image_size": (h, w),
              "instances": per_frame, "file_names": names, "mask_palette": [0] * 768}]
 
@@ -500,3 +501,11 @@ def prepare_targets_inputs():
         "custom_text": (dict(custom_videos_text=[["two zebras", "a red car"]]),
                         [dict(base, task="detection", dataset_name="my_videos", is_raw_video=True)]),
     }
+
+
+# (g) VIPOSeg (panoptic VOS): class scores live in the VIPSeg slice of the 3938-wide class table (start 2924); classes 5
+# and 9 are 'stuff' (dataset ids 6 and 10), so objects 1 / 2 (both class 5) and 3 borrow pixels from the semantic map
+VIPOSEG_CASE = dict(SCRIPT_CASE, name="viposeg", K=3938)
+VIPOSEG_CLASS_START = 2924
+VIPOSEG_OBJECTS = [(VIPOSEG_CLASS_START + o[0],) + tuple(o[1:]) for o in SCRIPT_OBJECTS]
+VIPOSEG_STUFF_IDS = (6, 10)

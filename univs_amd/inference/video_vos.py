@@ -15,8 +15,9 @@ same mutations of the per-video `targets[0]` dictionary (`masks`, `mask_logits`,
 
 Per-frame annotations are duck-typed like detectron2 `Instances` (`ori_ids`, `gt_boxes.tensor`, `gt_masks` (tensor or
 `.tensor`), `gt_classes`, `image_size`, `len()`, `.to(device)`); `FrameAnnotations` below is a minimal stand-in.
-Not built: the VIPOSeg panoptic-VOS extras (`use_semseg_pvos`, stuff regions from the semantic map) -- datasets
-whose name contains 'viposeg' raise NotImplementedError.
+Datasets whose name contains 'viposeg' (panoptic VOS) take the reference's extras: a semantic map from the learnable
+queries (class scores of the VIPSeg slice x mask probabilities) lends its pixels to 'stuff' objects (:320-325, :404-412,
+:502-506), and re-identification among learnable queries uses un-normalised similarities with threshold 0.5 (:444-445).
 """
 from typing import Tuple
 
@@ -71,6 +72,9 @@ class InferenceVideoVOS(nn.Module):
         clip_stride: int = 1,
         video_unified_inference_queries: str = "prompt",
         num_prev_frames_memory: int = 5,
+        stuff_dataset_ids=(),
+        use_semseg_pvos: bool = True,
+        dataset_category_info=None,
     ):
         super().__init__()
         self.hidden_dim = hidden_dim
@@ -86,6 +90,11 @@ class InferenceVideoVOS(nn.Module):
             raise ValueError(f"video_unified_inference_queries={video_unified_inference_queries!r}")
         self.video_unified_inference_queries = video_unified_inference_queries
         self.num_prev_frames_memory = max(num_prev_frames_memory, num_frames)
+        # VIPOSeg: 1-based dataset ids of the 'stuff' categories (the reference's metadata.stuff_dataset_id_to_contiguous_id keys)
+        self.stuff_dataset_ids = frozenset(int(c) for c in stuff_dataset_ids)
+        self.use_semseg_pvos = use_semseg_pvos
+        from .video_entity import COMBINED_DATASETS_CATEGORY_INFO
+        self.dataset_category_info = COMBINED_DATASETS_CATEGORY_INFO if dataset_category_info is None else dataset_category_info
 
     @classmethod
     def from_config(cls, cfg):
@@ -128,8 +137,6 @@ class InferenceVideoVOS(nn.Module):
         out_size = tuple(out_size) if out_size is not None else image_size
         video_len = len(x)
         tv = targets[0]
-        if "viposeg" in tv["dataset_name"]:
-            raise NotImplementedError("the VIPOSeg panoptic-VOS extras (semantic stuff regions) are not built")
         T = self.num_frames
         stride = min(self.clip_stride, T)
         results = []
@@ -227,6 +234,13 @@ class InferenceVideoVOS(nn.Module):
         _, _, h_gt, w_gt = gt_masks.shape
         masks = _resize(masks, (h_gt, w_gt))
         quality = calculate_mask_quality_scores(masks[..., : image_size[0], : image_size[1]])
+        viposeg = "viposeg" in tv["dataset_name"]
+        sem_mask = None
+        if viposeg and self.use_semseg_pvos:
+            n_cls, start = self.dataset_category_info["vipseg"]
+            cls_q = logits[..., start:start + n_cls] * quality.view(-1, 1)
+            sem_mask = torch.einsum("qc,qthw->cthw", cls_q[: self.num_queries], masks[: self.num_queries].sigmoid()).argmax(0)
+        labels = tv["labels"]
         mode = self.video_unified_inference_queries
         with_prompt = self.prompt_as_queries and mode in ("prompt", "prompt+learn", "learn+prompt")
         with_learn = mode in ("learn", "prompt+learn", "learn+prompt")
@@ -278,9 +292,13 @@ class InferenceVideoVOS(nn.Module):
                 ok = torch.ones(len(obj), dtype=torch.bool, device=obj.device)
             for i_, (ok_i, o_i, f_i) in enumerate(zip(ok.tolist(), obj.tolist(), faf.tolist())):
                 f_i = f_i + 1 if task == "sot" else f_i          # the annotated frame itself keeps its annotation
-                if not ok_i or f_i == 0:
+                label = int(labels[o_i])
+                is_stuff = viposeg and (label + 1) in self.stuff_dataset_ids
+                if (not ok_i and not is_stuff) or f_i == 0:
                     continue
                 cur = m_masks[i_, f_i:]
+                if is_stuff and sem_mask is not None:            # stuff regions follow the semantic map
+                    cur[sem_mask[f_i:] == label] = 10.0
                 gt_masks[o_i, f_i:] = cur.gt(0.0)
                 gt_logits[o_i, f_i:] = cur
                 gt_boxes[o_i, f_i:] = m_boxes[i_, f_i:]
@@ -297,10 +315,11 @@ class InferenceVideoVOS(nn.Module):
                 embds_p, boxes_p = embds[idx_p] * keep.view(-1, 1, 1), boxes[idx_p] * keep.view(-1, 1, 1)
                 sim_p = sim_p * cons.float()
             if with_learn:
+                use_norm = not viposeg
                 idx_l, sim_l = match_from_learnable_embds(tgt, embds[: self.num_queries], return_similarity=True,
-                                                          return_src_indices=False, use_norm=True)
+                                                          return_src_indices=False, use_norm=use_norm)
                 idx_l = torch.as_tensor(idx_l, device=masks.device)
-                cons = sim_l >= 0.65
+                cons = sim_l >= (0.65 if use_norm else 0.5)
                 keep = cons.view(-1, 1, 1, 1).float()
                 masks_l, q_l = masks[idx_l] * keep, quality[idx_l] * cons.float()
                 embds_l, boxes_l = embds[idx_l] * keep.view(-1, 1, 1), boxes[idx_l] * keep.view(-1, 1, 1)
@@ -327,8 +346,15 @@ class InferenceVideoVOS(nn.Module):
                 # every pixel to the object with the highest sim^2 x quality x probability; drop objects that keep
                 # less than a quarter of their own area
                 orig = (m_masks > 0).flatten(1).sum(1).clamp(min=1)
+                prob = m_masks.sigmoid()
+                if sem_mask is not None:
+                    for i_, label in enumerate(labels[seen].tolist()):
+                        if (int(label) + 1) in self.stuff_dataset_ids:
+                            region = sem_mask == int(label)
+                            prob[i_][region] = 1
+                            m_masks[i_][region] = 10
                 is_bg = (m_masks <= 0).all(0)
-                owner = (m_masks.sigmoid() * (sim ** 2 * m_q).view(-1, 1, 1, 1)).argmax(0)
+                owner = (prob * (sim ** 2 * m_q).view(-1, 1, 1, 1)).argmax(0)
                 owner = torch.where(is_bg, torch.full_like(owner, -1), owner)
                 binary = (owner[None] == torch.arange(m_masks.shape[0], device=owner.device).view(-1, 1, 1, 1)).float()
                 area = binary.flatten(1).sum(1)
