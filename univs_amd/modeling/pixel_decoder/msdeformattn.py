@@ -15,7 +15,6 @@ work is organised (results are the same):
     msdeformattn.py:62) are dropped: valid_ratio is identically 1;
   * everything stays fp32 regardless of autocast (msdeformattn.py:316,322).
 """
-import math
 from typing import Callable, Dict, List, Optional, Union
 
 import numpy as np

@@ -18,9 +18,7 @@ What is organised differently (same results up to fp32 re-association):
   * the attention mask is kept as [T, Q, HW] and broadcast over the 8 heads instead of being repeated;
   * shape-only tensors (the spatial part of the 3-D sine embedding, the self-attention mask) are cached.
 """
-import logging
 import math
-import os
 
 import torch
 import torch.nn.functional as F

@@ -10,7 +10,6 @@ mask2former/modeling/transformer_decoder/maskformer_transformer_decoder.py:16-27
 explicit keyword arguments.
 """
 import functools
-import inspect
 from dataclasses import dataclass
 from typing import Optional
 
