@@ -100,6 +100,10 @@ int univs_msda_set_impl(int impl);
 /* Which implementation the last univs_msda_forward_f32 call on this thread launched: 1 generic,
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
 int univs_msda_last_impl(void);
+/* Generation of the LDS-tiled kernel the last univs_msda_forward_f32 call on this thread launched: 3 = LDS-DMA fills +
+ * in-register sample records (msda_tiled3.hip), 2 = producer / consumer waves (msda_tiled2.hip), 1 = single window
+ * (msda_tiled.hip), 0 = none (generic kernel).  UNIVS_MSDA_TILED=<n> in the environment caps the generation. */
+int univs_msda_last_tiled_generation(void);
 
 /* y[M, N] = x[M, K] * W[N, K]^T + bias[N] (+ ReLU): torch.nn.functional.linear for contiguous float32 operands, as the
  * token projections of MSDeformAttn use it (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113:

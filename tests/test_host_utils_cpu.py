@@ -55,3 +55,49 @@ def test_runtime_gemm_table_is_inert_without_gpu():
     assert runtime.default_table() is not None and runtime.default_table().endswith(".csv")
     if not torch.cuda.is_available():
         assert runtime.enable_tuned_gemms() == "tunableop: no GPU"
+
+
+def test_level_table_is_never_cached_and_is_validated():
+    """a host copy of spatial_shapes keyed on (address, version) returned the previous
+    resolution's table for freshly allocated tensors.  There is no cache, and inconsistent tables raise."""
+    import pytest
+    import torch
+    from univs_amd import ops
+    seen = []
+    for rep in range(50):
+        for shapes in ([[16, 6], [2, 3]], [[8, 6], [2, 3]], [[5, 7], [3, 2]]):
+            starts = [0, shapes[0][0] * shapes[0][1]]
+            S = starts[1] + shapes[1][0] * shapes[1][1]
+            sh_t = torch.as_tensor(shapes, dtype=torch.long)       # fresh tensors every call, like the reference
+            st_t = torch.as_tensor(starts, dtype=torch.long)
+            sh, st, L = ops._host_shapes(sh_t, st_t, S)
+            seen.append((list(sh), list(st)))
+            assert list(sh) == [v for hw in shapes for v in hw] and list(st) == starts and L == 2
+            del sh_t, st_t
+    with pytest.raises(RuntimeError):   # a smaller table that merely fits inside S
+        ops._host_shapes([[8, 6], [2, 3]], [0, 30], 102)
+    with pytest.raises(RuntimeError):   # start index is not the running sum
+        ops._host_shapes([[8, 6], [2, 3]], [0, 50], 54)
+    with pytest.raises(RuntimeError):
+        ops._host_shapes([[8, 6], [0, 3]], [0, 48], 48)
+
+
+def test_inference_only_operators_refuse_to_drop_gradients():
+    """the HIP operators return tensors detached from autograd; with gradient recording on
+    they raise instead, and layers.linear keeps the ATen path so that autograd sees the Linear."""
+    import pytest
+    import torch
+    from univs_amd import layers, ops
+    x = torch.randn(4, 8, requires_grad=True)
+    w = torch.ones(8)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        ops.layer_norm(x, w, w)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.layer_norm(x, w, w)          # no_grad: passes the guard, then the CPU check of the operator
+    assert ops.needs_grad(x) and not ops.needs_grad(x.detach())
+    lin = torch.nn.Linear(256, 256)
+    big = torch.randn(4096, 256, requires_grad=True)
+    assert ops.linear_split(big, lin.weight, lin.bias) is None      # needs grad -> caller keeps F.linear
+    y = layers.linear(big, lin.weight, lin.bias)
+    y.sum().backward()
+    assert big.grad is not None and lin.weight.grad is not None

@@ -13,16 +13,28 @@ from univs_amd import ops, synth
 pytestmark = pytest.mark.gpu
 
 
-def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl):
+def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl, gen=3):
+    """impl 1 = generic kernel, 2 = LDS-tiled; `gen` caps the generation of the tiled kernel (3 = LDS-DMA +
+    in-register records, 2 = producer / consumer waves, 1 = single window) through UNIVS_MSDA_TILED."""
     ops.msda_set_impl(impl)
+    old = os.environ.get("UNIVS_MSDA_TILED")
+    os.environ["UNIVS_MSDA_TILED"] = str(gen)
     try:
         out = ops.ms_deform_attn_forward(value.to(dev), shapes, lsi, loc.to(dev), attn.to(dev), 128)
         torch.cuda.synchronize()
         ran = ops.msda_last_impl()
         tiled_ok = (value.shape[3] == 32 and loc.shape[4] == 4 and loc.shape[1] == value.shape[1])
         assert ran == (2 if (impl == 2 and tiled_ok) else 1), f"impl {impl} requested, {ran} ran"
+        if impl == 2 and tiled_ok:
+            L = loc.shape[3]
+            want = gen if gen == 3 or (gen == 2 and L >= 3) else 1
+            assert ops.msda_last_tiled_generation() == want, (gen, ops.msda_last_tiled_generation())
     finally:
         ops.msda_set_impl(0)
+        if old is None:
+            os.environ.pop("UNIVS_MSDA_TILED", None)
+        else:
+            os.environ["UNIVS_MSDA_TILED"] = old
     return out.cpu()
 
 
@@ -44,11 +56,11 @@ def test_g0_kat_float_and_double(cuda, golden_dir):
             assert np.allclose(out, ref, rtol=1e-2, atol=1e-3) and np.abs(out - ref).max() < 1e-8
 
 
-@pytest.mark.parametrize("impl", [1, 2], ids=["generic", "tiled"])
+@pytest.mark.parametrize("impl,gen", [(1, 3), (2, 3), (2, 2)], ids=["generic", "tiled3", "tiled2"])
 @pytest.mark.parametrize("case", cases.MSDA_CASES, ids=lambda c: c["name"])
-def test_msda_matches_oracle_and_golden(cuda, golden_dir, case, impl):
+def test_msda_matches_oracle_and_golden(cuda, golden_dir, case, impl, gen):
     value, shapes, lsi, loc, attn = cases.msda_inputs(case)
-    out = _msda_gpu(value, shapes, lsi, loc, attn, cuda, impl).numpy()
+    out = _msda_gpu(value, shapes, lsi, loc, attn, cuda, impl, gen).numpy()
     ref = c_ops.msda_forward(value.numpy(), shapes, lsi, loc.numpy(), attn.numpy())
     err = np.abs(out - ref).max()
     assert err < 2e-5, f"vs oracle: {err}"
@@ -70,6 +82,8 @@ def test_msda_cfg2_size_tiled_equals_generic_and_properties(cuda):
     o1 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 1)
     o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2)
     assert (o1 - o2).abs().max().item() < 2e-5
+    o2b = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=2)
+    assert (o1 - o2b).abs().max().item() < 2e-5
     v2 = synth.normal("cfg2/value2", tuple(value.shape))
     o_sum = _msda_gpu(value + 2.0 * v2, shapes, lsi, loc, attn, cuda, 2)
     o_b = _msda_gpu(v2, shapes, lsi, loc, attn, cuda, 2)
@@ -89,8 +103,37 @@ def test_msda_worst_case_uniform_locations(cuda):
     value, shapes, lsi, loc, attn = _cfg2_inputs(N=1, seed="cfg2u")
     loc = synth.uniform("cfg2u/loc", tuple(loc.shape), -0.05, 1.05)
     o1 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 1)
-    o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2)
-    assert (o1 - o2).abs().max().item() < 2e-5
+    for gen in (3, 2):
+        o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=gen)
+        assert (o1 - o2).abs().max().item() < 2e-5, gen
+
+
+def test_msda_fresh_shape_tensors_of_changing_values(cuda):
+    """The reference convention (compat drop-in): fresh device tensors for spatial_shapes / level_start_index on
+    every call.  The caching allocator hands the same address back for the next resolution's table, so a host-side
+    cache keyed on (address, version) would return the previous table; there is no such cache, and an inconsistent
+    table raises instead of sampling with the wrong geometry."""
+    M, D, P = 2, 32, 4
+    for rep in range(6):
+        for shapes in ([(8, 6), (4, 3)], [(16, 6), (2, 3)], [(5, 7), (3, 2)]):
+            lsi, S = cases.level_start_index(shapes)
+            L = len(shapes)
+            v = synth.normal(f"fresh/v{S}", (1, S, M, D))
+            loc = synth.uniform(f"fresh/l{S}", (1, S, M, L, P, 2), 0.0, 1.0)
+            a = torch.softmax(synth.normal(f"fresh/a{S}", (1, S, M, L * P)), -1).view(1, S, M, L, P)
+            sh_t = torch.as_tensor(shapes, dtype=torch.long, device=cuda)
+            st_t = torch.as_tensor(lsi, dtype=torch.long, device=cuda)
+            out = ops.ms_deform_attn_forward(v.to(cuda), sh_t, st_t, loc.to(cuda), a.to(cuda)).cpu().numpy()
+            del sh_t, st_t
+            ref = c_ops.msda_forward(v.numpy(), shapes, lsi, loc.numpy(), a.numpy())
+            assert np.abs(out - ref).max() < 2e-5, (rep, shapes)
+    v = torch.zeros(1, 54, 2, 32, device=cuda)
+    loc = torch.zeros(1, 54, 2, 2, 4, 2, device=cuda)
+    a = torch.zeros(1, 54, 2, 2, 4, device=cuda)
+    with pytest.raises(RuntimeError):   # the table of a SMALLER resolution fits inside S but is not this value's table
+        ops.ms_deform_attn_forward(v, [(5, 7), (3, 2)], [0, 35], loc, a)
+    with pytest.raises(RuntimeError):   # start index that is not the running sum
+        ops.ms_deform_attn_forward(v, [(8, 6), (2, 3)], [0, 40], loc, a)
 
 
 def test_msda_argument_errors(cuda):

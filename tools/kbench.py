@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--locs", default="local", choices=["local", "uniform", "far"])
     ap.add_argument("--only", default="")
+    ap.add_argument("--ablate", action="store_true", help="also time the gen-3 MSDA kernel with phases switched off")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     res = {}
@@ -46,10 +47,22 @@ def main():
     S = value.shape[1]
     alg = 3200.0 * S * T
     if not args.only or "msda" in args.only:
-        for impl, nm in ((1, "msda_generic"), (2, "msda_tiled")):
-            ops.msda_set_impl(impl)
-            t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
-            res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+        ops.msda_set_impl(1)
+        t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
+        res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+        ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+        ops.msda_set_impl(2)
+        for gen in (3, 2, 1):
+            os.environ["UNIVS_MSDA_TILED"] = str(gen)
+            for abl in ([0, 1, 4, 5] if (gen == 3 and args.ablate) else [0]):
+                os.environ["UNIVS_MSDA_ABLATE"] = str(abl)
+                t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
+                out = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+                nm = f"msda_tiled{gen}" + (f"_ablate{abl}" if abl else "")
+                res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+                               gen=ops.msda_last_tiled_generation(), max_abs_diff_vs_generic=(out - ref).abs().max().item())
+            os.environ.pop("UNIVS_MSDA_ABLATE", None)
+        os.environ.pop("UNIVS_MSDA_TILED", None)
         ops.msda_set_impl(0)
     if not args.only or "mask" in args.only:
         Q, C, H, W = 100, 256, 184, 320

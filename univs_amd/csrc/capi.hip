@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 
 static int g_msda_impl = 0;  // 0 auto, 1 generic, 2 tiled
 static thread_local int g_msda_last = 0;
+static thread_local int g_msda_gen = 0;   // generation of the LDS-tiled kernel that ran last (0: none)
 
 int msda_forward_generic_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                              int, int, int, int, int, float*, hipStream_t);
@@ -25,6 +26,8 @@ int msda_forward_generic_f64(const double*, const LevelTable&, const double*, co
                              int, int, int, int, int, int, double*, hipStream_t);
 // returns 1 if the tiled kernel was launched, 0 if its preconditions do not hold, <0 on error
 int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
+                            int, float*, hipStream_t);
+int msda_forward_tiled3_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
                             int, float*, hipStream_t);
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
@@ -60,16 +63,25 @@ static int make_levels(const int64_t* shapes, const int64_t* starts, int L, int 
     set_error("%s: spatial_shapes / level_start_index must be host pointers, got NULL", what);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
+  // The table must describe the concatenation `value` holds (ms_deform_attn.py:95: the levels are flattened and
+  // concatenated in order): start[l] is the running sum of H*W and the levels cover exactly S tokens.  A table that
+  // merely fits inside S (e.g. the previous, smaller resolution's) would sample with the wrong geometry silently.
+  int64_t run = 0;
   for (int l = 0; l < L; ++l) {
     const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], st = starts[l];
-    if (H <= 0 || W <= 0 || st < 0 || st + H * W > (int64_t)S) {
-      set_error("%s: level %d (H=%lld, W=%lld, start=%lld) does not fit value length S=%d", what, l,
-                (long long)H, (long long)W, (long long)st, S);
+    if (H <= 0 || W <= 0 || st != run || st + H * W > (int64_t)S) {
+      set_error("%s: level %d (H=%lld, W=%lld, start=%lld) is inconsistent: expected start=%lld, value length S=%d",
+                what, l, (long long)H, (long long)W, (long long)st, (long long)run, S);
       return UNIVS_ERR_INVALID_ARGUMENT;
     }
+    run += H * W;
     lv->H[l] = (int)H;
     lv->W[l] = (int)W;
     lv->start[l] = (int)st;
+  }
+  if (run != (int64_t)S) {
+    set_error("%s: the %d levels hold %lld tokens but value has S=%d", what, L, (long long)run, S);
+    return UNIVS_ERR_INVALID_ARGUMENT;
   }
   for (int l = L; l < UNIVS_MAX_LEVELS; ++l) lv->H[l] = lv->W[l] = lv->start[l] = 0;
   return UNIVS_OK;
@@ -94,6 +106,7 @@ int univs_msda_set_impl(int impl) {
 }
 
 int univs_msda_last_impl(void) { return g_msda_last; }
+int univs_msda_last_tiled_generation(void) { return g_msda_gen; }
 
 int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                            int relu, float* y, void* stream) {
@@ -147,17 +160,25 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   if (rc != UNIVS_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g_msda_impl != 1) {
-    // LDS-tiled kernels for the encoder geometry: the double-buffered 16-wave generation first
-    // (UNIVS_MSDA_TILED=1 selects the single-buffer kernel), each returns 0 when its preconditions fail
-    static const int tiled_gen = [] { const char* e = getenv("UNIVS_MSDA_TILED"); return (e && *e) ? atoi(e) : 2; }();
+    // LDS-tiled kernels for the encoder geometry, newest generation first; each returns 0 when its preconditions
+    // fail.  UNIVS_MSDA_TILED=2 / 1 (read per call: the kernel benchmarks flip it) starts at the second / first
+    // generation instead.
+    const char* e = getenv("UNIVS_MSDA_TILED");
+    const int tiled_gen = (e && *e) ? atoi(e) : 3;
+    g_msda_gen = 0;
+    rc = tiled_gen >= 3 ? msda_forward_tiled3_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
+    if (rc != 0) {
+      if (rc > 0) { g_msda_last = 2; g_msda_gen = 3; }
+      return rc < 0 ? rc : UNIVS_OK;
+    }
     rc = tiled_gen >= 2 ? msda_forward_tiled2_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
     if (rc != 0) {
-      if (rc > 0) g_msda_last = 2;
+      if (rc > 0) { g_msda_last = 2; g_msda_gen = 2; }
       return rc < 0 ? rc : UNIVS_OK;
     }
     rc = msda_forward_tiled_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
     if (rc != 0) {
-      if (rc > 0) g_msda_last = 2;
+      if (rc > 0) { g_msda_last = 2; g_msda_gen = 1; }
       return rc < 0 ? rc : UNIVS_OK;
     }
   }

@@ -26,7 +26,7 @@ struct Footprint {
   float w00, w01, w10, w11; // weights of (h0,w0) (h0,w1) (h1,w0) (h1,w1)
 };
 
-__device__ __forceinline__ Footprint footprint(int H, int W, float x, float y, float aw) {
+__host__ __device__ __forceinline__ Footprint footprint(int H, int W, float x, float y, float aw) {
   Footprint f;
   const float him = y * (float)H - 0.5f, wim = x * (float)W - 0.5f;
   const bool inb = him > -1.f && wim > -1.f && him < (float)H && wim < (float)W;

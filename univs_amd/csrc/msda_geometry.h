@@ -25,11 +25,11 @@ static inline long long ceil_div(long long a, long long b) {  // b > 0
 // ---- host-side geometry: built once per (device, level shapes, tile parameters), kept for the
 // lifetime of the process (a few hundred bytes of device memory per distinct geometry).
 struct GeoKey {
-  int dev, L, TH, TW, R;
+  int dev, L, TH, TW, R, ring;
   long long cap_px;
   int H[UNIVS_MAX_LEVELS], W[UNIVS_MAX_LEVELS];
   bool operator==(const GeoKey& o) const {
-    if (dev != o.dev || L != o.L || TH != o.TH || TW != o.TW || R != o.R || cap_px != o.cap_px) return false;
+    if (dev != o.dev || L != o.L || TH != o.TH || TW != o.TW || R != o.R || ring != o.ring || cap_px != o.cap_px) return false;
     for (int l = 0; l < L; ++l)
       if (H[l] != o.H[l] || W[l] != o.W[l]) return false;
     return true;
@@ -45,26 +45,31 @@ struct GeoEntry {
 };
 
 // one axis of one level: query interval and window interval of tile t
-static void axis_entry(int t, int ntile, int T, int Nq, int Nf, int R, int cap, int4& e) {
+// ring = 1: the window may include the one-pixel zero ring around the level (pixels -1 and Nq: msda_tiled.hip /
+// msda_tiled2.hip stage zeros there); ring = 0: the window is clipped to the level (msda_tiled3.hip folds the
+// border cases into the corner weights instead).
+static void axis_entry(int t, int ntile, int T, int Nq, int Nf, int R, int cap, int ring, int4& e) {
   // queries: pixel centres (i + 0.5) / Nq inside [t*T/Nf, (t+1)*T/Nf)
   long long lo = std::max<long long>(0, ceil_div(2LL * t * T * Nq - Nf, 2LL * Nf));
   long long hi = (t + 1 == ntile) ? Nq : ceil_div(2LL * (t + 1) * T * Nq - Nf, 2LL * Nf);
   hi = std::min<long long>(std::max(hi, lo), Nq);
   // window: bilinear corners of samples within R pixels of the tile's box, clipped to the zero ring
   const long long num1 = std::min<long long>((long long)(t + 1) * T, Nf);
-  long long w0 = std::max<long long>(-1, floor_div(2LL * t * T * Nq - (1 + 2LL * R) * Nf, 2LL * Nf));
-  long long w1 = std::min<long long>(Nq, floor_div(2LL * num1 * Nq - (1 - 2LL * R) * Nf, 2LL * Nf) + 1);
+  long long w0 = std::max<long long>(ring ? -1 : 0, floor_div(2LL * t * T * Nq - (1 + 2LL * R) * Nf, 2LL * Nf));
+  long long w1 = std::min<long long>(ring ? Nq : Nq - 1, floor_div(2LL * num1 * Nq - (1 - 2LL * R) * Nf, 2LL * Nf) + 1);
+  if (!ring) w0 = std::min<long long>(w0, std::max<long long>(Nq - 2, 0));   // two pixels inside the level
   long long wn = std::max<long long>(w1 - w0 + 1, 2);
   wn = std::min<long long>(wn, cap);
   e.x = (int)lo; e.y = (int)(hi - lo); e.z = (int)w0; e.w = (int)wn;
 }
 
-static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, long long cap_px) {
+static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, long long cap_px,
+                                int ring = 1) {
   static std::mutex mu;
   static std::vector<GeoEntry*> cache;
   GeoKey key{};
   if (hipGetDevice(&key.dev) != hipSuccess) return nullptr;
-  key.L = L; key.TH = TH; key.TW = TW; key.R = R; key.cap_px = cap_px;
+  key.L = L; key.TH = TH; key.TW = TW; key.R = R; key.ring = ring; key.cap_px = cap_px;
   for (int l = 0; l < L; ++l) { key.H[l] = lv.H[l]; key.W[l] = lv.W[l]; }
   std::lock_guard<std::mutex> lock(mu);
   for (const GeoEntry* e : cache)
@@ -77,9 +82,9 @@ static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, i
   std::vector<int4> tab((size_t)L * (ge->tiles_x + ge->tiles_y));
   for (int l = 0; l < L; ++l) {
     for (int tx = 0; tx < ge->tiles_x; ++tx)
-      axis_entry(tx, ge->tiles_x, TW, lv.W[l], lv.W[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, tab[(size_t)l * ge->tiles_x + tx]);
+      axis_entry(tx, ge->tiles_x, TW, lv.W[l], lv.W[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, ring, tab[(size_t)l * ge->tiles_x + tx]);
     for (int ty = 0; ty < ge->tiles_y; ++ty)
-      axis_entry(ty, ge->tiles_y, TH, lv.H[l], lv.H[fine], R, UNIVS_MSDA_WIN_EDGE_MAX,
+      axis_entry(ty, ge->tiles_y, TH, lv.H[l], lv.H[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, ring,
                  tab[(size_t)L * ge->tiles_x + (size_t)l * ge->tiles_y + ty]);
   }
   // windows must fit the LDS carve: shrink rows where a (tile, level) would not (samples beyond go

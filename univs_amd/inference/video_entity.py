@@ -41,7 +41,11 @@ COMBINED_DATASETS_CATEGORY_INFO = {
     "ade20k": (150, 2774), "vipseg": (124, 2924), "vspw": (124, 2924), "viposeg": (124, 2924), "ytvis19": (40, 3048),
     "entityseg_instance": (206, 3088), "entityseg_panoptic": (644, 3294),
 }
-ENTITY_SUBTASK_DATASET = {
+ENTITY_SUBTASK_DATASET = {   # inference_video_entity.py:320-333
+    "entity_vss_entityseg": "entityseg_panoptic",
+    "entity_vps_entityseg": "entityseg_panoptic",
+    "entity_vss_vipseg": "vipseg",
+    "entity_vps_vipseg": "vipseg",
     "entity_vis_entityseg": "entityseg_instance",
     "entity_vis_coco": "coco",
 }

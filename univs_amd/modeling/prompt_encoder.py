@@ -248,7 +248,10 @@ class VisualPromptEncoder:
         pf = pf / fw.sum((-2, -1)).clamp(min=mask_thresh)[:, None]
         query_feats = pf[:, None].repeat(1, self.num_frames, 1)
         if boxes is None:
-            normlizer = torch.tensor([w_img * s, h_img * s, w_img * s, h_img * s]).reshape(1, -1)
+            # the reference builds this normaliser on the host and divides a device tensor by it
+            # (prompt_encoder.py:243-244: device mismatch on a GPU); same values, on the masks' device
+            normlizer = torch.tensor([w_img * s, h_img * s, w_img * s, h_img * s], dtype=torch.float32,
+                                     device=masks.device).reshape(1, -1)
             boxes = convert_mask_to_box(masks > mask_thresh) / normlizer
         attn = torch.zeros((self.num_frames, 1, n, h_img * w_img), dtype=torch.bool, device=device)
         attn[key_fid, 0] = torch.logical_not(convert_box_to_mask(boxes, h_img, w_img).flatten(-2))

@@ -9,9 +9,6 @@ import torch
 
 from . import _lib
 
-_shape_cache = {}
-
-
 def _stream_ptr(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -29,20 +26,35 @@ def _require_gpu(name, *tensors):
             raise RuntimeError(f"{name}: all tensors have to be contiguous")
 
 
-def _host_shapes(spatial_shapes, level_start_index):
+def _inference_only(name, *tensors):
+    """The kernels behind these wrappers return tensors that are detached from autograd.  Called with gradient
+    recording on and an input that requires grad they would train with silently missing gradients, so that
+    case raises; wrap inference in `torch.no_grad()` (the reference's eval loop does, train_net.py:334) or use
+    the autograd pair `ms_deform_attn_forward` / `ms_deform_attn_backward` through an autograd.Function."""
+    if torch.is_grad_enabled():
+        for t in tensors:
+            if t is not None and t.requires_grad:
+                raise RuntimeError(f"{name}: inference-only HIP operator called with gradient recording enabled on a "
+                                   "tensor that requires grad; its result would be detached from autograd. Use "
+                                   "torch.no_grad() / torch.inference_mode().")
+
+
+def needs_grad(*tensors):
+    """True when autograd would record an op on these tensors (layers.linear then keeps the ATen path)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _host_shapes(spatial_shapes, level_start_index, S=None):
     """Level table as host int64 ctypes arrays.  Accepts tensors (device or host), lists or tuples.
-    Device tensors cost one D2H copy the first time a given table is seen; the encoder passes the
-    Python lists it already owns, so the hot path never syncs."""
+    A device tensor costs one small D2H copy per call (the reference's operator reads the table on the
+    device; there is deliberately NO cache here: an address/version key does not identify the contents
+    of a freshly allocated tensor).  The encoder passes the Python lists it already owns, so the hot
+    path never syncs.  The table is validated: start[l] must be the running sum of H*W and, when `S`
+    is given, the levels must cover exactly S tokens -- an inconsistent table raises instead of sampling
+    with the wrong geometry."""
     def to_list(x):
         if isinstance(x, torch.Tensor):
-            key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
-            hit = _shape_cache.get(key)
-            if hit is None:
-                if len(_shape_cache) > 256:
-                    _shape_cache.clear()
-                hit = [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
-                _shape_cache[key] = hit
-            return hit
+            return [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
         out = []
         for v in x:
             if isinstance(v, (list, tuple)):
@@ -55,6 +67,16 @@ def _host_shapes(spatial_shapes, level_start_index):
     L = len(st)
     if len(sh) != 2 * L:
         raise RuntimeError(f"spatial_shapes has {len(sh)} entries, expected 2*{L}")
+    if S is not None:
+        run = 0
+        for l in range(L):
+            if sh[2 * l] <= 0 or sh[2 * l + 1] <= 0:
+                raise RuntimeError(f"spatial_shapes[{l}] = ({sh[2 * l]}, {sh[2 * l + 1]}) is not positive")
+            if st[l] != run:
+                raise RuntimeError(f"level_start_index[{l}] = {st[l]} but the levels before it hold {run} tokens")
+            run += sh[2 * l] * sh[2 * l + 1]
+        if run != int(S):
+            raise RuntimeError(f"spatial_shapes cover {run} tokens but value has {int(S)}")
     return (ctypes.c_int64 * len(sh))(*sh), (ctypes.c_int64 * L)(*st), L
 
 
@@ -77,7 +99,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     step = min(N, int(im2col_step)) if N > 0 else 1
     if step <= 0 or N % step != 0:
         raise RuntimeError(f"batch({N}) must divide im2col_step({step})")
-    sh, st, L2 = _host_shapes(spatial_shapes, level_start_index)
+    sh, st, L2 = _host_shapes(spatial_shapes, level_start_index, S)
     if L2 != L:
         raise RuntimeError(f"ms_deform_attn_forward: {L2} levels in spatial_shapes, {L} in sampling_loc")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
@@ -99,7 +121,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         raise RuntimeError("ms_deform_attn_backward: float32 only")
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
-    shapes, starts, L2 = _host_shapes(spatial_shapes, level_start_index)
+    shapes, starts, L2 = _host_shapes(spatial_shapes, level_start_index, S)
     if L2 != L or tuple(grad_output.shape) != (N, Lq, M * D) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
         raise RuntimeError("ms_deform_attn_backward: inconsistent shapes")
     gv = torch.empty_like(value)
@@ -123,6 +145,11 @@ def msda_last_impl() -> int:
     return int(_lib.load().univs_msda_last_impl())
 
 
+def msda_last_tiled_generation() -> int:
+    """3 / 2 / 1 = generation of the LDS-tiled kernel that ran for the last forward on this thread, 0 = generic."""
+    return int(_lib.load().univs_msda_last_tiled_generation())
+
+
 def linear_split(x, weight, bias=None, relu=False):
     """F.linear(x, weight, bias) [+ relu] for float32 on the GPU through the split-bf16 kernel (fp32-accurate: an exact
     3-way bf16 split of both operands, six MFMA terms) -- the K = 256 token projections of MSDeformAttn
@@ -131,6 +158,8 @@ def linear_split(x, weight, bias=None, relu=False):
     K = x.shape[-1]
     N = weight.shape[0]
     M = x.numel() // max(K, 1)
+    if needs_grad(x, weight, bias):
+        return None   # autograd has to see this Linear: the library GEMM path records it
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.shape[1] != K
             or K % 128 != 0 or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1):
         return None
@@ -162,6 +191,7 @@ def mask_decode_last_impl() -> int:
 def mask_decode(mask_embed, mask_features):
     """einsum('tqc,tchw->qthw'): mask_embed [T,Q,C], mask_features [T,C,H,W] -> logits [Q,T,H,W]
     (== ...decoder_univs.py:527-528 for batch 1)."""
+    _inference_only("mask_decode", mask_embed, mask_features)
     _require_gpu("mask_decode", mask_embed, mask_features)
     if mask_embed.dtype != torch.float32 or mask_features.dtype != torch.float32:
         raise RuntimeError("mask_decode: float32 only")
@@ -181,6 +211,7 @@ def mask_decode_attn(mask_embed, feat_lowres):
     """Fused attention-mask generation: mask_embed [T,Q,C], feat_lowres [T,C,h,w] (mask features
     resampled to the next level's size) -> bool [T,Q,h*w], True = key masked out; rows that would be
     fully masked come back all-False (...decoder_univs.py:555-566 + :390)."""
+    _inference_only("mask_decode_attn", mask_embed, feat_lowres)
     _require_gpu("mask_decode_attn", mask_embed, feat_lowres)
     if mask_embed.dtype != torch.float32 or feat_lowres.dtype != torch.float32:
         raise RuntimeError("mask_decode_attn: float32 only")
@@ -201,6 +232,7 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
     """Swin window-attention core (swin.py:137-168 between the qkv and proj linears).
     qkv [B_, Ntok, 3, nH, hd]; bias [nH, Ntok, Ntok]; shift_mask [nW, Ntok, Ntok] or None
     -> [B_, Ntok, nH*hd]."""
+    _inference_only("window_attention", qkv, bias)
     _require_gpu("window_attention", qkv, bias)
     if qkv.dtype != torch.float32:
         raise RuntimeError("window_attention: float32 only")
@@ -224,6 +256,7 @@ def bilinear_resample(x, size, addend=None):
     """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for float32 [..., Hin, Win] on the
     GPU (decoder attention-mask path, ...decoder_univs.py:555-558); with `addend` [..., Hout, Wout] the FPN
     top-down step `addend + interpolate(x)` (msdeformattn.py:350-351) in one pass."""
+    _inference_only("bilinear_resample", x, addend)
     x = x.contiguous()
     _require_gpu("bilinear_resample", x)
     if x.dtype != torch.float32 or x.dim() < 2:
@@ -251,6 +284,7 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
     (swin.py:236-262), encoder layers (msdeformattn.py:61-95) and decoder layers.
     Returns `out` or `(x + residual, out)`."""
     x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()   # views (e.g. NCHW -> tokens) are copied once
+    _inference_only("layer_norm", x, weight, bias, residual)
     _require_gpu("layer_norm", x, weight, bias)
     if x.dtype != torch.float32:
         raise RuntimeError("layer_norm: float32 only")
@@ -279,6 +313,7 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     """F.group_norm(x, num_groups, weight, bias, eps) [+ relu] for contiguous float32 NCHW `x` on the GPU: the
     Conv2d(norm=GN, activation=relu) epilogues of the pixel decoder (msdeformattn.py:214-232, :262-283)."""
     x = x.contiguous()
+    _inference_only("group_norm", x, weight, bias)
     _require_gpu("group_norm", x, weight, bias)
     if x.dtype != torch.float32 or x.dim() < 2:
         raise RuntimeError("group_norm: float32 [N, C, ...] only")
@@ -300,6 +335,7 @@ def masked_softmax_(scores, mask=None):
     """In-place softmax over the last dimension of contiguous float32 attention scores [N, h, L, S] with an
     optional boolean / uint8 mask [N, L, S] (True = masked out, shared by the heads): the masked softmax inside
     nn.MultiheadAttention (transformer_layers.py:101-105).  Returns `scores`."""
+    _inference_only("masked_softmax_", scores)
     _require_gpu("masked_softmax_", scores)
     if scores.dtype != torch.float32 or scores.dim() != 4:
         raise RuntimeError("masked_softmax_: float32 [N, h, L, S] only")
@@ -321,6 +357,7 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
     un-padded tokens) -> [B, H*W, nH*hd]; pad / roll / window_partition / window_reverse / crop of
     swin.py:252-284 happen inside the kernel.  `qkv_bias` [3*nH*hd] or None supplies q/k/v of the padded
     pixels; `shift_mask` [nW, ws*ws, ws*ws] is required when shift > 0."""
+    _inference_only("window_attention_image", qkv, qkv_bias, bias)
     _require_gpu("window_attention_image", qkv, bias)
     if qkv.dtype != torch.float32 or qkv.dim() != 5:
         raise RuntimeError("window_attention_image: float32 [B, H*W, 3, nH, hd] only")
@@ -359,6 +396,7 @@ def msda_prepare(proj, n_off, reference_points, spatial_shapes, num_heads, num_l
     [N,Lq,M,L,P]) -- the operands of `ms_deform_attn_forward`."""
     proj = proj.contiguous()
     reference_points = reference_points.contiguous()
+    _inference_only("msda_prepare", proj, reference_points)
     _require_gpu("msda_prepare", proj, reference_points)
     if proj.dtype != torch.float32 or proj.dim() != 3 or reference_points.dtype != torch.float32:
         raise RuntimeError("msda_prepare: float32 proj [N, Lq, C] and reference_points only")
