@@ -52,16 +52,20 @@ def main():
         res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
         ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
         ops.msda_set_impl(2)
-        for gen in (3, 2, 1):
+        for gen, variant in ((3, 0), (3, 1), (2, 0), (1, 0)):
             os.environ["UNIVS_MSDA_TILED"] = str(gen)
+            os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
             for abl in ([0, 1, 4, 5] if (gen == 3 and args.ablate) else [0]):
                 os.environ["UNIVS_MSDA_ABLATE"] = str(abl)
                 t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
                 out = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
-                nm = f"msda_tiled{gen}" + (f"_ablate{abl}" if abl else "")
+                nm = f"msda_tiled{gen}" + (f"_v{variant}" if gen == 3 else "") + (f"_ablate{abl}" if abl else "")
+                d = (out - ref).abs()
                 res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
-                               gen=ops.msda_last_tiled_generation(), max_abs_diff_vs_generic=(out - ref).abs().max().item())
+                               gen=ops.msda_last_tiled_generation(), max_abs_diff_vs_generic=d.max().item(),
+                               mean_abs_diff_vs_generic=d.mean().item())
             os.environ.pop("UNIVS_MSDA_ABLATE", None)
+        os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
         os.environ.pop("UNIVS_MSDA_TILED", None)
         ops.msda_set_impl(0)
     if not args.only or "mask" in args.only:
@@ -117,7 +121,7 @@ def main():
             t = timeit(lambda: torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False))
             res[f"resample_{h}x{w}_aten"] = dict(ms=t * 1e3)
     for k, v in res.items():
-        print(k, json.dumps({kk: round(vv, 4) for kk, vv in v.items()}))
+        print(k, json.dumps({kk: (round(vv, 4) if abs(vv) > 1e-3 or vv == 0 else float(f'{vv:.3e}')) for kk, vv in v.items()}))
 
 
 if __name__ == "__main__":
