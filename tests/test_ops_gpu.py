@@ -27,7 +27,7 @@ def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl, gen=3):
         assert ran == (2 if (impl == 2 and tiled_ok) else 1), f"impl {impl} requested, {ran} ran"
         if impl == 2 and tiled_ok:
             L = loc.shape[3]
-            want = gen if gen == 3 or (gen == 2 and L >= 3) else 1
+            want = 3 if (gen == 3 and L >= 2) else 2 if (gen >= 2 and L >= 3) else 1
             assert ops.msda_last_tiled_generation() == want, (gen, ops.msda_last_tiled_generation())
     finally:
         ops.msda_set_impl(0)

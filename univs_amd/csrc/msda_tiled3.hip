@@ -43,13 +43,20 @@ typedef float t3v4 __attribute__((ext_vector_type(4)));
 #define T3_LDS __attribute__((address_space(3)))
 
 constexpr int T3_WIN_PX = 704;    // cap on one window (pixels); the two regions together must fit 160 KiB
+constexpr int T3_NP = 4;          // fill waves
+constexpr int T3_CHUNK = 2;       // staged rows per uniform branch of the fill waves; regions are padded to whole chunks
 
-struct Tile3Geom {
-  int tiles_y, tiles_x;
-  int ord[2][UNIVS_MAX_LEVELS];   // level visited at step k of an even / odd item
-  int reg[2][UNIVS_MAX_LEVELS];   // LDS byte offset of that step's window region
-  int ablate;
+// One step of one tile, everything the kernel needs as workgroup-uniform scalars, precomputed on the host: the first
+// version derived these per step on the scalar unit (selects over the level table, prefix sums, divisions) and was
+// SALU-bound -- 15 waves x ~300 scalar instructions per step on the CU's single scalar pipe (profiles/r02_msda_kbench_v2.txt).
+// Table index: (tile * 2 + item parity) * L + step; 64 bytes = one s_load_dwordx16.
+struct T3Entry {
+  int H, W, start, l;           // the level visited at this step
+  int wx0, wy0, ww, wh;         // staged window (inside the level)
+  int npx, reg, qfirst, qcount; // window pixels; LDS byte offset of the region; this level's queries within the item
+  int qx0, qy0, qnx, total;     // query box origin / width; queries of the whole item
 };
+static_assert(sizeof(T3Entry) == 64, "one scalar load");
 
 // addr_top = bcast_k(slot) + off_top, addr_bottom = bcast_k(slot) + off_bottom   (k = K, lane K of my DPP row).
 // NOP: pad the VALU-write -> DPP-read hazard (2 wait states) for the first use of a record register; hipcc does not
@@ -93,8 +100,8 @@ __device__ __forceinline__ int t3_bcast(int v) {
 // NP fill waves (waves 0 .. NP-1), NG gather waves, NB record batches per gather wave and step (a batch = 2 row
 // pairs x 4 queries x 4 points); 8 * NB * NG query slots per item.
 template <int L, int NP, int NG, int NB>
-__global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* __restrict__ value, LevelTable lv,
-                                                                   Tile3Geom tg, const int4* __restrict__ geo,
+__global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* __restrict__ value,
+                                                                   const T3Entry* __restrict__ tab, int ntiles, int ablate,
                                                                    const float* __restrict__ loc,
                                                                    const float* __restrict__ attn, int N, int S, int M,
                                                                    float* __restrict__ out, unsigned nitems) {
@@ -106,7 +113,6 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int ntiles = tg.tiles_y * tg.tiles_x;
 
   // ---- this workgroup's items (XCD-chunked, fixed stride; see msda_tiled.hip)
   const unsigned nxcd = min(8u, gridDim.x);
@@ -119,49 +125,40 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
   struct Item {   // workgroup-uniform
     long long nm;   // n * S * M + m
-    int tx, ty;
+    int tile;
   };
   auto make_item = [&](unsigned idx) __attribute__((always_inline)) {
     const unsigned item = cbase + idx;
-    const int m = item % M;
-    const int tile = (item / M) % ntiles;
-    const int n = item / (M * ntiles);
+    const unsigned tm = item / (unsigned)M;
+    const unsigned n = tm / (unsigned)ntiles;
+    // (the divisions run on the vector ALU; pin the results to scalars -- they are workgroup-uniform -- or everything
+    // derived from them, buffer resources included, is treated as divergent: waterfall loops around every load)
+    const unsigned nu = __builtin_amdgcn_readfirstlane(n), tmu = __builtin_amdgcn_readfirstlane(tm);
     Item it;
-    it.nm = (long long)n * S * M + m;
-    it.ty = tile / tg.tiles_x;
-    it.tx = tile % tg.tiles_x;
+    it.nm = (long long)nu * S * M + (item - tmu * (unsigned)M);
+    it.tile = (int)(tmu - nu * (unsigned)ntiles);
     return it;
   };
-  struct LevelGeo {   // workgroup-uniform: one level of one item
-    int l, H, W, start, wx0, wy0, ww, wh, npx, reg;
-  };
-  auto level_geo = [&](const Item& it, int par, int kk) __attribute__((always_inline)) {
-    const int l = tg.ord[par][kk];
-    const int4 gx = geo[l * tg.tiles_x + it.tx], gy = geo[L * tg.tiles_x + l * tg.tiles_y + it.ty];   // scalar loads
-    LevelGeo q;
-    q.l = l;
-    q.H = lv.H[0]; q.W = lv.W[0]; q.start = lv.start[0];
-#pragma unroll
-    for (int jl = 1; jl < L; ++jl) {   // selects on values: an `if` with several assignments becomes a pointer phi
-      const bool c = l == jl;          // into the kernarg struct, which then lives in scratch
-      q.H = c ? lv.H[jl] : q.H; q.W = c ? lv.W[jl] : q.W; q.start = c ? lv.start[jl] : q.start;
-    }
-    q.wx0 = gx.z; q.ww = gx.w; q.wy0 = gy.z; q.wh = gy.w; q.npx = gx.w * gy.w;
-    q.reg = tg.reg[par][kk];
-    return q;
+  // the step's scalars: one 64-byte scalar load
+  auto entry = [&](const Item& it, int par, int kk) __attribute__((always_inline)) {
+    return tab[__builtin_amdgcn_readfirstlane((it.tile * 2 + par) * L + kk)];
   };
 
   if (wave < NP) {
     // =========================== fill waves ===========================
     constexpr int OCT = NP * 8;                          // copy octets (8 lanes x 16 B = one pixel-head)
     constexpr int WR = (T3_WIN_PX + OCT - 1) / OCT;      // staged 16-B rows per lane
+    constexpr int CH = T3_CHUNK;                         // staged rows per uniform branch
     const int lane8 = tid & 7, oct = tid >> 3;
     t3v4 wreg[WR];
-    auto load_window = [&](const Item& it, const LevelGeo& q) __attribute__((always_inline)) {
-      if (tg.ablate & 1) return;
+    auto load_window = [&](const Item& it, const T3Entry& q) __attribute__((always_inline)) {
+      if (ablate & 1) return;
+      // (explicitly scalar: left to itself hipcc keeps this descriptor in VGPRs and wraps every load in a waterfall loop)
+      const unsigned long long pv = (unsigned long long)(value + (it.nm + (long long)q.start * M) * D);
+      const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pv), phi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+      const int nrec = __builtin_amdgcn_readfirstlane((int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4));
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(value + (it.nm + (long long)q.start * M) * D), 0,
-          (int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4), 0x00020000);
+          reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, nrec, 0x00020000);
       const unsigned pstride = (unsigned)(M * D * 4);
       const int sy = (int)(((float)OCT + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));
       const int sx = OCT - sy * q.ww;
@@ -171,35 +168,38 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       const unsigned step_n = (unsigned)(sy * q.W + sx) * pstride;
       const unsigned step_c = (unsigned)((sy + 1) * q.W + sx - q.ww) * pstride;
 #pragma unroll
-      for (int u = 0; u < WR; ++u) {
-        if (u * OCT < q.npx) {   // uniform; pixels past the window's end fall out of the resource or are not committed
-          wreg[u] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-          rx += sx;
-          const bool carry = rx >= q.ww;
-          rx -= carry ? q.ww : 0;
-          off += carry ? step_c : step_n;
+      for (int u0 = 0; u0 < WR; u0 += CH) {
+        if (u0 * OCT < q.npx) {   // uniform, one branch per CH rows: pixels past the window's end fall out of the
+#pragma unroll                    // resource (reads return 0) and are not committed
+          for (int u = u0; u < u0 + CH && u < WR; ++u) {
+            wreg[u] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            rx += sx;
+            const bool carry = rx >= q.ww;
+            rx -= carry ? q.ww : 0;
+            off += carry ? step_c : step_n;
+          }
         }
       }
     };
-    auto commit = [&](const LevelGeo& q) __attribute__((always_inline)) {
+    auto commit = [&](const T3Entry& q) __attribute__((always_inline)) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): explicit and unconditional, see msda_tiled.hip
-      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + q.reg);
+      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + q.reg) + (oct * 8 + lane8);
 #pragma unroll
-      for (int u = 0; u < WR; ++u) {
-        if (u * OCT < q.npx) {   // uniform
-          const int jpx = oct + u * OCT;
-          if (jpx < q.npx) win[jpx * 8 + lane8] = wreg[u];
+      for (int u0 = 0; u0 < WR; u0 += CH) {
+        if (u0 * OCT < q.npx) {   // uniform.  No per-lane bound: the regions are padded to whole chunks (host), rows past
+#pragma unroll                    // the window's end land in the padding
+          for (int u = u0; u < u0 + CH && u < WR; ++u) win[u * OCT * 8] = wreg[u];
         }
       }
     };
 
     Item cur = make_item(widx);
     {
-      const LevelGeo g0 = level_geo(cur, 0, 0);
+      const T3Entry g0 = entry(cur, 0, 0);
       load_window(cur, g0);
       commit(g0);
     }
-    LevelGeo geo_p = level_geo(cur, 0, 1);          // the step held staged in registers
+    T3Entry geo_p = entry(cur, 0, 1);          // the step held staged in registers
     load_window(cur, geo_p);
     __syncthreads();   // step 0 is ready for the gather waves
 
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       for (int kk = 0; kk < L; ++kk) {
         // while the gather waves work on step (cur, kk): commit step + 1 (staged) and load step + 2
         const bool valid1 = (kk + 1 < L) || has_next, valid2 = (kk + 2 < L) || has_next;
-        const LevelGeo geo_n = (kk + 2 < L) ? level_geo(cur, par, (kk + 2) % L) : level_geo(nxt, par ^ 1, (kk + 2) % L);
+        const T3Entry geo_n = (kk + 2 < L) ? entry(cur, par, (kk + 2) % L) : entry(nxt, par ^ 1, (kk + 2) % L);
         if (valid1) commit(geo_p);
         if (valid2) load_window((kk + 2 < L) ? cur : nxt, geo_n);
         __syncthreads();   // the one barrier of the step
@@ -229,33 +229,32 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     const int side = (lane >> 4) & 1;    // corner column of my DPP row: 0 left, 1 right
     const int k = lane & 15;             // my record: sample k of my row pair = (query k >> 2, point k & 3)
     const int ch = (lane & 15) * 2;      // my two channels as a gathering lane
-
-    // my queries of an item (levels in order, raster inside the level's query box): global index and input offset
-    struct Mine { int total; int qg[NB]; };
-    auto my_queries = [&](const Item& it) __attribute__((always_inline)) {
-      int pre[L + 1], gqx0[L], gqy0[L], gqnx[L];
-      pre[0] = 0;
+    int qslot[NB];                       // my query's index within an item, per batch
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const int4 gx = geo[l * tg.tiles_x + it.tx], gy = geo[L * tg.tiles_x + l * tg.tiles_y + it.ty];
-        gqx0[l] = gx.x; gqnx[l] = gx.y; gqy0[l] = gy.x;
-        pre[l + 1] = pre[l] + gx.y * gy.y;
-      }
+    for (int b = 0; b < NB; ++b) qslot[b] = ((gw * NB + b) * 2 + rp) * 4 + (k >> 2);
+
+    // my queries of an item (levels in order, raster inside the level's query box): global query index per batch
+    struct Mine { int total; int qg[NB]; };
+    auto my_queries = [&](const Item& it, int par) __attribute__((always_inline)) {
       Mine me;
-      me.total = pre[L];   // 1 .. 8 * NB * NG (host-checked)
+      int li[NB], qx0[NB], qnx[NB], qy0[NB], Wq[NB], st[NB];
+#pragma unroll
+      for (int kk = 0; kk < L; ++kk) {
+        const T3Entry e = entry(it, par, kk);
+        me.total = e.total;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int i = min(qslot[b], e.total - 1);
+          const bool c = kk == 0 || (unsigned)(i - e.qfirst) < (unsigned)e.qcount;   // the levels partition [0, total)
+          li[b] = c ? i - e.qfirst : li[b];
+          qx0[b] = c ? e.qx0 : qx0[b]; qnx[b] = c ? e.qnx : qnx[b]; qy0[b] = c ? e.qy0 : qy0[b];
+          Wq[b] = c ? e.W : Wq[b]; st[b] = c ? e.start : st[b];
+        }
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int i = min(((gw * NB + b) * 2 + rp) * 4 + (k >> 2), me.total - 1);
-        int li = i, qx0 = gqx0[0], qnx = gqnx[0], qy0 = gqy0[0], Wq = lv.W[0], st = lv.start[0];
-#pragma unroll
-        for (int jl = 1; jl < L; ++jl) {
-          const bool c = i >= pre[jl];
-          li = c ? i - pre[jl] : li;
-          qx0 = c ? gqx0[jl] : qx0; qnx = c ? gqnx[jl] : qnx; qy0 = c ? gqy0[jl] : qy0;
-          Wq = c ? lv.W[jl] : Wq; st = c ? lv.start[jl] : st;
-        }
-        const int row = (int)(((float)li + 0.5f) * __builtin_amdgcn_rcpf((float)qnx));
-        me.qg[b] = st + (qy0 + row) * Wq + qx0 + (li - row * qnx);
+        const int row = (int)(((float)li[b] + 0.5f) * __builtin_amdgcn_rcpf((float)qnx[b]));
+        me.qg[b] = st[b] + (qy0[b] + row) * Wq[b] + qx0[b] + (li[b] - row * qnx[b]);
       }
       return me;
     };
@@ -274,10 +273,10 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
     // ---- prologue: inputs of steps 0 and 1
     Item cur = make_item(widx);
-    Mine me_cur = my_queries(cur);
+    Mine me_cur = my_queries(cur, 0);
     Inputs in0, in1;
-    load_inputs(cur, tg.ord[0][0], me_cur, in0);
-    load_inputs(cur, tg.ord[0][1], me_cur, in1);
+    load_inputs(cur, entry(cur, 0, 0).l, me_cur, in0);
+    load_inputs(cur, entry(cur, 0, 1).l, me_cur, in1);
     __syncthreads();   // step 0's window is staged
 
     int par = 0;
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     for (unsigned idx = widx;; idx += nw) {
       const bool has_next = idx + nw < csize;
       const Item nxt = make_item(has_next ? idx + nw : idx);
-      const Mine me_nxt = my_queries(nxt);
+      Mine me_nxt = me_cur;
       float ax[NB][4], ay[NB][4];
 #pragma unroll
       for (int b = 0; b < NB; ++b)
@@ -294,15 +293,15 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
-        const LevelGeo q = level_geo(cur, par, kk);
+        const T3Entry q = entry(cur, par, kk);
         // ---- A. records of this step for my corner column (inputs were loaded two steps ago)
         int slot[NB];
         float wT[NB], wB[NB];
         bool miss[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const bool qvalid = ((gw * NB + b) * 2 + rp) * 4 + (k >> 2) < me_cur.total;
-          const T3Record r = t3_record(in0.x[b], in0.y[b], in0.a[b], side, qvalid, q.H, q.W, q.wx0, q.wy0, q.ww, q.wh);
+          const T3Record r = t3_record(in0.x[b], in0.y[b], in0.a[b], side, qslot[b] < q.total, q.H, q.W, q.wx0, q.wy0,
+                                       q.ww, q.wh);
           miss[b] = r.miss;
           slot[b] = r.slot;
           wT[b] = r.wt;
@@ -311,18 +310,22 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
           asm volatile("" : "+v"(slot[b]), "+v"(wT[b]), "+v"(wB[b]));
         }
 
-        // ---- B. inputs of step + 2
+        // ---- B. inputs of step + 2 (the next item's query indices are needed from its first prefetch on)
         in0 = in1;
-        if (kk + 2 < L) load_inputs(cur, tg.ord[par][(kk + 2) % L], me_cur, in1);
-        else load_inputs(nxt, tg.ord[par ^ 1][(kk + 2) % L], me_nxt, in1);
+        if (kk + 2 < L) {
+          load_inputs(cur, entry(cur, par, (kk + 2) % L).l, me_cur, in1);
+        } else {
+          if (kk + 2 == L) me_nxt = my_queries(nxt, par ^ 1);
+          load_inputs(nxt, entry(nxt, par ^ 1, (kk + 2) % L).l, me_nxt, in1);
+        }
 
         // ---- C. gathers: 16 samples per row pair and batch
         const int off_t = (int)lds_base + q.reg + (lane & 15) * 8;
         const int off_b = off_t + q.ww * (D * 4);
-        if (!(tg.ablate & 4)) {
+        if (!(ablate & 4)) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            if ((gw * NB + b) * 8 < me_cur.total) {   // uniform
+            if ((gw * NB + b) * 8 < q.total) {   // uniform
               int a_t[16], a_b[16];
               t3v2 dt[16], db[16];
 #define T3_ADDR(K) t3_addr<K, (K & 3) == 0>(slot[b], off_t, off_b, a_t[K], a_b[K]);
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           unsigned long long mm = __ballot(miss[b]);
-          if (mm != 0 && !(tg.ablate & 8)) {
+          if (mm != 0 && !(ablate & 8)) {
             const float* vl = value + (cur.nm + (long long)q.start * M) * D + ch;
 #pragma unroll 1
             while (mm) {
@@ -378,16 +381,16 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
         }
 
         // ---- D. last level: add the two corner columns (rows 2i / 2i+1) and store
-        if (kk + 1 == L && !(tg.ablate & 16)) {
+        if (kk + 1 == L && !(ablate & 16)) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            if ((gw * NB + b) * 8 < me_cur.total) {   // uniform
+            if ((gw * NB + b) * 8 < q.total) {   // uniform
               const int qb = ((gw * NB + b) * 2 + rp) * 4;
 #define T3_OUT(JJ)                                                                                                 \
   {                                                                                                                \
     const float sx = ax[b][JJ] + __shfl_xor(ax[b][JJ], 16, 64), sy = ay[b][JJ] + __shfl_xor(ay[b][JJ], 16, 64);   \
     const int qgj = t3_bcast<4 * JJ>(me_cur.qg[b]);                                                                \
-    if (side == 0 && qb + JJ < me_cur.total)                                                                       \
+    if (side == 0 && qb + JJ < q.total)                                                                            \
       *reinterpret_cast<t3v2*>(reinterpret_cast<char*>(out + cur.nm * D) + ((unsigned)(qgj * M * D + ch) * 4u)) =  \
           (t3v2){sx, sy};                                                                                          \
   }
@@ -406,13 +409,114 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
   }
 }
 
+// ---- host side: per-geometry step table, built once per (device, level shapes, tile parameters)
+struct T3Key {
+  int dev, L, TH, TW, R;
+  int H[UNIVS_MAX_LEVELS], W[UNIVS_MAX_LEVELS];
+  bool operator==(const T3Key& o) const {
+    if (dev != o.dev || L != o.L || TH != o.TH || TW != o.TW || R != o.R) return false;
+    for (int l = 0; l < L; ++l)
+      if (H[l] != o.H[l] || W[l] != o.W[l]) return false;
+    return true;
+  }
+};
+struct T3Geo {
+  T3Key key;
+  T3Entry* table;   // device
+  int ntiles;
+  long long qmax;   // max queries of a tile
+  size_t lds;       // bytes of the two window regions
+};
+
+static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R) {
+  static std::mutex mu;
+  static std::vector<T3Geo*> cache;
+  T3Key key{};
+  if (hipGetDevice(&key.dev) != hipSuccess) return nullptr;
+  key.L = L; key.TH = TH; key.TW = TW; key.R = R;
+  for (int l = 0; l < L; ++l) { key.H[l] = lv.H[l]; key.W[l] = lv.W[l]; }
+  std::lock_guard<std::mutex> lock(mu);
+  for (const T3Geo* e : cache)
+    if (e->key == key) return e;
+
+  const int tiles_y = (lv.H[fine] + TH - 1) / TH, tiles_x = (lv.W[fine] + TW - 1) / TW;
+  std::vector<int4> ax((size_t)L * tiles_x), ay((size_t)L * tiles_y);
+  long long lvl_px[UNIVS_MAX_LEVELS] = {0, 0, 0, 0};
+  for (int l = 0; l < L; ++l) {
+    int mw = 2;
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      axis_entry(tx, tiles_x, TW, lv.W[l], lv.W[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, /*ring=*/0, ax[(size_t)l * tiles_x + tx]);
+      mw = std::max(mw, ax[(size_t)l * tiles_x + tx].w);
+    }
+    for (int ty = 0; ty < tiles_y; ++ty) {
+      int4& e = ay[(size_t)l * tiles_y + ty];
+      axis_entry(ty, tiles_y, TH, lv.H[l], lv.H[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, /*ring=*/0, e);
+      // windows must fit the LDS carve: shrink rows where a (tile, level) would not (samples beyond go through the
+      // global fallback, results unchanged)
+      e.w = (int)std::max<long long>(2, std::min<long long>(e.w, T3_WIN_PX / mw));
+      lvl_px[l] = std::max<long long>(lvl_px[l], (long long)mw * e.w);
+    }
+  }
+  // region plan: step parity picks the region; an odd level count makes odd items start in B, so they visit their
+  // two largest windows in swapped order (the accumulators do not care)
+  int by_size[UNIVS_MAX_LEVELS], ord[2][UNIVS_MAX_LEVELS], reg[2][UNIVS_MAX_LEVELS];
+  for (int l = 0; l < L; ++l) by_size[l] = l;
+  std::sort(by_size, by_size + L, [&](int a, int b) { return lvl_px[a] > lvl_px[b]; });
+  long long capA = 0, capB = 0;
+  for (int par = 0; par < 2; ++par) {
+    for (int kk = 0; kk < L; ++kk) ord[par][kk] = by_size[kk];
+    const int first_region = (par == 1 && (L & 1)) ? 1 : 0;
+    if (first_region == 1) std::swap(ord[par][0], ord[par][1]);
+    for (int kk = 0; kk < L; ++kk) {
+      const int region = (first_region + kk) & 1;
+      long long& cap = region ? capB : capA;
+      cap = std::max(cap, lvl_px[ord[par][kk]]);
+      reg[par][kk] = region;
+    }
+  }
+  T3Geo* g = new T3Geo();
+  g->key = key;
+  g->ntiles = tiles_y * tiles_x;
+  const long long chunk_px = (long long)T3_CHUNK * T3_NP * 8;   // the fill waves write whole chunks
+  capA = (capA + chunk_px - 1) / chunk_px * chunk_px;
+  capB = (capB + chunk_px - 1) / chunk_px * chunk_px;
+  g->lds = (size_t)(capA + capB) * 128;
+  g->qmax = 0;
+  std::vector<T3Entry> tab((size_t)g->ntiles * 2 * L);
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      int pre[UNIVS_MAX_LEVELS + 1] = {0};
+      for (int l = 0; l < L; ++l) pre[l + 1] = pre[l] + ax[(size_t)l * tiles_x + tx].y * ay[(size_t)l * tiles_y + ty].y;
+      g->qmax = std::max<long long>(g->qmax, pre[L]);
+      for (int par = 0; par < 2; ++par)
+        for (int kk = 0; kk < L; ++kk) {
+          const int l = ord[par][kk];
+          const int4 gx = ax[(size_t)l * tiles_x + tx], gy = ay[(size_t)l * tiles_y + ty];
+          T3Entry& e = tab[((size_t)(ty * tiles_x + tx) * 2 + par) * L + kk];
+          e.H = lv.H[l]; e.W = lv.W[l]; e.start = lv.start[l]; e.l = l;
+          e.wx0 = gx.z; e.wy0 = gy.z; e.ww = gx.w; e.wh = gy.w;
+          e.npx = gx.w * gy.w; e.reg = reg[par][kk] ? (int)(capA * 128) : 0;
+          e.qfirst = pre[l]; e.qcount = gx.y * gy.y;
+          e.qx0 = gx.x; e.qy0 = gy.x; e.qnx = std::max(gx.y, 1); e.total = pre[L];
+        }
+    }
+  if (hipMalloc(reinterpret_cast<void**>(&g->table), tab.size() * sizeof(T3Entry)) != hipSuccess ||
+      hipMemcpy(g->table, tab.data(), tab.size() * sizeof(T3Entry), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    delete g;
+    return nullptr;
+  }
+  cache.push_back(g);
+  return g;
+}
+
 template <int L, int NP, int NG, int NB>
-static void launch_tiled3(unsigned grid, unsigned nitems, size_t lds, hipStream_t st, const float* value,
-                          const LevelTable& lv, const Tile3Geom& tg, const int4* geo, const float* loc,
-                          const float* attn, int N, int S, int M, float* out) {
+static void launch_tiled3(unsigned grid, unsigned nitems, hipStream_t st, const float* value, const T3Geo* g, int ablate,
+                          const float* loc, const float* attn, int N, int S, int M, float* out) {
   auto kfn = msda_fwd_tiled3<L, NP, NG, NB>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), lds, st, value, lv, tg, geo, loc, attn, N, S, M, out, nitems);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), g->lds, st, value, g->table, g->ntiles, ablate, loc, attn, N, S,
+                     M, out, nitems);
 }
 
 // returns 1 if launched, 0 if preconditions do not hold (caller tries the next implementation), <0 on error
@@ -432,38 +536,13 @@ int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const floa
   const int TH = env_int("UNIVS_MSDA_TILE3_H", 8), TW = env_int("UNIVS_MSDA_TILE3_W", 16);
   const int R = env_int("UNIVS_MSDA_HALO", 6);
   const int variant = env_int("UNIVS_MSDA_T3_VARIANT", 0);   // 0: 4 fill + 8 gather waves x 3 batches; 1: 4 + 11 x 2
+  const int ablate = env_int("UNIVS_MSDA_ABLATE", 0);
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
-  const GeoEntry* ge = geometry(lv, L, fine, TH, TW, R, T3_WIN_PX, /*ring=*/0);
+  const T3Geo* g = t3_geometry(lv, L, fine, TH, TW, R);
   const int qcap = variant == 1 ? 11 * 16 : 8 * 24;
-  if (!ge || ge->qmax > qcap) return 0;
+  if (!g || g->qmax > qcap || g->qmax < 1 || g->lds > 160 * 1024) return 0;
 
-  // region plan: step parity picks the region; an odd level count makes odd items start in B, so they visit their
-  // two largest windows in swapped order (the accumulators do not care)
-  Tile3Geom tg{};
-  tg.tiles_y = ge->tiles_y;
-  tg.tiles_x = ge->tiles_x;
-  tg.ablate = env_int("UNIVS_MSDA_ABLATE", 0);
-  int by_size[UNIVS_MAX_LEVELS];
-  for (int l = 0; l < L; ++l) by_size[l] = l;
-  std::sort(by_size, by_size + L, [&](int a, int b) { return ge->lvl_px[a] > ge->lvl_px[b]; });
-  long long capA = 0, capB = 0;
-  for (int par = 0; par < 2; ++par) {
-    for (int kk = 0; kk < L; ++kk) tg.ord[par][kk] = by_size[kk];
-    const int first_region = (par == 1 && (L & 1)) ? 1 : 0;
-    if (first_region == 1) std::swap(tg.ord[par][0], tg.ord[par][1]);
-    for (int kk = 0; kk < L; ++kk) {
-      const int region = (first_region + kk) & 1;
-      long long& cap = region ? capB : capA;
-      cap = std::max(cap, ge->lvl_px[tg.ord[par][kk]]);
-      tg.reg[par][kk] = region;   // resolved to an offset below
-    }
-  }
-  const size_t lds = (size_t)(capA + capB) * 128;
-  if (lds > 160 * 1024) return 0;
-  for (int par = 0; par < 2; ++par)
-    for (int kk = 0; kk < L; ++kk) tg.reg[par][kk] = tg.reg[par][kk] ? (int)(capA * 128) : 0;
-
-  const long long nb = (long long)N * M * tg.tiles_y * tg.tiles_x;
+  const long long nb = (long long)N * M * g->ntiles;
   if (nb <= 0 || nb > 0x7fffffffLL) return 0;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -475,9 +554,9 @@ int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const floa
     n_cu = v;
   }
   const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", n_cu), 1));
-#define T3_LAUNCH(LL)                                                                                                   \
-  if (variant == 1) launch_tiled3<LL, 4, 11, 2>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); \
-  else launch_tiled3<LL, 4, 8, 3>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out);
+#define T3_LAUNCH(LL)                                                                                     \
+  if (variant == 1) launch_tiled3<LL, T3_NP, 11, 2>(grid, (unsigned)nb, st, value, g, ablate, loc, attn, N, S, M, out); \
+  else launch_tiled3<LL, T3_NP, 8, 3>(grid, (unsigned)nb, st, value, g, ablate, loc, attn, N, S, M, out);
   switch (L) {
     case 2: T3_LAUNCH(2) break;
     case 3: T3_LAUNCH(3) break;
