@@ -93,6 +93,20 @@ int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const f
                            long long ref_batch_stride, const int64_t* spatial_shapes, int N, int Lq, int M,
                            int L, int P, float* loc, float* attn, void* stream);
 
+/* MSDeformAttn core fed with the RAW projections (fusion of univs_msda_prepare_f32 and univs_msda_forward_f32):
+ *   out = ms_deform_attn_forward(value, ..., loc, attn)   with
+ *   loc  = ref_points[:, :, None, :, None, :] + offsets / (W_l, H_l)          (ms_deform_attn.py:106-109)
+ *   attn = softmax(logits.view(N, Lq, M, L*P), -1)                            (ms_deform_attn.py:103)
+ * `proj` [N, Lq, row_stride]: sampling offsets in columns [0, M*L*P*2), attention logits in columns
+ * [n_off, n_off + M*L*P) (the two Linears of ms_deform_attn.py:101-102 as one GEMM); `ref_points` [N or 1, Lq, L, 2]
+ * with ref_batch_stride = Lq*L*2 or 0.  The [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] tensors are never materialised.
+ * Covered: D == 32, P == 4, 2 <= L <= 4, Lq == S (the encoder geometry); otherwise UNIVS_ERR_NOT_IMPLEMENTED and the
+ * caller runs the two operators one after the other. */
+int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* proj, int row_stride, int n_off, const float* ref_points,
+                                 long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                 void* stream);
+
 /* Selects the MSDA forward implementation: 0 = auto (default), 1 = generic direct-gather kernel,
  * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
  * Used by the parity tests and bench to exercise each path explicitly. */

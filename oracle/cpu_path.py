@@ -112,6 +112,15 @@ def msda_prepare(proj, n_off, reference_points, spatial_shapes, num_heads, num_l
     return loc, attn
 
 
+def msda_forward_fused(value, proj, n_off, reference_points, spatial_shapes, level_start_index, num_points):
+    """The fused operator = the reference's own sequence (ms_deform_attn.py:100-116): prepare, then the core."""
+    N, S, M, D = value.shape
+    shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else spatial_shapes
+    L = len(shapes)
+    loc, attn = msda_prepare(proj, n_off, reference_points, shapes, M, L, num_points)
+    return ms_deform_attn_forward(value, shapes, level_start_index, loc.contiguous(), attn.contiguous())
+
+
 def msda_set_impl(impl):
     return None
 
@@ -120,7 +129,7 @@ def msda_last_impl():
     return 0
 
 
-_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_", "window_attention_image", "msda_prepare")
+_NAMES = ("ms_deform_attn_forward", "mask_decode", "mask_decode_attn", "window_attention", "bilinear_resample", "layer_norm", "group_norm", "masked_softmax_", "window_attention_image", "msda_prepare", "msda_forward_fused")
 
 
 @contextlib.contextmanager

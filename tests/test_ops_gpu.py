@@ -108,6 +108,61 @@ def test_msda_worst_case_uniform_locations(cuda):
         assert (o1 - o2).abs().max().item() < 2e-5, gen
 
 
+def _fused_inputs(case):
+    """Raw projections [N, S, 288-like] + reference points for an encoder-style case: the offsets that reproduce the
+    case's sampling locations, random attention logits."""
+    value, shapes, lsi, loc, _ = cases.msda_inputs(case)
+    N, S, M, D = value.shape
+    L, P = len(shapes), case["P"]
+    refs = []
+    for (h, w) in shapes:
+        ys = (torch.arange(h, dtype=torch.float32) + 0.5) / h
+        xs = (torch.arange(w, dtype=torch.float32) + 0.5) / w
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        refs.append(torch.stack([xx.reshape(-1), yy.reshape(-1)], -1))
+    ref = torch.cat(refs, 0).view(1, S, 1, 2).expand(1, S, L, 2).contiguous()
+    norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    off = (loc - ref.view(1, S, 1, L, 1, 2)) * norm                        # pixels of the target level
+    logits = synth.normal("msda/" + case["name"] + "/logits", (N, S, M * L * P), std=1.5)
+    pad = 7                                                                 # columns between the two blocks: n_off is free
+    proj = torch.cat([off.reshape(N, S, M * L * P * 2), torch.zeros(N, S, pad), logits], -1).contiguous()
+    return value, shapes, lsi, proj, M * L * P * 2 + pad, ref
+
+
+@pytest.mark.parametrize("variant", [1, 0], ids=["11x2", "8x3"])
+@pytest.mark.parametrize("case", [c for c in cases.MSDA_CASES if c["encoder"] and len(c["shapes"]) >= 2 and c["D"] == 32],
+                         ids=lambda c: c["name"])
+def test_msda_fused_matches_reference_sequence(cuda, case, variant):
+    """Fused MSDeformAttn core (raw projections in, sampled output out) == the reference's sequence softmax /
+    reference + offset / normaliser -> ms_deform_attn_forward, evaluated by the oracle, and == our two-operator path."""
+    from oracle import cpu_path
+    value, shapes, lsi, proj, n_off, ref = _fused_inputs(case)
+    M, L, P = value.shape[2], len(shapes), case["P"]
+    want = cpu_path.msda_forward_fused(value, proj, n_off, ref, shapes, lsi, P).numpy()
+    old = os.environ.get("UNIVS_MSDA_T3_VARIANT")
+    os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
+    try:
+        got = ops.msda_forward_fused(value.to(cuda), proj.to(cuda), n_off, ref.to(cuda), shapes, lsi, P)
+        assert got is not None and ops.msda_last_tiled_generation() == 3
+        loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+        two = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
+    finally:
+        if old is None:
+            os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
+        else:
+            os.environ["UNIVS_MSDA_T3_VARIANT"] = old
+    torch.cuda.synchronize()
+    assert np.abs(got.cpu().numpy() - want).max() < 3e-5
+    assert (got - two).abs().max().item() < 3e-5
+
+
+def test_msda_fused_uncovered_geometry_returns_none(cuda):
+    v = torch.zeros(1, 6, 2, 16, device=cuda)           # D = 16: not covered -> the caller keeps the two operators
+    proj = torch.zeros(1, 6, 2 * 1 * 4 * 3, device=cuda)
+    ref = torch.zeros(1, 6, 1, 2, device=cuda)
+    assert ops.msda_forward_fused(v, proj, 16, ref, [(2, 3)], [0], 4) is None
+
+
 def test_msda_fresh_shape_tensors_of_changing_values(cuda):
     """The reference convention (compat drop-in): fresh device tensors for spatial_shapes / level_start_index on
     every call.  The caching allocator hands the same address back for the next resolution's table, so a host-side

@@ -68,6 +68,25 @@ def main():
         os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
         os.environ.pop("UNIVS_MSDA_TILED", None)
         ops.msda_set_impl(0)
+        # the pair msda_prepare + forward against the fused operator (raw projections in)
+        M_, L_, P_ = 8, 3, 4
+        proj = synth.normal("kb/proj", (T, S, M_ * L_ * P_ * 3), std=1.5).to(dev)
+        refp = loc[:1, :, 0, :, 0, :].contiguous()          # any in-range reference points
+        n_off = M_ * L_ * P_ * 2
+        t = timeit(lambda: ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_))
+        res["msda_prepare"] = dict(ms=t * 1e3)
+        for variant in (1, 0):
+            os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
+            def pair():
+                l_, a_ = ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_)
+                return ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
+            t = timeit(pair)
+            res[f"msda_prepare+tiled3_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+            t = timeit(lambda: ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_))
+            d = (ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_) - pair()).abs()
+            res[f"msda_fused_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+                                                 max_abs_diff_vs_pair=d.max().item())
+        os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
     if not args.only or "mask" in args.only:
         Q, C, H, W = 100, 256, 184, 320
         e = synth.normal("kb/e", (T, Q, C)).to(dev)

@@ -29,6 +29,8 @@ int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const
                             int, float*, hipStream_t);
 int msda_forward_tiled3_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
                             int, float*, hipStream_t);
+int msda_forward_fused_tiled3_f32(const float*, const LevelTable&, const float*, int, int, const float*, long long, int, int,
+                                  int, int, int, int, int, float*, hipStream_t);
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
@@ -390,6 +392,40 @@ int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const f
   const int rc = msda_prepare_f32(proj, row_stride, n_off, ref_points, ref_batch_stride, lv, N, Lq, M, L, P, loc, attn,
                                   static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_msda_prepare_f32: (L=%d, P=%d) not instantiated (P == 4, L <= 4)", L, P);
+  return rc;
+}
+
+int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                 const float* proj, int row_stride, int n_off, const float* ref_points,
+                                 long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                 void* stream) {
+  if (N < 0 || S < 0 || M < 1 || D < 0 || Lq < 0 || P < 1 || L < 1 || L > UNIVS_MAX_LEVELS || row_stride < M * L * P * 3 ||
+      n_off < M * L * P * 2 || n_off + M * L * P > row_stride || ref_batch_stride < 0) {
+    set_error("univs_msda_forward_fused_f32: bad dimensions N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d row_stride=%d n_off=%d", N, S,
+              M, D, L, Lq, P, row_stride, n_off);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
+  clear_sticky_error();
+  if (!value || !proj || !ref_points || !out) {
+    set_error("univs_msda_forward_fused_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_fused_f32");
+  if (rc != UNIVS_OK) return rc;
+  g_msda_gen = 0;
+  rc = msda_forward_fused_tiled3_f32(value, lv, proj, row_stride, n_off, ref_points, ref_batch_stride, N, S, M, D, L, Lq, P,
+                                     out, static_cast<hipStream_t>(stream));
+  if (rc > 0) {
+    g_msda_last = 2;
+    g_msda_gen = 3;
+    return UNIVS_OK;
+  }
+  if (rc == 0) {
+    set_error("univs_msda_forward_fused_f32: geometry not covered by the fused kernel (D == 32, P == 4, 2 <= L <= 4, Lq == S)");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
   return rc;
 }
 

@@ -58,53 +58,36 @@ struct T3Entry {
 };
 static_assert(sizeof(T3Entry) == 64, "one scalar load");
 
-// addr_top = bcast_k(slot) + off_top, addr_bottom = bcast_k(slot) + off_bottom   (k = K, lane K of my DPP row).
-// NOP: pad the VALU-write -> DPP-read hazard (2 wait states) for the first use of a record register; hipcc does not
-// look inside the asm, so it cannot do it.
-template <int K, bool NOP>
-__device__ __forceinline__ void t3_addr(int slot, int off_t, int off_b, int& a_t, int& a_b) {
-  if (NOP)
-    asm("s_nop 1\n\t"
-        "v_add_u32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_u32_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
-        : "=&v"(a_t), "=&v"(a_b)
-        : "v"(slot), "v"(off_t), "v"(off_b), "n"(K));
-  else
-    asm("v_add_u32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_u32_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
-        : "=&v"(a_t), "=&v"(a_b)
-        : "v"(slot), "v"(off_t), "v"(off_b), "n"(K));
-}
-
-// acc += bcast_k(w) * d on my two channels
-template <int K, bool NOP>
-__device__ __forceinline__ void t3_fma(float& ax, float& ay, float w, t3v2 d) {
-  if (NOP)
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
-        : "+v"(ax), "+v"(ay)
-        : "v"(w), "v"(d.x), "v"(d.y), "n"(K));
-  else
-    asm("v_fmac_f32_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
-        : "+v"(ax), "+v"(ay)
-        : "v"(w), "v"(d.x), "v"(d.y), "n"(K));
-}
-
+// lane K of my DPP row (row_newbcast); every lane has a source, so there is no "old" value to materialise
 template <int K>
 __device__ __forceinline__ int t3_bcast(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true);
 }
 
 // NP fill waves (waves 0 .. NP-1), NG gather waves, NB record batches per gather wave and step (a batch = 2 row
 // pairs x 4 queries x 4 points); 8 * NB * NG query slots per item.
-template <int L, int NP, int NG, int NB>
+// FUSED: the sampling locations and attention weights are not read from memory but made from the raw projections of
+// MSDeformAttn.forward (ms_deform_attn.py:100-113), exactly as csrc/msda_prepare.hip makes them:
+//   loc  = reference_point + offset / (W_l, H_l)            (IEEE division, then the add)
+//   attn = softmax over the L*P logits of (query, head)     (exp(x - max) / sum)
+// `in.loc` / `in.attn` are then unused; `in.proj` [N, Lq, row_stride] holds the offsets in columns [0, M*L*P*2) and the
+// logits in columns [n_off, n_off + M*L*P), `in.ref` [N or 1, Lq, L, 2] the reference points.
+struct T3Inputs {
+  const float* loc;
+  const float* attn;
+  const float* proj;
+  const float* ref;
+  int row_stride, n_off;
+  long long ref_batch_stride;   // 0: one set of reference points for all frames
+};
+
+template <int L, int NP, int NG, int NB, bool FUSED>
 __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* __restrict__ value,
                                                                    const T3Entry* __restrict__ tab, int ntiles, int ablate,
-                                                                   const float* __restrict__ loc,
-                                                                   const float* __restrict__ attn, int N, int S, int M,
+                                                                   T3Inputs in, int N, int S, int M,
                                                                    float* __restrict__ out, unsigned nitems) {
+  const float* __restrict__ loc = in.loc;
+  const float* __restrict__ attn = in.attn;
   static_assert(L >= 2, "inputs are prefetched two steps ahead: at most one item ahead needs L >= 2");
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(1024))) char lds3[];
@@ -125,7 +108,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
   struct Item {   // workgroup-uniform
     long long nm;   // n * S * M + m
-    int tile;
+    int tile, n, m;
   };
   auto make_item = [&](unsigned idx) __attribute__((always_inline)) {
     const unsigned item = cbase + idx;
@@ -135,7 +118,9 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     // derived from them, buffer resources included, is treated as divergent: waterfall loops around every load)
     const unsigned nu = __builtin_amdgcn_readfirstlane(n), tmu = __builtin_amdgcn_readfirstlane(tm);
     Item it;
-    it.nm = (long long)nu * S * M + (item - tmu * (unsigned)M);
+    it.n = (int)nu;
+    it.m = (int)(item - tmu * (unsigned)M);
+    it.nm = (long long)nu * S * M + it.m;
     it.tile = (int)(tmu - nu * (unsigned)ntiles);
     return it;
   };
@@ -258,25 +243,69 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       }
       return me;
     };
-    struct Inputs { float x[NB], y[NB], a[NB]; };
-    auto load_inputs = [&](const Item& it, int l, const Mine& me, Inputs& in) __attribute__((always_inline)) {
-      const char* lb = reinterpret_cast<const char*>(loc + it.nm * (L * P * 2));
-      const char* ab = reinterpret_cast<const char*>(attn + it.nm * (L * P));
+    // sampling location + attention weight of my (query, point) at every level of an item, in visiting order
+    struct Inputs { float x[L][NB], y[L][NB], a[L][NB]; };
+    auto load_inputs = [&](const Item& it, int par, const Mine& me, Inputs& iv) __attribute__((always_inline)) {
+      if constexpr (!FUSED) {
+        const char* lb = reinterpret_cast<const char*>(loc + it.nm * (L * P * 2));
+        const char* ab = reinterpret_cast<const char*>(attn + it.nm * (L * P));
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const unsigned e = (unsigned)(me.qg[b] * (M * L * P) + l * P + (k & 3));
-        const float2 xy = *reinterpret_cast<const float2*>(lb + e * 8u);
-        in.x[b] = xy.x; in.y[b] = xy.y;
-        in.a[b] = *reinterpret_cast<const float*>(ab + e * 4u);
+        for (int kk = 0; kk < L; ++kk) {
+          const int l = entry(it, par, kk).l;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const unsigned e = (unsigned)(me.qg[b] * (M * L * P) + l * P + (k & 3));
+            const float2 xy = *reinterpret_cast<const float2*>(lb + e * 8u);
+            iv.x[kk][b] = xy.x; iv.y[kk][b] = xy.y;
+            iv.a[kk][b] = *reinterpret_cast<const float*>(ab + e * 4u);
+          }
+        }
+      } else {
+        // raw projections -> locations / weights (csrc/msda_prepare.hip's arithmetic; the softmax sums in a different
+        // order: per point over the levels, then over the 4 points of the quad)
+        const float* row0 = in.proj + (long long)it.n * S * in.row_stride;
+        const float* ref0 = in.ref + it.n * in.ref_batch_stride;
+        float lg[L][NB];
+#pragma unroll
+        for (int kk = 0; kk < L; ++kk) {
+          const T3Entry e = entry(it, par, kk);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float* row = row0 + (long long)me.qg[b] * in.row_stride;
+            const float2 off = *reinterpret_cast<const float2*>(row + it.m * (L * P * 2) + (e.l * P + (k & 3)) * 2);
+            const float2 rp2 = *reinterpret_cast<const float2*>(ref0 + ((long long)me.qg[b] * L + e.l) * 2);
+            lg[kk][b] = row[in.n_off + it.m * (L * P) + e.l * P + (k & 3)];
+            iv.x[kk][b] = rp2.x + off.x / (float)e.W;
+            iv.y[kk][b] = rp2.y + off.y / (float)e.H;
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float mx = lg[0][b];
+#pragma unroll
+          for (int kk = 1; kk < L; ++kk) mx = fmaxf(mx, lg[kk][b]);
+          // the 4 points of a query sit in one quad of lanes: quad_perm [1,0,3,2] and [2,3,0,1]
+          mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false)));
+          mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, false)));
+          float sum = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < L; ++kk) {
+            iv.a[kk][b] = expf(lg[kk][b] - mx);
+            sum += iv.a[kk][b];
+          }
+          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
+          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
+#pragma unroll
+          for (int kk = 0; kk < L; ++kk) iv.a[kk][b] = iv.a[kk][b] / sum;
+        }
       }
     };
 
-    // ---- prologue: inputs of steps 0 and 1
+    // ---- prologue: inputs of the first item
     Item cur = make_item(widx);
     Mine me_cur = my_queries(cur, 0);
-    Inputs in0, in1;
-    load_inputs(cur, entry(cur, 0, 0).l, me_cur, in0);
-    load_inputs(cur, entry(cur, 0, 1).l, me_cur, in1);
+    Inputs in_cur;
+    load_inputs(cur, 0, me_cur, in_cur);
     __syncthreads();   // step 0's window is staged
 
     int par = 0;
@@ -284,7 +313,12 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     for (unsigned idx = widx;; idx += nw) {
       const bool has_next = idx + nw < csize;
       const Item nxt = make_item(has_next ? idx + nw : idx);
-      Mine me_nxt = me_cur;
+      // the next item's queries and inputs: issued now, used from the next iteration on (a whole item of cover for the
+      // one stream of this operator that is touched exactly once and comes from HBM)
+      const Mine me_nxt = my_queries(nxt, par ^ 1);
+      Inputs in_nxt;
+      load_inputs(nxt, par ^ 1, me_nxt, in_nxt);
+
       float ax[NB][4], ay[NB][4];
 #pragma unroll
       for (int b = 0; b < NB; ++b)
@@ -294,56 +328,46 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
         const T3Entry q = entry(cur, par, kk);
-        // ---- A. records of this step for my corner column (inputs were loaded two steps ago)
+        // ---- A. records of this step for my corner column
         int slot[NB];
         float wT[NB], wB[NB];
         bool miss[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const T3Record r = t3_record(in0.x[b], in0.y[b], in0.a[b], side, qslot[b] < q.total, q.H, q.W, q.wx0, q.wy0,
-                                       q.ww, q.wh);
+          const T3Record r = t3_record(in_cur.x[kk][b], in_cur.y[kk][b], in_cur.a[kk][b], side, qslot[b] < q.total, q.H,
+                                       q.W, q.wx0, q.wy0, q.ww, q.wh);
           miss[b] = r.miss;
           slot[b] = r.slot;
           wT[b] = r.wt;
           wB[b] = r.wb;
-          // the records are complete HERE (not sunk next to their first DPP use, see t3_fma)
-          asm volatile("" : "+v"(slot[b]), "+v"(wT[b]), "+v"(wB[b]));
         }
 
-        // ---- B. inputs of step + 2 (the next item's query indices are needed from its first prefetch on)
-        in0 = in1;
-        if (kk + 2 < L) {
-          load_inputs(cur, entry(cur, par, (kk + 2) % L).l, me_cur, in1);
-        } else {
-          if (kk + 2 == L) me_nxt = my_queries(nxt, par ^ 1);
-          load_inputs(nxt, entry(nxt, par ^ 1, (kk + 2) % L).l, me_nxt, in1);
-        }
-
-        // ---- C. gathers: 16 samples per row pair and batch
+        // ---- B. gathers: 16 samples per row pair and batch.  Per sample and row: one DPP add (address of the top row),
+        // one plain add (bottom row), two DPP moves (weights), four plain FMAs -- on gfx950 every DPP form issues at half
+        // rate, so the broadcasts are not folded into the FMAs (profiles/r02_gfx950_issue_costs.txt)
         const int off_t = (int)lds_base + q.reg + (lane & 15) * 8;
-        const int off_b = off_t + q.ww * (D * 4);
+        int pitchv = q.ww * (D * 4);
+        asm volatile("" : "+v"(pitchv));   // a VGPR: an SGPR source operand halves the add's rate
         if (!(ablate & 4)) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             if ((gw * NB + b) * 8 < q.total) {   // uniform
-              int a_t[16], a_b[16];
-              t3v2 dt[16], db[16];
-#define T3_ADDR(K) t3_addr<K, (K & 3) == 0>(slot[b], off_t, off_b, a_t[K], a_b[K]);
-#define T3_READ(K)                                                    \
-  dt[K] = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_t[K];  \
-  db[K] = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_b[K];
-#define T3_FMA(K)                                                           \
-  t3_fma<K, (K & 3) == 0>(ax[b][K >> 2], ay[b][K >> 2], wT[b], dt[K]);      \
-  t3_fma<K, (K & 3) == 0>(ax[b][K >> 2], ay[b][K >> 2], wB[b], db[K]);
-#define T3_AR(K0) T3_ADDR(K0) T3_ADDR(K0 + 1) T3_ADDR(K0 + 2) T3_ADDR(K0 + 3) T3_READ(K0) T3_READ(K0 + 1) T3_READ(K0 + 2) T3_READ(K0 + 3)
-#define T3_F(K0) T3_FMA(K0) T3_FMA(K0 + 1) T3_FMA(K0 + 2) T3_FMA(K0 + 3)
-              // quarters of 4 samples, two in flight: the reads of quarter i+1 are issued before the products of quarter i
-              T3_AR(0) T3_AR(4) T3_F(0) T3_AR(8) T3_F(4) T3_AR(12) T3_F(8) T3_F(12)
-#undef T3_AR
-#undef T3_F
-#undef T3_ADDR
-#undef T3_READ
-#undef T3_FMA
+#define T3_IT(K)                                                                                          \
+  {                                                                                                       \
+    const int a_t = t3_bcast<K>(slot[b]) + off_t;                                                         \
+    const int a_b = a_t + pitchv;                                                                         \
+    const t3v2 dt = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_t;                               \
+    const t3v2 db = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_b;                               \
+    const float wt = __int_as_float(t3_bcast<K>(__float_as_int(wT[b])));                                  \
+    const float wb = __int_as_float(t3_bcast<K>(__float_as_int(wB[b])));                                  \
+    ax[b][K >> 2] = __builtin_fmaf(wt, dt.x, ax[b][K >> 2]);                                              \
+    ay[b][K >> 2] = __builtin_fmaf(wt, dt.y, ay[b][K >> 2]);                                              \
+    ax[b][K >> 2] = __builtin_fmaf(wb, db.x, ax[b][K >> 2]);                                              \
+    ay[b][K >> 2] = __builtin_fmaf(wb, db.y, ay[b][K >> 2]);                                              \
+  }
+              T3_IT(0) T3_IT(1) T3_IT(2) T3_IT(3) T3_IT(4) T3_IT(5) T3_IT(6) T3_IT(7)
+              T3_IT(8) T3_IT(9) T3_IT(10) T3_IT(11) T3_IT(12) T3_IT(13) T3_IT(14) T3_IT(15)
+#undef T3_IT
             }
           }
         }
@@ -357,12 +381,8 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
             while (mm) {
               const int bl = __builtin_ctzll(mm);
               mm &= mm - 1;
-              // the sample's inputs again, from memory (uniform address): keeping this step's inputs in registers
-              // for a path that runs for < 0.03 % of the samples costs 3 VGPRs per batch in the hot loop
-              const int qgm = __shfl(me_cur.qg[b], bl, 64);
-              const unsigned em = (unsigned)(qgm * (M * L * P) + q.l * P + (bl & 3));
-              const float2 mxy = reinterpret_cast<const float2*>(loc + cur.nm * (L * P * 2))[em];
-              const float mx = mxy.x, my = mxy.y, ma = (attn + cur.nm * (L * P))[em];
+              const float mx = __shfl(in_cur.x[kk][b], bl, 64), my = __shfl(in_cur.y[kk][b], bl, 64),
+                          ma = __shfl(in_cur.a[kk][b], bl, 64);
               const Footprint fp = footprint(q.H, q.W, mx, my, ma);
               const int sd = (bl >> 4) & 1;
               const int wc = sd ? fp.w1 : fp.w0;
@@ -380,7 +400,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
           }
         }
 
-        // ---- D. last level: add the two corner columns (rows 2i / 2i+1) and store
+        // ---- C. last level: add the two corner columns (rows 2i / 2i+1) and store
         if (kk + 1 == L && !(ablate & 16)) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       if (!has_next) break;
       cur = nxt;
       me_cur = me_nxt;
+      in_cur = in_nxt;
       par ^= 1;
     }
   }
@@ -510,20 +531,21 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
   return g;
 }
 
-template <int L, int NP, int NG, int NB>
+template <int L, int NP, int NG, int NB, bool FUSED>
 static void launch_tiled3(unsigned grid, unsigned nitems, hipStream_t st, const float* value, const T3Geo* g, int ablate,
-                          const float* loc, const float* attn, int N, int S, int M, float* out) {
-  auto kfn = msda_fwd_tiled3<L, NP, NG, NB>;
+                          const T3Inputs& in, int N, int S, int M, float* out) {
+  auto kfn = msda_fwd_tiled3<L, NP, NG, NB, FUSED>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), g->lds, st, value, g->table, g->ntiles, ablate, loc, attn, N, S,
-                     M, out, nitems);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), g->lds, st, value, g->table, g->ntiles, ablate, in, N, S, M, out,
+                     nitems);
 }
 
 // returns 1 if launched, 0 if preconditions do not hold (caller tries the next implementation), <0 on error
-int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const float* loc, const float* attn, int N,
-                            int S, int M, int D, int L, int Lq, int P, float* out, hipStream_t st) {
+static int t3_forward(const float* value, const LevelTable& lv, const T3Inputs& in, bool fused, int N, int S, int M, int D,
+                      int L, int Lq, int P, float* out, hipStream_t st) {
   if (D != 32 || P != 4 || L < 2 || L > 4 || Lq != S || M < 1) return 0;
   if ((long long)S * M * D * 4 >= (1LL << 31) || (long long)S * M * L * P * 8 >= (1LL << 31)) return 0;
+  if (fused && (long long)S * in.row_stride * 4 >= (1LL << 31)) return 0;
   long long expect = 0;
   int fine = 0;
   for (int l = 0; l < L; ++l) {
@@ -535,7 +557,7 @@ int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const floa
 
   const int TH = env_int("UNIVS_MSDA_TILE3_H", 8), TW = env_int("UNIVS_MSDA_TILE3_W", 16);
   const int R = env_int("UNIVS_MSDA_HALO", 6);
-  const int variant = env_int("UNIVS_MSDA_T3_VARIANT", 0);   // 0: 4 fill + 8 gather waves x 3 batches; 1: 4 + 11 x 2
+  const int variant = env_int("UNIVS_MSDA_T3_VARIANT", 1);   // 1: 4 fill + 11 gather waves x 2 batches; 0: 4 + 8 x 3
   const int ablate = env_int("UNIVS_MSDA_ABLATE", 0);
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
   const T3Geo* g = t3_geometry(lv, L, fine, TH, TW, R);
@@ -554,17 +576,43 @@ int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const floa
     n_cu = v;
   }
   const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", n_cu), 1));
-#define T3_LAUNCH(LL)                                                                                     \
-  if (variant == 1) launch_tiled3<LL, T3_NP, 11, 2>(grid, (unsigned)nb, st, value, g, ablate, loc, attn, N, S, M, out); \
-  else launch_tiled3<LL, T3_NP, 8, 3>(grid, (unsigned)nb, st, value, g, ablate, loc, attn, N, S, M, out);
+#define T3_LAUNCH2(LL, FF)                                                                              \
+  if (variant == 1) launch_tiled3<LL, T3_NP, 11, 2, FF>(grid, (unsigned)nb, st, value, g, ablate, in, N, S, M, out); \
+  else launch_tiled3<LL, T3_NP, 8, 3, FF>(grid, (unsigned)nb, st, value, g, ablate, in, N, S, M, out);
+#define T3_LAUNCH(LL)              \
+  if (fused) { T3_LAUNCH2(LL, true) } \
+  else { T3_LAUNCH2(LL, false) }
   switch (L) {
     case 2: T3_LAUNCH(2) break;
     case 3: T3_LAUNCH(3) break;
     default: T3_LAUNCH(4) break;
   }
 #undef T3_LAUNCH
+#undef T3_LAUNCH2
   int rc = check_launch("msda_fwd_tiled3");
   return rc == UNIVS_OK ? 1 : rc;
+}
+
+int msda_forward_tiled3_f32(const float* value, const LevelTable& lv, const float* loc, const float* attn, int N,
+                            int S, int M, int D, int L, int Lq, int P, float* out, hipStream_t st) {
+  T3Inputs in{};
+  in.loc = loc;
+  in.attn = attn;
+  return t3_forward(value, lv, in, false, N, S, M, D, L, Lq, P, out, st);
+}
+
+// MSDeformAttn core fed with the raw projections: msda_prepare (softmax + reference + offset / normaliser) happens
+// inside the sampling kernel, the [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] tensors never exist.
+int msda_forward_fused_tiled3_f32(const float* value, const LevelTable& lv, const float* proj, int row_stride, int n_off,
+                                  const float* ref, long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq,
+                                  int P, float* out, hipStream_t st) {
+  T3Inputs in{};
+  in.proj = proj;
+  in.ref = ref;
+  in.row_stride = row_stride;
+  in.n_off = n_off;
+  in.ref_batch_stride = ref_batch_stride;
+  return t3_forward(value, lv, in, true, N, S, M, D, L, Lq, P, out, st);
 }
 
 }  // namespace univs

@@ -15,6 +15,7 @@ work is organised (results are the same):
     msdeformattn.py:62) are dropped: valid_ratio is identically 1;
   * everything stays fp32 regardless of autocast (msdeformattn.py:316,322).
 """
+import os
 from typing import Callable, Dict, List, Optional, Union
 
 import numpy as np
@@ -26,6 +27,10 @@ from ... import ops
 from ...layers import Conv2d, get_activation_fn, get_norm, layer_norm, linear, linear_act
 from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
+
+
+# UNIVS_MSDA_FUSED=0: keep msda_prepare + ms_deform_attn_forward as two operators (A/B switch)
+_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "1") != "0"
 
 
 def _shape_list(spatial_shapes):
@@ -70,6 +75,14 @@ class MSDeformAttn(nn.Module):
         # instead of 192 + 96, `query` is read once
         w, b, n_off = self._merged_query_proj()
         qp = linear(query, w, b)
+        if (reference_points.shape[-1] == 2 and P == 4 and L <= 4 and _MSDA_FUSED and Len_q == Len_in
+                and input_padding_mask is None):
+            # the whole core from the raw projections: softmax + reference + offset / (W_l, H_l) happen inside the
+            # sampling kernel, the location / weight tensors (36 % of the operator's bytes) never exist
+            output = ops.msda_forward_fused(value, qp, n_off, reference_points, input_spatial_shapes,
+                                            input_level_start_index, P)
+            if output is not None:
+                return linear(output, self.output_proj.weight, self.output_proj.bias)
         if reference_points.shape[-1] == 2 and P == 4 and L <= 4:
             # softmax over the L*P logits + reference point + offset / (W_l, H_l): one pass (HIP operator)
             sampling_locations, attention_weights = ops.msda_prepare(qp, n_off, reference_points, input_spatial_shapes,

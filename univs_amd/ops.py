@@ -135,6 +135,35 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [gv, gl, ga]
 
 
+def msda_forward_fused(value, proj, n_off, reference_points, spatial_shapes, level_start_index, num_points):
+    """MSDeformAttn core straight from the raw projections (ms_deform_attn.py:100-116 in one operator): value
+    [N,S,M,D]; `proj` [N,Lq,C] with the sampling offsets in columns [0, M*L*P*2) and the attention logits in columns
+    [n_off, n_off + M*L*P); reference_points [N or 1, Lq, L, 2].  Returns [N, Lq, M*D], or None when the geometry is
+    not covered (the caller then runs `msda_prepare` + `ms_deform_attn_forward`)."""
+    _inference_only("msda_forward_fused", value, proj, reference_points)
+    value, proj, reference_points = value.contiguous(), proj.contiguous(), reference_points.contiguous()
+    _require_gpu("msda_forward_fused", value, proj, reference_points)
+    if value.dtype != torch.float32 or proj.dtype != torch.float32 or reference_points.dtype != torch.float32:
+        return None
+    N, S, M, D = value.shape
+    N2, Lq, C = proj.shape
+    sh, st, L = _host_shapes(spatial_shapes, level_start_index, S)
+    P = int(num_points)
+    if N2 != N or tuple(reference_points.shape[1:]) != (Lq, L, 2) or reference_points.shape[0] not in (1, N):
+        raise RuntimeError("msda_forward_fused: inconsistent shapes")
+    if D != 32 or P != 4 or not (2 <= L <= 4) or Lq != S:
+        return None
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    rbs = 0 if reference_points.shape[0] == 1 else Lq * L * 2
+    with torch.cuda.device(value.device):
+        rc = _lib.load().univs_msda_forward_fused_f32(_ptr(value), sh, st, _ptr(proj), C, int(n_off), _ptr(reference_points),
+                                                      rbs, N, S, M, D, L, Lq, P, _ptr(out), _stream_ptr(value))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "msda_forward_fused")
+    return out
+
+
 def msda_set_impl(impl: int):
     """0 auto, 1 generic direct-gather kernel, 2 LDS-tiled encoder kernel."""
     _lib.check(_lib.load().univs_msda_set_impl(int(impl)), "msda_set_impl")
