@@ -70,8 +70,18 @@ def main():
         ops.msda_set_impl(0)
         # the pair msda_prepare + forward against the fused operator (raw projections in)
         M_, L_, P_ = 8, 3, 4
-        proj = synth.normal("kb/proj", (T, S, M_ * L_ * P_ * 3), std=1.5).to(dev)
-        refp = loc[:1, :, 0, :, 0, :].contiguous()          # any in-range reference points
+        # raw projections that reproduce the benchmark's sampling locations: offsets in pixels of the target level
+        # relative to the query's own pixel centre (the encoder's reference points), logits whose softmax is `attn`
+        refs = []
+        for (h, w) in shapes:
+            ys = (torch.arange(h, dtype=torch.float32) + 0.5) / h
+            xs = (torch.arange(w, dtype=torch.float32) + 0.5) / w
+            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+            refs.append(torch.stack([xx.reshape(-1), yy.reshape(-1)], -1))
+        refp = torch.cat(refs, 0).view(1, S, 1, 2).expand(1, S, L_, 2).contiguous().to(dev)
+        norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32, device=dev).view(1, 1, 1, L_, 1, 2)
+        off = (loc - refp.view(1, S, 1, L_, 1, 2)) * norm
+        proj = torch.cat([off.reshape(T, S, -1), attn.clamp_min(1e-30).log().reshape(T, S, -1)], -1).contiguous()
         n_off = M_ * L_ * P_ * 2
         t = timeit(lambda: ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_))
         res["msda_prepare"] = dict(ms=t * 1e3)

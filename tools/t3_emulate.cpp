@@ -75,8 +75,8 @@ int main() {
     const int tiles_y = (lv.H[fine] + c.TH - 1) / c.TH, tiles_x = (lv.W[fine] + c.TW - 1) / c.TW;
     std::vector<int4> tab((size_t)L * (tiles_x + tiles_y));
     for (int l = 0; l < L; ++l) {
-      for (int tx = 0; tx < tiles_x; ++tx) axis_entry(tx, tiles_x, c.TW, lv.W[l], lv.W[fine], c.R, UNIVS_MSDA_WIN_EDGE_MAX, 0, tab[(size_t)l * tiles_x + tx]);
-      for (int ty = 0; ty < tiles_y; ++ty) axis_entry(ty, tiles_y, c.TH, lv.H[l], lv.H[fine], c.R, UNIVS_MSDA_WIN_EDGE_MAX, 0, tab[(size_t)L * tiles_x + (size_t)l * tiles_y + ty]);
+      for (int tx = 0; tx < tiles_x; ++tx) axis_entry(tx, tiles_x, c.TW, lv.W[l], lv.W[fine], c.R, 32, 1, tab[(size_t)l * tiles_x + tx]);
+      for (int ty = 0; ty < tiles_y; ++ty) axis_entry(ty, tiles_y, c.TH, lv.H[l], lv.H[fine], c.R, 24, 1, tab[(size_t)L * tiles_x + (size_t)l * tiles_y + ty]);
     }
     std::vector<double> out((size_t)c.N * S * c.M * 32, 0.0);
     std::vector<int> covered((size_t)c.N * S * c.M, 0);
@@ -91,9 +91,10 @@ int main() {
               gx[l] = tab[(size_t)l * tiles_x + tx];
               gy[l] = tab[(size_t)L * tiles_x + (size_t)l * tiles_y + ty];
               pre[l + 1] = pre[l] + gx[l].y * gy[l].y;
-              // window inside the level
-              if (gx[l].z < 0 || gy[l].z < 0 || gx[l].z + gx[l].w > lv.W[l] || gy[l].z + gy[l].w > lv.H[l] || gx[l].w < 2 || gy[l].w < 2) {
-                printf("%s: window of tile (%d,%d) level %d leaves the level: x %d+%d / %d, y %d+%d / %d\n", c.name, ty, tx, l, gx[l].z, gx[l].w, lv.W[l], gy[l].z, gy[l].w, lv.H[l]);
+              // window inside the level + its one-pixel zero ring, and inside the fill grid
+              if (gx[l].z < -1 || gy[l].z < -1 || gx[l].z + gx[l].w > lv.W[l] + 1 || gy[l].z + gy[l].w > lv.H[l] + 1 || gx[l].w < 2 || gy[l].w < 2 ||
+                  gx[l].w > 32 || gy[l].w > 24) {
+                printf("%s: window of tile (%d,%d) level %d out of bounds: x %d+%d / %d, y %d+%d / %d\n", c.name, ty, tx, l, gx[l].z, gx[l].w, lv.W[l], gy[l].z, gy[l].w, lv.H[l]);
                 ++bad_total;
               }
             }
@@ -114,18 +115,18 @@ int main() {
                   const float x = loc[e * 2], y = loc[e * 2 + 1], aw = attn[e];
                   ++nsamp;
                   for (int side = 0; side < 2; ++side) {
-                    const T3Record r = t3_record(x, y, aw, side, true, H, W, wx0, wy0, ww, wh);
-                    if (r.slot < 0 || r.slot / 128 + ww >= ww * wh + (r.wb == 0.f && r.wt == 0.f ? ww : 0)) {
-                      if (!(r.wt == 0.f && r.wb == 0.f && r.slot == 0)) { printf("%s: slot out of window\n", c.name); ++bad_total; }
-                    }
-                    const int px = r.slot / 128, wr = px / ww, wc = px % ww;
+                    const int pitch = (ww + 7) / 8 * 8;
+                    const T3Record r = t3_record(x, y, aw, side, side ? 1.f : -1.f, side ? 0.f : 1.f, true, H, W, wx0, wy0, ww, wh, pitch);
+                    const int px = r.slot / 128, wr = px / pitch, wc = px % pitch;
+                    if (r.slot < 0 || wr + 1 >= wh || wc >= ww) { printf("%s: slot out of window\n", c.name); ++bad_total; }
+                    auto staged = [&](int row, int col, int ch) -> float {   // what the fill waves put there: level data or the zero ring
+                      const int gy_ = wy0 + row, gx_ = wx0 + col;
+                      if (gy_ < 0 || gy_ >= H || gx_ < 0 || gx_ >= W) return 0.f;
+                      return value[(((size_t)n * S + lv.start[l] + (size_t)gy_ * W + gx_) * c.M + m) * 32 + ch];
+                    };
                     for (int ch = 0; ch < 32; ++ch) {
                       double acc = 0;
-                      if (r.wt != 0.f || r.wb != 0.f) {
-                        const float vt = value[(((size_t)n * S + lv.start[l] + (size_t)(wy0 + wr) * W + wx0 + wc) * c.M + m) * 32 + ch];
-                        const float vb = value[(((size_t)n * S + lv.start[l] + (size_t)(wy0 + wr + 1) * W + wx0 + wc) * c.M + m) * 32 + ch];
-                        acc = (double)r.wt * vt + (double)r.wb * vb;
-                      }
+                      if (r.wt != 0.f || r.wb != 0.f) acc = (double)r.wt * staged(wr, wc, ch) + (double)r.wb * staged(wr + 1, wc, ch);
                       if (r.miss) {
                         const Footprint f = footprint(H, W, x, y, aw);
                         const int cc = side ? f.w1 : f.w0;

@@ -42,9 +42,10 @@ typedef float t3v2 __attribute__((ext_vector_type(2)));
 typedef float t3v4 __attribute__((ext_vector_type(4)));
 #define T3_LDS __attribute__((address_space(3)))
 
-constexpr int T3_WIN_PX = 704;    // cap on one window (pixels); the two regions together must fit 160 KiB
-constexpr int T3_NP = 4;          // fill waves
-constexpr int T3_CHUNK = 2;       // staged rows per uniform branch of the fill waves; regions are padded to whole chunks
+constexpr int T3_NP = 4;          // fill waves: 32 copy octets (8 lanes x 16 B = one pixel-head) as an 8 x 4 grid
+constexpr int T3_OX = 8, T3_OY = 4;
+constexpr int T3_PITCH_MAX = 32;  // window width cap (pixels), a multiple of T3_OX
+constexpr int T3_ROWS_MAX = 24;   // window height cap, a multiple of T3_OY
 
 // One step of one tile, everything the kernel needs as workgroup-uniform scalars, precomputed on the host: the first
 // version derived these per step on the scalar unit (selects over the level table, prefix sums, divisions) and was
@@ -52,8 +53,9 @@ constexpr int T3_CHUNK = 2;       // staged rows per uniform branch of the fill 
 // Table index: (tile * 2 + item parity) * L + step; 64 bytes = one s_load_dwordx16.
 struct T3Entry {
   int H, W, start, l;           // the level visited at this step
-  int wx0, wy0, ww, wh;         // staged window (inside the level)
-  int npx, reg, qfirst, qcount; // window pixels; LDS byte offset of the region; this level's queries within the item
+  int wx0, wy0, ww, wh;         // staged window (may include the zero ring around the level)
+  int pitch, reg, qfirst, qcount; // LDS row pitch of the window (pixels, a multiple of 8); LDS byte offset of the region;
+                                  // this level's queries within the item
   int qx0, qy0, qnx, total;     // query box origin / width; queries of the whole item
 };
 static_assert(sizeof(T3Entry) == 64, "one scalar load");
@@ -131,11 +133,16 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
   if (wave < NP) {
     // =========================== fill waves ===========================
-    constexpr int OCT = NP * 8;                          // copy octets (8 lanes x 16 B = one pixel-head)
-    constexpr int WR = (T3_WIN_PX + OCT - 1) / OCT;      // staged 16-B rows per lane
-    constexpr int CH = T3_CHUNK;                         // staged rows per uniform branch
+    // 32 copy octets as an 8 x 4 grid that tiles the window: octet (ox, oy) stages the pixels (oy + 4 vy, ox + 8 vx).
+    // The per-lane part of every address is fixed for a step and the (vy, vx) part is uniform, so a staged row costs
+    // one full-rate add; there is no per-pixel row / column arithmetic (the first version spent ~20 issue clocks per
+    // staged row on it).  LDS rows have a pitch that is a multiple of 8 pixels and the regions hold whole 4-row groups,
+    // so the writes need no bounds either: pad pixels receive garbage nobody reads.
+    static_assert(NP == T3_NP, "octet grid is laid out for 4 fill waves");
+    constexpr int VX = T3_PITCH_MAX / T3_OX, VY = T3_ROWS_MAX / T3_OY;
     const int lane8 = tid & 7, oct = tid >> 3;
-    t3v4 wreg[WR];
+    const int ox = oct & (T3_OX - 1), oy = oct >> 3;
+    t3v4 wreg[VY][VX];
     auto load_window = [&](const Item& it, const T3Entry& q) __attribute__((always_inline)) {
       if (ablate & 1) return;
       // (explicitly scalar: left to itself hipcc keeps this descriptor in VGPRs and wraps every load in a waterfall loop)
@@ -144,36 +151,43 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       const int nrec = __builtin_amdgcn_readfirstlane((int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4));
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, nrec, 0x00020000);
-      const unsigned pstride = (unsigned)(M * D * 4);
-      const int sy = (int)(((float)OCT + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));
-      const int sx = OCT - sy * q.ww;
-      int ry = (int)(((float)oct + 0.5f) * __builtin_amdgcn_rcpf((float)q.ww));
-      int rx = oct - ry * q.ww;
-      unsigned off = (unsigned)((q.wy0 + ry) * q.W + q.wx0 + rx) * pstride + (unsigned)lane8 * 16u;
-      const unsigned step_n = (unsigned)(sy * q.W + sx) * pstride;
-      const unsigned step_c = (unsigned)((sy + 1) * q.W + sx - q.ww) * pstride;
+      const int pstride = M * D * 4;
+      // columns: out-of-level ones (the zero ring; pad columns past the level's edge) get an offset far outside the
+      // resource, which makes the load return 0; rows outside the level fall out of it by themselves
+      unsigned cb[VX];
 #pragma unroll
-      for (int u0 = 0; u0 < WR; u0 += CH) {
-        if (u0 * OCT < q.npx) {   // uniform, one branch per CH rows: pixels past the window's end fall out of the
-#pragma unroll                    // resource (reads return 0) and are not committed
-          for (int u = u0; u < u0 + CH && u < WR; ++u) {
-            wreg[u] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-            rx += sx;
-            const bool carry = rx >= q.ww;
-            rx -= carry ? q.ww : 0;
-            off += carry ? step_c : step_n;
-          }
+      for (int vx = 0; vx < VX; ++vx) {
+        const int gx = q.wx0 + ox + vx * T3_OX;
+        cb[vx] = (unsigned)gx < (unsigned)q.W ? (unsigned)(gx * pstride + lane8 * 16) : 0xC0000000u;
+      }
+      unsigned rowoff = (unsigned)((q.wy0 + oy) * q.W * pstride);
+      unsigned rowstep = (unsigned)(T3_OY * q.W * pstride);
+      asm volatile("" : "+v"(rowstep));   // a VGPR: an SGPR source operand halves the add's rate
+      const int nvx = q.pitch / T3_OX;
+#pragma unroll
+      for (int vy = 0; vy < VY; ++vy) {
+        if (vy * T3_OY < q.wh) {   // uniform
+#pragma unroll
+          for (int vx = 0; vx < VX; ++vx)
+            if (vx == 0 || vx < nvx)   // uniform
+              wreg[vy][vx] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cb[vx] + rowoff, 0, 0));
+          rowoff += rowstep;
         }
       }
     };
     auto commit = [&](const T3Entry& q) __attribute__((always_inline)) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): explicit and unconditional, see msda_tiled.hip
-      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + q.reg) + (oct * 8 + lane8);
+      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + q.reg) + ((oy * q.pitch + ox) * 8 + lane8);
+      int rowstep = T3_OY * q.pitch * 8;   // in 16-byte units
+      asm volatile("" : "+v"(rowstep));
+      const int nvx = q.pitch / T3_OX;
 #pragma unroll
-      for (int u0 = 0; u0 < WR; u0 += CH) {
-        if (u0 * OCT < q.npx) {   // uniform.  No per-lane bound: the regions are padded to whole chunks (host), rows past
-#pragma unroll                    // the window's end land in the padding
-          for (int u = u0; u < u0 + CH && u < WR; ++u) win[u * OCT * 8] = wreg[u];
+      for (int vy = 0; vy < VY; ++vy) {
+        if (vy * T3_OY < q.wh) {   // uniform
+#pragma unroll
+          for (int vx = 0; vx < VX; ++vx)
+            if (vx == 0 || vx < nvx) win[vx * T3_OX * 8] = wreg[vy][vx];   // uniform; the column block is an immediate offset
+          win += rowstep;
         }
       }
     };
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     const int side = (lane >> 4) & 1;    // corner column of my DPP row: 0 left, 1 right
     const int k = lane & 15;             // my record: sample k of my row pair = (query k >> 2, point k & 3)
     const int ch = (lane & 15) * 2;      // my two channels as a gathering lane
+    const float side_sign = side ? 1.f : -1.f, side_one = side ? 0.f : 1.f;   // column factor = lw * sign + one
     int qslot[NB];                       // my query's index within an item, per batch
 #pragma unroll
     for (int b = 0; b < NB; ++b) qslot[b] = ((gw * NB + b) * 2 + rp) * 4 + (k >> 2);
@@ -334,8 +349,8 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
         bool miss[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const T3Record r = t3_record(in_cur.x[kk][b], in_cur.y[kk][b], in_cur.a[kk][b], side, qslot[b] < q.total, q.H,
-                                       q.W, q.wx0, q.wy0, q.ww, q.wh);
+          const T3Record r = t3_record(in_cur.x[kk][b], in_cur.y[kk][b], in_cur.a[kk][b], side, side_sign, side_one,
+                                       qslot[b] < q.total, q.H, q.W, q.wx0, q.wy0, q.ww, q.wh, q.pitch);
           miss[b] = r.miss;
           slot[b] = r.slot;
           wT[b] = r.wt;
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
         // one plain add (bottom row), two DPP moves (weights), four plain FMAs -- on gfx950 every DPP form issues at half
         // rate, so the broadcasts are not folded into the FMAs (profiles/r02_gfx950_issue_costs.txt)
         const int off_t = (int)lds_base + q.reg + (lane & 15) * 8;
-        int pitchv = q.ww * (D * 4);
+        int pitchv = q.pitch * (D * 4);
         asm volatile("" : "+v"(pitchv));   // a VGPR: an SGPR source operand halves the add's rate
         if (!(ablate & 4)) {
 #pragma unroll
@@ -463,20 +478,23 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
   const int tiles_y = (lv.H[fine] + TH - 1) / TH, tiles_x = (lv.W[fine] + TW - 1) / TW;
   std::vector<int4> ax((size_t)L * tiles_x), ay((size_t)L * tiles_y);
   long long lvl_px[UNIVS_MAX_LEVELS] = {0, 0, 0, 0};
+  int pitch[UNIVS_MAX_LEVELS] = {0, 0, 0, 0};
   for (int l = 0; l < L; ++l) {
-    int mw = 2;
+    // windows with the zero ring (ring = 1), capped at the fill grid's extent: samples beyond go through the global
+    // fallback, results unchanged
+    int mw = 2, mh = 2;
     for (int tx = 0; tx < tiles_x; ++tx) {
-      axis_entry(tx, tiles_x, TW, lv.W[l], lv.W[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, /*ring=*/0, ax[(size_t)l * tiles_x + tx]);
-      mw = std::max(mw, ax[(size_t)l * tiles_x + tx].w);
+      int4& e = ax[(size_t)l * tiles_x + tx];
+      axis_entry(tx, tiles_x, TW, lv.W[l], lv.W[fine], R, T3_PITCH_MAX, /*ring=*/1, e);
+      mw = std::max(mw, e.w);
     }
     for (int ty = 0; ty < tiles_y; ++ty) {
       int4& e = ay[(size_t)l * tiles_y + ty];
-      axis_entry(ty, tiles_y, TH, lv.H[l], lv.H[fine], R, UNIVS_MSDA_WIN_EDGE_MAX, /*ring=*/0, e);
-      // windows must fit the LDS carve: shrink rows where a (tile, level) would not (samples beyond go through the
-      // global fallback, results unchanged)
-      e.w = (int)std::max<long long>(2, std::min<long long>(e.w, T3_WIN_PX / mw));
-      lvl_px[l] = std::max<long long>(lvl_px[l], (long long)mw * e.w);
+      axis_entry(ty, tiles_y, TH, lv.H[l], lv.H[fine], R, T3_ROWS_MAX, /*ring=*/1, e);
+      mh = std::max(mh, e.w);
     }
+    pitch[l] = (mw + T3_OX - 1) / T3_OX * T3_OX;
+    lvl_px[l] = (long long)pitch[l] * ((mh + T3_OY - 1) / T3_OY * T3_OY);   // whole 4-row groups of whole 8-pixel blocks
   }
   // region plan: step parity picks the region; an odd level count makes odd items start in B, so they visit their
   // two largest windows in swapped order (the accumulators do not care)
@@ -498,9 +516,6 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
   T3Geo* g = new T3Geo();
   g->key = key;
   g->ntiles = tiles_y * tiles_x;
-  const long long chunk_px = (long long)T3_CHUNK * T3_NP * 8;   // the fill waves write whole chunks
-  capA = (capA + chunk_px - 1) / chunk_px * chunk_px;
-  capB = (capB + chunk_px - 1) / chunk_px * chunk_px;
   g->lds = (size_t)(capA + capB) * 128;
   g->qmax = 0;
   std::vector<T3Entry> tab((size_t)g->ntiles * 2 * L);
@@ -516,7 +531,7 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
           T3Entry& e = tab[((size_t)(ty * tiles_x + tx) * 2 + par) * L + kk];
           e.H = lv.H[l]; e.W = lv.W[l]; e.start = lv.start[l]; e.l = l;
           e.wx0 = gx.z; e.wy0 = gy.z; e.ww = gx.w; e.wh = gy.w;
-          e.npx = gx.w * gy.w; e.reg = reg[par][kk] ? (int)(capA * 128) : 0;
+          e.pitch = pitch[l]; e.reg = reg[par][kk] ? (int)(capA * 128) : 0;
           e.qfirst = pre[l]; e.qcount = gx.y * gy.y;
           e.qx0 = gx.x; e.qy0 = gy.x; e.qnx = std::max(gx.y, 1); e.total = pre[L];
         }
