@@ -13,7 +13,7 @@ from univs_amd import ops, synth
 pytestmark = pytest.mark.gpu
 
 
-def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl, gen=3):
+def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl, gen=2):
     """impl 1 = generic kernel, 2 = LDS-tiled; `gen` caps the generation of the tiled kernel (3 = LDS-DMA +
     in-register records, 2 = producer / consumer waves, 1 = single window) through UNIVS_MSDA_TILED."""
     ops.msda_set_impl(impl)
@@ -82,7 +82,7 @@ def test_msda_cfg2_size_tiled_equals_generic_and_properties(cuda):
     o1 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 1)
     o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2)
     assert (o1 - o2).abs().max().item() < 2e-5
-    o2b = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=2)
+    o2b = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=3)
     assert (o1 - o2b).abs().max().item() < 2e-5
     v2 = synth.normal("cfg2/value2", tuple(value.shape))
     o_sum = _msda_gpu(value + 2.0 * v2, shapes, lsi, loc, attn, cuda, 2)

@@ -162,11 +162,13 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   if (rc != UNIVS_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g_msda_impl != 1) {
-    // LDS-tiled kernels for the encoder geometry, newest generation first; each returns 0 when its preconditions
-    // fail.  UNIVS_MSDA_TILED=2 / 1 (read per call: the kernel benchmarks flip it) starts at the second / first
-    // generation instead.
+    // LDS-tiled kernels for the encoder geometry; each returns 0 when its preconditions fail.  Default: the second
+    // generation (msda_tiled2.hip).  UNIVS_MSDA_TILED=3 (read per call: tests and kernel benchmarks flip it) starts at the
+    // third generation (msda_tiled3.hip: register records + DPP gathers, optional fused input preparation) -- on MI355X
+    // it is within 6 % of the second generation, both being bound by the window re-reads that miss L2
+    // (profiles/r02_msda_kbench_v3.txt), so it is not the default yet; =1 selects the first generation.
     const char* e = getenv("UNIVS_MSDA_TILED");
-    const int tiled_gen = (e && *e) ? atoi(e) : 3;
+    const int tiled_gen = (e && *e) ? atoi(e) : 2;
     g_msda_gen = 0;
     rc = tiled_gen >= 3 ? msda_forward_tiled3_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
     if (rc != 0) {

@@ -29,8 +29,10 @@ from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
 
-# UNIVS_MSDA_FUSED=0: keep msda_prepare + ms_deform_attn_forward as two operators (A/B switch)
-_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "1") != "0"
+# UNIVS_MSDA_FUSED=1: msda_prepare + ms_deform_attn_forward as ONE operator (third-generation kernel fed with the raw
+# projections).  Measured on MI355X: 196 us per 5-frame layer against 48 + 157 us for the two operators -- a 4 % gain on
+# the pair, so it stays opt-in until the third-generation kernel itself is faster (profiles/r02_msda_kbench_v3.txt).
+_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "0") == "1"
 
 
 def _shape_list(spatial_shapes):
