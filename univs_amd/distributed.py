@@ -31,13 +31,18 @@ class FrameShard:
         return slice(self.rank * t_local, (self.rank + 1) * t_local)
 
     def all_gather_frames(self, x: torch.Tensor, dim: int) -> torch.Tensor:
-        """Concatenate every rank's block along `dim` in rank order (one collective)."""
+        """Concatenate every rank's block along `dim` in rank order: ONE collective into ONE preallocated tensor
+        (`all_gather_into_tensor`; no per-rank temporaries, no concatenation pass when dim == 0)."""
         if self.world == 1:
             return x
         x = x.contiguous()
-        parts = [torch.empty_like(x) for _ in range(self.world)]
-        dist.all_gather(parts, x, group=self.group)
-        return torch.cat(parts, dim=dim)
+        out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)   # rank-major along dim 0 (the form both RCCL and gloo take)
+        if dim == 0:
+            return out
+        # [world, ..., n_dim, ...] -> [..., world * n_dim, ...]
+        out = out.view((self.world,) + tuple(x.shape))
+        return out.movedim(0, dim).reshape(tuple(x.shape[:dim]) + (self.world * x.shape[dim],) + tuple(x.shape[dim + 1:]))
 
     def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
