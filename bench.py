@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (default: min(cores, 32))")
     ap.add_argument("--no-frame-sharded", action="store_true", help="N>1: skip the config-3 frame-sharded measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo plumbing check (tests): launcher, rendezvous, barrier-bracketed timing, max over "
@@ -414,8 +415,7 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         # the build's CPU restatement (oracle/cpu_path.py: ATen CPU + plain-C MSDA) on the host cores,
-        # 1 warm-up + 3 timed clips, median; thread count = the better of all hardware threads and 32 (ATen's CPU
-        # kernels stop scaling well before 256 threads on this model; both warm-up times are reported)
+        # 1 warm-up + 3 timed clips, median
         from oracle.cpu_path import cpu_ops
         swin_c = helpers.build_swin("cpu")
         head_c = helpers.build_head(case, "cpu", return_aux=False)
@@ -427,15 +427,14 @@ def main():
                 head_c(swin_c(cases.preprocess(fr)), targets=cases.targets_first_clip(case))
                 return time.perf_counter() - t1
 
+        # thread count: 32.  Measured on the GPU box (2 x EPYC 9575F, 256 hardware threads; profiles/r02_bench_cfg2_n1_v1.json):
+        # one clip takes 182.7 s with all 256 threads (ATen's CPU kernels oversubscribe on this model's many small ops)
+        # and 8.9 s with 32 -- so os.cpu_count() threads would make the baseline 20x slower, not faster.
         ncpu = os.cpu_count() or 1
-        sweep = {}
-        for nt in sorted({ncpu, min(ncpu, 32)}, reverse=True):
-            torch.set_num_threads(nt)
-            os.environ["OMP_NUM_THREADS"] = str(nt)
-            sweep[nt] = cpu_clip()                                # warm-up at this thread count
-        cores = min(sweep, key=sweep.get)
+        cores = args.cpu_threads if args.cpu_threads > 0 else min(ncpu, 32)
         torch.set_num_threads(cores)
         os.environ["OMP_NUM_THREADS"] = str(cores)
+        sweep = {cores: cpu_clip()}                               # warm-up
         runs = sorted(cpu_clip() for _ in range(3))
         res["cpu_baseline"] = {"value": T / runs[1], "unit": "frames/s", "cores": cores, "kind": "port",
                                "cpu": cpu_model_name(), "hardware_threads": ncpu,
