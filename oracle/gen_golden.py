@@ -322,11 +322,15 @@ def _ref_loop(case, model, **over):
     def snapshot(tag, tv):
         for k in LOOP_STATE_KEYS:
             if k in tv:
-                dumps[f"{tag}_{k}"] = tv[k].detach().clone().float() if tv[k].dtype == torch.bool else tv[k].detach().clone()
+                if case.get("reduce"):
+                    dumps.update(cases.loop_reduce(tag, k, tv[k]))
+                else:
+                    dumps[f"{tag}_{k}"] = tv[k].detach().clone().float() if tv[k].dtype == torch.bool else tv[k].detach().clone()
 
     def hooked(features, targets=None, **k):
         snapshot(f"clip{len(calls)}_in", targets[0])
         calls.append(int(targets[0]["first_frame_idx"]))
+        print("      clip at frame", calls[-1], flush=True)
         return head(features, targets=targets, **k)
     model = types.SimpleNamespace(backbone=model.backbone, sem_seg_head=hooked)
     x = cases.preprocess(cases.loop_frames(case))
@@ -350,6 +354,47 @@ def g11a_clip_loop_model():
     d = _ref_loop(case, model, stability_score_thresh=0.0)
     print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist())
     save("g11a_clip_loop_model", **d)
+
+
+@gen
+def g20_cfg3_long_video():
+    """BASELINE config 3: the reference's sliding clip loop (inference_video_entity.py:301-404) over a 40-frame 720p video,
+    Swin-T, 100 queries, clips of 5 frames at stride 4 (10 clips), windows of 5 frames; reduced per-clip states."""
+    R = rh.ref()
+    case = cases.CFG3_LOOP
+    model = types.SimpleNamespace(backbone=_ref_swin(R), sem_seg_head=_ref_head(R, case))
+    d = _ref_loop(case, model, stability_score_thresh=0.0, clip_stride=4)
+    print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist())
+    save("g20_cfg3_long_video", **d)
+
+
+@gen
+def g19_cfg5_swinl_1080p():
+    """BASELINE config 5's network (Swin-L window 12 + head, 200 queries) at 1080p on the first TWO frames of the clip
+    through the real reference on CPU: strided samples + checksums, as G12 / G14."""
+    import hashlib
+    R = rh.ref()
+    case = dict(cases.CFG5, T=cases.CFG5_GOLDEN_T)
+    swin = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_L)
+    swin.eval()
+    synth.load_synthetic(swin, prefix="backbone.")
+    head = _ref_head(R, case)
+    x = cases.preprocess(cases.cfg5_frames(case["T"]))
+    feats = swin(x)
+    out = head(feats, targets=cases.targets_first_clip(case))
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k + "_s"] = v[:, ::16, ::4, ::4]
+    pm = out["pred_masks"]
+    d["pred_masks_s"] = pm[0, :, :, ::16, ::16]
+    d["pred_masks_abs_mean"] = pm.double().abs().mean()
+    d["pred_masks_pos_count"] = (pm > 0).sum()
+    d["pred_masks_near_zero_1e-3"] = (pm.abs() < 1e-3).sum()
+    d["pred_masks_sign_sha256"] = np.frombuffer(
+        hashlib.sha256(np.packbits((pm > 0).numpy()).tobytes()).digest(), dtype=np.uint8)
+    d["pred_logits"] = out["pred_logits"]
+    d["pred_embds"] = out["pred_embds"][:, :, :, ::4]
+    save("g19_cfg5_swinl_1080p", **d)
 
 
 @gen

@@ -248,6 +248,21 @@ SWIN_B = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=128, de
 SWINB_CASE = dict(name="swin_b", N=1, H=96, W=160)
 
 
+# Swin-L (configs/univs_inf/vids/vis/univs_swinl_yt21_c1+univs.yaml:5-13) -- BASELINE config 5: T=10 @ 1080p (padded to
+# 1088x1920), 200 queries.  The reference's CPU run of the full clip needs > 100 GB, so the golden (g19) is the same
+# network on the first TWO frames; the T=10 run is checked through size-independent properties on the GPU.
+SWIN_L = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=192, depths=[2, 2, 18, 2],
+              num_heads=[6, 12, 24, 48], window_size=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+              ape=False, patch_norm=True)
+SWINL_SHAPES = {"res2": (192, 4), "res3": (384, 8), "res4": (768, 16), "res5": (1536, 32)}
+CFG5 = dict(name="cfg5", T=10, H=1080, W=1920, Q=200, shapes=SWINL_SHAPES)
+CFG5_GOLDEN_T = 2
+
+
+def cfg5_frames(T):
+    return synth.synthetic_frames(T, CFG5["H"], CFG5["W"], "cfg5/frames")
+
+
 # ---------------------------------------------------------------------------------------------------
 # Clip loop (univs_amd/inference/video_entity.py  <->  univs/inference/inference_video_entity.py)
 # ---------------------------------------------------------------------------------------------------
@@ -257,7 +272,7 @@ LOOP_CASE = dict(name="loop", T=3, H=64, W=96, Q=20, shapes=SWINT_SHAPES, n_fram
 
 def loop_frames(case=LOOP_CASE):
     h, w = case["image_size"]
-    return synth.synthetic_frames(case["n_frames"], h, w, "loop/frames")
+    return synth.synthetic_frames(case["n_frames"], h, w, case.get("frames_name", "loop/frames"))
 
 
 def loop_kwargs(case=LOOP_CASE, **over):
@@ -280,6 +295,30 @@ def loop_targets(case=LOOP_CASE):
 
 def loop_batched_inputs(case=LOOP_CASE):
     return [{"video_len": case["n_frames"], "height": case["image_size"][0], "width": case["image_size"][1]}]
+
+
+# (a') BASELINE config 3: a 40-frame 720p video through the sliding 5-frame clip loop (Swin-T, 100 queries); clip stride 4
+# -> 10 clips with one frame of overlap, window 5.  The per-clip state is far too large to store at this size, so both
+# sides reduce it the same way before comparing (loop_reduce).
+CFG3_LOOP = dict(name="cfg3", T=5, H=736, W=1280, Q=100, shapes=SWINT_SHAPES, n_frames=40, image_size=(720, 1280),
+                 reduce=True, frames_name="cfg3/frames")
+
+
+def loop_reduce(tag, key, v):
+    """Compact form of one state tensor of the clip loop -> {name: tensor}.  Masks become per-(entity, frame) areas,
+    mask logits a 32x32-strided sample of the newest frames plus the count of near-zero logits per (entity, frame) (the
+    slack the area comparison is allowed), the prompt memory a strided sample."""
+    v = v.detach()
+    if key == "masks":
+        return {f"{tag}_masks_area": v.flatten(-2).double().sum(-1).long()}
+    if key == "mask_logits":
+        return {f"{tag}_mask_logits_s": v[:, -5:, ::32, ::32].float().clone(),
+                f"{tag}_mask_logits_near0": (v.abs() < 1e-3).flatten(-2).sum(-1).long()}
+    if key in ("prompt_pe", "prompt_feats"):
+        return {f"{tag}_{key}_s": v[:, ::16, :, ::16].float().clone()}
+    if key == "prompt_attn_masks":
+        return {f"{tag}_prompt_attn_masks_frac": v.float().mean(-1)}
+    return {f"{tag}_{key}": v.float().clone() if v.dtype == torch.bool else v.clone()}
 
 
 # (b) a scripted scene instead of the network: rectangles that move, appear, leave and duplicate each

@@ -94,7 +94,7 @@ def test_config2_full_size_against_reference(cuda, golden_dir):
     err = np.abs(got_s - ref_s).max()
     flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
     print(f"cfg2 pred_masks: max-abs-err {err:.3e}, |ref| max {np.abs(ref_s).max():.2f}, sign flips {flips.sum()}")
-    assert err < 1e-3 * max(1.0, np.abs(ref_s).max() / 10.0), err
+    assert err < 1e-3, err      # the north star's bound, absolute
     assert flips.sum() == 0
     # whole-tensor checks: sign map hash (argmax/>0 identical), positive count, mean |logit|
     pmc = pm.cpu()
@@ -200,13 +200,129 @@ def test_config4_full_size_against_reference(cuda, golden_dir):
     err = np.abs(got_s - ref_s).max()
     flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
     print(f"cfg4 pred_masks: max-abs-err {err:.3e}, |ref| max {np.abs(ref_s).max():.2f}, sign flips {flips.sum()}")
-    assert err < 1e-3 * max(1.0, np.abs(ref_s).max() / 10.0), err
+    # absolute 1e-3 on logits of magnitude up to 18.7: met by the default path (split-bf16 Linear: 7.8e-4; library fp32
+    # GEMMs alone give 1.67e-3 -- profiles/r02_cfg4_error_budget.txt)
+    assert err < 1e-3, err
     assert flips.sum() == 0
     pos = int((pm > 0).sum())
     assert abs(pos - int(g["pred_masks_pos_count"])) <= int(g["pred_masks_near_zero_1e-3"]) + 8
     assert abs(float(pm.double().abs().mean()) - float(g["pred_masks_abs_mean"])) < 1e-4
     assert np.abs(out["pred_logits"].cpu().numpy() - g["pred_logits"]).max() < 3e-3
     assert np.abs(out["pred_embds"][:, :, :, ::4].cpu().numpy() - g["pred_embds"]).max() < 3e-3
+
+
+def test_config5_swinl_1080p_against_reference(cuda, golden_dir):
+    """BASELINE config 5's network (Swin-L window 12 -> window_attn_f32<9>, 200 queries) at 1080p (1088x1920 padded):
+    the first two frames against the reference's own CPU run (g19), absolute 1e-3 on the mask logits."""
+    g = _g(golden_dir, "g19_cfg5_swinl_1080p")
+    case = dict(cases.CFG5, T=cases.CFG5_GOLDEN_T)
+    swin = helpers.build_swin(cuda, variant=cases.SWIN_L)
+    head = helpers.build_head(case, cuda, return_aux=False)
+    x = cases.preprocess(cases.cfg5_frames(case["T"])).to(cuda)
+    assert tuple(x.shape[-2:]) == (1088, 1920)
+    with torch.no_grad():
+        feats = swin(x)
+        out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
+    for k, v in feats.items():
+        err = np.abs(v[:, ::16, ::4, ::4].cpu().numpy() - g["feat_" + k + "_s"]).max()
+        assert err < 3e-3, (k, err)
+    pm = out["pred_masks"]
+    assert tuple(pm.shape) == (1, case["Q"], case["T"], 272, 480)
+    ref_s = g["pred_masks_s"]
+    got_s = pm[0, :, :, ::16, ::16].cpu().numpy()
+    err = np.abs(got_s - ref_s).max()
+    flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
+    print(f"cfg5 (T=2) pred_masks: max-abs-err {err:.3e}, |ref| max {np.abs(ref_s).max():.2f}, sign flips {flips.sum()}")
+    assert err < 1e-3, err
+    assert flips.sum() == 0
+    pos = int((pm > 0).sum())
+    assert abs(pos - int(g["pred_masks_pos_count"])) <= int(g["pred_masks_near_zero_1e-3"]) + 8
+    assert abs(float(pm.double().abs().mean()) - float(g["pred_masks_abs_mean"])) < 1e-4
+    assert np.abs(out["pred_logits"].cpu().numpy() - g["pred_logits"]).max() < 3e-3
+    assert np.abs(out["pred_embds"][:, :, :, ::4].cpu().numpy() - g["pred_embds"]).max() < 3e-3
+
+
+def test_config5_full_clip_properties(cuda):
+    """BASELINE config 5 at FULL size on the GPU (Swin-L, T=10 @ 1080p, 200 queries; the reference's CPU run of this clip
+    needs > 100 GB): size-independent properties of the hot operators on the tensors the model really produces --
+    finite outputs; LDS-tiled MSDA (generations 2 and 3) == generic kernel on every encoder layer's inputs; oracle C on
+    every 37th query of the first layer; full-resolution mask decode == fp64 einsum on a strided subset; the first two
+    frames' features == the T=2 run (frames are independent in the backbone)."""
+    from oracle import c_ops
+    case = cases.CFG5
+    swin = helpers.build_swin(cuda, variant=cases.SWIN_L)
+    head = helpers.build_head(case, cuda, return_aux=False)
+    x = cases.preprocess(cases.cfg5_frames(case["T"])).to(cuda)
+    seen = {"msda": [], "dec": []}
+    orig_msda, orig_dec = ops.ms_deform_attn_forward, ops.mask_decode
+
+    def msda_hook(value, shapes, lsi, loc, attn, step=128):
+        out = orig_msda(value, shapes, lsi, loc, attn, step)
+        assert ops.msda_last_impl() == 2, "the LDS-tiled kernel must cover the 1080p geometry"
+        if len(seen["msda"]) < 2:
+            seen["msda"].append((value, shapes, lsi, loc, attn, out))
+        return out
+
+    def dec_hook(e, f):
+        out = orig_dec(e, f)
+        seen["dec"].append((e, f, out, ops.mask_decode_last_impl()))
+        return out
+    ops.ms_deform_attn_forward, ops.mask_decode = msda_hook, dec_hook
+    try:
+        with torch.no_grad():
+            feats = swin(x)
+            out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
+    finally:
+        ops.ms_deform_attn_forward, ops.mask_decode = orig_msda, orig_dec
+    pm = out["pred_masks"]
+    assert tuple(pm.shape) == (1, 200, 10, 272, 480) and torch.isfinite(pm).all()
+    assert torch.isfinite(out["pred_logits"]).all() and torch.isfinite(out["pred_embds"]).all()
+    # MSDA: S = 34*60 + 68*120 + 136*240 = 42840 tokens per frame
+    value, shapes, lsi, loc, attn, got = seen["msda"][0]
+    assert value.shape[1] == 42840 and value.shape[0] == 10
+    ops.msda_set_impl(1)
+    try:
+        generic = orig_msda(value, shapes, lsi, loc, attn)
+    finally:
+        ops.msda_set_impl(0)
+    assert (got - generic).abs().max().item() < 2e-5
+    os.environ["UNIVS_MSDA_TILED"] = "3"
+    try:
+        g3 = orig_msda(value, shapes, lsi, loc, attn)
+        assert ops.msda_last_tiled_generation() == 3
+    finally:
+        os.environ.pop("UNIVS_MSDA_TILED", None)
+    assert (g3 - generic).abs().max().item() < 2e-5
+    sub = torch.arange(0, loc.shape[1], 37, device=loc.device)
+    ref = c_ops.msda_forward(value[:2].cpu().numpy(), shapes, lsi, loc[:2, sub].contiguous().cpu().numpy(),
+                             attn[:2, sub].contiguous().cpu().numpy())
+    assert np.abs(got[:2, sub].cpu().numpy() - ref).max() < 2e-5
+    # mask decode (the last call is the full-resolution one that feeds pred_masks)
+    e, f, dec, impl = seen["dec"][-1]
+    assert tuple(f.shape) == (10, 256, 272, 480) and impl == 2
+    ref64 = torch.einsum("tqc,tchw->qthw", e.double(), f[:, :, ::17, ::13].double())
+    assert (dec[:, :, ::17, ::13].double() - ref64).abs().max().item() < 1e-4
+    # frames are independent in the backbone: the first two frames equal the T=2 run
+    with torch.no_grad():
+        feats2 = swin(x[:2])
+    for k in feats:
+        assert (feats[k][:2] - feats2[k]).abs().max().item() < 1e-4, k
+
+
+def test_config3_long_video_on_device_matches_reference(cuda, golden_dir):
+    """BASELINE config 3 on one GPU: the 40-frame 720p video through the sliding 5-frame clip loop (10 clips, stride 4,
+    prompt memory pool carried from clip to clip) against the REFERENCE's loop (g20: reduced per-clip states)."""
+    import types
+
+    from tests.test_clip_loop_cpu import compare_reduced_states, run_loop
+    g = _g(golden_dir, "g20_cfg3_long_video")
+    case = cases.CFG3_LOOP
+    model = types.SimpleNamespace(backbone=helpers.build_swin(cuda), sem_seg_head=helpers.build_head(case, cuda))
+    got, results = run_loop(case, model, device=cuda, stability_score_thresh=0.0, clip_stride=4)
+    assert got["clip_first_frames"].tolist() == g["clip_first_frames"].tolist() == list(range(0, 40, 4))
+    worst = compare_reduced_states(got, g, tol=1e-3)
+    print("cfg3 long video: worst abs errors", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+    assert len(results) == 1
 
 
 @pytest.mark.parametrize("name,cfg,tol,stride", [("g16b_text_encoder_small", cases.TEXT_SMALL, 1e-4, 1),
