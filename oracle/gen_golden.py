@@ -359,11 +359,11 @@ def g11a_clip_loop_model():
 @gen
 def g20_cfg3_long_video():
     """BASELINE config 3: the reference's sliding clip loop (inference_video_entity.py:301-404) over a 40-frame 720p video,
-    Swin-T, 100 queries, clips of 5 frames at stride 4 (10 clips), windows of 5 frames; reduced per-clip states."""
+    Swin-T, 100 queries, clips of 5 frames at stride 3 (the only stride besides 1 the reference's memory-pool update accepts at T=5), windows of 5 frames; reduced per-clip states."""
     R = rh.ref()
     case = cases.CFG3_LOOP
     model = types.SimpleNamespace(backbone=_ref_swin(R), sem_seg_head=_ref_head(R, case))
-    d = _ref_loop(case, model, stability_score_thresh=0.0, clip_stride=4)
+    d = _ref_loop(case, model, stability_score_thresh=0.0, clip_stride=3)
     print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist())
     save("g20_cfg3_long_video", **d)
 

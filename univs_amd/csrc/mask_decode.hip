@@ -676,12 +676,18 @@ template <typename Epilogue>
 static int launch_skinny(const float* A, const float* B, int T, int Q, int K, long long N,
                          Epilogue ep, hipStream_t st, const char* what) {
   if (T == 0 || Q == 0 || N == 0) return UNIVS_OK;
-  // rows per block-tile: 128 when Q is large, else the smallest multiple of 32 covering Q
+  // rows per block-tile: 128 when Q is large, else the smallest multiple of 32 covering Q -- unless that leaves most of
+  // the chip idle: the attention-mask maps of the coarse levels (23x40, 46x80) have 4 / 15 column tiles per frame, i.e.
+  // 20 / 75 workgroups at 128 rows per workgroup, each running 512 dependent MFMAs per wave (measured 57-71 us for a 5-20 MB
+  // problem: pure latency).  Fewer rows per workgroup = more workgroups and proportionally shorter MFMA chains; B is
+  // re-read from L2 once per row block, which is noise at these sizes.
+  const long long ctiles = (N + MD_BLOCK_N - 1) / MD_BLOCK_N;
   int MI = (Q + 31) / 32;
   if (MI > 4) MI = 4;
+  while (MI > 1 && ctiles * ((Q + 32 * MI - 1) / (32 * MI)) * T < 192) --MI;
+  if (MI == 3 && (Q + 63) / 64 == (Q + 95) / 96) MI = 2;   // same number of row blocks with less padding
   const int QP = 32 * MI;
   const int qtiles = (Q + QP - 1) / QP;
-  const long long ctiles = (N + MD_BLOCK_N - 1) / MD_BLOCK_N;
   // amortise the A staging and balance the grid: just under one block per CU (256 CUs) when the
   // problem is large enough, one tile per block otherwise
   long long tpb = (ctiles * qtiles * T + 255) / 256;

@@ -107,3 +107,44 @@ class UniVS_Prompt_LongVideo(UniVS_Prompt):
             return self.inference_video_vos.eval(self, batched_inputs)
         raise NotImplementedError("the non-unified trackers (MinVIS / MDQE style association) are not built: set "
                                   "MODEL.UniVS.TEST.VIDEO_UNIFIED_INFERENCE_ENABLE True")
+
+
+@META_ARCH_REGISTRY.register()
+class MaskFormer_Video(nn.Module):
+    """Inference consumer with the call pattern of `mask2former_video/video_maskformer_model.py:203-209` -- the second
+    META_ARCHITECTURE the north star names: normalise + pad the clip's frames, `features = self.backbone(images.tensor)`,
+    `outputs = self.sem_seg_head(features)` (NO targets).  Returns the head's raw outputs for the clip; the vanilla
+    Mask2Former-video post-processing (`inference_video`: top-k over queries x classes, :281-330) and its own
+    transformer decoder are a different model family, outside SURVEY.md 8a."""
+
+    @configurable
+    def __init__(self, *, backbone, sem_seg_head, num_frames, size_divisibility, pixel_mean, pixel_std):
+        super().__init__()
+        self.backbone = backbone
+        self.sem_seg_head = sem_seg_head
+        self.num_frames = num_frames
+        self.size_divisibility = size_divisibility if size_divisibility >= 0 else getattr(backbone, "size_divisibility", 32)
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+
+    @classmethod
+    def from_config(cls, cfg):
+        from ..build import build_backbone, build_sem_seg_head
+        backbone = build_backbone(cfg)
+        return {"backbone": backbone, "sem_seg_head": build_sem_seg_head(cfg, backbone.output_shape()),
+                "num_frames": cfg.INPUT.SAMPLING_FRAME_NUM, "size_divisibility": cfg.MODEL.MASK_FORMER.SIZE_DIVISIBILITY,
+                "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        if self.training:
+            raise NotImplementedError("training (losses, matcher) is out of scope of the inference hot path")
+        from ...inference.video_entity import ImageList
+        frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
+        images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        features = self.backbone(images.tensor)
+        return self.sem_seg_head(features)

@@ -139,6 +139,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         self.semantic_extraction_enable = semantic_extraction_enable
         self.return_aux_outputs = return_aux_outputs
         self.frame_shard = None  # univs_amd.distributed.FrameShard: frames of the clip sharded over ranks
+        self.default_dataset_name = "ytvis_2021_dev"   # class vocabulary when the caller passes no targets (MaskFormer_Video)
         self._clip_norm_cache = None
         self._sa_mask_cache = {}
         with torch.no_grad():  # the reference's init for the two temperatures (:233-236)
@@ -195,6 +196,12 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         src, pos, size_list = [], [], []
         fs = self.frame_shard  # None, or this rank's view of a clip whose frames are sharded over ranks
         t_total = t if fs is None else fs.total(t)
+        if targets is None:
+            # `MaskFormer_Video`'s call, `self.sem_seg_head(features)` (mask2former_video/video_maskformer_model.py:209):
+            # no caller-owned state -> a category-specified first clip (the reference's UniVS decoder dereferences
+            # `targets[0]` unconditionally, :310-333, so this combination raises there)
+            targets = [{"task": "detection", "dataset_name": self.default_dataset_name, "prompt_type": "visual",
+                        "num_frames": t_total, "first_frame_idx": 0, "frame_indices": torch.arange(t_total, device=dev)}]
         if "frame_indices" in targets[0]:
             frame_indices = torch.stack([tv["frame_indices"] for tv in targets]).to(dev)
         else:
