@@ -330,7 +330,7 @@ def _ref_loop(case, model, **over):
     def hooked(features, targets=None, **k):
         snapshot(f"clip{len(calls)}_in", targets[0])
         calls.append(int(targets[0]["first_frame_idx"]))
-        print("      clip at frame", calls[-1], flush=True)
+        print("      clip at frame", calls[-1], file=sys.stderr, flush=True)
         return head(features, targets=targets, **k)
     model = types.SimpleNamespace(backbone=model.backbone, sem_seg_head=hooked)
     x = cases.preprocess(cases.loop_frames(case))
@@ -359,11 +359,12 @@ def g11a_clip_loop_model():
 @gen
 def g20_cfg3_long_video():
     """BASELINE config 3: the reference's sliding clip loop (inference_video_entity.py:301-404) over a 40-frame 720p video,
-    Swin-T, 100 queries, clips of 5 frames at stride 3 (the only stride besides 1 the reference's memory-pool update accepts at T=5), windows of 5 frames; reduced per-clip states."""
+    Swin-T, 100 queries, clips of 5 frames at the reference's default stride 1 (MODEL.UniVS.TEST.CLIP_STRIDE; strides 2, 4 and 5 make the reference's own
+    memory-pool update raise at T=5, stride 3 does on this video from a later clip on), windows of 5 frames; reduced per-clip states."""
     R = rh.ref()
     case = cases.CFG3_LOOP
     model = types.SimpleNamespace(backbone=_ref_swin(R), sem_seg_head=_ref_head(R, case))
-    d = _ref_loop(case, model, stability_score_thresh=0.0, clip_stride=3)
+    d = _ref_loop(case, model, stability_score_thresh=0.0, clip_stride=1)
     print("   clips at", d["clip_first_frames"].tolist(), "entities", d["final_ids"].tolist())
     save("g20_cfg3_long_video", **d)
 

@@ -297,8 +297,8 @@ def loop_batched_inputs(case=LOOP_CASE):
     return [{"video_len": case["n_frames"], "height": case["image_size"][0], "width": case["image_size"][1]}]
 
 
-# (a') BASELINE config 3: a 40-frame 720p video through the sliding 5-frame clip loop (Swin-T, 100 queries); clip stride 3
-# -> 13 clips with two frames of overlap, window 5 (strides 2, 4 and 5 make the reference's own memory-pool update raise at T=5).  The per-clip state is far too large to store at this size, so both
+# (a') BASELINE config 3: a 40-frame 720p video through the sliding 5-frame clip loop (Swin-T, 100 queries); clip stride 1
+# (the reference's default) -> 36 clips, window 5 (other strides make the reference's own memory-pool update raise at T=5).  The per-clip state is far too large to store at this size, so both
 # sides reduce it the same way before comparing (loop_reduce).
 CFG3_LOOP = dict(name="cfg3", T=5, H=736, W=1280, Q=100, shapes=SWINT_SHAPES, n_frames=40, image_size=(720, 1280),
                  reduce=True, frames_name="cfg3/frames")

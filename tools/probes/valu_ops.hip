@@ -58,6 +58,23 @@ PROBE(fmac_sgpr, "v_fmac_f32", "s20, %9")
 PROBE(mul_lit, "v_mul_f32", "0x40400000, %9")
 PROBE(fma_mix, "v_fma_f32", "%8, %9, 1.0")
 
+__global__ void k_mov64_dpp(unsigned long long* out, float* sink, int iters) {   // v_mov_b64_dpp row_newbcast (DPALU form)
+  double a0 = threadIdx.x, a1 = 1., a2 = 2., a3 = 3., x = 1.5 + threadIdx.x;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it)
+    asm volatile("v_mov_b64_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %2, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %2, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %2, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %0, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b64_dpp %2, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %3, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(x));
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = (t1 - t0) * 4;
+  sink[threadIdx.x] = (float)(a0 + a1 + a2 + a3);
+}
 __global__ void k_cmp(unsigned long long* out, float* sink, int iters) {   // v_cmp writing an SGPR pair
   float x = 1.0001f + threadIdx.x, y = 0.5f;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -93,7 +110,7 @@ int main() {
 #define E(N) {#N, k_##N}
       E(fmac), E(fma3), E(mul), E(add), E(sub_abs), E(maxf), E(minf), E(med3f), E(floorf_), E(fract), E(cvt_i32), E(cvt_f32), E(rcp), E(exp), E(mov),
       E(addu), E(lshl_add), E(add3), E(mad24), E(mullo), E(and_), E(maxi), E(med3i), E(cndvcc), E(mov_dpp), E(mov_dpp_qp), E(mul_dpp),
-      E(fmac_sgpr), E(mul_lit), E(fma_mix), E(cmp), E(salu)};
+      E(fmac_sgpr), E(mul_lit), E(fma_mix), E(mov64_dpp), E(cmp), E(salu)};
   const int iters = 200;
   printf("%-12s %s\n", "op", "clk per instr per SIMD  @2 waves/SIMD  @4 waves/SIMD   (1 wave/SIMD: clk per instr per wave)");
   for (auto& k : ks) {

@@ -40,6 +40,7 @@ namespace univs {
 
 typedef float t3v2 __attribute__((ext_vector_type(2)));
 typedef float t3v4 __attribute__((ext_vector_type(4)));
+typedef unsigned t3u2 __attribute__((ext_vector_type(2)));
 #define T3_LDS __attribute__((address_space(3)))
 
 constexpr int T3_NP = 4;          // fill waves: 32 copy octets (8 lanes x 16 B = one pixel-head) as an 8 x 4 grid
@@ -66,6 +67,17 @@ __device__ __forceinline__ int t3_bcast(int v) {
   return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true);
 }
 
+// the same for a register PAIR: one v_mov_b64_dpp (4.7-5.4 clk for two dwords against 2 x 4.2 for two v_mov_b32_dpp;
+// row_newbcast is the one DPP control the 64-bit form accepts)
+template <int K>
+__device__ __forceinline__ long long t3_bcast64(long long v) {
+  // (inline asm: the builtin form materialises an "old" value -- two extra moves per broadcast; the s_nop pads the
+  // VALU-write -> DPP-read hazard hipcc cannot see inside the asm)
+  long long r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
+
 // NP fill waves (waves 0 .. NP-1), NG gather waves, NB record batches per gather wave and step (a batch = 2 row
 // pairs x 4 queries x 4 points); 8 * NB * NG query slots per item.
 // FUSED: the sampling locations and attention weights are not read from memory but made from the raw projections of
@@ -85,8 +97,9 @@ struct T3Inputs {
 
 template <int L, int NP, int NG, int NB, bool FUSED>
 __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* __restrict__ value,
-                                                                   const T3Entry* __restrict__ tab, int ntiles, int ablate,
-                                                                   T3Inputs in, int N, int S, int M,
+                                                                   const T3Entry* __restrict__ tab,
+                                                                   const int* __restrict__ qtab, int qcap, int ntiles,
+                                                                   int ablate, T3Inputs in, int N, int S, int M,
                                                                    float* __restrict__ out, unsigned nitems) {
   const float* __restrict__ loc = in.loc;
   const float* __restrict__ attn = in.attn;
@@ -233,29 +246,15 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 #pragma unroll
     for (int b = 0; b < NB; ++b) qslot[b] = ((gw * NB + b) * 2 + rp) * 4 + (k >> 2);
 
-    // my queries of an item (levels in order, raster inside the level's query box): global query index per batch
+    // my queries of an item: global query index per batch, from the host-built per-tile list (levels in order, raster
+    // inside the level's query box) -- one load instead of ~50 half-rate VALU per query to derive it
     struct Mine { int total; int qg[NB]; };
     auto my_queries = [&](const Item& it, int par) __attribute__((always_inline)) {
       Mine me;
-      int li[NB], qx0[NB], qnx[NB], qy0[NB], Wq[NB], st[NB];
+      me.total = entry(it, par, 0).total;
+      const int* ql = qtab + it.tile * qcap;
 #pragma unroll
-      for (int kk = 0; kk < L; ++kk) {
-        const T3Entry e = entry(it, par, kk);
-        me.total = e.total;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int i = min(qslot[b], e.total - 1);
-          const bool c = kk == 0 || (unsigned)(i - e.qfirst) < (unsigned)e.qcount;   // the levels partition [0, total)
-          li[b] = c ? i - e.qfirst : li[b];
-          qx0[b] = c ? e.qx0 : qx0[b]; qnx[b] = c ? e.qnx : qnx[b]; qy0[b] = c ? e.qy0 : qy0[b];
-          Wq[b] = c ? e.W : Wq[b]; st[b] = c ? e.start : st[b];
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int row = (int)(((float)li[b] + 0.5f) * __builtin_amdgcn_rcpf((float)qnx[b]));
-        me.qg[b] = st[b] + (qy0[b] + row) * Wq[b] + qx0[b] + (li[b] - row * qnx[b]);
-      }
+      for (int b = 0; b < NB; ++b) me.qg[b] = ql[min(qslot[b], me.total - 1)];
       return me;
     };
     // sampling location + attention weight of my (query, point) at every level of an item, in visiting order
@@ -334,11 +333,11 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       Inputs in_nxt;
       load_inputs(nxt, par ^ 1, me_nxt, in_nxt);
 
-      float ax[NB][4], ay[NB][4];
+      t3v2 acc[NB][4];   // (channel 2k, channel 2k + 1) of my corner column, per batch and query
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ax[b][jj] = ay[b][jj] = 0.f;
+        for (int jj = 0; jj < 4; ++jj) acc[b][jj] = (t3v2){0.f, 0.f};
 
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
@@ -358,8 +357,8 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
         }
 
         // ---- B. gathers: 16 samples per row pair and batch.  Per sample and row: one DPP add (address of the top row),
-        // one plain add (bottom row), two DPP moves (weights), four plain FMAs -- on gfx950 every DPP form issues at half
-        // rate, so the broadcasts are not folded into the FMAs (profiles/r02_gfx950_issue_costs.txt)
+        // one plain add (bottom row), ONE 64-bit DPP move (both weights), two packed FMAs -- on gfx950 every DPP form issues
+        // at half rate, so the broadcasts are not folded into the FMAs (profiles/r02_gfx950_issue_costs.txt)
         const int off_t = (int)lds_base + q.reg + (lane & 15) * 8;
         int pitchv = q.pitch * (D * 4);
         asm volatile("" : "+v"(pitchv));   // a VGPR: an SGPR source operand halves the add's rate
@@ -367,18 +366,18 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             if ((gw * NB + b) * 8 < q.total) {   // uniform
+              const long long wpair = __builtin_bit_cast(long long, (t3v2){wT[b], wB[b]});   // (w_top, w_bottom): one 64-bit DPP per sample
 #define T3_IT(K)                                                                                          \
   {                                                                                                       \
     const int a_t = t3_bcast<K>(slot[b]) + off_t;                                                         \
     const int a_b = a_t + pitchv;                                                                         \
     const t3v2 dt = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_t;                               \
     const t3v2 db = *(const T3_LDS t3v2*)(unsigned long long)(unsigned)a_b;                               \
-    const float wt = __int_as_float(t3_bcast<K>(__float_as_int(wT[b])));                                  \
-    const float wb = __int_as_float(t3_bcast<K>(__float_as_int(wB[b])));                                  \
-    ax[b][K >> 2] = __builtin_fmaf(wt, dt.x, ax[b][K >> 2]);                                              \
-    ay[b][K >> 2] = __builtin_fmaf(wt, dt.y, ay[b][K >> 2]);                                              \
-    ax[b][K >> 2] = __builtin_fmaf(wb, db.x, ax[b][K >> 2]);                                              \
-    ay[b][K >> 2] = __builtin_fmaf(wb, db.y, ay[b][K >> 2]);                                              \
+    const t3v2 w = __builtin_bit_cast(t3v2, t3_bcast64<K>(wpair));                                        \
+    /* packed math on the pairs exactly as loaded (left to the SLP vectoriser the FMAs of DIFFERENT samples get */ \
+    /* paired and every pair costs two v_mov to assemble)                                                       */ \
+    acc[b][K >> 2] = __builtin_elementwise_fma((t3v2){w.x, w.x}, dt, acc[b][K >> 2]);                     \
+    acc[b][K >> 2] = __builtin_elementwise_fma((t3v2){w.y, w.y}, db, acc[b][K >> 2]);                     \
   }
               T3_IT(0) T3_IT(1) T3_IT(2) T3_IT(3) T3_IT(4) T3_IT(5) T3_IT(6) T3_IT(7)
               T3_IT(8) T3_IT(9) T3_IT(10) T3_IT(11) T3_IT(12) T3_IT(13) T3_IT(14) T3_IT(15)
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
                 const int jb = (bl & 15) >> 2;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
-                  if (jb == jj) { ax[b][jj] += cx; ay[b][jj] += cy; }
+                  if (jb == jj) acc[b][jj] += (t3v2){cx, cy};
               }
             }
           }
@@ -423,11 +422,13 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
               const int qb = ((gw * NB + b) * 2 + rp) * 4;
 #define T3_OUT(JJ)                                                                                                 \
   {                                                                                                                \
-    const float sx = ax[b][JJ] + __shfl_xor(ax[b][JJ], 16, 64), sy = ay[b][JJ] + __shfl_xor(ay[b][JJ], 16, 64);   \
+    /* rows 2i / 2i+1 hold the two corner columns: swap the odd rows of x with the even rows of y, add -> the even  */ \
+    /* rows hold channel 2k, the odd rows channel 2k+1 of the finished output: 32 lanes = 128 contiguous bytes       */ \
+    const t3u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[b][JJ].x), __float_as_uint(acc[b][JJ].y), false, false); \
+    const float tot = __uint_as_float(sw.x) + __uint_as_float(sw.y);                                               \
     const int qgj = t3_bcast<4 * JJ>(me_cur.qg[b]);                                                                \
-    if (side == 0 && qb + JJ < q.total)                                                                            \
-      *reinterpret_cast<t3v2*>(reinterpret_cast<char*>(out + cur.nm * D) + ((unsigned)(qgj * M * D + ch) * 4u)) =  \
-          (t3v2){sx, sy};                                                                                          \
+    if (qb + JJ < q.total)                                                                                         \
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(out + cur.nm * D) + ((unsigned)(qgj * M * D + ch + side) * 4u)) = tot; \
   }
               T3_OUT(0) T3_OUT(1) T3_OUT(2) T3_OUT(3)
 #undef T3_OUT
@@ -459,6 +460,8 @@ struct T3Key {
 struct T3Geo {
   T3Key key;
   T3Entry* table;   // device
+  int* qtable;      // device: [ntiles][qcap] global query index of the tile's i-th query
+  int qcap;
   int ntiles;
   long long qmax;   // max queries of a tile
   size_t lds;       // bytes of the two window regions
@@ -519,11 +522,18 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
   g->lds = (size_t)(capA + capB) * 128;
   g->qmax = 0;
   std::vector<T3Entry> tab((size_t)g->ntiles * 2 * L);
+  g->qcap = 192;
+  std::vector<int> qtab((size_t)g->ntiles * g->qcap, 0);
   for (int ty = 0; ty < tiles_y; ++ty)
     for (int tx = 0; tx < tiles_x; ++tx) {
       int pre[UNIVS_MAX_LEVELS + 1] = {0};
       for (int l = 0; l < L; ++l) pre[l + 1] = pre[l] + ax[(size_t)l * tiles_x + tx].y * ay[(size_t)l * tiles_y + ty].y;
       g->qmax = std::max<long long>(g->qmax, pre[L]);
+      for (int l = 0; l < L && pre[L] <= g->qcap; ++l) {
+        const int4 gx = ax[(size_t)l * tiles_x + tx], gy = ay[(size_t)l * tiles_y + ty];
+        for (int i = 0; i < gx.y * gy.y; ++i)
+          qtab[(size_t)(ty * tiles_x + tx) * g->qcap + pre[l] + i] = lv.start[l] + (gy.x + i / gx.y) * lv.W[l] + gx.x + i % gx.y;
+      }
       for (int par = 0; par < 2; ++par)
         for (int kk = 0; kk < L; ++kk) {
           const int l = ord[par][kk];
@@ -537,7 +547,9 @@ static const T3Geo* t3_geometry(const LevelTable& lv, int L, int fine, int TH, i
         }
     }
   if (hipMalloc(reinterpret_cast<void**>(&g->table), tab.size() * sizeof(T3Entry)) != hipSuccess ||
-      hipMemcpy(g->table, tab.data(), tab.size() * sizeof(T3Entry), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(g->table, tab.data(), tab.size() * sizeof(T3Entry), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&g->qtable), qtab.size() * sizeof(int)) != hipSuccess ||
+      hipMemcpy(g->qtable, qtab.data(), qtab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipGetLastError();
     delete g;
     return nullptr;
@@ -551,8 +563,8 @@ static void launch_tiled3(unsigned grid, unsigned nitems, hipStream_t st, const 
                           const T3Inputs& in, int N, int S, int M, float* out) {
   auto kfn = msda_fwd_tiled3<L, NP, NG, NB, FUSED>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), g->lds, st, value, g->table, g->ntiles, ablate, in, N, S, M, out,
-                     nitems);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * (NP + NG)), g->lds, st, value, g->table, g->qtable, g->qcap, g->ntiles, ablate,
+                     in, N, S, M, out, nitems);
 }
 
 // returns 1 if launched, 0 if preconditions do not hold (caller tries the next implementation), <0 on error
