@@ -33,8 +33,26 @@
 //     record weights are 0 and a wave-uniform slow path adds them from global memory.
 //
 // LDS holds windows only (two regions).
+#include <type_traits>
+
 #include "msda_geometry.h"
 #include "msda_tiled3_record.h"
+
+#ifdef UNIVS_MSDA_TRACE
+// Debug builds only (tools/msda_trace3.py): s_memtime stamps of the second item of every workgroup.
+// slots 0..14: gather wave 0, per step k: 5k + {0 top, 1 records built, 2 gathers done, 3 at barrier, 4 past barrier};
+// slots 16..27: fill wave 0, per step k: 16 + 4k + {0 top, 1 committed, 2 loads issued, 3 past barrier}
+__device__ unsigned long long g_msda_trace3[4096 * 32];
+#define T3STAMP(cond, i)                                                                                  \
+  do {                                                                                                    \
+    if ((cond) && (threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_msda_trace3[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" __attribute__((visibility("default"))) int univs_msda_trace3_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_msda_trace3), sizeof(unsigned long long) * 32 * n);
+}
+#else
+#define T3STAMP(cond, i)
+#endif
 
 namespace univs {
 
@@ -156,12 +174,22 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     const int lane8 = tid & 7, oct = tid >> 3;
     const int ox = oct & (T3_OX - 1), oy = oct >> 3;
     t3v4 wreg[VY][VX];
-    auto load_window = [&](const Item& it, const T3Entry& q) __attribute__((always_inline)) {
-      if (ablate & 1) return;
+    // One pass over the staged rows does BOTH jobs of a step: row group vy of the window held in registers (`p`, loaded
+    // one step ago) goes to LDS, and the same registers are refilled with row group vy of the next window (`n`).  The LDS
+    // write path (13 clk per ds_write_b128) and the address path of the loads (16 clk per 1-KiB buffer_load_dwordx4) then
+    // run side by side; done one after the other they cost 1.2k + 1.5k clocks per step and made the fill waves the
+    // critical path (profiles/r02_msda_trace_v4.txt).  do_commit / do_load are workgroup-uniform.
+    // Commit and load are UNCONDITIONAL (only the prologue skips the commit, at compile time): behind a runtime condition
+    // -- even a uniform one like "there is a next item" -- hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of
+    // every load and every write and the step's loads return one by one.  After the last item the fill waves therefore
+    // stage one more window of the same tile into the region nobody reads any more.
+    auto commit_and_load = [&](auto do_commit_c, const T3Entry& p, const Item& it, const T3Entry& n)
+                               __attribute__((always_inline)) {
+      constexpr bool do_commit = decltype(do_commit_c)::value;
       // (explicitly scalar: left to itself hipcc keeps this descriptor in VGPRs and wraps every load in a waterfall loop)
-      const unsigned long long pv = (unsigned long long)(value + (it.nm + (long long)q.start * M) * D);
+      const unsigned long long pv = (unsigned long long)(value + (it.nm + (long long)n.start * M) * D);
       const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pv), phi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-      const int nrec = __builtin_amdgcn_readfirstlane((int)(((long long)q.H * q.W - 1) * M * D * 4 + D * 4));
+      const int nrec = __builtin_amdgcn_readfirstlane((int)(((long long)n.H * n.W - 1) * M * D * 4 + D * 4));
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, nrec, 0x00020000);
       const int pstride = M * D * 4;
@@ -170,64 +198,60 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
       unsigned cb[VX];
 #pragma unroll
       for (int vx = 0; vx < VX; ++vx) {
-        const int gx = q.wx0 + ox + vx * T3_OX;
-        cb[vx] = (unsigned)gx < (unsigned)q.W ? (unsigned)(gx * pstride + lane8 * 16) : 0xC0000000u;
+        const int gx = n.wx0 + ox + vx * T3_OX;
+        cb[vx] = (unsigned)gx < (unsigned)n.W ? (unsigned)(gx * pstride + lane8 * 16) : 0xC0000000u;
       }
-      unsigned rowoff = (unsigned)((q.wy0 + oy) * q.W * pstride);
-      unsigned rowstep = (unsigned)(T3_OY * q.W * pstride);
-      asm volatile("" : "+v"(rowstep));   // a VGPR: an SGPR source operand halves the add's rate
-      const int nvx = q.pitch / T3_OX;
+      unsigned rowoff = (unsigned)((n.wy0 + oy) * n.W * pstride);
+      unsigned rowstep = (unsigned)(T3_OY * n.W * pstride);
+      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + p.reg) + ((oy * p.pitch + ox) * 8 + lane8);
+      int winstep = T3_OY * p.pitch * 8;   // in 16-byte units
+      asm volatile("" : "+v"(rowstep), "+v"(winstep));   // VGPRs: an SGPR source operand halves the add's rate
+      const int nvx_p = p.pitch / T3_OX, nvx_n = n.pitch / T3_OX;
+      if (do_commit) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the staged window has arrived (explicit, see msda_tiled.hip)
 #pragma unroll
       for (int vy = 0; vy < VY; ++vy) {
-        if (vy * T3_OY < q.wh) {   // uniform
+        if (do_commit && vy * T3_OY < p.wh) {   // uniform.  No per-lane bound: regions hold whole row groups of whole column
+#pragma unroll                                  // blocks, pad pixels receive garbage nobody reads
+          for (int vx = 0; vx < VX; ++vx)
+            if (vx == 0 || vx < nvx_p) win[vx * T3_OX * 8] = wreg[vy][vx];   // the column block is an immediate offset
+          win += winstep;
+        }
+        if (vy * T3_OY < n.wh) {   // uniform
 #pragma unroll
           for (int vx = 0; vx < VX; ++vx)
-            if (vx == 0 || vx < nvx)   // uniform
+            if (vx == 0 || vx < nvx_n)
               wreg[vy][vx] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cb[vx] + rowoff, 0, 0));
           rowoff += rowstep;
         }
       }
     };
-    auto commit = [&](const T3Entry& q) __attribute__((always_inline)) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): explicit and unconditional, see msda_tiled.hip
-      T3_LDS t3v4* win = (T3_LDS t3v4*)(T3_LDS char*)(lds3 + q.reg) + ((oy * q.pitch + ox) * 8 + lane8);
-      int rowstep = T3_OY * q.pitch * 8;   // in 16-byte units
-      asm volatile("" : "+v"(rowstep));
-      const int nvx = q.pitch / T3_OX;
-#pragma unroll
-      for (int vy = 0; vy < VY; ++vy) {
-        if (vy * T3_OY < q.wh) {   // uniform
-#pragma unroll
-          for (int vx = 0; vx < VX; ++vx)
-            if (vx == 0 || vx < nvx) win[vx * T3_OX * 8] = wreg[vy][vx];   // uniform; the column block is an immediate offset
-          win += rowstep;
-        }
-      }
-    };
 
     Item cur = make_item(widx);
+    T3Entry geo_p = entry(cur, 0, 0);
+    commit_and_load(std::false_type{}, geo_p, cur, geo_p);        // step 0 -> registers
     {
-      const T3Entry g0 = entry(cur, 0, 0);
-      load_window(cur, g0);
-      commit(g0);
+      const T3Entry g1 = entry(cur, 0, 1);
+      commit_and_load(std::true_type{}, geo_p, cur, g1);          // step 0 -> LDS, step 1 -> registers (the step held staged)
+      geo_p = g1;
     }
-    T3Entry geo_p = entry(cur, 0, 1);          // the step held staged in registers
-    load_window(cur, geo_p);
     __syncthreads();   // step 0 is ready for the gather waves
 
     int par = 0;
+    [[maybe_unused]] int itn = 0;
 #pragma unroll 1
-    for (unsigned idx = widx;; idx += nw) {
+    for (unsigned idx = widx;; idx += nw, ++itn) {
       const bool has_next = idx + nw < csize;
       const Item nxt = make_item(has_next ? idx + nw : idx);
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
         // while the gather waves work on step (cur, kk): commit step + 1 (staged) and load step + 2
-        const bool valid1 = (kk + 1 < L) || has_next, valid2 = (kk + 2 < L) || has_next;
+        T3STAMP(itn == 1 && wave == 0 && kk < 3, 16 + 4 * kk);
         const T3Entry geo_n = (kk + 2 < L) ? entry(cur, par, (kk + 2) % L) : entry(nxt, par ^ 1, (kk + 2) % L);
-        if (valid1) commit(geo_p);
-        if (valid2) load_window((kk + 2 < L) ? cur : nxt, geo_n);
+        T3STAMP(itn == 1 && wave == 0 && kk < 3, 16 + 4 * kk + 1);
+        commit_and_load(std::true_type{}, geo_p, (kk + 2 < L) ? cur : nxt, geo_n);
+        T3STAMP(itn == 1 && wave == 0 && kk < 3, 16 + 4 * kk + 2);
         __syncthreads();   // the one barrier of the step
+        T3STAMP(itn == 1 && wave == 0 && kk < 3, 16 + 4 * kk + 3);
         geo_p = geo_n;
       }
       if (!has_next) break;
@@ -323,8 +347,9 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
     __syncthreads();   // step 0's window is staged
 
     int par = 0;
+    [[maybe_unused]] int itn = 0;
 #pragma unroll 1
-    for (unsigned idx = widx;; idx += nw) {
+    for (unsigned idx = widx;; idx += nw, ++itn) {
       const bool has_next = idx + nw < csize;
       const Item nxt = make_item(has_next ? idx + nw : idx);
       // the next item's queries and inputs: issued now, used from the next iteration on (a whole item of cover for the
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
 
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
+        T3STAMP(itn == 1 && gw == 0 && kk < 3, 5 * kk);
         const T3Entry q = entry(cur, par, kk);
         // ---- A. records of this step for my corner column
         int slot[NB];
@@ -356,6 +382,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
           wB[b] = r.wb;
         }
 
+        T3STAMP(itn == 1 && gw == 0 && kk < 3, 5 * kk + 1);
         // ---- B. gathers: 16 samples per row pair and batch.  Per sample and row: one DPP add (address of the top row),
         // one plain add (bottom row), ONE 64-bit DPP move (both weights), two packed FMAs -- on gfx950 every DPP form issues
         // at half rate, so the broadcasts are not folded into the FMAs (profiles/r02_gfx950_issue_costs.txt)
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
             }
           }
         }
+        T3STAMP(itn == 1 && gw == 0 && kk < 3, 5 * kk + 2);
         // rare: corner columns outside the staged window -> straight from global memory (wave-uniform loop)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -435,7 +463,9 @@ __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* _
             }
           }
         }
+        T3STAMP(itn == 1 && gw == 0 && kk < 3, 5 * kk + 3);
         __syncthreads();   // the one barrier of the step
+        T3STAMP(itn == 1 && gw == 0 && kk < 3, 5 * kk + 4);
       }
       if (!has_next) break;
       cur = nxt;
