@@ -314,6 +314,9 @@ def loop_reduce(tag, key, v):
     if key == "mask_logits":
         return {f"{tag}_mask_logits_s": v[:, -5:, ::32, ::32].float().clone(),
                 f"{tag}_mask_logits_near0": (v.abs() < 1e-3).flatten(-2).sum(-1).long()}
+    if key == "logits":     # [N_ent, frames, 3938 classes]: every 16th class + the winner
+        return {f"{tag}_logits_s": v[..., ::16].float().clone(), f"{tag}_logits_max": v.max(-1).values.float(),
+                f"{tag}_logits_argmax": v.argmax(-1).long()}
     if key in ("prompt_pe", "prompt_feats"):
         return {f"{tag}_{key}_s": v[:, ::16, :, ::16].float().clone()}
     if key == "prompt_attn_masks":

@@ -78,6 +78,7 @@ def test_long_video_split_call_and_attributes():
 
 def test_maskformer_video_is_registered_and_calls_the_head_without_targets():
     """video_maskformer_model.py:208-209: `features = self.backbone(images.tensor); outputs = self.sem_seg_head(features)`."""
+    import univs_amd.modeling.meta_arch.univs_prompt  # noqa: F401  (registers the META_ARCH classes, as build_model does)
     from univs_amd.registry import META_ARCH_REGISTRY
     assert "MaskFormer_Video" in META_ARCH_REGISTRY
     from univs_amd.modeling.meta_arch.univs_prompt import MaskFormer_Video
