@@ -27,8 +27,11 @@ def _msda_gpu(value, shapes, lsi, loc, attn, dev, impl, gen=2):
         assert ran == (2 if (impl == 2 and tiled_ok) else 1), f"impl {impl} requested, {ran} ran"
         if impl == 2 and tiled_ok:
             L = loc.shape[3]
-            want = 3 if (gen == 3 and L >= 2) else 2 if (gen >= 2 and L >= 3) else 1
-            assert ops.msda_last_tiled_generation() == want, (gen, ops.msda_last_tiled_generation())
+            want = 4 if gen == 4 else 3 if (gen == 3 and L >= 2) else 2 if (gen >= 2 and L >= 3) else 1
+            ran_gen = ops.msda_last_tiled_generation()
+            # (generation 4 hands over to 3 when four levels of resident windows do not fit the 160 KB of LDS, or when a
+            # tile of an irregular pyramid has more than 128 queries)
+            assert ran_gen == want or (gen == 4 and L >= 2 and ran_gen == 3), (gen, ran_gen)
     finally:
         ops.msda_set_impl(0)
         if old is None:
@@ -56,7 +59,7 @@ def test_g0_kat_float_and_double(cuda, golden_dir):
             assert np.allclose(out, ref, rtol=1e-2, atol=1e-3) and np.abs(out - ref).max() < 1e-8
 
 
-@pytest.mark.parametrize("impl,gen", [(1, 3), (2, 3), (2, 2)], ids=["generic", "tiled3", "tiled2"])
+@pytest.mark.parametrize("impl,gen", [(1, 3), (2, 4), (2, 3), (2, 2)], ids=["generic", "tiled4", "tiled3", "tiled2"])
 @pytest.mark.parametrize("case", cases.MSDA_CASES, ids=lambda c: c["name"])
 def test_msda_matches_oracle_and_golden(cuda, golden_dir, case, impl, gen):
     value, shapes, lsi, loc, attn = cases.msda_inputs(case)
@@ -82,8 +85,9 @@ def test_msda_cfg2_size_tiled_equals_generic_and_properties(cuda):
     o1 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 1)
     o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2)
     assert (o1 - o2).abs().max().item() < 2e-5
-    o2b = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=3)
-    assert (o1 - o2b).abs().max().item() < 2e-5
+    for gen in (3, 4):
+        o2b = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=gen)
+        assert (o1 - o2b).abs().max().item() < 2e-5, gen
     v2 = synth.normal("cfg2/value2", tuple(value.shape))
     o_sum = _msda_gpu(value + 2.0 * v2, shapes, lsi, loc, attn, cuda, 2)
     o_b = _msda_gpu(v2, shapes, lsi, loc, attn, cuda, 2)
@@ -103,7 +107,7 @@ def test_msda_worst_case_uniform_locations(cuda):
     value, shapes, lsi, loc, attn = _cfg2_inputs(N=1, seed="cfg2u")
     loc = synth.uniform("cfg2u/loc", tuple(loc.shape), -0.05, 1.05)
     o1 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 1)
-    for gen in (3, 2):
+    for gen in (4, 3, 2):
         o2 = _msda_gpu(value, shapes, lsi, loc, attn, cuda, 2, gen=gen)
         assert (o1 - o2).abs().max().item() < 2e-5, gen
 
@@ -129,28 +133,30 @@ def _fused_inputs(case):
     return value, shapes, lsi, proj, M * L * P * 2 + pad, ref
 
 
-@pytest.mark.parametrize("variant", [1, 0], ids=["11x2", "8x3"])
+@pytest.mark.parametrize("gen,variant", [(4, 0), (3, 1), (3, 0)], ids=["strips", "11x2", "8x3"])
 @pytest.mark.parametrize("case", [c for c in cases.MSDA_CASES if c["encoder"] and len(c["shapes"]) >= 2 and c["D"] == 32],
                          ids=lambda c: c["name"])
-def test_msda_fused_matches_reference_sequence(cuda, case, variant):
+def test_msda_fused_matches_reference_sequence(cuda, case, gen, variant):
     """Fused MSDeformAttn core (raw projections in, sampled output out) == the reference's sequence softmax /
     reference + offset / normaliser -> ms_deform_attn_forward, evaluated by the oracle, and == our two-operator path."""
     from oracle import cpu_path
     value, shapes, lsi, proj, n_off, ref = _fused_inputs(case)
     M, L, P = value.shape[2], len(shapes), case["P"]
     want = cpu_path.msda_forward_fused(value, proj, n_off, ref, shapes, lsi, P).numpy()
-    old = os.environ.get("UNIVS_MSDA_T3_VARIANT")
+    old = {k: os.environ.get(k) for k in ("UNIVS_MSDA_T3_VARIANT", "UNIVS_MSDA_TILED")}
     os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
+    os.environ["UNIVS_MSDA_TILED"] = str(gen)
     try:
         got = ops.msda_forward_fused(value.to(cuda), proj.to(cuda), n_off, ref.to(cuda), shapes, lsi, P)
-        assert got is not None and ops.msda_last_tiled_generation() == 3
+        assert got is not None and ops.msda_last_tiled_generation() in (gen, 3)
         loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
         two = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
     finally:
-        if old is None:
-            os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
-        else:
-            os.environ["UNIVS_MSDA_T3_VARIANT"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     torch.cuda.synchronize()
     assert np.abs(got.cpu().numpy() - want).max() < 3e-5
     assert (got - two).abs().max().item() < 3e-5

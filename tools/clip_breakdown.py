@@ -1,0 +1,63 @@
+"""Steady-state per-clip kernel breakdown from a rocprofv3 kernel trace of bench.py.
+
+rocprofv3's --stats summary covers the whole process, warm-up included (MIOpen's find pass alone launches seconds of
+naive reference convolutions).  This takes the kernel-trace CSV, uses an anchor kernel launched a fixed number of times
+per clip (the MSDeformAttn forward: 6 encoder layers) to cut the trace into clips, keeps the last `--last` clips and
+prints the time per clip by kernel, plus the GPU-idle time between kernels.
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline
+    python tools/clip_breakdown.py gpurun_out/prof/*/*_kernel_trace.csv --last 8 > profiles/rNN_bench_clip_breakdown.txt
+"""
+import argparse
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name[:110]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv")
+    ap.add_argument("--anchor", default="msda_fwd")
+    ap.add_argument("--per-clip", type=int, default=6)
+    ap.add_argument("--last", type=int, default=8)
+    ap.add_argument("--top", type=int, default=45)
+    args = ap.parse_args()
+    rows = []
+    with open(args.csv) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    anchors = [i for i, r in enumerate(rows) if args.anchor in r[2]]
+    nclips = len(anchors) // args.per_clip
+    if nclips < args.last + 1:
+        sys.exit(f"only {nclips} clips in the trace")
+    # a clip = from the first anchor launch of clip c to the first anchor launch of clip c + 1 (same phase of every clip)
+    first = anchors[(nclips - args.last - 1) * args.per_clip]
+    end = anchors[(nclips - 1) * args.per_clip]
+    seg = rows[first:end]
+    span = (seg[-1][1] - seg[0][0]) / args.last
+    busy = defaultdict(float)
+    calls = defaultdict(int)
+    tot = 0.0
+    for s, e, n in seg:
+        busy[short(n)] += (e - s)
+        calls[short(n)] += 1
+        tot += e - s
+    print(f"# {args.csv}: last {args.last} of {nclips} clips; {len(seg) / args.last:.0f} launches per clip")
+    print(f"# per clip: wall {span / 1e6:.3f} ms, kernels busy {tot / args.last / 1e6:.3f} ms, idle between kernels {(span - tot / args.last) / 1e6:.3f} ms")
+    print(f"# {'ms/clip':>9} {'%busy':>6} {'calls/clip':>10} {'us/call':>9}  kernel")
+    for n, t in sorted(busy.items(), key=lambda kv: -kv[1])[:args.top]:
+        print(f"  {t / args.last / 1e6:9.3f} {100 * t / tot:6.2f} {calls[n] / args.last:10.1f} {t / calls[n] / 1e3:9.1f}  {n}")
+    rest = sorted(busy.items(), key=lambda kv: -kv[1])[args.top:]
+    print(f"  {sum(t for _, t in rest) / args.last / 1e6:9.3f} {100 * sum(t for _, t in rest) / tot:6.2f} {sum(calls[n] for n, _ in rest) / args.last:10.1f} {'':>9}  ({len(rest)} more kernels)")
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ def main():
         res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
         ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
         ops.msda_set_impl(2)
-        for gen, variant in ((3, 0), (3, 1), (2, 0), (1, 0)):
+        for gen, variant in ((4, 0), (3, 0), (3, 1), (2, 0), (1, 0)):
             os.environ["UNIVS_MSDA_TILED"] = str(gen)
             os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
             for abl in ([0, 4, 16] if (gen == 3 and args.ablate) else [0]):
@@ -85,18 +85,20 @@ def main():
         n_off = M_ * L_ * P_ * 2
         t = timeit(lambda: ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_))
         res["msda_prepare"] = dict(ms=t * 1e3)
-        for variant in (1, 0):
+        for gen, variant in ((4, 0), (3, 1), (3, 0)):
             os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
+            os.environ["UNIVS_MSDA_TILED"] = str(gen)
             def pair():
                 l_, a_ = ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_)
                 return ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
             t = timeit(pair)
-            res[f"msda_prepare+tiled3_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+            res[f"msda_prepare+tiled{gen}_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
             t = timeit(lambda: ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_))
             d = (ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_) - pair()).abs()
-            res[f"msda_fused_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+            res[f"msda_fused{gen}_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK, gen=ops.msda_last_tiled_generation(),
                                                  max_abs_diff_vs_pair=d.max().item())
         os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
+        os.environ.pop("UNIVS_MSDA_TILED", None)
     if not args.only or "mask" in args.only:
         Q, C, H, W = 100, 256, 184, 320
         e = synth.normal("kb/e", (T, Q, C)).to(dev)

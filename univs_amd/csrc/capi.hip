@@ -31,6 +31,10 @@ int msda_forward_tiled3_f32(const float*, const LevelTable&, const float*, const
                             int, float*, hipStream_t);
 int msda_forward_fused_tiled3_f32(const float*, const LevelTable&, const float*, int, int, const float*, long long, int, int,
                                   int, int, int, int, int, float*, hipStream_t);
+int msda_forward_tiled4_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
+                            int, float*, hipStream_t);
+int msda_forward_fused_tiled4_f32(const float*, const LevelTable&, const float*, int, int, const float*, long long, int, int,
+                                  int, int, int, int, int, float*, hipStream_t);
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
@@ -170,6 +174,11 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
     const char* e = getenv("UNIVS_MSDA_TILED");
     const int tiled_gen = (e && *e) ? atoi(e) : 2;
     g_msda_gen = 0;
+    rc = tiled_gen >= 4 ? msda_forward_tiled4_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
+    if (rc != 0) {
+      if (rc > 0) { g_msda_last = 2; g_msda_gen = 4; }
+      return rc < 0 ? rc : UNIVS_OK;
+    }
     rc = tiled_gen >= 3 ? msda_forward_tiled3_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
     if (rc != 0) {
       if (rc > 0) { g_msda_last = 2; g_msda_gen = 3; }
@@ -417,6 +426,19 @@ int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shap
   int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_fused_f32");
   if (rc != UNIVS_OK) return rc;
   g_msda_gen = 0;
+  {
+    const char* e = getenv("UNIVS_MSDA_TILED");
+    const int tiled_gen = (e && *e) ? atoi(e) : 2;
+    rc = tiled_gen >= 4 ? msda_forward_fused_tiled4_f32(value, lv, proj, row_stride, n_off, ref_points, ref_batch_stride, N, S,
+                                                        M, D, L, Lq, P, out, static_cast<hipStream_t>(stream))
+                        : 0;
+    if (rc > 0) {
+      g_msda_last = 2;
+      g_msda_gen = 4;
+      return UNIVS_OK;
+    }
+    if (rc < 0) return rc;
+  }
   rc = msda_forward_fused_tiled3_f32(value, lv, proj, row_stride, n_off, ref_points, ref_batch_stride, N, S, M, D, L, Lq, P,
                                      out, static_cast<hipStream_t>(stream));
   if (rc > 0) {

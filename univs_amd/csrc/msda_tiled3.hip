@@ -37,6 +37,7 @@
 
 #include "msda_geometry.h"
 #include "msda_tiled3_record.h"
+#include "msda_tiled3_dev.h"
 
 #ifdef UNIVS_MSDA_TRACE
 // Debug builds only (tools/msda_trace3.py): s_memtime stamps of the second item of every workgroup.
@@ -56,11 +57,6 @@ extern "C" __attribute__((visibility("default"))) int univs_msda_trace3_read(uns
 
 namespace univs {
 
-typedef float t3v2 __attribute__((ext_vector_type(2)));
-typedef float t3v4 __attribute__((ext_vector_type(4)));
-typedef unsigned t3u2 __attribute__((ext_vector_type(2)));
-#define T3_LDS __attribute__((address_space(3)))
-
 constexpr int T3_NP = 4;          // fill waves: 32 copy octets (8 lanes x 16 B = one pixel-head) as an 8 x 4 grid
 constexpr int T3_OX = 8, T3_OY = 4;
 constexpr int T3_PITCH_MAX = 32;  // window width cap (pixels), a multiple of T3_OX
@@ -79,40 +75,8 @@ struct T3Entry {
 };
 static_assert(sizeof(T3Entry) == 64, "one scalar load");
 
-// lane K of my DPP row (row_newbcast); every lane has a source, so there is no "old" value to materialise
-template <int K>
-__device__ __forceinline__ int t3_bcast(int v) {
-  return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true);
-}
-
-// the same for a register PAIR: one v_mov_b64_dpp (4.7-5.4 clk for two dwords against 2 x 4.2 for two v_mov_b32_dpp;
-// row_newbcast is the one DPP control the 64-bit form accepts)
-template <int K>
-__device__ __forceinline__ long long t3_bcast64(long long v) {
-  // (inline asm: the builtin form materialises an "old" value -- two extra moves per broadcast; the s_nop pads the
-  // VALU-write -> DPP-read hazard hipcc cannot see inside the asm)
-  long long r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%c2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
-  return r;
-}
-
 // NP fill waves (waves 0 .. NP-1), NG gather waves, NB record batches per gather wave and step (a batch = 2 row
 // pairs x 4 queries x 4 points); 8 * NB * NG query slots per item.
-// FUSED: the sampling locations and attention weights are not read from memory but made from the raw projections of
-// MSDeformAttn.forward (ms_deform_attn.py:100-113), exactly as csrc/msda_prepare.hip makes them:
-//   loc  = reference_point + offset / (W_l, H_l)            (IEEE division, then the add)
-//   attn = softmax over the L*P logits of (query, head)     (exp(x - max) / sum)
-// `in.loc` / `in.attn` are then unused; `in.proj` [N, Lq, row_stride] holds the offsets in columns [0, M*L*P*2) and the
-// logits in columns [n_off, n_off + M*L*P), `in.ref` [N or 1, Lq, L, 2] the reference points.
-struct T3Inputs {
-  const float* loc;
-  const float* attn;
-  const float* proj;
-  const float* ref;
-  int row_stride, n_off;
-  long long ref_batch_stride;   // 0: one set of reference points for all frames
-};
-
 template <int L, int NP, int NG, int NB, bool FUSED>
 __global__ __launch_bounds__(64 * (NP + NG)) void msda_fwd_tiled3(const float* __restrict__ value,
                                                                    const T3Entry* __restrict__ tab,

@@ -26,9 +26,13 @@ struct T3Record {
   bool miss;
 };
 
-// side_sign / side_one: (-1, 1) for the left column (weight 1 - lw), (+1, 0) for the right column (weight lw)
+// side_sign / side_one: (-1, 1) for the left column (weight 1 - lw), (+1, 0) for the right column (weight lw).
+// WRAP (msda_tiled4.hip): the window is a row-circular buffer of `nr` rows -- window row r lives in LDS row
+// (r + rot) mod nr, and LDS row `nr` duplicates LDS row 0 so that the bottom corner is always one row below the top one.
+template <bool WRAP = false>
 __host__ __device__ inline T3Record t3_record(float x, float y, float aw, int side, float side_sign, float side_one,
-                                              bool qvalid, int H, int W, int wx0, int wy0, int ww, int wh, int pitch) {
+                                              bool qvalid, int H, int W, int wx0, int wy0, int ww, int wh, int pitch,
+                                              int rot = 0, int nr = 0) {
   const float Hf = (float)H, Wf = (float)W;
   const float him = y * Hf - 0.5f, wim = x * Wf - 0.5f;
   const float hf = floorf(him), wf = floorf(wim);
@@ -45,7 +49,14 @@ __host__ __device__ inline T3Record t3_record(float x, float y, float aw, int si
   const bool use = inband && inwin && qvalid;
   T3Record r;
   r.miss = inband && !inwin && qvalid && t != 0.f;
-  r.slot = use ? (r0 * pitch + c0) * 128 : 0;
+  int rl = r0;
+  if (WRAP) {
+    rl = r0 + rot;
+    rl -= rl >= nr ? nr : 0;
+  }
+  // (a record that must not contribute still reads: it points at the window's first pixel, which is always staged --
+  // LDS the strip has not filled yet may hold NaNs, and 0 * NaN is not 0)
+  r.slot = use ? (rl * pitch + c0) * 128 : (WRAP ? rot * pitch * 128 : 0);
   r.wt = use ? wt : 0.f;
   r.wb = use ? wb : 0.f;
   return r;
