@@ -6,7 +6,9 @@ per clip (the MSDeformAttn forward: 6 encoder layers) to cut the trace into clip
 prints the time per clip by kernel, plus the GPU-idle time between kernels.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline
-    python tools/clip_breakdown.py gpurun_out/prof/*/*_kernel_trace.csv --last 8 > profiles/rNN_bench_clip_breakdown.txt
+    python tools/clip_breakdown.py gpurun_out/prof/*/*_kernel_trace.csv --skip 4 --last 8 > profiles/rNN_bench_clip_breakdown.txt
+(--skip 4: the 3 warm-up clips and the first timed one; the clips after the timed loop belong to bench.py's instrumented
+per-operator pass, which synchronises after every operator)
 """
 import argparse
 import csv
@@ -26,7 +28,8 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--anchor", default="msda_fwd")
     ap.add_argument("--per-clip", type=int, default=6)
-    ap.add_argument("--last", type=int, default=8)
+    ap.add_argument("--last", type=int, default=8, help="clips to average over")
+    ap.add_argument("--skip", type=int, default=-1, help="clips to skip from the start (default: take the LAST clips of the trace)")
     ap.add_argument("--top", type=int, default=45)
     args = ap.parse_args()
     rows = []
@@ -39,8 +42,11 @@ def main():
     if nclips < args.last + 1:
         sys.exit(f"only {nclips} clips in the trace")
     # a clip = from the first anchor launch of clip c to the first anchor launch of clip c + 1 (same phase of every clip)
-    first = anchors[(nclips - args.last - 1) * args.per_clip]
-    end = anchors[(nclips - 1) * args.per_clip]
+    c0 = nclips - args.last - 1 if args.skip < 0 else args.skip
+    if c0 + args.last >= nclips:
+        sys.exit(f"clips {c0}..{c0 + args.last} requested, {nclips} in the trace")
+    first = anchors[c0 * args.per_clip]
+    end = anchors[(c0 + args.last) * args.per_clip]
     seg = rows[first:end]
     span = (seg[-1][1] - seg[0][0]) / args.last
     busy = defaultdict(float)
@@ -50,7 +56,7 @@ def main():
         busy[short(n)] += (e - s)
         calls[short(n)] += 1
         tot += e - s
-    print(f"# {args.csv}: last {args.last} of {nclips} clips; {len(seg) / args.last:.0f} launches per clip")
+    print(f"# {args.csv}: clips {c0}..{c0 + args.last - 1} of {nclips}; {len(seg) / args.last:.0f} launches per clip")
     print(f"# per clip: wall {span / 1e6:.3f} ms, kernels busy {tot / args.last / 1e6:.3f} ms, idle between kernels {(span - tot / args.last) / 1e6:.3f} ms")
     print(f"# {'ms/clip':>9} {'%busy':>6} {'calls/clip':>10} {'us/call':>9}  kernel")
     for n, t in sorted(busy.items(), key=lambda kv: -kv[1])[:args.top]:

@@ -167,10 +167,11 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   hipStream_t st = (hipStream_t)stream;
   if (g_msda_impl != 1) {
     // LDS-tiled kernels for the encoder geometry; each returns 0 when its preconditions fail.  Default: the second
-    // generation (msda_tiled2.hip).  UNIVS_MSDA_TILED=3 (read per call: tests and kernel benchmarks flip it) starts at the
-    // third generation (msda_tiled3.hip: register records + DPP gathers, optional fused input preparation) -- on MI355X
-    // it is within 6 % of the second generation, both being bound by the window re-reads that miss L2
-    // (profiles/r02_msda_kbench_v3.txt), so it is not the default yet; =1 selects the first generation.
+    // generation (msda_tiled2.hip).  UNIVS_MSDA_TILED (read per call: tests and kernel benchmarks flip it) starts at a later
+    // one: 3 = register records + DPP gathers (msda_tiled3.hip), 4 = strips with resident windows, a lane owns a sample
+    // (msda_tiled4.hip); both also take the raw projections (fused input preparation).  On MI355X all three are within 6 %
+    // of each other at the bench geometry (profiles/r02_msda_trace_v5.txt), so the default has not moved; =1 selects the
+    // first generation.
     const char* e = getenv("UNIVS_MSDA_TILED");
     const int tiled_gen = (e && *e) ? atoi(e) : 2;
     g_msda_gen = 0;
