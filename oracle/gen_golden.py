@@ -203,6 +203,68 @@ def g6_head_first_clip():
 
 
 @gen
+def g4_g5_teacher_forced():
+    """per-call fixtures from INSIDE the reference decoder (first clip of HEAD_CASE),
+    captured with module hooks while the unmodified reference runs:
+      G4  forward_prediction_heads (...decoder_univs.py:498-567): inputs (query states, mask features, target size) and
+          outputs (class logits, mask logits, bool attention mask of head 0 -- the reference repeats it over the heads) of
+          the first call (learnable queries only) and of the call after layer 3;
+      G5  decoder layer 4 teacher-forced (:383-432): query states before the layer, query embedding, the level's memory /
+          position tensors, the attention mask actually used (after the all-True-row reset of :390), the self-attention
+          mask; and the query states after the FFN.
+    The mask threshold (sigmoid < 0.5) makes the end-to-end head discontinuous; these pin the pieces around it."""
+    R = rh.ref()
+    head = _ref_head(R, cases.HEAD_CASE)
+    dec = head.predictor
+    d = {}
+    calls = {"n": 0}
+    orig_heads = dec.forward_prediction_heads
+
+    def heads_hook(output, mask_features, attn_mask_target_size, task, targets):
+        res = orig_heads(output, mask_features, attn_mask_target_size=attn_mask_target_size, task=task, targets=targets)
+        k = calls["n"]
+        calls["n"] += 1
+        if k in (0, 4):
+            tag = f"g4_call{k}_"
+            nh = dec.num_heads
+            d[tag + "output"] = output.detach().clone()
+            d[tag + "target_size"] = torch.tensor(list(attn_mask_target_size))
+            d[tag + "outputs_class"] = res[0].detach().clone()
+            d[tag + "outputs_mask"] = res[1].detach().clone()
+            d[tag + "attn_mask_head0"] = res[2].detach()[0::nh].clone()      # [(b t) h, q, hw] -> head 0 of every frame
+            if k == 0:
+                d["g4_mask_features"] = mask_features.detach().clone()
+        return res
+
+    dec.forward_prediction_heads = heads_hook
+    LAYER = 4
+    nh = dec.num_heads
+
+    def cross_pre(mod, args, kwargs):
+        d["g5_output_in"] = args[0].detach().clone()
+        d["g5_src"] = args[1].detach().clone()
+        d["g5_attn_mask_head0"] = kwargs["memory_mask"].detach()[0::nh].clone()
+        d["g5_pos"] = kwargs["pos"].detach().clone()
+        d["g5_query_embed"] = kwargs["query_pos"].detach().clone()
+
+    def self_pre(mod, args, kwargs):
+        m = kwargs.get("tgt_mask")
+        d["g5_self_attn_mask"] = m.detach().clone() if m is not None else torch.zeros(0)
+
+    def ffn_post(mod, args, out):
+        d["g5_output_out"] = out.detach().clone()
+
+    h1 = dec.transformer_cross_attention_layers[LAYER].register_forward_pre_hook(cross_pre, with_kwargs=True)
+    h2 = dec.transformer_self_attention_layers[LAYER].register_forward_pre_hook(self_pre, with_kwargs=True)
+    h3 = dec.transformer_ffn_layers[LAYER].register_forward_hook(ffn_post)
+    head(cases.backbone_features(), targets=cases.targets_first_clip())
+    for h in (h1, h2, h3):
+        h.remove()
+    d["g5_layer"] = torch.tensor(LAYER)
+    save("g4_g5_teacher_forced", **d)
+
+
+@gen
 def g7_head_visual_prompts():
     """Second clip with visual prompts: creates the memory pool.  torch.manual_seed(0) right before the
     call fixes the sampler's randperm draws (prompt_encoder.py:420,424,481)."""

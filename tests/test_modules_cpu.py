@@ -98,6 +98,16 @@ def test_head_matches_reference(golden_dir, name, dec_over, targets_fn, seed):
             assert np.abs(targets[0][k].numpy() - g["clip3_pool_" + k]).max() < 1e-4, k
 
 
+def test_g4_g5_prediction_heads_and_teacher_forced_layer(golden_dir):
+    """the prediction heads (class logits, mask logits, bool attention mask incl. the
+    all-True-row reset) and one decoder layer with every input supplied, against tensors captured inside the reference."""
+    from oracle import cpu_path
+    g = _g(golden_dir, "g4_g5_teacher_forced")
+    head = helpers.build_head(cases.HEAD_CASE)
+    with cpu_ops(), torch.no_grad():
+        helpers.check_g4_g5(head, g, "cpu", cpu_path)
+
+
 def test_config1_resnet50_plumbing_cpu():
     """BASELINE config 1: ResNet-50 UniVS, 1 clip x T=2 frames @ 256x448, 20 queries, CPU path (plumbing).
     ResNet parity is unpinned (detectron2 source is not in the reference tree): shapes, strides and the

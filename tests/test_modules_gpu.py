@@ -74,6 +74,16 @@ def test_head_matches_reference(cuda, golden_dir, name, dec_over, targets_fn, se
         helpers.check_head_outputs(out3, g, "clip3_", tol=1e-3)
 
 
+def test_g4_g5_prediction_heads_and_teacher_forced_layer(cuda, golden_dir):
+    """SURVEY.md Appendix B G4 / G5 through the HIP operators: prediction heads (mask decode + fused attention mask) and
+    one teacher-forced decoder layer against tensors captured inside the reference decoder."""
+    from univs_amd import ops
+    g = _g(golden_dir, "g4_g5_teacher_forced")
+    head = helpers.build_head(cases.HEAD_CASE, cuda)
+    with torch.no_grad():
+        helpers.check_g4_g5(head, g, cuda, ops)
+
+
 def test_config2_full_size_against_reference(cuda, golden_dir):
     """BASELINE config 2 (Swin-T, T=5 @ 720p -> 736x1280, 100 queries, first clip): every stage against
     strided samples / checksums of the reference's own CPU run (g12)."""

@@ -143,6 +143,24 @@ def main():
         t = timeit(lambda: ops.window_attention(qkv, bias, mask, nW, hd ** -0.5))
         byts = (qkv.numel() + qkv.numel() / 3) * 4.0
         res["window_attn_stage1"] = dict(ms=t * 1e3, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+        # image mode (what the backbone calls), the four Swin-T stages at 720p, plain and shifted windows
+        for (H_, W_, nh) in ((184, 320, 3), (92, 160, 6), (46, 80, 12), (23, 40, 24)):
+            ws = 7
+            q = synth.normal(f"kb/qkvi/{H_}", (T, H_ * W_, 3, nh, hd)).to(dev)
+            qb = synth.normal(f"kb/qb/{nh}", (3 * nh * hd,)).to(dev)
+            bi = synth.normal(f"kb/biasi/{nh}", (nh, ntok, ntok)).to(dev)
+            nWi = ((H_ + ws - 1) // ws) * ((W_ + ws - 1) // ws)
+            mk = torch.zeros(nWi, ntok, ntok, device=dev)
+            byts = (q.numel() + q.numel() / 3) * 4.0
+            for shift in (0, 3):
+                for v1 in ("0", "1"):
+                    os.environ["UNIVS_WINATTN_V1"] = v1
+                    try:
+                        t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5))
+                    finally:
+                        os.environ.pop("UNIVS_WINATTN_V1", None)
+                    res[f"window_attn_image_{H_}x{W_}_shift{shift}" + ("_v1" if v1 == "1" else "")] = dict(
+                        ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
     if not args.only or "resample" in args.only:
         f = synth.normal("kb/f", (T, 256, 184, 320)).to(dev)
         for (h, w) in ((92, 160), (46, 80), (23, 40)):
