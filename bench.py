@@ -385,7 +385,7 @@ def main():
             stages[f"{Hs}x{Ws}x{nH}h"] = {"avg_launch_us": s_ * 1e6, "launches_per_step": n_ // PROF_STEPS,
                                           "algorithmic_bytes_per_launch": byts, "achieved_GBps": byts / s_ / 1e9,
                                           "frac": byts / s_ / HBM_PEAK}
-        res["roofline_window_attn"] = {"kernel": "window_attn_f32<4,true> (Swin window attention in image order, f32 MFMA 16x16x4)",
+        res["roofline_window_attn"] = {"kernel": "window_attn_img7_f32 (Swin window attention in image order, 7x7 windows: persistent per head, bias table in LDS, f32 MFMA 16x16x4)",
                                        "bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "per_stage": stages,
                                        "ms_per_clip": t_win.total_seconds() / PROF_STEPS * 1e3}
 

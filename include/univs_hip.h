@@ -123,10 +123,19 @@ int univs_msda_last_tiled_generation(void);
  * token projections of MSDeformAttn use it (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113:
  * value_proj, sampling_offsets + attention_weights, output_proj).  fp32 emulated on the bf16 matrix cores from an exact
  * 3-way split of both operands (error <= 3 * 2^-24 per product, i.e. fp32 rounding level).
- * Covered: K % 128 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31; anything else returns
- * UNIVS_ERR_NOT_IMPLEMENTED without touching y (the caller keeps its library GEMM).  bias may be NULL. */
+ * Covered: K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31, at
+ * least 16 output features of K fit the LDS (K <= 1664); anything else returns UNIVS_ERR_NOT_IMPLEMENTED without touching
+ * y (the caller keeps its library GEMM).  bias may be NULL. */
 int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                            int relu, float* y, void* stream);
+
+/* The same Linear with a fused epilogue, for the Swin block's MLP (mask2former/modeling/backbone/swin.py:35-58 Mlp.forward:
+ * fc1 -> nn.GELU() -> fc2, and :291-293 `x = shortcut + self.mlp(...)`) and its qkv / proj projections (:137-141, :163):
+ *   act = 0: none, 1: ReLU, 2: exact GELU  x * 0.5 * (1 + erf(x / sqrt 2))  (nn.GELU(approximate='none'));
+ *   residual (NULL or [M, N], contiguous): y = x W^T + bias + residual.  act != 0 together with a residual is rejected.
+ * Same coverage rules and return codes as univs_linear_split_f32. */
+int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
+                           int K, int act, float* y, void* stream);
 
 /* Selects the mask-decode contraction kernel (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel

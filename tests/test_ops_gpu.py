@@ -527,12 +527,44 @@ def test_linear_split_matches_torch(cuda, M, K, N, relu, bias):
     assert torch.equal(y2, 2.0 * y1)
 
 
+@pytest.mark.parametrize("M,K,N,act,res", [(58880, 96, 288, None, False), (58880, 96, 384, "gelu", False), (14720, 384, 96, None, True),
+                                            (14720, 192, 576, None, False), (14720, 192, 768, "gelu", False), (3680, 768, 192, None, True),
+                                            (3680, 384, 1536, "gelu", False), (4099, 96, 100, "relu", False), (2500, 768, 2304, None, False)],
+                         ids=lambda v: str(v))
+def test_linear_fused_matches_torch(cuda, M, K, N, act, res):
+    """ops.linear_fused at the Swin-T widths (K = 96 / 192: register ring of three k-steps; 384 / 768: ring of four) with
+    the fused epilogues (exact GELU, residual add) == F.linear + F.gelu / + residual to fp32 rounding."""
+    F = torch.nn.functional
+    x = synth.normal(f"lf/x/{M}x{K}", (M, K), std=1.0)
+    w = synth.normal(f"lf/w/{N}x{K}", (N, K), std=K ** -0.5)
+    b = synth.normal(f"lf/b/{N}", (N,), std=0.5)
+    r = synth.normal(f"lf/r/{M}x{N}", (M, N), std=1.0) if res else None
+    xd, wd, bd, rd = x.to(cuda), w.to(cuda), b.to(cuda), (r.to(cuda) if res else None)
+    y = ops.linear_fused(xd, wd, bd, act=act, residual=rd)
+    assert y is not None and tuple(y.shape) == (M, N)
+    ref64 = F.linear(xd.double(), wd.double(), bd.double())
+    ref32 = F.linear(xd, wd, bd)
+    if act == "gelu":
+        ref64, ref32 = F.gelu(ref64), F.gelu(ref32)
+    if act == "relu":
+        ref64, ref32 = ref64.relu(), ref32.relu()
+    if res:
+        ref64, ref32 = ref64 + rd.double(), ref32 + rd
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+    with pytest.raises(RuntimeError):
+        ops.linear_fused(xd, wd, bd, act="tanh")
+    assert ops.linear_fused(xd, wd, bd, act="gelu", residual=torch.zeros(M, N, device=cuda)) is None   # not both
+
+
 def test_linear_split_uncovered_shapes_return_none(cuda):
-    x = torch.zeros(4096, 96, device=cuda)
-    assert ops.linear_split(x, torch.zeros(96, 96, device=cuda)) is None                      # K % 128
+    x = torch.zeros(4096, 80, device=cuda)
+    assert ops.linear_split(x, torch.zeros(96, 80, device=cuda)) is None                      # K % 96 and K % 128
+    assert ops.linear_split(torch.zeros(4096, 1024, device=cuda), torch.zeros(8, 1024, device=cuda)) is None   # K > 768
     assert ops.linear_split(torch.zeros(4096, 256, device=cuda), torch.zeros(6, 256, device=cuda)) is None     # N % 4
     assert ops.linear_split(torch.zeros(100, 256, device=cuda), torch.zeros(8, 256, device=cuda)) is None      # few rows
     assert ops.linear_split(torch.zeros(4096, 256), torch.zeros(8, 256)) is None                               # CPU tensors
     from univs_amd import layers
-    y = layers.linear(x, torch.ones(96, 96, device=cuda), None)                                # falls through to ATen
+    y = layers.linear(x, torch.ones(96, 80, device=cuda), None)                                # falls through to ATen
     assert tuple(y.shape) == (4096, 96)

@@ -134,6 +134,31 @@ def main():
             else:
                 t = timeit(lambda: torch.nn.functional.linear(xs, w_, b_))
             res[f"linear_aten_{N_}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12)
+    if args.only and "swinlin" in args.only:
+        # the Swin-T linears at 720p x 5 frames through the library GEMM: time against the HBM floor and the fp32 MFMA peak
+        for stage, (tok, C) in enumerate(((184 * 320, 96), (92 * 160, 192), (46 * 80, 384), (23 * 40, 768)), 1):
+            Mr = T * tok
+            for nm, K_, N_ in (("qkv", C, 3 * C), ("proj", C, C), ("fc1", C, 4 * C), ("fc2", 4 * C, C)):
+                xs = synth.normal(f"kb/sw/x{K_}/{Mr}", (Mr, K_)).to(dev)
+                w_ = synth.normal(f"kb/sw/w{K_}x{N_}", (N_, K_), std=1 / 16).to(dev)
+                b_ = synth.normal(f"kb/sw/b{N_}", (N_,)).to(dev)
+                t = timeit(lambda: torch.nn.functional.linear(xs, w_, b_))
+                byts = 4.0 * (Mr * K_ + Mr * N_ + N_ * K_)
+                fl = 2.0 * Mr * K_ * N_
+                res[f"swin_s{stage}_{nm}_{K_}x{N_}"] = dict(us=t * 1e6, TFLOPs=fl / t / 1e12, GBps=byts / t / 1e9,
+                                                           hbm_floor_us=byts / HBM_PEAK * 1e6, frac_hbm=byts / t / HBM_PEAK)
+                act = "gelu" if nm == "fc1" else None
+                rs = torch.zeros(Mr, N_, device=dev) if nm == "fc2" else None
+                y = ops.linear_fused(xs, w_, b_, act=act, residual=rs)
+                if y is not None:
+                    t2 = timeit(lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs))
+                    res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["fused_us"] = t2 * 1e6
+                    if act:
+                        t3 = timeit(lambda: torch.nn.functional.gelu(torch.nn.functional.linear(xs, w_, b_)))
+                        res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["library_plus_gelu_us"] = t3 * 1e6
+                    if rs is not None:
+                        t3 = timeit(lambda: rs + torch.nn.functional.linear(xs, w_, b_))
+                        res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["library_plus_add_us"] = t3 * 1e6
     if not args.only or "win" in args.only:
         # Swin-T stage 1 at 720p: 27x46 windows of 49 tokens, 3 heads, per frame
         nW, nH, ntok, hd = 27 * 46, 3, 49, 32

@@ -39,7 +39,7 @@ int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const 
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
 void mask_decode_set_impl(int);
-int linear_split_f32(const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t);
+int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t);
 int mask_decode_last_impl();
 int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
                          hipStream_t);
@@ -114,25 +114,32 @@ int univs_msda_set_impl(int impl) {
 int univs_msda_last_impl(void) { return g_msda_last; }
 int univs_msda_last_tiled_generation(void) { return g_msda_gen; }
 
-int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
-                           int relu, float* y, void* stream) {
+int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
+                           int K, int act, float* y, void* stream) {
   clear_sticky_error();
-  if (M < 0 || N < 0 || K < 1) {
-    set_error("univs_linear_split_f32: bad dimensions M=%lld N=%d K=%d", M, N, K);
+  if (M < 0 || N < 0 || K < 1 || act < 0 || act > 2 || (act != 0 && residual)) {
+    set_error("univs_linear_fused_f32: bad arguments M=%lld N=%d K=%d act=%d%s", M, N, K, act,
+              (act != 0 && residual) ? " (an activation and a residual exclude each other)" : "");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (M == 0 || N == 0) return UNIVS_OK;
   if (!x || !weight || !y) {
-    set_error("univs_linear_split_f32: NULL data pointer");
+    set_error("univs_linear_fused_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::linear_split_f32(x, weight, bias, y, M, N, K, relu, static_cast<hipStream_t>(stream));
+  const int epi = residual ? 3 : act;
+  const int rc = univs::linear_split_f32(x, weight, bias, residual, y, M, N, K, epi, static_cast<hipStream_t>(stream));
   if (rc == 1) return UNIVS_OK;
   if (rc == 0) {
-    set_error("univs_linear_split_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
+    set_error("univs_linear_fused_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
     return UNIVS_ERR_NOT_IMPLEMENTED;
   }
   return rc;
+}
+
+int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
+                           int relu, float* y, void* stream) {
+  return univs_linear_fused_f32(x, weight, bias, nullptr, M, N, K, relu ? 1 : 0, y, stream);
 }
 
 int univs_mask_decode_set_impl(int impl) {

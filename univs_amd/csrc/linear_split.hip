@@ -13,7 +13,10 @@
 //   * x is streamed: a wave tile is 32 rows; lane (j, g) of MFMA column tile c holds row 32 * tile + 16 c + j, k = 32 ks +
 //     8 g .. + 7 -- 32 contiguous bytes, two 16-byte loads; four register stages (three k-steps in flight);
 //   * D[i = feature][j = row]: a lane ends up with four consecutive features of one row -> one 16-byte store; the bias is
-//     the accumulators' initial value; optional ReLU in the store.
+//     the accumulators' initial value; the epilogue optionally applies ReLU, exact (erf) GELU, or adds a residual tensor
+//     of the output's shape -- the Swin block's fc1 -> GELU and shortcut + fc2 (swin.py:35-58, :291-293) without the
+//     separate elementwise passes.
+// K is a multiple of 128 (register ring of 4 k-steps) or of 96 (ring of 3: the Swin-T stage widths 96 and 192).
 // Everything about pinning the ring (sched_barrier, the opaque split mask, straight-line tile body, unconditional buffer
 // stores) is explained in mask_decode.hip / DESIGN.md "Toolchain hazards".
 #include "common.h"
@@ -31,8 +34,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int LS_THREADS = 512;   // 8 waves, two per SIMD
 constexpr int LS_TILE_M = 32;     // rows of x per wave tile (two 16-column MFMA tiles)
-constexpr int LS_RING = 4;
 constexpr int LS_MAX_RB = 7;
+enum { LS_EPI_NONE = 0, LS_EPI_RELU = 1, LS_EPI_GELU = 2, LS_EPI_RESIDUAL = 3 };
 
 // two fp32 bit patterns whose low halves are zero -> their bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned ls_pack(unsigned lo, unsigned hi) { return (lo >> 16) | hi; }
@@ -57,10 +60,12 @@ __device__ __forceinline__ void ls_split8(f32x4 v0, f32x4 v1, unsigned hi_mask, 
   l = __builtin_bit_cast(bf16x8, lp);
 }
 
-template <int RB, int KSC, bool RELU>   // KSC = K / 32 (8 for K = 256: straight-line tile body), 0 = runtime
+// KSC = K / 32 (8 for K = 256: straight-line tile body), 0 = runtime; LS_RING = register stages of x (K / 32 is a multiple)
+template <int RB, int KSC, int LS_RING, int EPI>
 __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __restrict__ X,      // [M, K]
                                                                 const float* __restrict__ W,      // [N, K]
                                                                 const float* __restrict__ bias,   // [N] or null
+                                                                const float* __restrict__ Res,    // [M, N] (EPI == RESIDUAL)
                                                                 float* __restrict__ Y,            // [M, N]
                                                                 int M, int N, int K, int rows_per_pass) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wsp[];   // [K/32][4 k-groups][R features][3 parts] | bias[R]
@@ -130,6 +135,8 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
   for (int rb = 0; rb < RB; ++rb) acc[rb][0] = acc[rb][1] = binit[rb];
 
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * N * 4), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == LS_EPI_RESIDUAL ? Res : X), 0, (int)((long long)M * N * 4), 0x00020000);
   auto epilogue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -138,9 +145,15 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
       for (int rb = 0; rb < RB; ++rb) {
         const int f = rb * 16 + 4 * g;
         f32x4 v = acc[rb][c];
-        if (RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
         const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (m < M && f < R) ? off : 0xFFFFFFF0u, 0, 0);
+        const unsigned offc = (m < M && f < R) ? off : 0xFFFFFFF0u;   // out of range: loads return 0, stores are dropped
+        if (EPI == LS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (EPI == LS_EPI_GELU) {   // x * 0.5 * (1 + erf(x / sqrt 2)): nn.GELU() (approximate = 'none')
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (EPI == LS_EPI_RESIDUAL) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
       }
     }
 #pragma unroll
@@ -209,12 +222,15 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
 }
 
 // returns 1 if launched, 0 if the shape is not covered (the caller uses the library GEMM), < 0 on error
-int linear_split_f32(const float* x, const float* w, const float* bias, float* y, long long M, int N, int K, int relu,
-                     hipStream_t st) {
+int linear_split_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
+                     int K, int epi, hipStream_t st) {
   if (M <= 0 || N <= 0) return 1;
-  if (K < 128 || K % (32 * LS_RING) != 0 || N % 4 != 0) return 0;
+  if (epi < 0 || epi > LS_EPI_RESIDUAL || (epi == LS_EPI_RESIDUAL) != (residual != nullptr)) return 0;
+  const int ring = K % 128 == 0 ? 4 : K % 96 == 0 ? 3 : 0;
+  if (K < 96 || ring == 0 || N % 4 != 0) return 0;
   if (M * (long long)N * 4 >= 0x7FFFFFFFLL || M * (long long)K * 4 >= 0x7FFFFFFFLL) return 0;
-  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (reinterpret_cast<uintptr_t>(residual) & 15))
     return 0;
   const long long lds_cap = 160 * 1024 - 512;
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);
@@ -243,19 +259,24 @@ int linear_split_f32(const float* x, const float* w, const float* bias, float* y
   if (gx >= 8) gx -= gx % 8;
   const size_t lds = (size_t)K * rows * 6 + 512;
   dim3 grid((unsigned)gx, (unsigned)passes), block(LS_THREADS);
-#define UNIVS_LS(rb, ksc, rl)                                                                                     \
-  do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16x6<rb, ksc, rl>),                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-    hipLaunchKernelGGL((linear_bf16x6<rb, ksc, rl>), grid, block, lds, st, x, w, bias, y, (int)M, N, K, rows);    \
+#define UNIVS_LS(rb, ksc, rg, ep)                                                                                        \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16x6<rb, ksc, rg, ep>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    hipLaunchKernelGGL((linear_bf16x6<rb, ksc, rg, ep>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K, rows); \
   } while (0)
-#define UNIVS_LS_RB(rb)                                              \
-  case rb:                                                           \
-    if (K == 256) {                                                  \
-      if (relu) UNIVS_LS(rb, 8, true); else UNIVS_LS(rb, 8, false);  \
-    } else {                                                         \
-      if (relu) UNIVS_LS(rb, 0, true); else UNIVS_LS(rb, 0, false);  \
-    }                                                                \
+#define UNIVS_LS_EPI(rb, ksc, rg)                                   \
+  switch (epi) {                                                    \
+    case LS_EPI_RELU: UNIVS_LS(rb, ksc, rg, LS_EPI_RELU); break;    \
+    case LS_EPI_GELU: UNIVS_LS(rb, ksc, rg, LS_EPI_GELU); break;    \
+    case LS_EPI_RESIDUAL: UNIVS_LS(rb, ksc, rg, LS_EPI_RESIDUAL); break; \
+    default: UNIVS_LS(rb, ksc, rg, LS_EPI_NONE); break;             \
+  }
+#define UNIVS_LS_RB(rb)                          \
+  case rb:                                       \
+    if (K == 256) { UNIVS_LS_EPI(rb, 8, 4) }     \
+    else if (ring == 4) { UNIVS_LS_EPI(rb, 0, 4) } \
+    else { UNIVS_LS_EPI(rb, 0, 3) }              \
     break
   switch (RB) {
     UNIVS_LS_RB(1);
@@ -267,6 +288,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, float* y
     default: UNIVS_LS_RB(7);
   }
 #undef UNIVS_LS_RB
+#undef UNIVS_LS_EPI
 #undef UNIVS_LS
   const int rc = check_launch("linear_split_f32");
   return rc == UNIVS_OK ? 1 : rc;

@@ -12,6 +12,8 @@ Interface and state-dict layout follow the reference's `D2SwinTransformer`
     (swin.py:148-155, :413-440);
   * inference only: DropPath / dropout are identities and are not instantiated.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -26,6 +28,15 @@ def _to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
 
+# UNIVS_SWIN_FUSED_LINEAR=0: the Swin Linears stay on the library GEMM (qkv, proj, fc1 + GELU, fc2 + shortcut)
+_FUSED_LINEAR = os.environ.get("UNIVS_SWIN_FUSED_LINEAR", "1") != "0"
+
+
+def _linear(mod, x):
+    y = ops.linear_fused(x, mod.weight, mod.bias) if (_FUSED_LINEAR and x.is_cuda) else None
+    return y if y is not None else mod(x)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None):
         super().__init__()
@@ -35,8 +46,19 @@ class Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = nn.Linear(hidden_features, out_features)
 
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x, residual=None):
+        """fc2(GELU(fc1(x))) (+ residual) (swin.py:35-58; the block's `shortcut + mlp(...)` of :291-293 rides in fc2's
+        epilogue).  On the GPU both Linears take the split-bf16 kernel with the GELU / the residual add fused into the
+        store where the shape is covered (ops.linear_fused); the library GEMM + elementwise passes otherwise."""
+        h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (_FUSED_LINEAR and x.is_cuda) else None
+        if h is None:
+            h = self.act(self.fc1(x))
+        y = ops.linear_fused(h, self.fc2.weight, self.fc2.bias, residual=residual) if (_FUSED_LINEAR and x.is_cuda) else None
+        if y is None:
+            y = self.fc2(h)
+            if residual is not None:
+                y = residual + y
+        return y
 
 
 def window_partition(x, window_size):
@@ -94,10 +116,10 @@ class WindowAttention(nn.Module):
         done by index arithmetic inside the attention kernel (the qkv / proj Linears are per token, so they
         commute with the partition)."""
         B, L, C = x.shape
-        qkv = self.qkv(x).view(B, L, 3, self.num_heads, C // self.num_heads)
+        qkv = _linear(self.qkv, x).view(B, L, 3, self.num_heads, C // self.num_heads)
         out = ops.window_attention_image(qkv, self.qkv.bias, self._bias(), mask, H, W, self.window_size[0], shift,
                                          self.scale)
-        return self.proj(out)
+        return _linear(self.proj, out)
 
     def forward(self, x, mask=None):
         """x: [num_windows*B, N, C]; mask: [nW, N, N] (0 / -100) or None."""
@@ -132,7 +154,7 @@ class SwinTransformerBlock(nn.Module):
                                     mask_matrix if self.shift_size > 0 else None)
         # residual add and norm2 in one pass: x = shortcut + attn branch, h = norm2(x)
         x, h = layer_norm(self.norm2, x.reshape(B, H * W, C), residual=shortcut, return_sum=True)
-        return x + self.mlp(h)
+        return self.mlp(h, residual=x)
 
 
 class PatchMerging(nn.Module):

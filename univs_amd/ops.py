@@ -179,33 +179,53 @@ def msda_last_tiled_generation() -> int:
     return int(_lib.load().univs_msda_last_tiled_generation())
 
 
-def linear_split(x, weight, bias=None, relu=False):
-    """F.linear(x, weight, bias) [+ relu] for float32 on the GPU through the split-bf16 kernel (fp32-accurate: an exact
-    3-way bf16 split of both operands, six MFMA terms) -- the K = 256 token projections of MSDeformAttn
-    (ms_deform_attn.py:95-113).  Returns None when the shape is not covered (K % 128, N % 4, fewer than 2048 rows,
-    ranges beyond 2^31 bytes): the caller then keeps the library GEMM."""
+_ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+
+
+def linear_fused(x, weight, bias=None, act=None, residual=None):
+    """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [exact, erf]) or `residual`
+    (a tensor of the output's shape that is added) -- for float32 on the GPU through the split-bf16 kernel (fp32-accurate:
+    an exact 3-way bf16 split of both operands, six MFMA terms): the token projections of MSDeformAttn
+    (ms_deform_attn.py:95-113) and of the Swin blocks (swin.py:35-58, :137-141, :163, :291-293).
+    Returns None when the shape is not covered or the library GEMM is the better choice (K not a multiple of 96 / 128 or
+    above 768, N % 4, fewer than 2048 rows, ranges beyond 2^31 bytes, autograd needed): the caller then keeps its own
+    Linear + activation + add."""
     K = x.shape[-1]
     N = weight.shape[0]
     M = x.numel() // max(K, 1)
-    if needs_grad(x, weight, bias):
+    if needs_grad(x, weight, bias, residual):
         return None   # autograd has to see this Linear: the library GEMM path records it
+    if act not in _ACTS:
+        raise RuntimeError(f"linear_fused: unknown activation {act!r}")
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.shape[1] != K
-            or K % 128 != 0 or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1):
+            or (K % 128 != 0 and K % 96 != 0) or K > 768 or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1
+            or (residual is not None and _ACTS[act] != 0)):
         return None
     x2 = x.contiguous().view(M, K)
     w = weight.contiguous()
     b = bias.contiguous() if bias is not None else None
-    _require_gpu("linear_split", x2, w)
+    _require_gpu("linear_fused", x2, w)
     if b is not None and (b.dtype != torch.float32 or tuple(b.shape) != (N,) or not b.is_cuda):
-        raise RuntimeError("linear_split: bias must be float32 [N] on the GPU")
+        raise RuntimeError("linear_fused: bias must be float32 [N] on the GPU")
+    r = None
+    if residual is not None:
+        if residual.dtype != torch.float32 or not residual.is_cuda or residual.numel() != M * N:
+            raise RuntimeError("linear_fused: residual must be float32 of the output's shape on the GPU")
+        r = residual.contiguous()
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().univs_linear_split_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, M, N, K,
-                                                int(bool(relu)), _ptr(y), _stream_ptr(x2))
+        rc = _lib.load().univs_linear_fused_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None,
+                                                _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
+                                                _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
-    _lib.check(rc, "linear_split")
+    _lib.check(rc, "linear_fused")
     return y.view(*x.shape[:-1], N)
+
+
+def linear_split(x, weight, bias=None, relu=False):
+    """linear_fused with the ReLU switch of the MSDeformAttn encoder's callers."""
+    return linear_fused(x, weight, bias, act="relu" if relu else None)
 
 
 def mask_decode_set_impl(impl: int):
