@@ -220,6 +220,16 @@ def main():
 
     sync = torch.cuda.synchronize
     dt, out = timed_loop(step, args.steps, args.warmup, world, sync, dev)
+    # diagnostic, outside the timed region: how long the host needs to ENQUEUE a clip (python + launch overhead + any
+    # host-device synchronisation inside the model).  Close to ms_per_step = the clip is host-bound, not GPU-bound.
+    sync()
+    t_enq = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        t_enq.append(time.perf_counter() - t0)
+        sync()
+    host_enqueue_ms = sorted(t_enq)[1] * 1e3
 
     res = {
         "metric": "frames/sec per node, 720p T=5 clip, Swin-T 100Q; mask-logit max-abs-err",
@@ -229,6 +239,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "host_enqueue_ms_per_step": host_enqueue_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

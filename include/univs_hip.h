@@ -137,6 +137,13 @@ int univs_linear_split_f32(const float* x, const float* weight, const float* bia
 int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
                            int K, int act, float* y, void* stream);
 
+/* out[b][c][r] = x[b][r][c]: contiguous float32 [B, R, C] -> [B, C, R].  The layout changes at the edges of the Swin
+ * backbone: stage outputs tokens [B, H*W, C] -> NCHW (mask2former/modeling/backbone/swin.py:676-683
+ * `permute(0, 3, 1, 2).contiguous()`), PatchEmbed's NCHW -> tokens (:331-336 `flatten(2).transpose(1, 2)`).
+ * Covered: R % 4 == 0, C % 4 == 0, B <= 65535, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller
+ * keeps its own permuted copy). */
+int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, void* stream);
+
 /* Selects the mask-decode contraction kernel (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel
  * (v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fp32 fmaf chain), 2 = fp32 emulated on the bf16 matrix

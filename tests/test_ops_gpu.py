@@ -529,7 +529,9 @@ def test_linear_split_matches_torch(cuda, M, K, N, relu, bias):
 
 @pytest.mark.parametrize("M,K,N,act,res", [(58880, 96, 288, None, False), (58880, 96, 384, "gelu", False), (14720, 384, 96, None, True),
                                             (14720, 192, 576, None, False), (14720, 192, 768, "gelu", False), (3680, 768, 192, None, True),
-                                            (3680, 384, 1536, "gelu", False), (4099, 96, 100, "relu", False), (2500, 768, 2304, None, False)],
+                                            (3680, 384, 1536, "gelu", False), (4099, 96, 100, "relu", False), (2500, 768, 2304, None, False),
+                                            (19320, 1024, 256, None, False), (4600, 1536, 384, None, True), (4613, 3072, 768, "gelu", False),
+                                            (5000, 1024, 128, "relu", False)],
                          ids=lambda v: str(v))
 def test_linear_fused_matches_torch(cuda, M, K, N, act, res):
     """ops.linear_fused at the Swin-T widths (K = 96 / 192: register ring of three k-steps; 384 / 768: ring of four) with
@@ -561,10 +563,19 @@ def test_linear_fused_matches_torch(cuda, M, K, N, act, res):
 def test_linear_split_uncovered_shapes_return_none(cuda):
     x = torch.zeros(4096, 80, device=cuda)
     assert ops.linear_split(x, torch.zeros(96, 80, device=cuda)) is None                      # K % 96 and K % 128
-    assert ops.linear_split(torch.zeros(4096, 1024, device=cuda), torch.zeros(8, 1024, device=cuda)) is None   # K > 768
+    assert ops.linear_split(torch.zeros(4096, 1024, device=cuda), torch.zeros(8, 1024, device=cuda)) is None   # K > 768: N % 16
     assert ops.linear_split(torch.zeros(4096, 256, device=cuda), torch.zeros(6, 256, device=cuda)) is None     # N % 4
     assert ops.linear_split(torch.zeros(100, 256, device=cuda), torch.zeros(8, 256, device=cuda)) is None      # few rows
     assert ops.linear_split(torch.zeros(4096, 256), torch.zeros(8, 256)) is None                               # CPU tensors
     from univs_amd import layers
     y = layers.linear(x, torch.ones(96, 80, device=cuda), None)                                # falls through to ATen
     assert tuple(y.shape) == (4096, 96)
+
+
+@pytest.mark.parametrize("shape", [(5, 58880, 96), (2, 920, 768), (3, 7, 96, 100), (1, 64, 64), (2, 10, 6), (1, 68, 132)], ids=str)
+def test_transpose_last2_is_exact(cuda, shape):
+    """ops.transpose_last2 == x.transpose(-2, -1).contiguous() bit for bit: LDS-tiled where both extents are multiples of
+    4 (edge tiles included), ATen otherwise."""
+    x = synth.normal(f"tr/{shape}", shape).to(cuda)
+    got = ops.transpose_last2(x)
+    assert got.is_contiguous() and torch.equal(got, x.transpose(-2, -1).contiguous())

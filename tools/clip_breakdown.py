@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--last", type=int, default=8, help="clips to average over")
     ap.add_argument("--skip", type=int, default=-1, help="clips to skip from the start (default: take the LAST clips of the trace)")
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--detail", default="", help="substring: list every launch of matching kernels in ONE clip with its neighbours")
     args = ap.parse_args()
     rows = []
     with open(args.csv) as f:
@@ -48,6 +49,15 @@ def main():
     first = anchors[c0 * args.per_clip]
     end = anchors[(c0 + args.last) * args.per_clip]
     seg = rows[first:end]
+    if args.detail:
+        one = rows[first:anchors[(c0 + 1) * args.per_clip]]
+        print(f"# launches matching {args.detail!r} in clip {c0} (us, previous kernel -> next kernel)")
+        for i, (s_, e_, n_) in enumerate(one):
+            if args.detail in n_ and (e_ - s_) > 8000:
+                prev = short(one[i - 1][2])[:60] if i else "-"
+                nxt = short(one[i + 1][2])[:60] if i + 1 < len(one) else "-"
+                print(f"  {(e_ - s_) / 1e3:8.1f}  {prev}  ->  {nxt}")
+        return
     span = (seg[-1][1] - seg[0][0]) / args.last
     busy = defaultdict(float)
     calls = defaultdict(int)

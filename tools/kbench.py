@@ -159,6 +159,16 @@ def main():
                     if rs is not None:
                         t3 = timeit(lambda: rs + torch.nn.functional.linear(xs, w_, b_))
                         res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["library_plus_add_us"] = t3 * 1e6
+    if args.only and "bigk" in args.only:
+        for nm, Mr, K_, N_ in (("enc_ffn2", T * 19320, 1024, 256), ("swin_s3_fc2", T * 3680, 1536, 384), ("swin_s4_fc2", T * 920, 3072, 768)):
+            xs = synth.normal(f"kb/bk/x{K_}/{Mr}", (Mr, K_)).to(dev)
+            w_ = synth.normal(f"kb/bk/w{K_}x{N_}", (N_, K_), std=1 / 16).to(dev)
+            b_ = synth.normal(f"kb/bk/b{N_}", (N_,)).to(dev)
+            t = timeit(lambda: torch.nn.functional.linear(xs, w_, b_))
+            res[nm] = dict(lib_us=t * 1e6)
+            y = ops.linear_fused(xs, w_, b_)
+            if y is not None:
+                res[nm]["fused_us"] = timeit(lambda: ops.linear_fused(xs, w_, b_)) * 1e6
     if not args.only or "win" in args.only:
         # Swin-T stage 1 at 720p: 27x46 windows of 49 tokens, 3 heads, per frame
         nW, nH, ntok, hd = 27 * 46, 3, 49, 32

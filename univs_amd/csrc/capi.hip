@@ -38,6 +38,7 @@ int msda_forward_fused_tiled4_f32(const float*, const LevelTable&, const float*,
 int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
                            int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
+int transpose_f32(const float*, float*, long long, int, int, hipStream_t);
 void mask_decode_set_impl(int);
 int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t);
 int mask_decode_last_impl();
@@ -140,6 +141,22 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
 int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                            int relu, float* y, void* stream) {
   return univs_linear_fused_f32(x, weight, bias, nullptr, M, N, K, relu ? 1 : 0, y, stream);
+}
+
+int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, void* stream) {
+  clear_sticky_error();
+  if (B < 0 || R < 0 || C < 0) {
+    set_error("univs_transpose_f32: bad dimensions B=%lld R=%d C=%d", B, R, C);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0 || R == 0 || C == 0) return UNIVS_OK;
+  if (!x || !out) {
+    set_error("univs_transpose_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::transpose_f32(x, out, B, R, C, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_transpose_f32: R=%d C=%d B=%lld not covered (R %% 4, C %% 4, B <= 65535, 16-byte alignment)", R, C, B);
+  return rc;
 }
 
 int univs_mask_decode_set_impl(int impl) {

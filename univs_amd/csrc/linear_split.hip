@@ -221,6 +221,187 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
   }
 }
 
+// ---- wide-K variant: x-stationary.
+// The kernel above keeps a slab of W (all of K for <= 112 output features) in LDS and makes one pass over x per slab: right
+// for K <= 768, hopeless beyond (K = 1024 leaves room for 24 features: eleven passes over x).  Here a wave keeps its 16
+// rows of x for ALL of K in flight and owns a [16 rows x NF * 16 features] block of accumulators; W streams through LDS in
+// k-steps of 32 (all NF * 16 features x 32 k = 49 KB at 256 features), double-buffered, split to bf16 x 3 by the whole
+// workgroup while the previous k-step is multiplied; one barrier per k-step.  Used for the encoder's second FFN Linear
+// (K = 1024 -> 256, msdeformattn.py:87-91) and the fc2 of the deeper Swin stages (K = 1536).
+template <int NF, int EPI>
+__global__ __launch_bounds__(LS_THREADS, NF <= 8 ? 2 : 1) void linear_bf16x6_wide(const float* __restrict__ X,      // [M, K]
+                                                                     const float* __restrict__ W,      // [N, K]
+                                                                     const float* __restrict__ bias,   // [N] or null
+                                                                     const float* __restrict__ Res,    // [M, N]
+                                                                     float* __restrict__ Y, int M, int N, int K) {
+  constexpr int RING = 4;
+  constexpr int NFEAT = NF * 16;
+  extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];   // [2 buffers][4 k-groups][NFEAT][3 parts]
+  const int n0 = blockIdx.y * NFEAT;
+  const int R = min(NFEAT, N - n0);                              // a multiple of 4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = K >> 5;
+  const int j = lane & 15, g = lane >> 4;
+  constexpr int NWV = LS_THREADS / 64;
+  const int WT = (M + 15) / 16;                                  // 16-row wave tiles
+  const int ST = (WT + NWV - 1) / NWV;                           // super-tiles of 8 wave tiles
+
+  // W staging, two phases a k-step apart so that the global latency hides behind a whole k-step of MFMAs:
+  //   fetch_w(ks): this pass's k-step `ks` of W -> registers (8 consecutive k of one feature per work item, <= 2 items);
+  //   commit_w(buf): registers -> split -> LDS buffer `buf` (fragment order)
+  constexpr int WITEMS = (NFEAT * 4 + LS_THREADS - 1) / LS_THREADS;
+  f32x4 wraw[WITEMS][2];
+  auto fetch_w = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < WITEMS; ++it) {
+      const int idx = tid + it * LS_THREADS;
+      const int r = idx >> 2, kg = idx & 3;
+      wraw[it][0] = wraw[it][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (idx < NFEAT * 4 && r < R) {
+        const float* src = W + (size_t)(n0 + r) * K + min(ks, KS - 1) * 32 + kg * 8;
+        wraw[it][0] = *reinterpret_cast<const f32x4*>(src);
+        wraw[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+    }
+  };
+  auto commit_w = [&](int buf) __attribute__((always_inline)) {
+    u32x4* dst0 = Wst + (size_t)buf * 4 * NFEAT * 3;
+#pragma unroll
+    for (int it = 0; it < WITEMS; ++it) {
+      const int idx = tid + it * LS_THREADS;
+      const int r = idx >> 2, kg = idx & 3;
+      if (idx < NFEAT * 4) {
+        bf16x8 h, m, l;
+        ls_split8(wraw[it][0], wraw[it][1], 0xFFFF0000u, h, m, l);
+        u32x4* dst = dst0 + (kg * NFEAT + r) * 3;
+        dst[0] = __builtin_bit_cast(u32x4, h);
+        dst[1] = __builtin_bit_cast(u32x4, m);
+        dst[2] = __builtin_bit_cast(u32x4, l);
+      }
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * N * 4), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == LS_EPI_RESIDUAL ? Res : X), 0, (int)((long long)M * N * 4), 0x00020000);
+  const char* Xb = reinterpret_cast<const char*>(X);
+
+#pragma unroll 1
+  for (int st = blockIdx.x; st < ST; st += gridDim.x) {
+    const int m = (st * NWV + wave) * 16 + j;                    // my row (lanes j; the 4 k-groups g share it)
+    const int mc = min(m, M - 1);
+    f32x4 raw[RING][2];
+    auto load_x = [&](f32x4 (&buf)[2], int ks) __attribute__((always_inline)) {
+      const char* p = Xb + ((unsigned)mc * (unsigned)K + (unsigned)(min(ks, KS - 1) * 32 + 8 * g)) * 4u;
+      buf[0] = *reinterpret_cast<const f32x4*>(p);
+      buf[1] = *reinterpret_cast<const f32x4*>(p + 16);
+    };
+#pragma unroll
+    for (int u = 0; u < RING; ++u) load_x(raw[u], u);
+    f32x4 acc[NF];
+#pragma unroll
+    for (int rb = 0; rb < NF; ++rb) {
+      const int f = rb * 16 + 4 * g;
+      acc[rb] = (bias && f < R) ? *reinterpret_cast<const f32x4*>(bias + n0 + f) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                                             // the previous super-tile's last k-step is done with the buffers
+    fetch_w(0);
+    commit_w(0);
+    fetch_w(1);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS; ks0 += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        const int ks = ks0 + u;
+        commit_w((ks + 1) & 1);                                  // W of k-step ks + 1 (fetched a k-step ago) -> the free buffer
+        fetch_w(ks + 2);                                         // ... and the one after it -> registers
+        bf16x8 bh, bm, bl;
+        ls_split8(raw[u][0], raw[u][1], 0xFFFF0000u, bh, bm, bl);
+        load_x(raw[u], ks + RING);
+        const u32x4* ap = Wst + (size_t)(ks & 1) * 4 * NFEAT * 3 + (g * NFEAT + j) * 3;
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (see above)
+#pragma unroll
+        for (int rb = 0; rb < NF; ++rb) {
+          bf16x8 a3[3];
+#pragma unroll
+          for (int p3 = 0; p3 < 3; ++p3) a3[p3] = __builtin_bit_cast(bf16x8, ap[rb * 48 + p3]);
+#pragma unroll
+          for (int term = 0; term < 6; ++term) {
+            const bf16x8 b = TB[term] == 0 ? bh : TB[term] == 1 ? bm : bl;
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[TA[term]], b, acc[rb], 0, 0, 0);
+          }
+        }
+        __syncthreads();                                         // buffer (ks + 1) & 1 is staged; buffer ks & 1 is free
+      }
+    }
+    // ---- epilogue: D[i = feature][j = row]: a lane holds four consecutive features of its row
+#pragma unroll
+    for (int rb = 0; rb < NF; ++rb) {
+      const int f = rb * 16 + 4 * g;
+      f32x4 v = acc[rb];
+      const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
+      const unsigned offc = (m < M && f < R) ? off : 0xFFFFFFF0u;
+      if (EPI == LS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+      if (EPI == LS_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+      }
+      if (EPI == LS_EPI_RESIDUAL) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+    }
+  }
+}
+
+// returns 1 if launched, 0 if not covered
+static int linear_split_wide_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M,
+                                 int N, int K, int epi, hipStream_t st) {
+  if (K % 128 != 0 || N % 16 != 0 || M < 4096) return 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n_cu = v;
+  }
+  const long long ST = ((M + 15) / 16 + 7) / 8;
+  // features per pass: 256 (one workgroup per CU, x read once) when the row super-tiles alone give every CU several
+  // rounds of work; otherwise 128 (two workgroups per CU, x read once per pass from L2 / the memory-side cache) --
+  // measured at 5 x 3680 x 1536 -> 384: 164 us against 211 us
+  int passes = (N + 255) / 256;
+  if (ST * passes < (n_cu * 3) / 2) passes = (N + 127) / 128;
+  if (const char* e = getenv("UNIVS_LSW_NFEAT")) { const int nf = atoi(e); if (nf >= 16) passes = (N + nf - 1) / nf; }
+  const int nfeat = ((N + passes - 1) / passes + 15) / 16 * 16;
+  const int NF = nfeat / 16;
+  if (NF != 8 && NF != 12 && NF != 16) return 0;
+  const unsigned gx = (unsigned)std::min<long long>(ST, std::max(1, n_cu / ((N + nfeat - 1) / nfeat)));
+  const size_t lds = (size_t)2 * 4 * nfeat * 3 * 16;
+  dim3 grid(gx, (unsigned)((N + nfeat - 1) / nfeat)), block(LS_THREADS);
+#define UNIVS_LSW(nf, ep)                                                                                       \
+  do {                                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16x6_wide<nf, ep>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipLaunchKernelGGL((linear_bf16x6_wide<nf, ep>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K); \
+  } while (0)
+#define UNIVS_LSW_EPI(nf)                                        \
+  switch (epi) {                                                 \
+    case LS_EPI_RELU: UNIVS_LSW(nf, LS_EPI_RELU); break;         \
+    case LS_EPI_GELU: UNIVS_LSW(nf, LS_EPI_GELU); break;         \
+    case LS_EPI_RESIDUAL: UNIVS_LSW(nf, LS_EPI_RESIDUAL); break; \
+    default: UNIVS_LSW(nf, LS_EPI_NONE); break;                  \
+  }
+  if (NF == 8) { UNIVS_LSW_EPI(8) } else if (NF == 12) { UNIVS_LSW_EPI(12) } else { UNIVS_LSW_EPI(16) }
+#undef UNIVS_LSW_EPI
+#undef UNIVS_LSW
+  const int rc = check_launch("linear_split_wide_f32");
+  return rc == UNIVS_OK ? 1 : rc;
+}
+
 // returns 1 if launched, 0 if the shape is not covered (the caller uses the library GEMM), < 0 on error
 int linear_split_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
                      int K, int epi, hipStream_t st) {
@@ -230,8 +411,9 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   if (K < 96 || ring == 0 || N % 4 != 0) return 0;
   if (M * (long long)N * 4 >= 0x7FFFFFFFLL || M * (long long)K * 4 >= 0x7FFFFFFFLL) return 0;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
-      (reinterpret_cast<uintptr_t>(residual) & 15))
+      (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
     return 0;
+  if (K > 768) return linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);   // x-stationary variant
   const long long lds_cap = 160 * 1024 - 512;
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);
   r_cap -= r_cap % 4;
@@ -256,7 +438,9 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   // share an XCD (workgroups are dealt to the 8 XCDs round-robin by linear id)
   long long gx = std::max<long long>(1, n_cu / passes);
   gx = std::min(gx, std::max<long long>(1, WT / (2 * (LS_THREADS / 64))));
-  if (gx >= 8) gx -= gx % 8;
+  // (... unless rounding down to a multiple of 8 would idle more than a tenth of the CUs: 17 passes -> 15 row ranges,
+  // not 8; the passes of a row range then sit on different XCDs and x comes from the memory-side cache instead of L2)
+  if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;
   const size_t lds = (size_t)K * rows * 6 + 512;
   dim3 grid((unsigned)gx, (unsigned)passes), block(LS_THREADS);
 #define UNIVS_LS(rb, ksc, rg, ep)                                                                                        \
@@ -272,11 +456,13 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
     case LS_EPI_RESIDUAL: UNIVS_LS(rb, ksc, rg, LS_EPI_RESIDUAL); break; \
     default: UNIVS_LS(rb, ksc, rg, LS_EPI_NONE); break;             \
   }
-#define UNIVS_LS_RB(rb)                          \
-  case rb:                                       \
-    if (K == 256) { UNIVS_LS_EPI(rb, 8, 4) }     \
-    else if (ring == 4) { UNIVS_LS_EPI(rb, 0, 4) } \
-    else { UNIVS_LS_EPI(rb, 0, 3) }              \
+  // a straight-line tile body for K = 256 (MSDeformAttn), a runtime k loop for anything else (straight-line bodies for
+  // the Swin widths 96 .. 768 were measured: no gain, 80 s of compile time)
+#define UNIVS_LS_RB(rb)                               \
+  case rb:                                            \
+    if (K == 256) { UNIVS_LS_EPI(rb, 8, 4) }          \
+    else if (ring == 4) { UNIVS_LS_EPI(rb, 0, 4) }    \
+    else { UNIVS_LS_EPI(rb, 0, 3) }                   \
     break
   switch (RB) {
     UNIVS_LS_RB(1);

@@ -239,7 +239,7 @@ class PatchEmbed(nn.Module):
         x = self.proj(x)
         if self.norm is not None:
             Wh, Ww = x.size(2), x.size(3)
-            x = layer_norm(self.norm, x.flatten(2).transpose(1, 2))
+            x = layer_norm(self.norm, ops.transpose_last2(x.flatten(2)))
             x = x.transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
         return x
 
@@ -278,7 +278,8 @@ class SwinTransformer(nn.Module):
             x_out, H, W, x, Wh, Ww = self.layers[i](x, Wh, Ww)
             if i in self.out_indices:
                 x_out = layer_norm(getattr(self, f"norm{i}"), x_out)
-                outs[f"res{i + 2}"] = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+                # tokens -> NCHW (swin.py:676-683 permute + contiguous): an LDS tile transpose on the GPU
+                outs[f"res{i + 2}"] = ops.transpose_last2(x_out).view(-1, self.num_features[i], H, W)
         return outs
 
 

@@ -4,6 +4,7 @@ libunivs_hip.so.  Every function raises on non-GPU tensors -- the reference does
 operator ("Not implemented on the CPU", ops/src/ms_deform_attn.h:43) and there is no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -180,6 +181,9 @@ def msda_last_tiled_generation() -> int:
 
 
 _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+# widest K routed to the split-bf16 kernels (K <= 768: W-stationary; beyond: the x-stationary variant, which wants
+# N % 16 == 0 and >= 4096 rows and hands anything else back to the library GEMM)
+_LINEAR_KMAX = int(os.environ.get("UNIVS_LINEAR_KMAX", "4096"))
 
 
 def linear_fused(x, weight, bias=None, act=None, residual=None):
@@ -198,7 +202,7 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
     if act not in _ACTS:
         raise RuntimeError(f"linear_fused: unknown activation {act!r}")
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.shape[1] != K
-            or (K % 128 != 0 and K % 96 != 0) or K > 768 or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1
+            or (K % 128 != 0 and K % 96 != 0) or K > _LINEAR_KMAX or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1
             or (residual is not None and _ACTS[act] != 0)):
         return None
     x2 = x.contiguous().view(M, K)
@@ -324,6 +328,24 @@ def bilinear_resample(x, size, addend=None):
         rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(addend) if addend is not None else None, _ptr(out),
                                                     planes, Hin, Win, Hout, Wout, _stream_ptr(x))
     _lib.check(rc, "bilinear_resample")
+    return out
+
+
+def transpose_last2(x):
+    """Contiguous copy of `x.transpose(-2, -1)` for a float32 tensor on the GPU (LDS tile transpose at HBM rate instead of
+    ATen's strided copy): tokens [B, H*W, C] <-> channel-major [B, C, H*W] at the edges of the Swin backbone
+    (swin.py:331-336, :676-683).  Any leading dimensions; falls back to ATen for shapes the kernel does not cover."""
+    if (not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2 or not x.is_contiguous()
+            or (torch.is_grad_enabled() and x.requires_grad)):
+        return x.transpose(-2, -1).contiguous()
+    R, C = x.shape[-2], x.shape[-1]
+    B = x.numel() // max(R * C, 1)
+    out = torch.empty(x.shape[:-2] + (C, R), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_transpose_f32(_ptr(x), B, R, C, _ptr(out), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return x.transpose(-2, -1).contiguous()
+    _lib.check(rc, "transpose_last2")
     return out
 
 
