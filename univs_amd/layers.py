@@ -84,7 +84,8 @@ class MultiheadAttention(nn.Module):
         S = key.shape[0]
         h, d = self.num_heads, self.head_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        lin = linear if _SPLIT_LINEAR_LEVEL >= 2 else F.linear
+        lin = F.linear   # (the split-bf16 kernel was measured for these in-projections -- cross-attention K / V of tall memories --
+        #                  and is no faster than the tuned library GEMM: profiles/r02_bench_ab_split_linear.txt)
         if query is key and key is value:
             q, k, v = lin(query, w, b).chunk(3, dim=-1)
         else:
@@ -144,10 +145,8 @@ def layer_norm(norm, x, residual=None, return_sum=False):
 
 
 # UNIVS_SPLIT_LINEAR: 0 = library GEMMs only, 1 (default) = the MSDeformAttn token projections + encoder FFN through the
-# split-bf16 kernel (measured), 2 = additionally the attention in-projections of tall memories
-# (decoder cross-attention K / V: covered shapes, routing not yet measured on the GPU -- opt-in until it is)
-_SPLIT_LINEAR_LEVEL = int(os.environ.get("UNIVS_SPLIT_LINEAR", "1") or 0)
-_SPLIT_LINEAR = _SPLIT_LINEAR_LEVEL != 0
+# split-bf16 kernels (measured)
+_SPLIT_LINEAR = (os.environ.get("UNIVS_SPLIT_LINEAR", "1") or "0") != "0"
 
 
 def linear(x, weight, bias=None):

@@ -122,7 +122,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         src2 = self.self_attn(src if pos is None else src + pos, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
         src = layer_norm(self.norm1, src2, residual=src)
-        src = layer_norm(self.norm2, self.linear2(linear_act(src, self.linear1, self.activation)), residual=src)
+        src = layer_norm(self.norm2, linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias),
+                         residual=src)
         return src
 
 
