@@ -112,6 +112,55 @@ def _visual_prompt_clips(case, feats, world):
     assert torch.equal(tv["img_emb_per_video"][sl], tv_ref["img_emb_per_video"][sl])
 
 
+def _box_point_worker(rank, world, port):
+    """Box and point prompts in frame-sharded mode (prompt_encoder.py:362-442): the rank that owns the key frame holds its
+    features, the others zeros; token features summed over the ranks == the single-process tokens on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from univs_amd import synth
+        from univs_amd.distributed import FrameShard
+        from univs_amd.modeling.prompt_encoder import VisualPromptEncoder
+        enc = VisualPromptEncoder(pretrain_img_size=64, hidden_dim=32, num_frames=4, num_dense_points=6,
+                                  position_embedding_sin3d_type="FixedT")
+        C, h, w = 32, 8, 12
+        feats = synth.normal("dist/bp/f", (C, h, w))
+        pos = synth.normal("dist/bp/p", (C, h, w))
+        boxes = torch.tensor([[0.1, 0.2, 0.6, 0.7], [0.5, 0.5, 0.9, 0.95], [0.3, 0.3, 0.3, 0.3], [0.92, 0.93, 0.99, 0.99]])
+        points = torch.tensor([[0.2, 0.3], [0.8, 0.6], [1.2, 0.5]])
+
+        def run():
+            torch.manual_seed(3)          # the dense-token sampler draws from the CPU generator: same state on every rank
+            b = enc.get_box_prompt(f_local, pos, boxes)
+            torch.manual_seed(4)
+            p = enc.get_point_prompt(f_local, pos, point_coords=points)
+            return b, p
+
+        f_local = feats
+        ref_b, ref_p = run()
+        shard = FrameShard()
+        f_local = feats if rank == 1 else torch.zeros_like(feats)      # rank 1 owns the key frame
+        enc.feature_reduce = shard.all_reduce_sum
+        got_b, got_p = run()
+        for got, ref in ((got_b, ref_b), (got_p, ref_p)):
+            for g_, r_ in zip(got, ref):
+                assert g_.shape == r_.shape
+                if g_.dtype == torch.bool:
+                    assert torch.equal(g_, r_)
+                else:
+                    assert (g_ - r_).abs().max().item() < 1e-6
+        assert ref_b[2].abs().max().item() > 0 and ref_p[2].abs().max().item() > 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_sharded_box_and_point_prompts():
+    world = 2
+    mp.spawn(_box_point_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
 @pytest.mark.parametrize("scenario", ["first_clip", "grounding", "visual_prompts"])
 def test_frame_sharded_decoder_matches_single_process(scenario):
     world = 2

@@ -181,8 +181,6 @@ class VisualPromptEncoder:
     @torch.no_grad()
     def get_point_prompt(self, img_features, img_pos, point_coords=None, boxes=None, masks=None, key_fid=None,
                          key_fid_original=None, is_train=False, enable_dense_prompt=True):
-        if self.feature_reduce is not None:
-            raise NotImplementedError("point prompts are not covered by the frame-sharded mode (mask prompts are)")
         key_fid = self.key_fid if key_fid is None else key_fid
         key_fid_original = key_fid if key_fid_original is None else key_fid_original
         h_img, w_img = img_features.shape[-2:]
@@ -208,6 +206,10 @@ class VisualPromptEncoder:
         if enable_dense_prompt:
             fd = fd.repeat(1, self.num_dense_points, 1, 1)
             pd = pd.repeat(1, self.num_dense_points, 1, 1)
+        if self.feature_reduce is not None:
+            # frame-sharded mode: only the rank that owns the key frame holds its features (zeros elsewhere); the token
+            # features are linear in them, so their sum over the ranks is the single-process value on every rank
+            fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
         if (~valid).any():
             pd = pd * valid.view(-1, 1, 1, 1)
             fd = fd * valid.view(-1, 1, 1, 1)
@@ -271,8 +273,6 @@ class VisualPromptEncoder:
     @torch.no_grad()
     def get_box_prompt(self, img_features, img_pos, boxes, key_fid=None, key_fid_original=None, is_train=False,
                        enable_dense_prompt=True):
-        if self.feature_reduce is not None:
-            raise NotImplementedError("box prompts are not covered by the frame-sharded mode (mask prompts are)")
         key_fid = self.key_fid if key_fid is None else key_fid
         key_fid_original = key_fid if key_fid_original is None else key_fid_original
         h_img, w_img = img_features.shape[-2:]
@@ -294,6 +294,8 @@ class VisualPromptEncoder:
         fd, pd = query_feats[:, None], query_pe[:, None]
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, box_masks, query_pe, query_feats, is_train=is_train)
+        if self.feature_reduce is not None:   # frame-sharded mode (see get_point_prompt)
+            fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
         if (~valid).any():
             pd = pd * valid.view(-1, 1, 1, 1)
             fd = fd * valid.view(-1, 1, 1, 1)
