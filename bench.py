@@ -332,6 +332,13 @@ def main():
                            "traffic": None, "avg_launch_us": sec * 1e6, "launches_per_step": n // PROF_STEPS,
                            "algorithmic_bytes_per_launch": alg,
                            "timing": f"HIP events around each launch in a separate pass of {PROF_STEPS} clips after the timed region"}
+        if fused:
+            # the fused operator also does msda_prepare's work (softmax + reference + offset / normaliser): SURVEY 8d's
+            # 3200*S prices the sampling operator alone; un-fused accounting adds the bytes the separate pass would move
+            # (the merged projection row in, locations + weights out: 4 * S * T * M * L * P * 3 * 2 bytes)
+            prep = 4.0 * S * T * 8 * 3 * 4 * 3 * 2
+            res["roofline"]["unfused_accounting"] = {"algorithmic_bytes_per_launch": alg + prep,
+                                                     "achieved": (alg + prep) / sec / 1e9, "frac": (alg + prep) / sec / HBM_PEAK}
         # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
         # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
         for fn in ("r02_msda_traffic.json", "r01_msda_traffic.json"):

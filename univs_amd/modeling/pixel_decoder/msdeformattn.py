@@ -29,10 +29,11 @@ from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
 
-# UNIVS_MSDA_FUSED=1: msda_prepare + ms_deform_attn_forward as ONE operator (third-generation kernel fed with the raw
-# projections).  Measured on MI355X: 196 us per 5-frame layer against 48 + 157 us for the two operators -- a 4 % gain on
-# the pair, so it stays opt-in until the third-generation kernel itself is faster (profiles/r02_msda_kbench_v3.txt).
-_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "0") == "1"
+# UNIVS_MSDA_FUSED (default 1): msda_prepare + ms_deform_attn_forward as ONE operator (register-record kernel fed with the raw
+# projections: the [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] location and weight tensors never exist).  Measured on MI355X: 181 us
+# per 5-frame layer against 48 + 157 us for the two operators; -0.2 ms per config-2 clip in bench.py (A/B on one box,
+# profiles/r02_bench_ab_msda_fused.txt).  0: the two operators.
+_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "1") == "1"
 
 
 def _shape_list(spatial_shapes):
