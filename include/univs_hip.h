@@ -137,6 +137,16 @@ int univs_linear_split_f32(const float* x, const float* weight, const float* bia
 int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
                            int K, int act, float* y, void* stream);
 
+/* y = conv2d(x, w, bias=None, stride=1, padding=1) for a 3 x 3 kernel on contiguous float32 NCHW tensors:
+ * x [T, Cin, H, W], y [T, Cout, H, W]; `w_tap_major` [Cout, 9 * Cin] is the weight [Cout, Cin, 3, 3] permuted to
+ * [Cout, ky, kx, Cin] (w.permute(0, 2, 3, 1)).  The FPN output convolution of the pixel decoder
+ * (mask2former/modeling/pixel_decoder/msdeformattn.py:227-232, :352; its GroupNorm + ReLU stay separate).  fp32 emulated on
+ * the bf16 matrix cores from an exact 3-way split, like univs_linear_split_f32.
+ * Covered: Cin % 128 == 0, Cout = 128 or a multiple of 256 up to what one or more 256-feature passes cover, T*H*W >= 4096,
+ * 16-byte aligned pointers, tensors < 2^31 bytes; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps its library
+ * convolution). */
+int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, int Cout, int H, int W, float* y, void* stream);
+
 /* out[b][c][r] = x[b][r][c]: contiguous float32 [B, R, C] -> [B, C, R].  The layout changes at the edges of the Swin
  * backbone: stage outputs tokens [B, H*W, C] -> NCHW (mask2former/modeling/backbone/swin.py:676-683
  * `permute(0, 3, 1, 2).contiguous()`), PatchEmbed's NCHW -> tokens (:331-336 `flatten(2).transpose(1, 2)`).

@@ -579,3 +579,21 @@ def test_transpose_last2_is_exact(cuda, shape):
     x = synth.normal(f"tr/{shape}", shape).to(cuda)
     got = ops.transpose_last2(x)
     assert got.is_contiguous() and torch.equal(got, x.transpose(-2, -1).contiguous())
+
+
+@pytest.mark.parametrize("T,Cin,Cout,H,W", [(2, 256, 256, 48, 44), (1, 128, 128, 70, 64), (3, 256, 256, 17, 83), (1, 384, 256, 64, 64)], ids=str)
+def test_conv3x3_matches_torch(cuda, T, Cin, Cout, H, W):
+    """ops.conv3x3 (3 x 3, stride 1, padding 1, no bias: the split-bf16 x-stationary GEMM with tap addressing) ==
+    F.conv2d to fp32 rounding, borders and ragged row tiles included."""
+    F = torch.nn.functional
+    x = synth.normal(f"cv/x/{T}/{Cin}/{H}/{W}", (T, Cin, H, W)).to(cuda)
+    w = synth.normal(f"cv/w/{Cout}/{Cin}", (Cout, Cin, 3, 3), std=(9 * Cin) ** -0.5).to(cuda)
+    y = ops.conv3x3(x, w)
+    assert y is not None and tuple(y.shape) == (T, Cout, H, W)
+    ref64 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    ref32 = F.conv2d(x, w, None, 1, 1)
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+    assert ops.conv3x3(torch.zeros(1, 96, 64, 64, device=cuda), torch.zeros(64, 96, 3, 3, device=cuda)) is None   # Cin % 128
+    assert ops.conv3x3(torch.zeros(1, 128, 16, 16, device=cuda), torch.zeros(128, 128, 3, 3, device=cuda)) is None  # < 4096 pixels

@@ -11,6 +11,10 @@ import torch.nn.functional as F
 from torch import nn
 
 
+# UNIVS_SPLIT_CONV=0: the 3 x 3 FPN output convolution stays on MIOpen
+_SPLIT_CONV = (os.environ.get("UNIVS_SPLIT_CONV", "1") or "0") != "0"
+
+
 class Conv2d(nn.Conv2d):
     """detectron2.layers.Conv2d: conv -> optional norm -> optional activation, with the sub-module
     name `norm` (state-dict keys `<name>.weight`, `<name>.norm.weight`, ...)."""
@@ -23,7 +27,12 @@ class Conv2d(nn.Conv2d):
         self.activation = activation
 
     def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        y = None
+        if (_SPLIT_CONV and x.is_cuda and self.bias is None and self.kernel_size == (3, 3) and self.stride == (1, 1)
+                and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1):
+            from . import ops
+            y = ops.conv3x3(x, self.weight)       # None when not covered
+        x = y if y is not None else F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if isinstance(self.norm, nn.GroupNorm) and x.dtype == torch.float32:
             # GroupNorm (+ ReLU) epilogue through the HIP operator; the module only holds the parameters
             from . import ops

@@ -331,6 +331,26 @@ def bilinear_resample(x, size, addend=None):
     return out
 
 
+def conv3x3(x, weight):
+    """F.conv2d(x, weight, None, stride=1, padding=1) for a 3 x 3 kernel, float32 NCHW on the GPU, through the split-bf16
+    x-stationary GEMM with tap addressing (the FPN output convolution, msdeformattn.py:227-232).  Returns None when the
+    shape is not covered: the caller keeps the library convolution."""
+    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or x.dim() != 4
+            or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x.shape[1] or needs_grad(x, weight)):
+        return None
+    T, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    x = x.contiguous()
+    w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()      # [Cout, ky, kx, Cin]: a k-step = 32 channels of a tap
+    y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_conv3x3_f32(_ptr(x), _ptr(w2), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "conv3x3")
+    return y
+
+
 def transpose_last2(x):
     """Contiguous copy of `x.transpose(-2, -1)` for a float32 tensor on the GPU (LDS tile transpose at HBM rate instead of
     ATen's strided copy): tokens [B, H*W, C] <-> channel-major [B, C, H*W] at the edges of the Swin backbone
