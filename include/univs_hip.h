@@ -252,6 +252,15 @@ int univs_bilinear_resample_f32(const float* in, const float* addend, float* out
 int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                          long long rows, int C, float eps, float* sum_out, float* out, void* stream);
 
+/* The same with a second output  out2 = LayerNorm(x + residual) + addend  ([rows, C]; addend [addend_rows, C] is repeated
+ * every addend_rows rows, rows % addend_rows == 0: position embeddings [1, S, C] against tokens [N, S, C]): the encoder layer's
+ * `src = norm2(src + ffn(src))` followed by the next layer's `with_pos_embed(src, pos)`
+ * (mask2former/modeling/pixel_decoder/msdeformattn.py:61-63, :85-95) in one pass.  addend / out2 come together (or both
+ * NULL: plain univs_layer_norm_f32), need a residual and exclude sum_out. */
+int univs_layer_norm_add_f32(const float* x, const float* residual, const float* gamma, const float* beta, const float* addend,
+                             long long addend_rows, long long rows, int C, float eps, float* sum_out, float* out, float* out2,
+                             void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm (+ optional ReLU) on NCHW tensors.
  * Replaces: detectron2 Conv2d(..., norm=GroupNorm(32, C)[, activation=F.relu]) epilogues of the pixel

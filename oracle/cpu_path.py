@@ -58,9 +58,11 @@ def bilinear_resample(x, size, addend=None):
     return y if addend is None else addend + y
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, post_add=None):
     s = x if residual is None else x + residual
     out = torch.nn.functional.layer_norm(s, (x.shape[-1],), weight, bias, eps)
+    if post_add is not None:
+        return out, out + post_add
     return (s, out) if return_sum else out
 
 

@@ -597,3 +597,22 @@ def test_conv3x3_matches_torch(cuda, T, Cin, Cout, H, W):
     assert err < max(4.0 * err32, 5e-6), (err, err32)
     assert ops.conv3x3(torch.zeros(1, 96, 64, 64, device=cuda), torch.zeros(64, 96, 3, 3, device=cuda)) is None   # Cin % 128
     assert ops.conv3x3(torch.zeros(1, 128, 16, 16, device=cuda), torch.zeros(128, 128, 3, 3, device=cuda)) is None  # < 4096 pixels
+
+
+def test_layer_norm_second_output(cuda):
+    """ops.layer_norm(..., post_add=p) == (LayerNorm(x + r), LayerNorm(x + r) + p): the encoder's norm2 and the next layer's
+    `src + pos` from one pass."""
+    x = synth.normal("ln2/x", (3, 1000, 256)).to(cuda)
+    r = synth.normal("ln2/r", (3, 1000, 256)).to(cuda)
+    p = synth.normal("ln2/p", (3, 1000, 256)).to(cuda)
+    w = synth.normal("ln2/w", (256,)).to(cuda)
+    b = synth.normal("ln2/b", (256,)).to(cuda)
+    out, out2 = ops.layer_norm(x, w, b, 1e-5, residual=r, post_add=p)
+    ref = ops.layer_norm(x, w, b, 1e-5, residual=r)
+    assert torch.equal(out, ref) and torch.equal(out2, ref + p)
+    out, out2 = ops.layer_norm(x, w, b, 1e-5, residual=r, post_add=p[:1])          # [1, S, C] repeated over the batch
+    assert torch.equal(out, ref) and torch.equal(out2, ref + p[:1])
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(x, w, b, 1e-5, post_add=p)
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(x, w, b, 1e-5, residual=r, post_add=p[:, :1])                  # broadcast over rows: not covered

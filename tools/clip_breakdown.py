@@ -18,6 +18,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
     return name[:110]

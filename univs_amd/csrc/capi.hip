@@ -51,8 +51,8 @@ int msda_backward_f32(const float*, const LevelTable&, const float*, const float
 int msda_prepare_f32(const float*, int, int, const float*, long long, const LevelTable&, int, int, int, int, int,
                      float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
-int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*,
-                   hipStream_t);
+int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
+                   long long, hipStream_t);
 int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
                    float*, hipStream_t);
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
@@ -354,21 +354,30 @@ int univs_bilinear_resample_f32(const float* in, const float* addend, float* out
   return bilinear_resample_f32(in, addend, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
 }
 
-int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
-                         long long rows, int C, float eps, float* sum_out, float* out, void* stream) {
+int univs_layer_norm_add_f32(const float* x, const float* residual, const float* gamma, const float* beta, const float* addend,
+                             long long addend_rows, long long rows, int C, float eps, float* sum_out, float* out, float* out2,
+                             void* stream) {
   clear_sticky_error();
   if (rows < 0 || C < 1) {
     set_error("univs_layer_norm_f32: bad dimensions rows=%lld C=%d", rows, C);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (rows == 0) return UNIVS_OK;
-  if (!x || !gamma || !beta || !out || (sum_out && !residual)) {
-    set_error("univs_layer_norm_f32: NULL data pointer (sum_out needs a residual)");
+  if (!x || !gamma || !beta || !out || (sum_out && !residual) || ((addend != nullptr) != (out2 != nullptr)) ||
+      (addend && (!residual || sum_out || addend_rows < 1 || rows % addend_rows != 0))) {
+    set_error("univs_layer_norm_f32: NULL data pointer (sum_out needs a residual; addend / out2 come together, with a residual, "
+              "without sum_out; rows must be a multiple of addend_rows)");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = layer_norm_f32(x, residual, gamma, beta, rows, C, eps, sum_out, out, static_cast<hipStream_t>(stream));
+  const int rc = layer_norm_f32(x, residual, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend ? addend_rows : 1,
+                                static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_layer_norm_f32: C=%d not supported (C %% 4 == 0, C <= 3072)", C);
   return rc;
+}
+
+int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                         long long rows, int C, float eps, float* sum_out, float* out, void* stream) {
+  return univs_layer_norm_add_f32(x, residual, gamma, beta, nullptr, 1, rows, C, eps, sum_out, out, nullptr, stream);
 }
 
 int univs_group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW,

@@ -23,13 +23,16 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // NV: 16-B chunks per lane; G: lanes per row.  C % 4 == 0, C <= 4 * G * NV.
-template <int G, int NV, bool HAS_RES, bool WRITE_SUM>
+// POST_ADD: a second output out2 = y + addend (the encoder layer's `src + pos` for the next layer's query,
+// msdeformattn.py:61-63, 85-95: the normalised row is still in registers).
+template <int G, int NV, bool HAS_RES, bool WRITE_SUM, bool POST_ADD = false>
 __global__ __launch_bounds__(256) void layer_norm_f32_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ res,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int C,
                                                              float eps, float* __restrict__ sum_out,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, const float* __restrict__ addend = nullptr,
+                                                             float* __restrict__ out2 = nullptr, long long addend_rows = 1) {
   constexpr int RPB = 256 / G;   // rows per block
   const int sub = threadIdx.x / G, lane = threadIdx.x % G;
   const int nchunk = C / 4;
@@ -65,7 +68,10 @@ __global__ __launch_bounds__(256) void layer_norm_f32_kernel(const float* __rest
       const int c = lane + j * G;
       if (c < nchunk) {
         const v4f g = reinterpret_cast<const v4f*>(gamma)[c], b = reinterpret_cast<const v4f*>(beta)[c];
-        reinterpret_cast<v4f*>(out + row * C)[c] = (v[j] - mean) * rstd * g + b;
+        const v4f y = (v[j] - mean) * rstd * g + b;
+        reinterpret_cast<v4f*>(out + row * C)[c] = y;
+        // (the addend may have fewer rows than x: [1, S, C] position embeddings against [N, S, C] tokens)
+        if (POST_ADD) reinterpret_cast<v4f*>(out2 + row * C)[c] = y + reinterpret_cast<const v4f*>(addend + (row % addend_rows) * C)[c];
       }
     }
   }
@@ -73,31 +79,37 @@ __global__ __launch_bounds__(256) void layer_norm_f32_kernel(const float* __rest
 
 template <int G, int NV>
 static void launch_ln(const float* x, const float* res, const float* gamma, const float* beta, long long rows, int C,
-                      float eps, float* sum_out, float* out, hipStream_t st) {
+                      float eps, float* sum_out, float* out, const float* addend, float* out2, long long addend_rows, hipStream_t st) {
   constexpr int RPB = 256 / G;
   const long long want = (rows + RPB - 1) / RPB;
   const unsigned grid = (unsigned)(want < 256LL * 32 ? want : 256LL * 32);   // grid-stride beyond 32 blocks per CU
 #define UNIVS_LN_LAUNCH(R, S) \
   hipLaunchKernelGGL((layer_norm_f32_kernel<G, NV, R, S>), dim3(grid), dim3(256), 0, st, x, res, gamma, beta, rows, C, eps, sum_out, out)
-  if (res && sum_out) UNIVS_LN_LAUNCH(true, true);
+  if (addend && res && !sum_out) {
+    hipLaunchKernelGGL((layer_norm_f32_kernel<G, NV, true, false, true>), dim3(grid), dim3(256), 0, st, x, res, gamma, beta, rows, C, eps,
+                       sum_out, out, addend, out2, addend_rows);
+  } else if (res && sum_out) UNIVS_LN_LAUNCH(true, true);
   else if (res) UNIVS_LN_LAUNCH(true, false);
   else UNIVS_LN_LAUNCH(false, false);
 #undef UNIVS_LN_LAUNCH
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED for row lengths this kernel does not cover
+// addend / out2 (both or neither): the second output y + addend; only together with `res` and without `sum_out`
 int layer_norm_f32(const float* x, const float* res, const float* gamma, const float* beta, long long rows, int C,
-                   float eps, float* sum_out, float* out, hipStream_t st) {
+                   float eps, float* sum_out, float* out, const float* addend, float* out2, long long addend_rows, hipStream_t st) {
   const int nchunk = C / 4;
   if (C % 4 != 0 || nchunk > 64 * 12) return UNIVS_ERR_NOT_IMPLEMENTED;
-  if (nchunk <= 32) launch_ln<32, 1>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 64) launch_ln<64, 1>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 128) launch_ln<64, 2>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 192) launch_ln<64, 3>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 256) launch_ln<64, 4>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 384) launch_ln<64, 6>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else if (nchunk <= 512) launch_ln<64, 8>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
-  else launch_ln<64, 12>(x, res, gamma, beta, rows, C, eps, sum_out, out, st);
+  if ((addend != nullptr) != (out2 != nullptr) || (addend && (!res || sum_out || addend_rows < 1 || rows % addend_rows != 0)))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  if (nchunk <= 32) launch_ln<32, 1>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 64) launch_ln<64, 1>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 128) launch_ln<64, 2>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 192) launch_ln<64, 3>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 256) launch_ln<64, 4>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 384) launch_ln<64, 6>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else if (nchunk <= 512) launch_ln<64, 8>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
+  else launch_ln<64, 12>(x, res, gamma, beta, rows, C, eps, sum_out, out, addend, out2, addend_rows, st);
   return check_launch("layer_norm_f32");
 }
 

@@ -146,11 +146,11 @@ class MLP(nn.Module):
         return x
 
 
-def layer_norm(norm, x, residual=None, return_sum=False):
+def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
     """`norm(x)` / `norm(x + residual)` for an nn.LayerNorm module through the HIP operator (the module
-    only holds the parameters, so the state-dict layout is the reference's)."""
+    only holds the parameters, so the state-dict layout is the reference's); `post_add`: see ops.layer_norm."""
     from . import ops
-    return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, residual=residual, return_sum=return_sum)
+    return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, residual=residual, return_sum=return_sum, post_add=post_add)
 
 
 # UNIVS_SPLIT_LINEAR: 0 = library GEMMs only, 1 (default) = the MSDeformAttn token projections + encoder FFN through the

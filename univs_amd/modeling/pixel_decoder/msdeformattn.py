@@ -119,13 +119,19 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        src2 = self.self_attn(src if pos is None else src + pos, reference_points, src, spatial_shapes,
-                              level_start_index, padding_mask)
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, query=None,
+                want_next_query=False):
+        """`query` = `src + pos` when the caller already has it (the previous layer's norm2 pass made it);
+        `want_next_query`: also return `out + pos` for the next layer (same pass as norm2)."""
+        if query is None:
+            query = src if pos is None else src + pos
+        src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = layer_norm(self.norm1, src2, residual=src)
-        src = layer_norm(self.norm2, linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias),
-                         residual=src)
-        return src
+        ffn = linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias)
+        if want_next_query and pos is not None and src.is_cuda:
+            return layer_norm(self.norm2, ffn, residual=src, post_add=pos)
+        src = layer_norm(self.norm2, ffn, residual=src)
+        return (src, None) if want_next_query else src
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -151,9 +157,13 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         return reference_points[:, :, None].expand(-1, -1, len(spatial_shapes), -1).contiguous()
 
     def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None):
-        output = src
-        for layer in self.layers:
-            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, None)
+        output, query = src, None
+        for i, layer in enumerate(self.layers):
+            if i + 1 < self.num_layers:
+                output, query = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query,
+                                      want_next_query=True)
+            else:
+                output = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query)
         return output
 
 

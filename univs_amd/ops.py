@@ -369,11 +369,13 @@ def transpose_last2(x):
     return out
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, post_add=None):
     """LayerNorm over the last dimension of contiguous float32 `x` on the GPU, optionally of
     `x + residual` (and then optionally also returning that sum): nn.LayerNorm in the Swin blocks
     (swin.py:236-262), encoder layers (msdeformattn.py:61-95) and decoder layers.
-    Returns `out` or `(x + residual, out)`."""
+    `post_add` (with a residual, without return_sum): additionally returns `out + post_add` -- the encoder's
+    `with_pos_embed(src, pos)` for the next layer, from the same pass.
+    Returns `out`, `(x + residual, out)` or `(out, out + post_add)`."""
     x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()   # views (e.g. NCHW -> tokens) are copied once
     _inference_only("layer_norm", x, weight, bias, residual)
     _require_gpu("layer_norm", x, weight, bias)
@@ -392,6 +394,25 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
     out = torch.empty_like(x)
     s = torch.empty_like(x) if return_sum else None
     rows = x.numel() // max(C, 1)
+    if post_add is not None:
+        if residual is None or return_sum:
+            raise RuntimeError("layer_norm: post_add needs a residual and excludes return_sum")
+        post_add = post_add.contiguous()
+        _require_gpu("layer_norm", post_add)
+        # same shape, or broadcast over the leading dimensions ([1, S, C] position embeddings against [N, S, C] tokens)
+        arows = post_add.numel() // max(C, 1)
+        lead = x.dim() - post_add.dim()
+        ok = (post_add.dtype == torch.float32 and lead >= 0 and post_add.shape[-1] == C and rows % max(arows, 1) == 0
+              and all(a == b or (i < post_add.dim() - 1 and all(int(d) == 1 for d in post_add.shape[:i + 1]))
+                      for i, (a, b) in enumerate(zip(post_add.shape, x.shape[lead:]))))
+        if not ok:
+            raise RuntimeError("layer_norm: post_add must match x or broadcast over its leading dimensions")
+        out2 = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().univs_layer_norm_add_f32(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(post_add), arows, rows,
+                                                      C, float(eps), None, _ptr(out), _ptr(out2), _stream_ptr(x))
+        _lib.check(rc, "layer_norm")
+        return out, out2
     with torch.cuda.device(x.device):
         rc = _lib.load().univs_layer_norm_f32(_ptr(x), _ptr(residual) if residual is not None else None,
                                              _ptr(weight.contiguous()), _ptr(bias.contiguous()), rows, C, float(eps),
