@@ -585,7 +585,9 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
       (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
     return 0;
   static const int wide_kmin = [] { const char* e = getenv("UNIVS_LS_WIDE_KMIN"); return e && *e ? atoi(e) : 768; }();
-  if (K >= wide_kmin) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,
+  // (... except the one K = 768 shape with many rows and few features, Swin stage 2's fc2 at 73 600 x 768 -> 192: 203 us
+  // W-stationary against 221 us)
+  if (K >= wide_kmin && !(K == 768 && M >= 32768 && N <= 256)) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,
                     // 133 / 47 / 167 us against 159 / 61 / 228 us for the stage-4 qkv / proj / fc1 at K = 768)
     const int rc = linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);
     if (rc != 0 || K > 768) return rc;
