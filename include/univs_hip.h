@@ -125,7 +125,8 @@ int univs_msda_last_tiled_generation(void);
  * 3-way split of both operands (error <= 3 * 2^-24 per product, i.e. fp32 rounding level).
  * Covered: K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31, at
  * least 16 output features of K fit the LDS (K <= 1664); anything else returns UNIVS_ERR_NOT_IMPLEMENTED without touching
- * y (the caller keeps its library GEMM).  bias may be NULL. */
+ * y (the caller keeps its library GEMM).  bias may be NULL.  Finite inputs only: the 3-way split of +-Inf is Inf - Inf,
+ * so an infinite operand yields NaN where an fp32 GEMM yields Inf. */
 int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                            int relu, float* y, void* stream);
 

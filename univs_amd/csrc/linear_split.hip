@@ -119,6 +119,10 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
       dst[2] = __builtin_bit_cast(u32x4, l);
     }
     for (int r = tid; r < R; r += LS_THREADS) bias_lds[r] = bias ? bias[n0 + r] : 0.f;
+    // Feature blocks of a SHORT last pass (R < rows_per_pass) read A fragments for rows >= R: those addresses belong to the
+    // next k-group's rows, and for the last k-group to the bias area and up to 16 rows x 48 B behind it.  Their products
+    // only reach features that are never stored (the f < R guard); zero the tail so that they are at least finite.
+    for (int i = tid; i < 16 * 3 * 4; i += LS_THREADS) reinterpret_cast<unsigned*>(bias_lds + R)[i] = 0u;
   }
   __syncthreads();   // the only barrier
   if (ntiles == 0) return;
@@ -592,7 +596,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
     const int rc = linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);
     if (rc != 0 || K > 768) return rc;
   }
-  const long long lds_cap = 160 * 1024 - 512;
+  const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + the zeroed tail (see the staging loop)
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);
   r_cap -= r_cap % 4;
   if (r_cap < 16) return 0;
@@ -619,7 +623,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   // (... unless rounding down to a multiple of 8 would idle more than a tenth of the CUs: 17 passes -> 15 row ranges,
   // not 8; the passes of a row range then sit on different XCDs and x comes from the memory-side cache instead of L2)
   if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;
-  const size_t lds = (size_t)K * rows * 6 + 512;
+  const size_t lds = (size_t)K * rows * 6 + 4 * (size_t)rows + 16 * 48 + 16;
   dim3 grid((unsigned)gx, (unsigned)passes), block(LS_THREADS);
 #define UNIVS_LS(rb, ksc, rg, ep)                                                                                        \
   do {                                                                                                                   \
