@@ -101,3 +101,29 @@ def test_inference_only_operators_refuse_to_drop_gradients():
     y = layers.linear(big, lin.weight, lin.bias)
     y.sum().backward()
     assert big.grad is not None and lin.weight.grad is not None
+
+
+def test_round2_operator_wrappers_on_cpu_tensors():
+    """The fused Linear / convolution wrappers hand CPU tensors back to their callers (None = "keep your own Linear"),
+    the transpose helper falls back to ATen, and the modules built on them give the ATen result on the CPU."""
+    import torch
+
+    from oracle import cpu_path
+    from univs_amd import ops
+    from univs_amd.modeling.backbone.swin import Mlp
+    x = torch.randn(4, 2048, 96)
+    w = torch.randn(288, 96)
+    assert ops.linear_fused(x, w, None) is None
+    assert ops.linear_fused(x, w, None, act="gelu") is None
+    assert ops.conv3x3(torch.randn(1, 128, 64, 64), torch.randn(128, 128, 3, 3)) is None
+    t = torch.randn(2, 8, 12)
+    assert torch.equal(ops.transpose_last2(t), t.transpose(1, 2).contiguous())
+    mlp = Mlp(96, 384).eval()
+    with torch.no_grad():
+        want = x + mlp.fc2(torch.nn.functional.gelu(mlp.fc1(x)))
+        assert torch.equal(mlp(x, residual=x), want)
+        # the oracle stand-in of the LayerNorm with a second output
+        g, b, r, p = torch.randn(96), torch.randn(96), torch.randn(4, 2048, 96), torch.randn(1, 2048, 96)
+        out, out2 = cpu_path.layer_norm(x, g, b, 1e-5, residual=r, post_add=p)
+        ref = torch.nn.functional.layer_norm(x + r, (96,), g, b, 1e-5)
+        assert torch.equal(out, ref) and torch.equal(out2, ref + p)
