@@ -323,8 +323,9 @@ def main():
         fused = True
     if n:
         gens = set(t_msda.notes.get("all", []))
-        gen = 3 if fused else (max(gens) if gens else 0)
-        kname = {3: "msda_fwd_tiled3 (MSDeformAttn forward: LDS-tiled, register records + DPP gathers, fill waves)",
+        gen = (4 if os.environ.get("UNIVS_MSDA_TILED", "") == "4" else 3) if fused else (max(gens) if gens else 0)
+        kname = {4: "msda_fwd_tiled4 (MSDeformAttn forward: strips with resident row-circular windows, a lane owns a sample)",
+                 3: "msda_fwd_tiled3 (MSDeformAttn forward: LDS-tiled, register records + DPP gathers, fill waves)",
                  2: "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)",
                  1: "msda_fwd_tiled<3> (MSDeformAttn forward: LDS-tiled, single window)"}.get(gen, "msda_fwd_vec4 (generic)")
         res["roofline"] = {"kernel": kname + (" + fused msda_prepare" if fused else ""), "bound": "hbm",
