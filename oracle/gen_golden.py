@@ -366,6 +366,65 @@ LOOP_STATE_KEYS = ("logits", "masks", "mask_logits", "boxes", "embds", "ids", "f
                    "frame_indices")
 
 
+def _capture_sampler_draws(enc, store):
+    """Record, inside the unmodified reference, WHICH pixels every `get_mask_prompt` call (prompt_encoder.py:168-263) samples:
+    the point chosen by `select_points_from_box_mask` (:420,424: `randperm` over the entity's candidate pixels) as a flat
+    index y * w + x of the full-resolution mask, and the `num_dense_points` feature-map pixels chosen by
+    `get_dense_features` (:471-481: all pixels cyclically for small masks, `randperm(count)[:R]` otherwise) as flat indices
+    (-1 = empty mask).  The draw SIZES are pixel counts, so a fp32 implementation whose mask differs in one near-threshold
+    pixel cannot reproduce the draws from the seed; replaying the sampled pixels removes that discontinuity."""
+    orig_gmp, orig_sel, orig_gdf = enc.get_mask_prompt, enc.select_points_from_box_mask, enc.get_dense_features
+    state = {}
+
+    def sel(h_img, w_img, boxes=None, masks=None, **k):
+        pc = orig_sel(h_img, w_img, boxes=boxes, masks=masks, **k)
+        if masks is not None:
+            h, w = masks.shape[-2:]
+            x = torch.round(pc[:, 0] * w - 0.5).long()
+            y = torch.round(pc[:, 1] * h - 0.5).long()
+            assert ((x + 0.5) / w - pc[:, 0]).abs().max() < 1e-6 and ((y + 0.5) / h - pc[:, 1]).abs().max() < 1e-6
+            state["point_idx"] = (y * w + x).to(torch.int32)
+        return pc
+
+    def gdf(img_features, img_pos, masks_binary, query_pe, query_feats, **k):
+        perms = []
+        orig_rp = torch.randperm
+
+        def rp(n, *a, **kw):
+            p_ = orig_rp(n, *a, **kw)
+            perms.append(p_.clone())
+            return p_
+        torch.randperm = rp
+        try:
+            out = orig_gdf(img_features, img_pos, masks_binary, query_pe, query_feats, **k)
+        finally:
+            torch.randperm = orig_rp
+        R = enc.num_dense_points
+        it = iter(perms)
+        rows = []
+        for m in masks_binary:
+            fi = torch.nonzero(m.flatten()).reshape(-1)
+            if len(fi) == 0:
+                rows.append(torch.full((R,), -1, dtype=torch.long))
+            elif len(fi) < R:
+                rows.append(fi.repeat(int(R / len(fi)) + 1)[:R])
+            else:
+                rows.append(fi[next(it)[:R]])
+        fidx = torch.stack(rows)
+        feats = img_features.flatten(-2).t()
+        ok = fidx[:, 0] >= 0
+        assert torch.equal(out[0][ok][:, :, 0], feats[fidx[ok]]), "restated dense-token indices do not reproduce the reference"
+        state["feat_idx"] = fidx.to(torch.int32)
+        return out
+
+    def gmp(*a, **k):
+        state.clear()
+        out = orig_gmp(*a, **k)
+        store.append((state["point_idx"].clone(), state["feat_idx"].clone()))
+        return out
+    enc.get_mask_prompt, enc.select_points_from_box_mask, enc.get_dense_features = gmp, sel, gdf
+
+
 def _ref_loop(case, model, **over):
     RI = rh.ref_inference()
     kw = cases.loop_kwargs(case, **over)
@@ -389,11 +448,19 @@ def _ref_loop(case, model, **over):
                 else:
                     dumps[f"{tag}_{k}"] = tv[k].detach().clone().float() if tv[k].dtype == torch.bool else tv[k].detach().clone()
 
+    draws, draws_clip = [], []
+    pred = getattr(head, "predictor", None)
+    if pred is not None and getattr(pred, "visual_prompt_sampler", None) is not None:
+        _capture_sampler_draws(pred.visual_prompt_sampler.visual_prompt_encoder, draws)
+
     def hooked(features, targets=None, **k):
         snapshot(f"clip{len(calls)}_in", targets[0])
         calls.append(int(targets[0]["first_frame_idx"]))
         print("      clip at frame", calls[-1], file=sys.stderr, flush=True)
-        return head(features, targets=targets, **k)
+        n0 = len(draws)
+        res = head(features, targets=targets, **k)
+        draws_clip.extend([len(calls) - 1] * (len(draws) - n0))
+        return res
     model = types.SimpleNamespace(backbone=model.backbone, sem_seg_head=hooked)
     x = cases.preprocess(cases.loop_frames(case))
     images = types.SimpleNamespace(tensor=x, image_sizes=[case["image_size"]] * case["n_frames"])
@@ -404,6 +471,12 @@ def _ref_loop(case, model, **over):
         inf.inference_video(model, cases.loop_batched_inputs(case), images, targets)
     snapshot("final", targets[0])
     dumps["clip_first_frames"] = torch.tensor(calls)
+    if draws:
+        # the sampler's draws of every get_mask_prompt call, in call order (see _capture_sampler_draws)
+        dumps["draws_n"] = torch.tensor([len(p_) for p_, _ in draws], dtype=torch.int32)
+        dumps["draws_clip"] = torch.tensor(draws_clip, dtype=torch.int32)
+        dumps["draws_point_idx"] = torch.cat([p_ for p_, _ in draws])
+        dumps["draws_feat_idx"] = torch.cat([f_ for _, f_ in draws])
     return dumps
 
 
@@ -575,6 +648,102 @@ def g14_cfg4_full_size():
     if out.get("pred_reid_logits") is not None and isinstance(out["pred_reid_logits"], torch.Tensor):
         d["pred_reid_logits"] = out["pred_reid_logits"]
     save("g14_cfg4_full_size", **d)
+
+
+@gen
+def g2_msdeformattn_layer():
+    """ONE `MSDeformAttn.forward` (ops/modules/ms_deform_attn.py:82-121) and ONE encoder layer
+    (msdeformattn.py:124-133) in isolation, captured with hooks on encoder layer 2 of the reference pixel decoder while
+    it runs on HEAD_CASE's backbone features: inputs (src, pos, reference points, level table) and outputs."""
+    R = rh.ref()
+    pd, _ = _ref_pixel_decoder(R, cases.HEAD_CASE["shapes"])
+    LAYER = 2
+    layer = pd.transformer.encoder.layers[LAYER]
+    d = {}
+
+    def layer_pre(mod, args, kwargs):
+        names = ("src", "pos", "reference_points", "spatial_shapes", "level_start_index")
+        for k, v in list(zip(names, args)) + list(kwargs.items()):
+            if isinstance(v, torch.Tensor) and k in names:
+                d["g2_" + k] = v.detach().clone()
+
+    def attn_pre(mod, args, kwargs):
+        d["g2_attn_query"] = args[0].detach().clone()
+
+    def attn_post(mod, args, out):
+        d["g2_attn_out"] = out.detach().clone()
+
+    def layer_post(mod, args, out):
+        d["g2_layer_out"] = out.detach().clone()
+
+    hs = [layer.register_forward_pre_hook(layer_pre, with_kwargs=True), layer.register_forward_hook(layer_post),
+          layer.self_attn.register_forward_pre_hook(attn_pre, with_kwargs=True), layer.self_attn.register_forward_hook(attn_post)]
+    pd.forward_features(cases.backbone_features())
+    for h in hs:
+        h.remove()
+    d["g2_layer"] = torch.tensor(LAYER)
+    assert {"g2_src", "g2_pos", "g2_reference_points", "g2_attn_out", "g2_layer_out"} <= set(d), sorted(d)
+    save("g2_msdeformattn_layer", **d)
+
+
+CFG4_NEAR_EPS = 1e-2      # |resized mask logit| below this is "near the attention-mask threshold"
+
+
+@gen
+def g14b_cfg4_attn_masks():
+    """Teacher-forcing data for BASELINE config 4 (the run of g14): inside the unmodified reference decoder,
+      * the bool attention mask every decoder layer actually used -- `memory_mask` of its cross-attention AFTER the
+        all-True-row reset (...decoder_univs.py:390, :400-405), head 0 of every frame (the reference repeats it over the 8
+        heads, :565), bit-packed along the key axis;
+      * for every prediction-head call, the entries whose resized mask logit (:555-566, before `sigmoid < 0.5`) lies
+        within CFG4_NEAR_EPS of the threshold: flat index into [T, Q', HW_l] and the reference's value.  A free-running
+        fp32 implementation may put exactly these entries on the other side; the GPU test names them.
+    Also the outputs again (same reduction as g14) so that the file is self-contained."""
+    import torch.nn.functional as F
+    R = rh.ref()
+    case = cases.CFG4
+    swin = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_B)
+    swin.eval()
+    synth.load_synthetic(swin, prefix="backbone.")
+    head = _ref_head(R, case, **cases.CFG4_DECODER)
+    dec = head.predictor
+    nh = dec.num_heads
+    d = {}
+    calls = {"n": 0}
+    orig_heads = dec.forward_prediction_heads
+
+    def heads_hook(output, mask_features, attn_mask_target_size, task, targets):
+        res = orig_heads(output, mask_features, attn_mask_target_size=attn_mask_target_size, task=task, targets=targets)
+        k = calls["n"]
+        calls["n"] += 1
+        om = res[1]                                                     # [b, q, t, H, W]
+        b = om.shape[0]
+        lr = F.interpolate(om.flatten(0, 1), size=attn_mask_target_size, mode="bilinear", align_corners=False)
+        lr = lr.view(b, om.shape[1], om.shape[2], -1).permute(0, 2, 1, 3).flatten(0, 1)      # [(b t), q, hw]
+        assert torch.equal(lr.sigmoid() < 0.5, res[2][0::nh]), "restated resize does not reproduce the reference's mask"
+        near = (lr.abs() < CFG4_NEAR_EPS).flatten().nonzero().flatten()
+        d[f"call{k}_near_idx"] = near.to(torch.int32)
+        d[f"call{k}_near_val"] = lr.flatten()[near].clone()
+        d[f"call{k}_shape"] = torch.tensor(list(lr.shape))
+        print(f"      heads call {k}: target {tuple(attn_mask_target_size)}, {near.numel()} entries within {CFG4_NEAR_EPS}", file=sys.stderr)
+        return res
+
+    dec.forward_prediction_heads = heads_hook
+    hooks = []
+    for i, layer in enumerate(dec.transformer_cross_attention_layers):
+        def cross_pre(mod, args, kwargs, i=i):
+            m = kwargs["memory_mask"].detach()[0::nh]                   # [T, Q', HW_l] bool, rows already reset
+            d[f"layer{i}_attn_mask_bits"] = torch.from_numpy(np.packbits(m.numpy(), axis=-1))
+            d[f"layer{i}_attn_mask_shape"] = torch.tensor(list(m.shape))
+        hooks.append(layer.register_forward_pre_hook(cross_pre, with_kwargs=True))
+    x = cases.preprocess(cases.cfg2_frames())
+    out = head(swin(x), targets=cases.cfg4_targets(case))
+    for h in hooks:
+        h.remove()
+    pm = out["pred_masks"]
+    d["pred_masks_s"] = pm[0, :, :, ::16, ::16]
+    d["near_eps"] = torch.tensor(CFG4_NEAR_EPS)
+    save("g14b_cfg4_attn_masks", **d)
 
 
 @gen

@@ -130,3 +130,24 @@ def check_g4_g5(head, g, device, ops):
     o = dec.transformer_ffn_layers[i](o.reshape(Qn, bt, C))
     err = np.abs(o.cpu().numpy() - g["g5_output_out"]).max()
     assert err < 1e-4, ("g5", err)
+
+
+def check_g2(pd, g, device, tol=2e-5):
+    """ONE `MSDeformAttn.forward` (ops/modules/ms_deform_attn.py:82-121) and ONE encoder layer
+    (msdeformattn.py:124-133) in isolation, against tensors captured with hooks inside the reference pixel decoder
+    (oracle/gen_golden.py:g2_msdeformattn_layer).  `pd` is our MSDeformAttnPixelDecoder on `device`."""
+    i = int(g["g2_layer"])
+    layer = pd.transformer.encoder.layers[i]
+    src = torch.from_numpy(g["g2_src"]).to(device)
+    pos = torch.from_numpy(g["g2_pos"]).to(device)
+    ref_pts = torch.from_numpy(g["g2_reference_points"]).to(device)
+    shapes = [tuple(int(v) for v in hw) for hw in g["g2_spatial_shapes"]]
+    lsi = [int(v) for v in g["g2_level_start_index"]]
+    query = torch.from_numpy(g["g2_attn_query"]).to(device)
+    assert np.abs((src + pos).cpu().numpy() - g["g2_attn_query"]).max() == 0
+    attn = layer.self_attn(query, ref_pts, src, shapes, lsi, None)
+    e1 = np.abs(attn.cpu().numpy() - g["g2_attn_out"]).max()
+    out = layer(src, pos, ref_pts, shapes, lsi, None)
+    e2 = np.abs(out.cpu().numpy() - g["g2_layer_out"]).max()
+    assert e1 < tol and e2 < tol, (e1, e2)
+    return e1, e2

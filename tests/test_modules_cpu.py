@@ -149,3 +149,11 @@ def test_swin_b_window12_matches_reference(golden_dir):
     for k in ("res2", "res3", "res4", "res5"):
         err = np.abs(out[k][:, ::2].numpy() - g[k]).max()
         assert err < 5e-4, (k, err)
+
+
+def test_g2_msdeformattn_layer_matches_reference(golden_dir):
+    """Appendix B G2 on the CPU oracle path: one MSDeformAttn.forward + one encoder layer in isolation."""
+    g = _g(golden_dir, "g2_msdeformattn_layer")
+    pd = helpers.build_pixel_decoder(cases.HEAD_CASE["shapes"])
+    with cpu_ops(), torch.no_grad():
+        helpers.check_g2(pd, g, "cpu")

@@ -84,6 +84,18 @@ def test_g4_g5_prediction_heads_and_teacher_forced_layer(cuda, golden_dir):
         helpers.check_g4_g5(head, g, cuda, ops)
 
 
+def test_g2_msdeformattn_layer_matches_reference(cuda, golden_dir):
+    """SURVEY.md Appendix B G2 through the HIP operators: ONE MSDeformAttn.forward (value / offset / weight projections,
+    fused input preparation + LDS-tiled sampling kernel, output projection) and ONE encoder layer in isolation, against
+    tensors captured inside the reference pixel decoder."""
+    g = _g(golden_dir, "g2_msdeformattn_layer")
+    pd = helpers.build_pixel_decoder(cases.HEAD_CASE["shapes"], cuda)
+    with torch.no_grad():
+        e1, e2 = helpers.check_g2(pd, g, cuda, tol=1e-4)
+    assert ops.msda_last_impl() == 2, "the LDS-tiled MSDA kernel must be the one that ran"
+    print(f"G2: MSDeformAttn.forward max-abs-err {e1:.2e}, encoder layer {e2:.2e}")
+
+
 def test_config2_full_size_against_reference(cuda, golden_dir):
     """BASELINE config 2 (Swin-T, T=5 @ 720p -> 736x1280, 100 queries, first clip): every stage against
     strided samples / checksums of the reference's own CPU run (g12)."""
@@ -186,42 +198,134 @@ def test_clip_loop_on_device_matches_reference(cuda, golden_dir):
     assert len(results) == 1 and results[0][0]["masks"].shape[-2:] == case["image_size"]
 
 
-def test_config4_full_size_against_reference(cuda, golden_dir):
-    """BASELINE config 4 (Swin-B window 12, grounding with 4 expressions 'sep-blocked', 200 queries, T=5 @ 720p):
-    every stage against strided samples / checksums of the reference's own CPU run (g14)."""
-    path = os.path.join(golden_dir, "g14_cfg4_full_size.npz")
-    if not os.path.exists(path):
-        pytest.skip("g14 golden not generated")
-    g = np.load(path)
+def _cfg4_run(cuda, attn_hook=None):
+    """Config 4 at full size through the HIP path; `attn_hook(call_index, our_mask) -> mask to use` wraps the fused
+    attention-mask operator (ops.mask_decode_attn: one call per prediction head, 10 per clip)."""
     case = cases.CFG4
     swin = helpers.build_swin(cuda, variant=cases.SWIN_B)
     head = helpers.build_head(case, cuda, return_aux=False, **cases.CFG4_DECODER)
     x = cases.preprocess(cases.cfg2_frames()).to(cuda)
-    with torch.no_grad():
-        feats = swin(x)
-        out = head(feats, targets=_targets_to(cases.cfg4_targets(case), cuda))
+    orig = ops.mask_decode_attn
+    calls = {"n": 0}
+
+    def hooked(e, f):
+        m = orig(e, f)
+        k = calls["n"]
+        calls["n"] += 1
+        return m if attn_hook is None else attn_hook(k, m)
+    ops.mask_decode_attn = hooked
+    try:
+        with torch.no_grad():
+            feats = swin(x)
+            out = head(feats, targets=_targets_to(cases.cfg4_targets(case), cuda))
+    finally:
+        ops.mask_decode_attn = orig
+    assert calls["n"] == 10
+    return feats, out
+
+
+def _cfg4_ref_mask(gm, i):
+    shape = tuple(int(v) for v in gm[f"layer{i}_attn_mask_shape"])
+    return np.unpackbits(gm[f"layer{i}_attn_mask_bits"], axis=-1, count=shape[-1]).astype(bool).reshape(shape)
+
+
+def test_config4_teacher_forced_attention_masks(cuda, golden_dir):
+    """BASELINE config 4 with the reference's OWN per-layer bool attention masks supplied (g14b: `memory_mask` of every
+    decoder layer's cross-attention, captured inside the unmodified reference, ...decoder_univs.py:390,400-405,555-566).
+    With the mask threshold's discontinuity taken out, the north star's bound holds with no escape clause:
+    ALL 204 queries within 1e-3 max-abs of the reference's mask logits, no sign flips."""
+    gm = _g(golden_dir, "g14b_cfg4_attn_masks")
+    case = cases.CFG4
+
+    def force(k, ours):
+        if k >= 9:                      # the last head's attention mask is not consumed
+            return ours
+        ref = torch.from_numpy(_cfg4_ref_mask(gm, k)).to(ours.device)
+        assert ref.shape == ours.shape
+        return ref
+    feats, out = _cfg4_run(cuda, force)
+    pm = out["pred_masks"]
+    assert pm.shape[1] == case["Q"] + case["n_exp"]
+    ref_s = gm["pred_masks_s"]
+    got_s = pm[0, :, :, ::16, ::16].cpu().numpy()
+    per_q = np.abs(got_s - ref_s).reshape(got_s.shape[0], -1).max(1)
+    flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
+    print(f"cfg4 teacher-forced: max-abs-err {per_q.max():.3e} (query {int(per_q.argmax())}), queries over 5e-4: "
+          f"{int((per_q > 5e-4).sum())} of {len(per_q)}, sign flips {int(flips.sum())}")
+    assert per_q.max() < 1e-3, (int(per_q.argmax()), float(per_q.max()))
+    assert flips.sum() == 0
+
+
+def test_config4_full_size_against_reference(cuda, golden_dir):
+    """BASELINE config 4 (Swin-B window 12, grounding with 4 expressions 'sep-blocked', 200 queries, T=5 @ 720p), FREE
+    RUNNING: every stage against strided samples / checksums of the reference's own CPU run (g14).
+
+    Every decoder layer thresholds the resized mask logits into a bool attention mask (`sigmoid < 0.5`,
+    ...decoder_univs.py:563): an entry whose reference logit is within rounding of 0 can land on the other side in any
+    other fp32 implementation, and the query's following cross-attentions then see one key more or less.  The test does
+    not grant that as a blanket tolerance; it NAMES the entries from the golden (g14b holds the reference's masks of
+    every layer and all resized logits within 1e-2 of the threshold):
+      * every entry where our mask differs from the reference's must be one whose reference logit is near the threshold
+        (|logit| < 5e-3; the first flip of a query is at rounding level, later ones follow from the first);
+      * a query with NO differing entry in any layer must meet the north star's 1e-3; only queries that own a named flipped
+        entry may exceed it, and stay below 2e-3;
+      * no sign flips in the output anywhere."""
+    path = os.path.join(golden_dir, "g14_cfg4_full_size.npz")
+    if not os.path.exists(path):
+        pytest.skip("g14 golden not generated")
+    g = np.load(path)
+    gm = _g(golden_dir, "g14b_cfg4_attn_masks")
+    case = cases.CFG4
+    ours = {}
+
+    def record(k, m):
+        ours[k] = m.cpu().numpy()
+        return m
+    feats, out = _cfg4_run(cuda, record)
     for k, v in feats.items():
         err = np.abs(v[:, ::16, ::4, ::4].cpu().numpy() - g["feat_" + k + "_s"]).max()
         assert err < 3e-3, (k, err)
+    # ---- attention masks, layer by layer, against the reference's
+    flipped_queries = {}
+    for i in range(9):
+        ref = _cfg4_ref_mask(gm, i)
+        T, Q, HW = ref.shape
+        diff = np.flatnonzero(ours[i] != ref)
+        if diff.size == 0:
+            continue
+        near = dict(zip(gm[f"call{i}_near_idx"].tolist(), gm[f"call{i}_near_val"].tolist()))
+        for flat in diff.tolist():
+            t, q, p = flat // (Q * HW), (flat // HW) % Q, flat % HW
+            # a row the reference reset as fully masked (:390) differs wholesale when one of its entries flips
+            if flat not in near:
+                row_ref, row_our = ref[t, q], ours[i][t, q]
+                base = (t * Q + q) * HW
+                row_near = [near[j] for j in range(base, base + HW) if j in near]
+                assert ((not row_ref.any()) or (not row_our.any())) and row_near, \
+                    f"layer {i}: mask entry (t={t}, q={q}, pixel={p}) differs and the reference logit is not near 0"
+                if not any(e[0] == i and e[1] == t for e in flipped_queries.get(q, [])):
+                    flipped_queries.setdefault(q, []).append((i, t, -1, min(row_near, key=abs)))   # whole-row reset (:390)
+                continue
+            assert abs(near[flat]) < 5e-3, (i, t, q, p, near[flat])
+            flipped_queries.setdefault(q, []).append((i, t, p, near[flat]))
+    for q, ent in sorted(flipped_queries.items()):
+        i, t, p, v = ent[0]
+        print(f"cfg4 flipped attention-mask entry: query {q}, first in layer {i} (frame {t}, pixel {p}, reference logit {v:+.2e}); "
+              f"{len(ent)} entries over all layers")
     pm = out["pred_masks"]
     assert pm.shape[1] == case["Q"] + case["n_exp"]
     ref_s = g["pred_masks_s"]
     got_s = pm[0, :, :, ::16, ::16].cpu().numpy()
     err = np.abs(got_s - ref_s).max()
     flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > 1e-3)
-    print(f"cfg4 pred_masks: max-abs-err {err:.3e}, |ref| max {np.abs(ref_s).max():.2f}, sign flips {flips.sum()}")
     per_q = np.abs(got_s - ref_s).reshape(got_s.shape[0], -1).max(1)
-    order = np.argsort(-per_q)[:6]
-    print("cfg4 per-query max errors (query: err, mean ref):", [(int(q), float(f"{per_q[q]:.2e}"), float(f"{ref_s[q].mean():.2f}")) for q in order],
-          "queries over 5e-4:", int((per_q > 5e-4).sum()), "of", len(per_q))
-    # Absolute 1e-3 on logits of magnitude up to 18.7, query by query.  202-203 of the 204 queries sit at 1e-4 .. 5e-4 under
-    # every arithmetic variant measured (profiles/r02_cfg4_error_budget.txt); query 11 at 7.8e-4; and ONE query (29) has two
-    # outcomes, 1.5e-4 or 1.67e-3, depending on rounding-level differences upstream (library fp32 GEMMs everywhere give the
-    # 1.67e-3 outcome too): a thresholded attention-mask entry of that query (sigmoid < 0.5 on a logit within rounding of 0,
-    # ...decoder_univs.py:563) flips in one decoder layer.  That discontinuity is the reference's own, so the bound is
-    # stated per query: every query within 1e-3 except at most one, which stays within 2e-3; no sign flips anywhere.
-    over = per_q > 1e-3
-    assert over.sum() <= 1 and per_q.max() < 2e-3, (int(over.sum()), float(per_q.max()))
+    print(f"cfg4 pred_masks: max-abs-err {err:.3e} (query {int(per_q.argmax())}), |ref| max {np.abs(ref_s).max():.2f}, sign flips "
+          f"{flips.sum()}, queries over 5e-4: {int((per_q > 5e-4).sum())} of {len(per_q)}, queries with a flipped mask entry: "
+          f"{sorted(flipped_queries)}")
+    for q in np.flatnonzero(per_q > 1e-3).tolist():
+        assert q in flipped_queries, f"query {q}: {per_q[q]:.2e} > 1e-3 without any attention-mask entry on the other side"
+        assert abs(flipped_queries[q][0][3]) < 1e-3, (q, flipped_queries[q][0])
+    assert per_q.max() < 2e-3, float(per_q.max())
     assert flips.sum() == 0
     pos = int((pm > 0).sum())
     assert abs(pos - int(g["pred_masks_pos_count"])) <= int(g["pred_masks_near_zero_1e-3"]) + 8
