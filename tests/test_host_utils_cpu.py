@@ -127,3 +127,27 @@ def test_round2_operator_wrappers_on_cpu_tensors():
         out, out2 = cpu_path.layer_norm(x, g, b, 1e-5, residual=r, post_add=p)
         ref = torch.nn.functional.layer_norm(x + r, (96,), g, b, 1e-5)
         assert torch.equal(out, ref) and torch.equal(out2, ref + p)
+
+
+def test_fp32_region_leaves_autocast_and_upcasts_features_but_not_targets(monkeypatch):
+    """Boundary B1 under the reference's `with autocast():` (train_net.py:334): module entries decorated with
+    layers.fp32_region up-cast half-precision feature arguments (tensors, lists, dicts) and hand the caller-owned
+    `targets` list through by identity (the prompt memory pool is mutated in place).  The autocast state is faked here;
+    tests/test_modules_gpu.py runs the real thing."""
+    import torch
+
+    from univs_amd import layers
+
+    class M:
+        @layers.fp32_region
+        def f(self, x, targets, extra=None):
+            return x, targets, extra
+    t = [{"prompt_feats": torch.ones(1, dtype=torch.half), "task": "detection"}]
+    x, tt, e = M().f(torch.ones(2, dtype=torch.half), t, extra=torch.ones(1, dtype=torch.half))
+    assert x.dtype == torch.half and tt is t and e.dtype == torch.half                     # autocast off: untouched
+    monkeypatch.setattr(torch, "is_autocast_enabled", lambda *a: True)
+    x, tt, e = M().f(torch.ones(2, dtype=torch.half), t, extra={"res2": [torch.ones(1, dtype=torch.bfloat16)]})
+    assert x.dtype == torch.float32 and e["res2"][0].dtype == torch.float32
+    assert tt is t and tt[0]["prompt_feats"].dtype == torch.half
+    x, tt, _ = M().f(torch.ones(2, dtype=torch.int64), targets=t)
+    assert x.dtype == torch.int64 and tt is t

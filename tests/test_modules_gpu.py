@@ -96,15 +96,40 @@ def test_g2_msdeformattn_layer_matches_reference(cuda, golden_dir):
     print(f"G2: MSDeformAttn.forward max-abs-err {e1:.2e}, encoder layer {e2:.2e}")
 
 
-def test_config2_full_size_against_reference(cuda, golden_dir):
+def test_b1_under_the_reference_autocast_context(cuda, golden_dir):
+    """Boundary B1 in the reference's real calling context: `train_net.py:334` evaluates under `with autocast():`, so
+    `model.backbone(x)` and `model.sem_seg_head(features, targets=...)` (inference_video_entity.py:312,316) run inside an
+    fp16 autocast region and may be handed fp16 tensors.  The modules pin themselves to fp32 at their entries
+    (layers.fp32_region; the reference does the same for its pixel decoder only, msdeformattn.py:316): Swin-T (g9) and the
+    head (g6) reproduce the reference's fp32 CPU outputs at the usual bounds, also when the caller passes fp16 features."""
+    swin = helpers.build_swin(cuda)
+    head = helpers.build_head(cases.HEAD_CASE, cuda)
+    g9, g6 = _g(golden_dir, "g9_swin"), _g(golden_dir, "g6_head_first_clip")
+    with torch.no_grad(), torch.autocast("cuda"):
+        assert torch.is_autocast_enabled("cuda")
+        feats = swin(cases.swin_input().to(cuda))
+        out = head(_to(cases.backbone_features(), cuda), targets=_targets_to(cases.targets_first_clip(), cuda))
+        # an autocast caller's own ops produce fp16: conv output of the frames -> backbone must up-cast, not raise
+        half_in = cases.swin_input().to(cuda).half()
+        feats_h = swin(half_in)
+    for k in ("res2", "res3", "res4", "res5"):
+        assert feats[k].dtype == torch.float32 and feats_h[k].dtype == torch.float32
+        assert np.abs(feats[k].cpu().numpy() - g9[k]).max() < 5e-4, k
+    helpers.check_head_outputs(out, g6, "", tol=1e-3)
+    assert out["pred_masks"].dtype == torch.float32
+
+
+@pytest.mark.parametrize("autocast", [False, True], ids=["plain", "under_autocast"])
+def test_config2_full_size_against_reference(cuda, golden_dir, autocast):
     """BASELINE config 2 (Swin-T, T=5 @ 720p -> 736x1280, 100 queries, first clip): every stage against
-    strided samples / checksums of the reference's own CPU run (g12)."""
+    strided samples / checksums of the reference's own CPU run (g12) -- called plainly and inside the reference's
+    `with autocast():` evaluation context (train_net.py:334)."""
     g = _g(golden_dir, "g12_cfg2_full_size")
     case = cases.CFG2
     swin = helpers.build_swin(cuda)
     head = helpers.build_head(case, cuda, return_aux=False)
     x = cases.preprocess(cases.cfg2_frames()).to(cuda)
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast("cuda", enabled=autocast):
         feats = swin(x)
         out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
     for k, v in feats.items():

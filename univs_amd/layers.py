@@ -11,6 +11,37 @@ import torch.nn.functional as F
 from torch import nn
 
 
+def _as_fp32(v):
+    if isinstance(v, torch.Tensor):
+        return v.float() if v.is_floating_point() and v.dtype != torch.float32 else v
+    if isinstance(v, (list, tuple)):
+        return type(v)(_as_fp32(u) for u in v)
+    if isinstance(v, dict):
+        return {k: _as_fp32(u) for k, u in v.items()}
+    return v
+
+
+def fp32_region(fn):
+    """Decorator for the entry points of boundary B1: the reference evaluates under
+    `with autocast():` (train_net.py:334) and keeps only its pixel decoder in fp32 (msdeformattn.py:316).  This build is
+    fp32 end to end -- the parity contract is stated against the reference's fp32 CPU path and the HIP operators take
+    float32 only -- so every module entry leaves the caller's autocast region, and half-precision feature tensors handed
+    in by an autocast caller are up-cast at the edge.  `targets` (the caller-owned prompt memory pool, mutated in place)
+    is passed through untouched."""
+    import functools
+    import inspect
+    names = list(inspect.signature(fn).parameters)[1:]          # positional parameter names after `self`
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if not torch.is_autocast_enabled("cuda"):
+            return fn(self, *args, **kwargs)
+        with torch.autocast(device_type="cuda", enabled=False):
+            args = [a if (i < len(names) and names[i] == "targets") else _as_fp32(a) for i, a in enumerate(args)]
+            return fn(self, *args, **{k: (v if k == "targets" else _as_fp32(v)) for k, v in kwargs.items()})
+    return wrapper
+
+
 # UNIVS_SPLIT_CONV=0: the 3 x 3 FPN output convolution stays on MIOpen
 _SPLIT_CONV = (os.environ.get("UNIVS_SPLIT_CONV", "1") or "0") != "0"
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...layers import Conv2d
+from ...layers import Conv2d, fp32_region
 from ...registry import BACKBONE_REGISTRY, ShapeSpec
 
 
@@ -90,6 +90,7 @@ class ResNet(nn.Module):
             self._out_feature_strides[name] = stride
             self._out_feature_channels[name] = blocks[-1].out_channels
 
+    @fp32_region
     def forward(self, x):
         assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
         outputs = {}

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from ...layers import layer_norm
+from ...layers import fp32_region, layer_norm
 from ...registry import BACKBONE_REGISTRY, ShapeSpec
 
 
@@ -266,6 +266,7 @@ class SwinTransformer(nn.Module):
         for i in out_indices:
             self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
 
+    @fp32_region
     def forward(self, x):
         x = self.patch_embed(x)
         Wh, Ww = x.size(2), x.size(3)

@@ -16,7 +16,7 @@ import pickle
 import torch
 from torch import nn
 
-from ...layers import MultiheadAttention, layer_norm
+from ...layers import MultiheadAttention, fp32_region, layer_norm
 
 
 class QuickGELU(nn.Module):
@@ -73,6 +73,7 @@ class CLIPLangEncoder(nn.Module):
         return self.token_embedding.weight.device
 
     @torch.no_grad()
+    @fp32_region
     def encode_text(self, text: torch.Tensor, only_eot: bool = True):
         """text: int64 [N, context_length] token ids (0-padded; the end-of-text token has the highest id).
         -> x_eot [N, embed_dim]  (and x_word [N, context_length, embed_dim] first when only_eot=False)."""

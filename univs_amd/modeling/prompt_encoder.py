@@ -162,6 +162,21 @@ class VisualPromptEncoder:
         if self.sampler_rng not in ("reference", "device"):
             raise ValueError(f"UNIVS_SAMPLER={self.sampler_rng!r} (expected 'reference' or 'device')")
         self._dev_gen = {}
+        self._replay = None
+
+    def set_replay(self, draws):
+        """Replay recorded draws instead of drawing: `draws` = a sequence of (point_idx [n], feat_idx [n, R]) per
+        `get_mask_prompt` call, in call order -- the sampled point as a flat index y * w + x of the full-resolution mask and
+        the R dense-token pixels as flat feature-map indices (-1 = empty mask); None switches replay off.  The SIZES of the
+        reference's `randperm` draws are pixel counts of thresholded masks (prompt_encoder.py:420,424,481), so a run whose
+        mask differs from a recorded run in one near-threshold pixel cannot reproduce that run's tokens from the seed;
+        replaying the sampled pixels can (deterministic re-runs, and parity runs against draws recorded inside the
+        reference: tests/golden/g20, oracle/gen_golden.py:_capture_sampler_draws).  No host round trip in this mode."""
+        import collections
+        self._replay = None if draws is None else collections.deque(draws)
+
+    def replay_pending(self):
+        return 0 if self._replay is None else len(self._replay)
 
     def _generator(self, device):
         g = self._dev_gen.get(str(device))
@@ -235,8 +250,20 @@ class VisualPromptEncoder:
         # then dense tokens -- generated on the host in exactly that order)
         assert (h_img * s == h) and (w_img * s == w), \
             f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
-        sel, rowcnt = self._select_candidates(masks, boxes)
-        if self.sampler_rng == "device":
+        replay_feat_idx = None
+        if self._replay is not None:
+            assert self._replay, "sampler replay: more get_mask_prompt calls than recorded draws"
+            point_idx, replay_feat_idx = self._replay.popleft()
+            assert point_idx.shape[0] == n and replay_feat_idx.shape[0] == n, "sampler replay: entity count differs from the recording"
+            point_idx = _to_device_async(point_idx.to(torch.int64), device)
+            replay_feat_idx = _to_device_async(replay_feat_idx.to(torch.int64), device)
+            counts = [None] * (2 * n)
+            point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
+        else:
+            sel, rowcnt = self._select_candidates(masks, boxes)
+        if self._replay is not None:
+            pass
+        elif self.sampler_rng == "device":
             counts = [None] * (2 * n)                        # sizes stay on the device
             point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
                                                             _prepared=(sel, rowcnt, None))
@@ -261,7 +288,8 @@ class VisualPromptEncoder:
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
                                              prompt_type="masks", is_train=is_train,
-                                             _counts=None if self.sampler_rng == "device" else counts[n:])
+                                             _counts=None if self.sampler_rng == "device" else counts[n:],
+                                             _replay_idx=replay_feat_idx)
         if self.feature_reduce is not None:
             fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
         # invalid (empty) entities: zero tokens, nothing masked (unconditional: no host round trip for `.any()`)
@@ -363,12 +391,19 @@ class VisualPromptEncoder:
 
     @torch.no_grad()
     def get_dense_features(self, img_features, img_pos, masks_binary, query_pe, query_feats, prompt_type="masks",
-                           is_train=True, _counts=None):
+                           is_train=True, _counts=None, _replay_idx=None):
         assert img_features.shape[-2:] == masks_binary.shape[-2:]
         feats = img_features.flatten(-2).t()
         pos = img_pos.flatten(-2).t()
         R = self.num_dense_points
         m = masks_binary.flatten(1)
+        if _replay_idx is not None:
+            assert tuple(_replay_idx.shape) == (m.shape[0], R), "sampler replay: dense-token table has the wrong shape"
+            empty = (_replay_idx[:, :1] < 0).view(-1, 1, 1)
+            idx = _replay_idx.clamp(min=0)
+            fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
+            pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
+            return (fd[:, :, None].repeat(1, 1, self.num_frames, 1), pd[:, :, None].repeat(1, 1, self.num_frames, 1))
         if self.sampler_rng == "device":
             assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
             cnt = m.sum(1)                                                        # [n] on the device

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from ...layers import Conv2d
+from ...layers import Conv2d, fp32_region
 from ...registry import TRANSFORMER_DECODER_REGISTRY, configurable
 from ..position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
 from ..prompt_encoder import VisualPromptSampler
@@ -186,6 +186,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return ret
 
     # ---------------------------------------------------------------------------------------------
+    @fp32_region
     def forward(self, x, mask_features, mask_features_bfe_conv=None, mask=None, targets=None):
         assert not self.training, "inference-only module (training is out of scope of the hot path)"
         bt, c_m, h_m, w_m = mask_features.shape
@@ -383,6 +384,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return outputs_class, outputs_mask, attn_mask, outputs_reid
 
     # ---------------------------------------------------------------------------------------------
+    @fp32_region
     def forward_prompt_encoder(self, src, pos, size_list, targets, num_frames=None, prompt_type=None,
                                use_all_prev_frames=False):
         """:599-758 (inference branches)."""
