@@ -195,8 +195,9 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from tests import cases, helpers
     from univs_amd import ops, runtime, synth
+    from univs_amd import workloads as cases
+    helpers = cases                                           # model factories live in univs_amd/workloads.py
 
     gemm_note = runtime.enable_tuned_gemms()      # hipBLASLt / rocBLAS algorithm table (fp32 unchanged)
     swin = helpers.build_swin(dev)

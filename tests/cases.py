@@ -6,6 +6,9 @@ import numpy as np
 import torch
 
 from univs_amd import synth
+from univs_amd.workloads import (CFG2, HEAD_CASE, PIXDEC, R50_SHAPES, SWIN_B, SWIN_L, SWIN_T, SWINL_SHAPES,  # noqa: F401
+                                 SWINT_SHAPES, backbone_features, cfg2_frames, clip_table, decoder_kwargs, preprocess, sampler_kwargs,
+                                 targets_first_clip, targets_with_entities)
 
 # ---------------------------------------------------------------------------------------------------
 # MSDeformAttn forward
@@ -134,23 +137,8 @@ def maskdec_inputs(case):
 # ---------------------------------------------------------------------------------------------------
 # Module-level cases (Swin, pixel decoder, UniVS decoder / head)
 # ---------------------------------------------------------------------------------------------------
-SWIN_T = dict(pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
-              num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
-              ape=False, patch_norm=True)
 SWIN_CASE = dict(name="swin_t", N=2, H=96, W=128)
 
-R50_SHAPES = {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}   # cfg 1
-SWINT_SHAPES = {"res2": (96, 4), "res3": (192, 8), "res4": (384, 16), "res5": (768, 32)}
-
-PIXDEC = dict(transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024,
-              transformer_enc_layers=6, conv_dim=256, mask_dim=256, norm="GN",
-              transformer_in_features=["res3", "res4", "res5"], common_stride=4)
-
-HEAD_CASE = dict(name="head", T=2, H=64, W=96, Q=20, shapes=R50_SHAPES)   # features for a 64x96 padded input
-
-
-def clip_table():
-    return synth.uniform("clip_cls_emb", (3938, 640))
 
 
 def swin_input(case=SWIN_CASE):
@@ -158,57 +146,6 @@ def swin_input(case=SWIN_CASE):
     mean = torch.tensor(synth.PIXEL_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(synth.PIXEL_STD).view(1, 3, 1, 1)
     return (frames - mean) / std
-
-
-def backbone_features(case=HEAD_CASE):
-    """Synthetic res2..res5 (unit-variance, like LayerNorm'ed Swin outputs)."""
-    feats = {}
-    for k, (c, s) in case["shapes"].items():
-        feats[k] = synth.normal(f"{case['name']}/feat/{k}", (case["T"], c, case["H"] // s, case["W"] // s))
-    return feats
-
-
-def decoder_kwargs(case=HEAD_CASE, text_to_image=False, sa_mask="sep", num_dense_points=32, num_prev=5):
-    return dict(in_channels=256, mask_classification=True, num_classes=133, hidden_dim=256,
-                num_queries=case["Q"], nheads=8, dim_feedforward=2048, dec_layers=9, pre_norm=False,
-                mask_dim=256, enforce_input_project=False, prompt_self_attn_layers=-1, num_frames=case["T"],
-                num_dense_points=num_dense_points, text_prompt_enable=True, prompt_as_queries=True,
-                text_prompt_to_image_enable=text_to_image, maskdec_self_attn_mask_type=sa_mask,
-                position_embedding_sin3d_type="ArbitraryT", num_prev_frames_memory=num_prev,
-                enabled_prev_frames_memory=True, enabled_prev_visual_prompts_for_grounding=False)
-
-
-def sampler_kwargs(case=HEAD_CASE, num_dense_points=32, num_prev=5):
-    return dict(pretrain_img_size=1024, hidden_dim=256, num_heads=8, num_frames=case["T"],
-                num_prev_frames_memory=num_prev, num_dense_points=num_dense_points,
-                position_embedding_sin3d_type="ArbitraryT", clip_stride=1)
-
-
-def targets_first_clip(case=HEAD_CASE, task="detection", prompt_type="visual", dataset="ytvis_2021_dev"):
-    return [{"task": task, "dataset_name": dataset, "prompt_type": prompt_type, "num_frames": case["T"],
-             "first_frame_idx": 0, "frame_indices": torch.arange(0, case["T"])}]
-
-
-def targets_with_entities(case=HEAD_CASE, first_frame_idx=1, n_ent=3):
-    """Second clip of a video (stride 1): rectangular entity masks carried over from previous frames.
-    masks/boxes cover the frames seen so far plus the (zero-padded) newest frame, as the clip loop leaves
-    them (inference_video_entity.py:878-912)."""
-    T, H, W = case["T"], case["H"], case["W"]
-    t_hist = first_frame_idx + T          # frames 0 .. first_frame_idx+T-1
-    masks = torch.zeros(n_ent, t_hist, H, W)
-    boxes = torch.zeros(n_ent, t_hist, 4)
-    for e in range(n_ent):
-        for t in range(t_hist - 1):       # newest frame has no annotation yet
-            y0, x0 = 4 + 9 * e + t, 6 + 17 * e + 2 * t
-            hh, ww = 14 + 3 * e, 20 + 5 * e
-            masks[e, t, y0:y0 + hh, x0:x0 + ww] = 1.0
-            boxes[e, t] = torch.tensor([x0 / W, y0 / H, (x0 + ww) / W, (y0 + hh) / H])
-    tv = targets_first_clip(case)[0]
-    tv.update({"first_frame_idx": first_frame_idx,
-               "frame_indices": torch.arange(first_frame_idx, first_frame_idx + T),
-               "masks": masks, "boxes": boxes, "ids": torch.arange(n_ent)[:, None].repeat(1, t_hist),
-               "first_appear_frame_idxs": torch.zeros(n_ent, dtype=torch.long)})
-    return [tv]
 
 
 def targets_grounding(case=HEAD_CASE, n_exp=3):
@@ -223,38 +160,14 @@ def targets_grounding(case=HEAD_CASE, n_exp=3):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE config 2: Swin-T, T=5 @ 720p (padded 736x1280), 100 queries, first clip
 # ---------------------------------------------------------------------------------------------------
-CFG2 = dict(name="cfg2", T=5, H=720, W=1280, Q=100, shapes=SWINT_SHAPES)
-
-
-def cfg2_frames(case=CFG2):
-    return synth.synthetic_frames(case["T"], case["H"], case["W"], "frames/seed0")
-
-
-def preprocess(frames, divisibility=32):
-    """normalise + zero-pad to a multiple of 32 (univs/inference/inference_video_entity.py:251-260)."""
-    mean = torch.tensor(synth.PIXEL_MEAN).view(1, 3, 1, 1)
-    std = torch.tensor(synth.PIXEL_STD).view(1, 3, 1, 1)
-    x = (frames - mean) / std
-    H, W = x.shape[-2:]
-    Hp, Wp = (H + divisibility - 1) // divisibility * divisibility, (W + divisibility - 1) // divisibility * divisibility
-    return torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
-
-
 # Swin-B (configs/univs_inf/vids/refvos/univs_swinb_refvos_davis_c1+univs.yaml:5-9): window 12 -> 144-token
 # windows, the second instantiation of the window-attention kernel
-SWIN_B = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=128, depths=[2, 2, 18, 2],
-              num_heads=[4, 8, 16, 32], window_size=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
-              ape=False, patch_norm=True)
 SWINB_CASE = dict(name="swin_b", N=1, H=96, W=160)
 
 
 # Swin-L (configs/univs_inf/vids/vis/univs_swinl_yt21_c1+univs.yaml:5-13) -- BASELINE config 5: T=10 @ 1080p (padded to
 # 1088x1920), 200 queries.  The reference's CPU run of the full clip needs > 100 GB, so the golden (g19) is the same
 # network on the first TWO frames; the T=10 run is checked through size-independent properties on the GPU.
-SWIN_L = dict(pretrain_img_size=384, patch_size=4, in_chans=3, embed_dim=192, depths=[2, 2, 18, 2],
-              num_heads=[6, 12, 24, 48], window_size=12, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
-              ape=False, patch_norm=True)
-SWINL_SHAPES = {"res2": (192, 4), "res3": (384, 8), "res4": (768, 16), "res5": (1536, 32)}
 CFG5 = dict(name="cfg5", T=10, H=1080, W=1920, Q=200, shapes=SWINL_SHAPES)
 CFG5_GOLDEN_T = 2
 

@@ -4,40 +4,8 @@ import torch
 
 from tests import cases
 from univs_amd import synth
-from univs_amd.registry import ShapeSpec
-
-
-def build_swin(device="cpu", variant=None):
-    from univs_amd.modeling.backbone.swin import SwinTransformer
-    k = dict(variant or cases.SWIN_T)
-    m = SwinTransformer(k["pretrain_img_size"], k["patch_size"], k["in_chans"], k["embed_dim"], k["depths"],
-                        k["num_heads"], k["window_size"], k["mlp_ratio"], k["qkv_bias"], k["qk_scale"], k["ape"],
-                        k["patch_norm"]).eval()
-    synth.load_synthetic(m, prefix="backbone.")
-    return m.to(device)
-
-
-def build_pixel_decoder(shapes, device="cpu"):
-    from univs_amd.modeling.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
-    ish = {k: ShapeSpec(channels=c, stride=s) for k, (c, s) in shapes.items()}
-    m = MSDeformAttnPixelDecoder(ish, **cases.PIXDEC).eval()
-    synth.load_synthetic(m, prefix="sem_seg_head.pixel_decoder.")
-    return m.to(device)
-
-
-def build_head(case, device="cpu", return_aux=True, **dec_over):
-    from univs_amd.modeling.meta_arch.mask_former_head import MaskFormerHead
-    from univs_amd.modeling.prompt_encoder import VisualPromptSampler
-    from univs_amd.modeling.transformer_decoder.univs_decoder import VideoMultiScaleMaskedTransformerDecoderUniVS
-    pd = build_pixel_decoder(case["shapes"])
-    ish = {k: ShapeSpec(channels=c, stride=s) for k, (c, s) in case["shapes"].items()}
-    dec = VideoMultiScaleMaskedTransformerDecoderUniVS(
-        clip_class_embed_path=cases.clip_table(), visual_prompt_sampler=VisualPromptSampler(**cases.sampler_kwargs(case)),
-        return_aux_outputs=return_aux, **cases.decoder_kwargs(case, **dec_over)).eval()
-    synth.load_synthetic(dec, prefix="sem_seg_head.predictor.")
-    head = MaskFormerHead(ish, num_classes=133, pixel_decoder=pd, pixel_decoder_name="MSDeformAttnPixelDecoder",
-                          transformer_predictor=dec, transformer_in_feature="multi_scale_pixel_decoder").eval()
-    return head.to(device)
+from univs_amd.registry import ShapeSpec  # noqa: F401
+from univs_amd.workloads import build_head, build_pixel_decoder, build_swin  # noqa: F401
 
 
 HEAD_SCENARIOS = [

@@ -466,6 +466,45 @@ def test_config5_full_clip_properties(cuda):
         assert (feats[k][:2] - feats2[k]).abs().max().item() < 1e-4, k
 
 
+def test_config3_long_video_teacher_forced_sampler_strict(cuda, golden_dir):
+    """BASELINE config 3 on one GPU with the prompt sampler teacher-forced: the 40-frame 720p video through the sliding
+    5-frame clip loop (36 clips, memory pool carried along) with the sampler REPLAYING the pixels the reference sampled
+    (g20 `draws_*`: recorded inside the reference's get_mask_prompt calls, prompt_encoder.py:420-481, SURVEY section 7 "hard
+    parts").  The sizes of the reference's `randperm` draws are pixel counts of thresholded masks, so without this one
+    near-threshold pixel changes every token of a clip; with the draws supplied the two implementations stay on ONE
+    trajectory and the north star's bound is asserted for ALL 36 clips and the final state, no escape clause:
+    integers exact, mask logits / prompt memory / embeddings within 1e-3, areas within the near-threshold pixel count."""
+    import types
+
+    from tests.test_clip_loop_cpu import compare_reduced_states, recorded_draws, run_loop
+    g = _g(golden_dir, "g20_cfg3_long_video")
+    case = cases.CFG3_LOOP
+    model = types.SimpleNamespace(backbone=helpers.build_swin(cuda), sem_seg_head=helpers.build_head(case, cuda))
+    draws = recorded_draws(g)
+    assert len(draws) == len(g["draws_clip"]) and set(g["draws_clip"].tolist()) == set(range(1, 36))
+    got, results = run_loop(case, model, device=cuda, replay=draws, stability_score_thresh=0.0, clip_stride=1)
+    assert got["clip_first_frames"].tolist() == g["clip_first_frames"].tolist() and len(g["clip_first_frames"]) == 36
+
+    class View(dict):
+        @property
+        def files(self):
+            return list(self.keys())
+
+    per_clip, failures = [], []
+    for c in list(range(36)) + ["final"]:
+        keys = [k for k in g.files if k.startswith(f"clip{c}_in_" if c != "final" else "final_")]
+        ref, val = View({k: g[k] for k in keys}), {k: got[k] for k in keys}
+        k = f"clip{c}_in_mask_logits_s"
+        if k in ref and ref[k].size:
+            per_clip.append(f"{c}:{np.abs(val[k].numpy() - ref[k]).max():.1e}")
+        try:
+            compare_reduced_states(val, ref, tol=1e-3)
+        except AssertionError as e:
+            failures.append((c, str(e)[:400]))
+    print("cfg3 teacher-forced sampler: max |mask logit| error per clip:", " ".join(per_clip))
+    assert not failures, failures[:3]
+
+
 def test_config3_long_video_on_device_matches_reference(cuda, golden_dir):
     """BASELINE config 3 on one GPU: the 40-frame 720p video through the sliding 5-frame clip loop (36 clips at the
     reference's default stride 1, prompt memory pool carried from clip to clip) against the REFERENCE's loop (g20: reduced

@@ -3,10 +3,9 @@ import collections, os, sys, traceback, warnings
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench
-from tests import cases
+from univs_amd import workloads as cases
 dev = torch.device("cuda:0")
-swin, head = bench.build_model(dev)
+swin, head = cases.build_model(dev)
 case = dict(cases.CFG2, H=736, W=1280)
 x = cases.preprocess(cases.cfg2_frames()).to(dev)
 tv0 = cases.targets_with_entities(case, first_frame_idx=1, n_ent=10)[0]

@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import cases  # noqa: E402
+from univs_amd import workloads as cases  # noqa: E402
 from univs_amd import ops, synth  # noqa: E402
 
 HBM_PEAK = 8.0e12

@@ -7,13 +7,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from tests import cases  # noqa: E402
+from univs_amd import workloads as cases  # noqa: E402
 from univs_amd import runtime  # noqa: E402
 
 dev = torch.device("cuda:0")
 runtime.enable_tuned_gemms()
-swin, head = bench.build_model(dev)
+swin, head = cases.build_model(dev)
 case = dict(cases.CFG2, H=736, W=1280)
 x = cases.preprocess(cases.cfg2_frames()).to(dev)
 n_ent = int(sys.argv[1]) if len(sys.argv) > 1 else 10

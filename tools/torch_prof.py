@@ -6,11 +6,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from tests import cases  # noqa: E402
+from univs_amd import workloads as cases  # noqa: E402
 
 dev = torch.device("cuda:0")
-swin, head = bench.build_model(dev)
+swin, head = cases.build_model(dev)
 case = cases.CFG2
 x = cases.preprocess(cases.cfg2_frames()).to(dev)
 tg = lambda: [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}]
