@@ -107,6 +107,21 @@ int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shap
                                  long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
                                  void* stream);
 
+/* The same core on HEAD-MAJOR operands, half a head per workgroup (csrc/msda_strips.hip, generation 5: resident
+ * row-circular windows, a lane owns a sample, two workgroups per CU):
+ *   value_hm [N][M][2][S][16]   value_proj's output in blocks of 16 channels: univs_linear_blocked_f32(..., S, 16);
+ *   proj_hm  [N][M][S][P][3 L]  per (query, head, point): L offset pairs (x, y) then L attention logits, levels ordered by
+ *                               size, largest first (ties: lower index first) -- the merged sampling_offsets /
+ *                               attention_weights Linear with its weight rows permuted, univs_linear_blocked_f32(..., S, 3 L P);
+ *   ref_points [N or 1][S][2]   ONE reference point per query, shared by all levels (the encoder's normalised pixel
+ *                               centres, msdeformattn.py:143-158 with valid_ratio == 1); ref_batch_stride = 2 S or 0;
+ *   out [N][S][M * 32]          the standard layout output_proj consumes.
+ * Covered: D == 32, P == 4, 1 <= L <= 4, Lq == S; otherwise (or when the generic kernel is forced with
+ * univs_msda_set_impl(1)) UNIVS_ERR_NOT_IMPLEMENTED and the caller runs the standard-layout operators. */
+int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S,
+                                  int M, int D, int L, int Lq, int P, float* out, void* stream);
+
 /* Selects the MSDA forward implementation: 0 = auto (default), 1 = generic direct-gather kernel,
  * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
  * Used by the parity tests and bench to exercise each path explicitly. */
@@ -114,9 +129,9 @@ int univs_msda_set_impl(int impl);
 /* Which implementation the last univs_msda_forward_f32 call on this thread launched: 1 generic,
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
 int univs_msda_last_impl(void);
-/* Generation of the LDS-tiled kernel the last univs_msda_forward_f32 call on this thread launched: 3 = LDS-DMA fills +
- * in-register sample records (msda_tiled3.hip), 2 = producer / consumer waves (msda_tiled2.hip), 1 = single window
- * (msda_tiled.hip), 0 = none (generic kernel).  UNIVS_MSDA_TILED=<n> in the environment caps the generation. */
+/* Generation of the LDS-tiled kernel the last MSDA forward call on this thread launched: 5 = strips at half a head per
+ * workgroup (msda_strips.hip, head-major operands), 2 = producer / consumer waves (msda_tiled2.hip, standard layouts),
+ * 0 = none (generic kernel). */
 int univs_msda_last_tiled_generation(void);
 
 /* y[M, N] = x[M, K] * W[N, K]^T + bias[N] (+ ReLU): torch.nn.functional.linear for contiguous float32 operands, as the
@@ -137,6 +152,15 @@ int univs_linear_split_f32(const float* x, const float* weight, const float* bia
  * Same coverage rules and return codes as univs_linear_split_f32. */
 int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
                            int K, int act, float* y, void* stream);
+
+/* The same Linear (bias only) with a COLUMN-BLOCKED output per batch element:
+ *   y[M / rows_per_batch][N / col_block][rows_per_batch][col_block],  y[b][c][s][i] = (x W^T + bias)[b * rows_per_batch + s][c * col_block + i]
+ * -- the head-major operand layouts of univs_msda_forward_strips_f32, written by the producing Linear's epilogue at no
+ * extra cost (ms_deform_attn.py:95-102: value_proj with col_block = 16, the merged offset / logit projection with
+ * col_block = 3 L P).  Covered: K == 256, N % col_block == 0, col_block % 4 == 0, M % rows_per_batch == 0 and the
+ * coverage rules of univs_linear_split_f32; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
+int univs_linear_blocked_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
+                             int rows_per_batch, int col_block, float* y, void* stream);
 
 /* y = conv2d(x, w, bias=None, stride=1, padding=1) for a 3 x 3 kernel on contiguous float32 NCHW tensors:
  * x [T, Cin, H, W], y [T, Cout, H, W]; `w_tap_major` [Cout, 9 * Cin] is the weight [Cout, Cin, 3, 3] permuted to

@@ -162,6 +162,78 @@ def test_msda_fused_matches_reference_sequence(cuda, case, gen, variant):
     assert (got - two).abs().max().item() < 3e-5
 
 
+@pytest.mark.parametrize("case", [c for c in cases.MSDA_CASES if c["encoder"] and c["D"] == 32], ids=lambda c: c["name"])
+def test_msda_strips_matches_reference_sequence(cuda, case):
+    """Generation 5 (msda_strips.hip: head-major operands, half a head per workgroup) == the reference's sequence softmax /
+    reference + offset / normaliser -> ms_deform_attn_forward, evaluated by the oracle, and == our two-operator path on the
+    standard layouts; ragged pyramids, four levels (finest first), a single level, far offsets (global fallback)."""
+    from oracle import cpu_path
+    value, shapes, lsi, proj, n_off, ref = _fused_inputs(case)
+    M, L, P = value.shape[2], len(shapes), case["P"]
+    want = cpu_path.msda_forward_fused(value, proj, n_off, ref, shapes, lsi, P).numpy()
+    vhm, qhm = ops.msda_pack_head_major(value.to(cuda), proj.to(cuda), n_off, shapes, P)
+    ref_q = ref[:, :, 0].contiguous().to(cuda)                       # one reference point per query
+    assert (ref == ref[:, :, :1]).all()
+    got = ops.msda_forward_strips(vhm, qhm, ref_q, shapes, lsi, M, P)
+    assert got is not None and ops.msda_last_impl() == 2 and ops.msda_last_tiled_generation() == 5
+    loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+    ops.msda_set_impl(1)
+    try:
+        two = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
+        assert ops.msda_forward_strips(vhm, qhm, ref_q, shapes, lsi, M, P) is None    # generic forced: the caller's fallback
+    finally:
+        ops.msda_set_impl(0)
+    torch.cuda.synchronize()
+    err = np.abs(got.cpu().numpy() - want).max()
+    print(f"strips {case['name']}: max abs err vs oracle {err:.2e}, vs generic kernel {(got - two).abs().max().item():.2e}")
+    assert err < 3e-5
+    assert (got - two).abs().max().item() < 3e-5
+
+
+def test_msda_strips_cfg2_and_cfg5_size(cuda):
+    """Strips at the bench geometries (720p: S = 19 320; 1080p: S = 42 840), 2 frames: == generic kernel on the standard
+    layouts; linearity in value; oracle C on every 23rd query."""
+    for shapes in ([(23, 40), (46, 80), (92, 160)], [(34, 60), (68, 120), (136, 240)]):
+        case = dict(name=f"strips{shapes[0][0]}", shapes=shapes, N=2, M=8, D=32, P=4, encoder=True, far=False)
+        value, shapes_, lsi, proj, n_off, ref = _fused_inputs(case)
+        M, L, P = 8, 3, 4
+        vhm, qhm = ops.msda_pack_head_major(value.to(cuda), proj.to(cuda), n_off, shapes, P)
+        ref_q = ref[:, :, 0].contiguous().to(cuda)
+        got = ops.msda_forward_strips(vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert got is not None and ops.msda_last_tiled_generation() == 5
+        loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+        ops.msda_set_impl(1)
+        try:
+            generic = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
+        finally:
+            ops.msda_set_impl(0)
+        assert (got - generic).abs().max().item() < 3e-5
+        got2 = ops.msda_forward_strips(2.0 * vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert (got2 - 2.0 * got).abs().max().item() < 1e-5
+        sub = np.arange(0, loc.shape[1], 23)
+        want = c_ops.msda_forward(value[:1].numpy(), shapes, lsi, loc[:1, sub].contiguous().cpu().numpy(),
+                                  attn[:1, sub].contiguous().cpu().numpy())
+        assert np.abs(got[:1, sub].cpu().numpy() - want).max() < 3e-5
+
+
+@pytest.mark.parametrize("N,S,CB", [(5, 19320, 16), (5, 19320, 36), (2, 4200, 48), (3, 2352, 16)], ids=str)
+def test_linear_blocked_matches_standard_layout(cuda, N, S, CB):
+    """The Linear with the column-blocked epilogue (head-major operands of the strips kernel) == the standard-layout Linear,
+    permuted: bit for bit (same arithmetic, different store addresses)."""
+    K = 256
+    Nf = 256 if CB == 16 else 8 * CB
+    x = synth.normal("linblk/x", (N, S, K)).to(cuda)
+    w = synth.normal("linblk/w", (Nf, K), std=0.05).to(cuda)
+    b = synth.normal("linblk/b", (Nf,)).to(cuda)
+    std = ops.linear_fused(x, w, b)
+    blk = ops.linear_blocked(x, w, b, S, CB)
+    if std is None:
+        assert blk is None
+        return
+    assert blk is not None and tuple(blk.shape) == (N, Nf // CB, S, CB)
+    assert torch.equal(blk, std.view(N, S, Nf // CB, CB).permute(0, 2, 1, 3).contiguous())
+
+
 def test_msda_fused_uncovered_geometry_returns_none(cuda):
     v = torch.zeros(1, 6, 2, 16, device=cuda)           # D = 16: not covered -> the caller keeps the two operators
     proj = torch.zeros(1, 6, 2 * 1 * 4 * 3, device=cuda)

@@ -17,8 +17,8 @@ def run(tag, split_linear, maskdec_impl, tuned):
     import univs_amd.layers as layers
     layers._SPLIT_LINEAR_LEVEL = split_linear
     layers._SPLIT_LINEAR = split_linear != 0
-    from univs_amd import workloads as cases
-    helpers = cases
+    from tests import cases      # development tool: the tests' input builders
+    from tests import helpers
     from univs_amd import ops, runtime
     if tuned:
         runtime.enable_tuned_gemms()

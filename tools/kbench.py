@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from univs_amd import workloads as cases  # noqa: E402
+from tests import cases  # noqa: E402  (development tool: the tests' input builders)
 from univs_amd import ops, synth  # noqa: E402
 
 HBM_PEAK = 8.0e12
@@ -46,13 +46,14 @@ def main():
     value, loc, attn = value.to(dev), loc.to(dev), attn.to(dev)
     S = value.shape[1]
     alg = 3200.0 * S * T
-    if not args.only or "msda" in args.only:
+    only_strips = args.only == "strips"
+    if not args.only or "msda" in args.only or only_strips:
         ops.msda_set_impl(1)
         t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
         res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
         ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
         ops.msda_set_impl(2)
-        for gen, variant in ((4, 0), (3, 0), (3, 1), (2, 0), (1, 0)):
+        for gen, variant in (() if only_strips else ((4, 0), (3, 0), (3, 1), (2, 0), (1, 0))):
             os.environ["UNIVS_MSDA_TILED"] = str(gen)
             os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
             for abl in ([0, 4, 16] if (gen == 3 and args.ablate) else [0]):
@@ -85,7 +86,7 @@ def main():
         n_off = M_ * L_ * P_ * 2
         t = timeit(lambda: ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_))
         res["msda_prepare"] = dict(ms=t * 1e3)
-        for gen, variant in ((4, 0), (3, 1), (3, 0)):
+        for gen, variant in (() if only_strips else ((4, 0), (3, 1), (3, 0))):
             os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
             os.environ["UNIVS_MSDA_TILED"] = str(gen)
             def pair():
@@ -99,6 +100,31 @@ def main():
                                                  max_abs_diff_vs_pair=d.max().item())
         os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
         os.environ.pop("UNIVS_MSDA_TILED", None)
+        # generation 5: strips on head-major operands (half a head per workgroup, two workgroups per CU)
+        vhm, qhm = ops.msda_pack_head_major(value, proj, n_off, shapes, P_)
+        refq = refp[:, :, 0].contiguous()
+        l_, a_ = ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_)
+        ops.msda_set_impl(1)
+        want = ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
+        ops.msda_set_impl(0)
+        variants = (("", {}),) if only_strips else (("", {}), ("_th6", {"UNIVS_MSDA_STRIP_H": "6"}), ("_w8", {"UNIVS_MSDA_STRIP_W": "8"}),
+                                                     ("_grid256", {"UNIVS_MSDA_GRID": "256"}), ("_grid768", {"UNIVS_MSDA_GRID": "768"}),
+                                                     ("_grid1024", {"UNIVS_MSDA_GRID": "1024"}), ("_grid2048", {"UNIVS_MSDA_GRID": "2048"}))
+        for tag, env in variants:
+            os.environ.update(env)
+            got = ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_)
+            if got is not None:
+                t = timeit(lambda: ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_))
+                res["msda_strips" + tag] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK, gen=ops.msda_last_tiled_generation(),
+                                                max_abs_diff_vs_generic=(got - want).abs().max().item())
+            for k in env:
+                os.environ.pop(k, None)
+        x_tok = synth.normal("kb/tok", (T, S, 256)).to(dev)
+        w_v, b_v = synth.normal("kb/wv", (256, 256), std=0.05).to(dev), synth.normal("kb/bv", (256,)).to(dev)
+        w_q, b_q = synth.normal("kb/wq", (288, 256), std=0.05).to(dev), synth.normal("kb/bq", (288,)).to(dev)
+        for nm, w_, b_, cb in (("value", w_v, b_v, 16), ("qproj", w_q, b_q, 36)):
+            res[f"linear_{nm}_standard"] = dict(ms=timeit(lambda: ops.linear_fused(x_tok, w_, b_)) * 1e3)
+            res[f"linear_{nm}_blocked"] = dict(ms=timeit(lambda: ops.linear_blocked(x_tok, w_, b_, S, cb)) * 1e3)
     if not args.only or "mask" in args.only:
         Q, C, H, W = 100, 256, 184, 320
         e = synth.normal("kb/e", (T, Q, C)).to(dev)

@@ -40,7 +40,7 @@ def main():
     sys.path.insert(0, ROOT)
     import numpy as np
     import torch
-    from univs_amd import workloads as cases
+    from tests import cases      # development tool: the tests' input builders
     from univs_amd import _lib, ops
     dev = torch.device("cuda:0")
     T = args.T

@@ -32,6 +32,8 @@ SIGNATURES = {
     "univs_msda_forward_f64": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_msda_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "univs_msda_forward_fused_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_msda_forward_strips_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_linear_blocked_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P, _P]),
     "univs_msda_set_impl": (_I, [_I]),
     "univs_msda_last_impl": (_I, []),
     "univs_msda_last_tiled_generation": (_I, []),

@@ -41,7 +41,9 @@ int mask_decode_f32(const float*, const float*, int, int, int, long long, float*
 int transpose_f32(const float*, float*, long long, int, int, hipStream_t);
 int conv3x3_split_f32(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 void mask_decode_set_impl(int);
-int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t);
+int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0);
+int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
+                            int, int, float*, hipStream_t);
 int mask_decode_last_impl();
 int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
                          hipStream_t);
@@ -500,6 +502,65 @@ int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shap
   }
   if (rc == 0) {
     set_error("univs_msda_forward_fused_f32: geometry not covered by the fused kernel (D == 32, P == 4, 2 <= L <= 4, Lq == S)");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
+}
+
+int univs_linear_blocked_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
+                             int rows_per_batch, int col_block, float* y, void* stream) {
+  if (M < 0 || N < 1 || K < 1 || rows_per_batch < 1 || col_block < 4 || col_block % 4 != 0 || N % col_block != 0 ||
+      (M % rows_per_batch) != 0) {
+    set_error("univs_linear_blocked_f32: bad arguments M=%lld N=%d K=%d rows_per_batch=%d col_block=%d", M, N, K, rows_per_batch,
+              col_block);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return UNIVS_OK;
+  clear_sticky_error();
+  if (!x || !weight || !y) {
+    set_error("univs_linear_blocked_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::linear_split_f32(x, weight, bias, nullptr, y, M, N, K, /*LS_EPI_BLOCKED=*/4, static_cast<hipStream_t>(stream),
+                                         rows_per_batch, col_block);
+  if (rc > 0) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_linear_blocked_f32: shape M=%lld N=%d K=%d (or alignment) is not covered (K == 256, M >= 2048)", M, N, K);
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
+}
+
+int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start,
+                                  const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S, int M,
+                                  int D, int L, int Lq, int P, float* out, void* stream) {
+  if (N < 0 || S < 0 || M < 1 || D < 0 || Lq < 0 || P < 1 || L < 1 || L > UNIVS_MAX_LEVELS || ref_batch_stride < 0) {
+    set_error("univs_msda_forward_strips_f32: bad dimensions N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", N, S, M, D, L, Lq, P);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
+  clear_sticky_error();
+  g_msda_gen = 0;
+  if (!value_hm || !proj_hm || !ref_points || !out) {
+    set_error("univs_msda_forward_strips_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_strips_f32");
+  if (rc != UNIVS_OK) return rc;
+  if (g_msda_impl == 1) {   // the generic kernel was forced: it has no head-major variant, the caller takes the two-operator path
+    set_error("univs_msda_forward_strips_f32: generic implementation forced (univs_msda_set_impl(1))");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  rc = msda_forward_strips_f32(value_hm, lv, proj_hm, ref_points, ref_batch_stride, N, S, M, D, L, Lq, P, out,
+                               static_cast<hipStream_t>(stream));
+  if (rc > 0) {
+    g_msda_last = 2;
+    g_msda_gen = 5;
+    return UNIVS_OK;
+  }
+  if (rc == 0) {
+    set_error("univs_msda_forward_strips_f32: geometry not covered (D == 32, P == 4, 1 <= L <= 4, Lq == S, windows within 80 KB of LDS)");
     return UNIVS_ERR_NOT_IMPLEMENTED;
   }
   return rc;

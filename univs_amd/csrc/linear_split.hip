@@ -35,7 +35,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LS_THREADS = 512;   // 8 waves, two per SIMD
 constexpr int LS_TILE_M = 32;     // rows of x per wave tile (two 16-column MFMA tiles)
 constexpr int LS_MAX_RB = 7;
-enum { LS_EPI_NONE = 0, LS_EPI_RELU = 1, LS_EPI_GELU = 2, LS_EPI_RESIDUAL = 3 };
+enum { LS_EPI_NONE = 0, LS_EPI_RELU = 1, LS_EPI_GELU = 2, LS_EPI_RESIDUAL = 3, LS_EPI_BLOCKED = 4 };
+// LS_EPI_BLOCKED: the output is stored column-blocked per batch element, Y[M / blk_rows][N / blk_cols][blk_rows][blk_cols]
+// (row m = b * blk_rows + s, feature n = c * blk_cols + i -> ((b * (N / blk_cols) + c) * blk_rows + s) * blk_cols + i): the
+// head-major operand layouts of the MSDeformAttn sampling kernel (msda_strips.hip: value in blocks of 16 channels, the
+// merged offset / logit projection in blocks of one head), written by the producing Linear at no extra cost.
 
 // two fp32 bit patterns whose low halves are zero -> their bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned ls_pack(unsigned lo, unsigned hi) { return (lo >> 16) | hi; }
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
                                                                 const float* __restrict__ bias,   // [N] or null
                                                                 const float* __restrict__ Res,    // [M, N] (EPI == RESIDUAL)
                                                                 float* __restrict__ Y,            // [M, N]
-                                                                int M, int N, int K, int rows_per_pass) {
+                                                                int M, int N, int K, int rows_per_pass, int blk_rows,
+                                                                int blk_cols) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wsp[];   // [K/32][4 k-groups][R features][3 parts] | bias[R]
   const int n0 = blockIdx.y * rows_per_pass;
   const int R = min(rows_per_pass, N - n0);                      // a multiple of 4 (host-checked)
@@ -141,15 +146,31 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * N * 4), 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == LS_EPI_RESIDUAL ? Res : X), 0, (int)((long long)M * N * 4), 0x00020000);
+  // LS_EPI_BLOCKED: this lane's features in the blocked layout, element offset of (block, column) within a batch element
+  [[maybe_unused]] unsigned fblk[RB];
+  if constexpr (EPI == LS_EPI_BLOCKED) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const unsigned fg = (unsigned)(n0 + rb * 16 + 4 * g);
+      const unsigned cb = fg / (unsigned)blk_cols;
+      fblk[rb] = cb * (unsigned)blk_rows * (unsigned)blk_cols + (fg - cb * (unsigned)blk_cols);
+    }
+  }
   auto epilogue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int m = (wt0 + tile * NWV) * LS_TILE_M + 16 * c + j;
+      [[maybe_unused]] unsigned rowpart = 0;
+      if constexpr (EPI == LS_EPI_BLOCKED) {
+        const unsigned b = (unsigned)m / (unsigned)blk_rows;
+        rowpart = b * (unsigned)blk_rows * (unsigned)N + ((unsigned)m - b * (unsigned)blk_rows) * (unsigned)blk_cols;
+      }
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int f = rb * 16 + 4 * g;
         f32x4 v = acc[rb][c];
-        const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
+        const unsigned off = EPI == LS_EPI_BLOCKED ? (rowpart + fblk[rb]) * 4u
+                                                   : ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
         const unsigned offc = (m < M && f < R) ? off : 0xFFFFFFF0u;   // out of range: loads return 0, stores are dropped
         if (EPI == LS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
         if (EPI == LS_EPI_GELU) {   // x * 0.5 * (1 + erf(x / sqrt 2)): nn.GELU() (approximate = 'none')
@@ -579,9 +600,11 @@ static int linear_split_wide_f32(const float* x, const float* w, const float* bi
 
 // returns 1 if launched, 0 if the shape is not covered (the caller uses the library GEMM), < 0 on error
 int linear_split_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
-                     int K, int epi, hipStream_t st) {
+                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols) {
   if (M <= 0 || N <= 0) return 1;
-  if (epi < 0 || epi > LS_EPI_RESIDUAL || (epi == LS_EPI_RESIDUAL) != (residual != nullptr)) return 0;
+  if (epi < 0 || epi > LS_EPI_BLOCKED || (epi == LS_EPI_RESIDUAL) != (residual != nullptr)) return 0;
+  if (epi == LS_EPI_BLOCKED && (K != 256 || blk_rows < 1 || blk_cols < 4 || blk_cols % 4 != 0 || N % blk_cols != 0 || M % blk_rows != 0))
+    return 0;
   const int ring = K % 128 == 0 ? 4 : K % 96 == 0 ? 3 : 0;
   if (K < 96 || ring == 0 || N % 4 != 0) return 0;
   if (M * (long long)N * 4 >= 0x7FFFFFFFLL || M * (long long)K * 4 >= 0x7FFFFFFFLL) return 0;
@@ -591,7 +614,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   static const int wide_kmin = [] { const char* e = getenv("UNIVS_LS_WIDE_KMIN"); return e && *e ? atoi(e) : 768; }();
   // (... except the one K = 768 shape with many rows and few features, Swin stage 2's fc2 at 73 600 x 768 -> 192: 203 us
   // W-stationary against 221 us)
-  if (K >= wide_kmin && !(K == 768 && M >= 32768 && N <= 256)) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,
+  if (K >= wide_kmin && !(K == 768 && M >= 32768 && N <= 256) && epi != LS_EPI_BLOCKED) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,
                     // 133 / 47 / 167 us against 159 / 61 / 228 us for the stage-4 qkv / proj / fc1 at K = 768)
     const int rc = linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);
     if (rc != 0 || K > 768) return rc;
@@ -629,7 +652,8 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   do {                                                                                                                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16x6<rb, ksc, rg, ep>),                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-    hipLaunchKernelGGL((linear_bf16x6<rb, ksc, rg, ep>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K, rows); \
+    hipLaunchKernelGGL((linear_bf16x6<rb, ksc, rg, ep>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K, rows, \
+                       blk_rows, blk_cols);                                                                              \
   } while (0)
 #define UNIVS_LS_EPI(rb, ksc, rg)                                   \
   switch (epi) {                                                    \
@@ -640,11 +664,12 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   }
   // a straight-line tile body for K = 256 (MSDeformAttn), a runtime k loop for anything else (straight-line bodies for
   // the Swin widths 96 .. 768 were measured: no gain, 80 s of compile time)
-#define UNIVS_LS_RB(rb)                               \
-  case rb:                                            \
-    if (K == 256) { UNIVS_LS_EPI(rb, 8, 4) }          \
-    else if (ring == 4) { UNIVS_LS_EPI(rb, 0, 4) }    \
-    else { UNIVS_LS_EPI(rb, 0, 3) }                   \
+#define UNIVS_LS_RB(rb)                                               \
+  case rb:                                                            \
+    if (epi == LS_EPI_BLOCKED) { UNIVS_LS(rb, 8, 4, LS_EPI_BLOCKED); } \
+    else if (K == 256) { UNIVS_LS_EPI(rb, 8, 4) }                     \
+    else if (ring == 4) { UNIVS_LS_EPI(rb, 0, 4) }                    \
+    else { UNIVS_LS_EPI(rb, 0, 3) }                                   \
     break
   switch (RB) {
     UNIVS_LS_RB(1);

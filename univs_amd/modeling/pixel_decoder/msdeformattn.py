@@ -36,6 +36,12 @@ from ..position_encoding import PositionEmbeddingSine
 _MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "1") == "1"
 
 
+# UNIVS_MSDA_STRIPS (default 1): the encoder's MSDeformAttn core on head-major operands (csrc/msda_strips.hip, generation 5):
+# value_proj and the merged offset / logit projection store their outputs in the sampling kernel's layouts (blocked Linear
+# epilogue), the kernel handles half a head per workgroup with two workgroups per CU.  0: the standard-layout operators.
+_MSDA_STRIPS = os.environ.get("UNIVS_MSDA_STRIPS", "1") == "1"
+
+
 def _shape_list(spatial_shapes):
     return spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else list(spatial_shapes)
 
@@ -63,13 +69,50 @@ class MSDeformAttn(nn.Module):
             self._qproj_cache = c
         return c[1], c[2], so.weight.shape[0]
 
+    def _head_major_query_proj(self, order):
+        """The merged projection with its rows permuted to [head][point][L offset pairs, L logits], levels in `order`
+        (ops.msda_level_order): its blocked output is the strips kernel's projection operand."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight.data_ptr(), so.weight._version, aw.weight.data_ptr(), aw.weight._version,
+               so.bias._version, aw.bias._version, so.weight.device, order)
+        c = getattr(self, "_qproj_hm_cache", None)
+        if c is None or c[0] != key:
+            M, L, P = self.n_heads, self.n_levels, self.n_points
+            n_off = M * L * P * 2
+            idx = []
+            for m in range(M):
+                for p in range(P):
+                    idx += [((m * L + l) * P + p) * 2 + xy for l in order for xy in (0, 1)]
+                    idx += [n_off + (m * L + l) * P + p for l in order]
+            with torch.no_grad():
+                ix = torch.tensor(idx, dtype=torch.long, device=so.weight.device)
+                w = torch.cat([so.weight, aw.weight])[ix].contiguous()
+                b = torch.cat([so.bias, aw.bias])[ix].contiguous()
+            c = (key, w, b)
+            self._qproj_hm_cache = c
+        return c[1], c[2]
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
+                input_level_start_index, input_padding_mask=None, ref_per_query=None):
         """query [N,Lq,C]; reference_points [N|1,Lq,L,2]; input_flatten [N,S,C];
-        input_spatial_shapes / input_level_start_index: python lists (or tensors)."""
+        input_spatial_shapes / input_level_start_index: python lists (or tensors).
+        `ref_per_query` [N|1, Lq, 2] (optional): the caller's promise that every level shares one reference point per query
+        (the encoder's pixel centres, msdeformattn.py:143-158 with valid_ratio == 1) -- enables the head-major kernel."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
+        if (_MSDA_STRIPS and ref_per_query is not None and query.is_cuda and P == 4 and L <= 4 and Len_q == Len_in
+                and input_padding_mask is None and self.d_model == 32 * M and query.dtype == torch.float32):
+            shapes = _shape_list(input_spatial_shapes)
+            order = tuple(ops.msda_level_order(shapes))
+            value_hm = ops.linear_blocked(input_flatten, self.value_proj.weight, self.value_proj.bias, Len_in, 16)
+            if value_hm is not None:
+                w_hm, b_hm = self._head_major_query_proj(order)
+                qp_hm = ops.linear_blocked(query, w_hm, b_hm, Len_q, 3 * L * P)
+                if qp_hm is not None:
+                    output = ops.msda_forward_strips(value_hm, qp_hm, ref_per_query, shapes, input_level_start_index, M, P)
+                    if output is not None:
+                        return linear(output, self.output_proj.weight, self.output_proj.bias)
         value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
@@ -120,12 +163,14 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, query=None,
-                want_next_query=False):
+                want_next_query=False, ref_per_query=None):
         """`query` = `src + pos` when the caller already has it (the previous layer's norm2 pass made it);
-        `want_next_query`: also return `out + pos` for the next layer (same pass as norm2)."""
+        `want_next_query`: also return `out + pos` for the next layer (same pass as norm2); `ref_per_query`: see
+        MSDeformAttn.forward."""
         if query is None:
             query = src if pos is None else src + pos
-        src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                              ref_per_query=ref_per_query)
         src = layer_norm(self.norm1, src2, residual=src)
         ffn = linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias)
         if want_next_query and pos is not None and src.is_cuda:
@@ -156,14 +201,15 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         reference_points = torch.cat(refs, 1)
         return reference_points[:, :, None].expand(-1, -1, len(spatial_shapes), -1).contiguous()
 
-    def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None):
+    def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None, ref_per_query=None):
         output, query = src, None
         for i, layer in enumerate(self.layers):
             if i + 1 < self.num_layers:
                 output, query = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query,
-                                      want_next_query=True)
+                                      want_next_query=True, ref_per_query=ref_per_query)
             else:
-                output = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query)
+                output = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query,
+                               ref_per_query=ref_per_query)
         return output
 
 
@@ -192,9 +238,11 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         if ref is None:
             if len(self._ref_cache) > 8:
                 self._ref_cache.clear()
-            ref = MSDeformAttnTransformerEncoder.get_reference_points(spatial_shapes, src_flatten.device)
+            r = MSDeformAttnTransformerEncoder.get_reference_points(spatial_shapes, src_flatten.device)
+            # get_reference_points expands ONE point per query over the levels (valid_ratio == 1): keep that point too
+            ref = (r, r[:, :, 0].contiguous())
             self._ref_cache[key] = ref
-        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, ref, lvl_pos)
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, ref[0], lvl_pos, ref_per_query=ref[1])
         return memory, spatial_shapes, level_start_index
 
 

@@ -165,6 +165,56 @@ def msda_forward_fused(value, proj, n_off, reference_points, spatial_shapes, lev
     return out
 
 
+def msda_level_order(spatial_shapes):
+    """Slot order of the levels in the head-major projection layout of `msda_forward_strips`: by size, largest first, ties
+    by index (csrc/msda_strips_geom.h: s5_build_host)."""
+    sh = [(int(h), int(w)) for h, w in (spatial_shapes.tolist() if isinstance(spatial_shapes, torch.Tensor) else spatial_shapes)]
+    return sorted(range(len(sh)), key=lambda l: (-sh[l][0] * sh[l][1], l))
+
+
+def msda_pack_head_major(value, proj, n_off, spatial_shapes, num_points=4):
+    """Standard layouts -> the head-major operands of `msda_forward_strips`, with torch copies (tests, tools and shapes the
+    blocked Linear epilogue does not cover; the hot path gets these layouts from `linear_blocked` for free):
+    value [N, S, M, 32] -> [N, M*2, S, 16]; proj [N, S, C] (offsets in columns [0, M*L*P*2), logits from n_off) ->
+    [N, M, S, P*3L] with the levels in `msda_level_order`."""
+    N, S, M, D = value.shape
+    order = msda_level_order(spatial_shapes)
+    L, P = len(order), int(num_points)
+    off = proj[..., :M * L * P * 2].reshape(N, S, M, L, P, 2)[:, :, :, order]
+    lg = proj[..., n_off:n_off + M * L * P].reshape(N, S, M, L, P)[:, :, :, order]
+    row = torch.cat([off.permute(0, 2, 1, 4, 3, 5).reshape(N, M, S, P, 2 * L), lg.permute(0, 2, 1, 4, 3)], -1)
+    value_hm = value.reshape(N, S, M, 2, D // 2).permute(0, 2, 3, 1, 4).contiguous().view(N, 2 * M, S, D // 2)
+    return value_hm, row.reshape(N, M, S, P * 3 * L).contiguous()
+
+
+def msda_forward_strips(value_hm, proj_hm, ref_points, spatial_shapes, level_start_index, num_heads, num_points=4):
+    """MSDeformAttn core (ms_deform_attn.py:100-116) on head-major operands (include/univs_hip.h:
+    univs_msda_forward_strips_f32): value_hm [N, M*2, S, 16] and proj_hm [N, M, S, P*3L] as `linear_blocked` writes them
+    (levels of proj_hm in `msda_level_order`), ref_points [N or 1, S, 2] (one per query, shared by the levels).
+    Returns [N, S, M*32], or None when the geometry is not covered."""
+    _inference_only("msda_forward_strips", value_hm, proj_hm, ref_points)
+    _require_gpu("msda_forward_strips", value_hm, proj_hm, ref_points)
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (value_hm, proj_hm, ref_points)):
+        raise RuntimeError("msda_forward_strips: contiguous float32 operands only")
+    M, P = int(num_heads), int(num_points)
+    N, M2, S, DH = value_hm.shape
+    sh, st, L = _host_shapes(spatial_shapes, level_start_index, S)
+    if M2 != 2 * M or DH != 16 or tuple(proj_hm.shape) != (N, M, S, P * 3 * L) or tuple(ref_points.shape[1:]) != (S, 2) \
+            or ref_points.shape[0] not in (1, N):
+        raise RuntimeError("msda_forward_strips: inconsistent shapes")
+    if P != 4 or not (1 <= L <= 4):
+        return None
+    out = torch.empty((N, S, M * 32), dtype=torch.float32, device=value_hm.device)
+    rbs = 0 if ref_points.shape[0] == 1 else S * 2
+    with torch.cuda.device(value_hm.device):
+        rc = _lib.load().univs_msda_forward_strips_f32(_ptr(value_hm), sh, st, _ptr(proj_hm), _ptr(ref_points), rbs, N, S, M, 32,
+                                                       L, S, P, _ptr(out), _stream_ptr(value_hm))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "msda_forward_strips")
+    return out
+
+
 def msda_set_impl(impl: int):
     """0 auto, 1 generic direct-gather kernel, 2 LDS-tiled encoder kernel."""
     _lib.check(_lib.load().univs_msda_set_impl(int(impl)), "msda_set_impl")
@@ -176,7 +226,8 @@ def msda_last_impl() -> int:
 
 
 def msda_last_tiled_generation() -> int:
-    """3 / 2 / 1 = generation of the LDS-tiled kernel that ran for the last forward on this thread, 0 = generic."""
+    """5 (strips, head-major operands) / 2 = generation of the LDS-tiled kernel that ran for the last forward on this
+    thread, 0 = generic."""
     return int(_lib.load().univs_msda_last_tiled_generation())
 
 
@@ -225,6 +276,32 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
         return None
     _lib.check(rc, "linear_fused")
     return y.view(*x.shape[:-1], N)
+
+
+def linear_blocked(x, weight, bias, rows_per_batch, col_block):
+    """F.linear with a column-blocked output per batch element (include/univs_hip.h: univs_linear_blocked_f32):
+    x [B, rows_per_batch, K] (or [B * rows_per_batch, K]) -> y [B, N / col_block, rows_per_batch, col_block].  None when the
+    shape is not covered (the caller keeps the standard layout)."""
+    _inference_only("linear_blocked", x, weight)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K).contiguous()
+    w = weight.contiguous()
+    Mrows, N = x2.shape[0], w.shape[0]
+    if x2.dtype != torch.float32 or w.dtype != torch.float32 or w.shape[1] != K:
+        return None
+    _require_gpu("linear_blocked", x2, w)
+    rows, cb = int(rows_per_batch), int(col_block)
+    if rows < 1 or cb < 4 or cb % 4 or N % cb or Mrows % rows or K != 256:
+        return None
+    b = bias.contiguous() if bias is not None else None
+    y = torch.empty((Mrows // rows, N // cb, rows, cb), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        rc = _lib.load().univs_linear_blocked_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, Mrows, N, K, rows, cb,
+                                                  _ptr(y), _stream_ptr(x2))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "linear_blocked")
+    return y
 
 
 def linear_split(x, weight, bias=None, relu=False):
