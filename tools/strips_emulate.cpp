@@ -80,6 +80,11 @@ int main() {
       for (int q = 0; q < S; ++q)
         if (q % 11 == 5)
           for (size_t i = 0; i < (size_t)M * L * P * 2; ++i) off[((size_t)n * S + q) * M * L * P * 2 + i] *= 5.f;
+    int order[4] = {0, 1, 2, 3};
+    std::sort(order, order + L, [&](int a, int b) {
+      const long long sa = (long long)lv.H[a] * lv.W[a], sb = (long long)lv.H[b] * lv.W[b];
+      return sa != sb ? sa > sb : a < b;
+    });
     // head-major operands as the Linear epilogues write them
     std::vector<float> vhm((size_t)N * M * 2 * S * 16), qhm((size_t)N * M * S * P * 3 * L);
     for (int n = 0; n < N; ++n)
@@ -87,12 +92,13 @@ int main() {
         for (int m = 0; m < M; ++m) {
           for (int ch = 0; ch < 32; ++ch)
             vhm[((((size_t)n * M + m) * 2 + ch / 16) * S + s) * 16 + ch % 16] = value[(((size_t)n * S + s) * M + m) * 32 + ch];
-          for (int p = 0; p < P; ++p) {
+          for (int p = 0; p < P; ++p) {   // levels in SLOT order (largest first, ties by index), as ops.msda_pack_head_major
             float* row = &qhm[((((size_t)n * M + m) * S + s) * P + p) * 3 * L];
-            for (int l = 0; l < L; ++l) {
-              row[2 * l] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2];
-              row[2 * l + 1] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2 + 1];
-              row[2 * L + l] = logit[((((size_t)n * S + s) * M + m) * L + l) * P + p];
+            for (int kk = 0; kk < L; ++kk) {
+              const int l = order[kk];
+              row[2 * kk] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2];
+              row[2 * kk + 1] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2 + 1];
+              row[2 * L + kk] = logit[((((size_t)n * S + s) * M + m) * L + l) * P + p];
             }
           }
         }
@@ -105,7 +111,7 @@ int main() {
     if (!g.ok) { printf("%-14s tables not ok (qmax %lld lds %zu)\n", c.name, g.qmax, g.lds); ++bad_total; continue; }
     const unsigned nitems = (unsigned)((long long)N * M * 2 * g.ntiles);
     std::vector<float> out((size_t)N * S * M * 32, 0.f), cnt((size_t)N * S * M * 32, 0.f);
-    long long conflicts = 0, stale = 0, misses = 0, samples = 0, reads = 0;
+    long long conflicts = 0, stale = 0, misses = 0, samples = 0, reads = 0, inexact_div = 0;
     for (int wg = 0; wg < c.nwg; ++wg) {
       const unsigned g0 = (unsigned)((unsigned long long)wg * nitems / c.nwg), g1 = (unsigned)((unsigned long long)(wg + 1) * nitems / c.nwg);
       if (g0 >= g1) continue;
@@ -156,9 +162,15 @@ int main() {
             const float* row = &qhm[((((size_t)n * M + m) * S + qg[lane]) * P + pt) * 3 * L];
             for (int kk = 0; kk < L; ++kk) {
               const int l = g.lv.l[kk];
-              xs[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2] + row[2 * l] / (float)g.lv.W[kk];
-              ys[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2 + 1] + row[2 * l + 1] / (float)g.lv.H[kk];
-              as[lane][kk] = row[2 * L + l];
+              // the kernel's division: reciprocal multiply + exact-remainder correction; must equal the IEEE quotient
+              const float Wf = (float)g.lv.W[kk], Hf = (float)g.lv.H[kk];
+              if (g.lv.l[kk] != order[kk]) { printf("slot order mismatch\n"); ++bad_total; }
+              const float qx = row[2 * kk] * g.lv.rW[kk], qy = row[2 * kk + 1] * g.lv.rH[kk];
+              const float ox = fmaf(fmaf(-qx, Wf, row[2 * kk]), g.lv.rW[kk], qx), oy = fmaf(fmaf(-qy, Hf, row[2 * kk + 1]), g.lv.rH[kk], qy);
+              if (ox != row[2 * kk] / Wf || oy != row[2 * kk + 1] / Hf) ++inexact_div;
+              xs[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2] + ox;
+              ys[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2 + 1] + oy;
+              as[lane][kk] = row[2 * L + kk];
             }
           }
           for (int qi = 0; qi < 16; ++qi) {   // softmax over the L * P logits of the query (the 4 DPP rows)
@@ -170,8 +182,8 @@ int main() {
           for (int kk = 0; kk < L; ++kk) {
             S5Rec rec[64];
             for (int lane = 0; lane < 64; ++lane) {
-              rec[lane] = s5_record(xs[lane][kk], ys[lane][kk], as[lane][kk], (float)g.lv.H[kk], (float)g.lv.W[kk], t.wx0[kk], t.wy0[kk],
-                                    t.ww[kk], t.wh[kk], t.par[kk], t.rot[kk], g.lv.nsr[kk], g.lv.pitch[kk], (unsigned)g.lv.reg[kk], lane & 15);
+              rec[lane] = s5_record(xs[lane][kk], ys[lane][kk], as[lane][kk], (float)g.lv.H[kk], (float)g.lv.W[kk], t.p0[kk], t.p1[kk],
+                                    g.lv.nsr[kk], g.lv.pitch[kk], g.lv.next_d[kk], g.lv.wrap_d[kk], (unsigned)g.lv.reg[kk], lane & 15);
               ++samples;
             }
             for (int k = 0; k < 4; ++k)
@@ -197,7 +209,7 @@ int main() {
                 }
               }
             for (int lane = 0; lane < 64; ++lane)
-              if (rec[lane].miss) {   // global fallback: the footprint formula on the head-major value
+              if (!rec[lane].inwin && as[lane][kk] != 0.f && s5_inband(xs[lane][kk], ys[lane][kk], (float)g.lv.H[kk], (float)g.lv.W[kk])) {   // global fallback
                 ++misses;
                 const Footprint fp = footprint(g.lv.H[kk], g.lv.W[kk], xs[lane][kk], ys[lane][kk], as[lane][kk]);
                 const float* vl = &vhm[((size_t)hd * S + g.lv.start[kk]) * 16];
@@ -259,9 +271,9 @@ int main() {
         }
     long long zero_cnt = 0;
     for (float v : cnt) zero_cnt += v < 1.f;
-    const bool ok = maxerr < 2e-5 && conflicts == 0 && stale == 0 && zero_cnt == 0 && uncovered == 0;
+    const bool ok = maxerr < 2e-5 && conflicts == 0 && stale == 0 && zero_cnt == 0 && uncovered == 0 && inexact_div == 0;
     printf("%-14s tiles %3d (%dx%d) lds %6zu B qmax %3lld: max err %.2e, bank conflicts %lld, stale reads %lld, unwritten outputs %lld, "
-           "misses %.3f %% of %lld samples  %s\n", c.name, g.ntiles, g.tiles_x, g.tiles_y, g.lds, g.qmax, maxerr, conflicts, stale, zero_cnt,
+           "inexact divisions %lld, misses %.3f %% of %lld samples  %s\n", c.name, g.ntiles, g.tiles_x, g.tiles_y, g.lds, g.qmax, maxerr, conflicts, stale, zero_cnt, inexact_div,
            100.0 * misses / std::max<long long>(samples, 1), samples, ok ? "ok" : "FAIL");
     if (!ok) ++bad_total;
   }

@@ -93,10 +93,9 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
     return it;
   };
   auto header = [&](const Item& it) __attribute__((always_inline)) {
-    return reinterpret_cast<const int*>(tiles + it.tile)[lane & 31];
+    return reinterpret_cast<const int*>(tiles + it.tile)[lane & 15];
   };
-  enum { HD_WX0 = 0, HD_WY0 = S5_LMAX, HD_WW = 2 * S5_LMAX, HD_WH = 3 * S5_LMAX, HD_ROT = 4 * S5_LMAX, HD_PAR = 5 * S5_LMAX,
-         HD_TOTAL = 6 * S5_LMAX, HD_NCOLD = 6 * S5_LMAX + 1, HD_NENTER_NEXT = 6 * S5_LMAX + 2 };
+  enum { HD_P0 = 0, HD_P1 = S5_LMAX, HD_TOTAL = 2 * S5_LMAX, HD_NCOLD = 2 * S5_LMAX + 1, HD_NENTER_NEXT = 2 * S5_LMAX + 2 };
   auto hfield = [&](int hdv, int idx) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(hdv, idx); };
 
   // =========================== moving rows ===========================
@@ -143,36 +142,45 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
   const int qslot = wave * 16 + qi;                    // my query's index within an item
 
   auto my_query = [&](const Item& it) __attribute__((always_inline)) { return qtab[it.tile * S5_QCAP + qslot]; };
-  // The levels' sizes as floats, held in VGPRs on purpose: uniform, but an SGPR source operand halves the issue rate of
-  // the fp32 instructions that consume it (profiles/r02_gfx950_issue_costs.txt).
+  // The levels' sizes as floats (uniform; scalar operands: the 128-register budget has no room for vector copies)
   float Hf[L], Wf[L];
 #pragma unroll
-  for (int kk = 0; kk < L; ++kk) {
-    Hf[kk] = (float)lv.H[kk]; Wf[kk] = (float)lv.W[kk];
-    asm volatile("" : "+v"(Hf[kk]), "+v"(Wf[kk]));
-  }
+  for (int kk = 0; kk < L; ++kk) { Hf[kk] = (float)lv.H[kk]; Wf[kk] = (float)lv.W[kk]; }
 
   struct Inputs { float x[L], y[L], a[L]; };
-  auto load_inputs = [&](const Item& it, int qg, Inputs& iv) __attribute__((always_inline)) {
-    // my (query, head, point)'s 3 L floats: L offset pairs then L logits (slot order); the query's reference point
-    const float* row = a.qhm + ((((long long)it.n * M + it.m) * S + qg) * P + pt) * (3 * L);
-    const float2 rp2 = *reinterpret_cast<const float2*>(a.ref + it.n * a.ref_batch_stride + (long long)qg * 2);
-    float raw[3 * L];
+  struct RawInputs { float v[3 * L]; float2 rp; };
+  // my (query, head, point)'s 3 L floats -- L offset pairs then L logits (slot order) -- and the query's reference point:
+  // loads only; `finish_inputs` does the arithmetic an item later, when the loads have long arrived
+  auto load_raw = [&](const Item& it, int qg, RawInputs& r) __attribute__((always_inline)) {
+    // uniform 64-bit bases + 32-bit lane offsets (host-checked: the projections of one (frame, head) stay below 4 GB)
+    const char* rowb = reinterpret_cast<const char*>(a.qhm + ((long long)it.n * M + it.m) * S * (P * 3 * L));
+    const char* refb = reinterpret_cast<const char*>(a.ref + it.n * a.ref_batch_stride);
+    const unsigned ro = ((unsigned)qg * P + (unsigned)pt) * (unsigned)(3 * L * 4);
+    const float* row = reinterpret_cast<const float*>(rowb + ro);
+    r.rp = *reinterpret_cast<const float2*>(refb + (unsigned)qg * 8u);
     if constexpr (L == 3) {
       const s5v4u r0 = *reinterpret_cast<const s5v4u*>(row), r1 = *reinterpret_cast<const s5v4u*>(row + 4);
-      raw[0] = r0.x; raw[1] = r0.y; raw[2] = r0.z; raw[3] = r0.w;
-      raw[4] = r1.x; raw[5] = r1.y; raw[6] = r1.z; raw[7] = r1.w;
-      raw[8] = row[8];
+      r.v[0] = r0.x; r.v[1] = r0.y; r.v[2] = r0.z; r.v[3] = r0.w;
+      r.v[4] = r1.x; r.v[5] = r1.y; r.v[6] = r1.z; r.v[7] = r1.w;
+      r.v[8] = row[8];
     } else {
 #pragma unroll
-      for (int i = 0; i < 3 * L; ++i) raw[i] = row[i];
+      for (int i = 0; i < 3 * L; ++i) r.v[i] = row[i];
     }
+  };
+  auto finish_inputs = [&](const RawInputs& r, Inputs& iv) __attribute__((always_inline)) {
     float lg[L];
 #pragma unroll
     for (int kk = 0; kk < L; ++kk) {
-      lg[kk] = raw[2 * L + kk];
-      iv.x[kk] = rp2.x + raw[2 * kk] / Wf[kk];
-      iv.y[kk] = rp2.y + raw[2 * kk + 1] / Hf[kk];
+      lg[kk] = r.v[2 * L + kk];
+      // offset / (W_l, H_l), IEEE-exact: q = a * RN(1 / b), corrected by the exact remainder (two FMAs; b is a small integer
+      // and a is far from the ends of the exponent range, so the corrected quotient is the correctly rounded one --
+      // tools/strips_emulate.cpp compares it with the division on every sample)
+      const float qx = r.v[2 * kk] * lv.rW[kk], qy = r.v[2 * kk + 1] * lv.rH[kk];
+      const float ox = fmaf(fmaf(-qx, Wf[kk], r.v[2 * kk]), lv.rW[kk], qx);
+      const float oy = fmaf(fmaf(-qy, Hf[kk], r.v[2 * kk + 1]), lv.rH[kk], qy);
+      iv.x[kk] = r.rp.x + ox;
+      iv.y[kk] = r.rp.y + oy;
     }
     // softmax over the L * P logits of (query, head): the 4 points of a query sit in the 4 DPP rows
     auto all_rows = [&](float v, bool is_max) __attribute__((always_inline)) {
@@ -190,12 +198,13 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
     float sum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < L; ++kk) {
-      iv.a[kk] = expf(lg[kk] - mx);
+      iv.a[kk] = __builtin_amdgcn_exp2f((lg[kk] - mx) * 1.44269504088896340736f);   // arguments <= 0: no range handling needed
       sum += iv.a[kk];
     }
     sum = all_rows(sum, false);
+    const float rs = __builtin_amdgcn_rcpf(sum);   // sum in [1, L * P]
 #pragma unroll
-    for (int kk = 0; kk < L; ++kk) iv.a[kk] = iv.a[kk] / sum;
+    for (int kk = 0; kk < L; ++kk) iv.a[kk] = iv.a[kk] * rs;
   };
 
   // ---- prologue: the whole windows of the first tile (a cold start), the first two query lists, the first inputs
@@ -204,7 +213,11 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
   int qg_cur = my_query(cur);
   int qg_nxt = my_query(make_item(g0 + 1));
   Inputs in_cur;
-  load_inputs(cur, qg_cur, in_cur);
+  {
+    RawInputs r0;
+    load_raw(cur, qg_cur, r0);
+    finish_inputs(r0, in_cur);
+  }
   {
     const s5u3 list = piece_list(cur, 1);
     const int n_cold = hfield(hdv, HD_NCOLD);
@@ -223,9 +236,17 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
   for (unsigned g = g0;; ++g) {
     const bool has_next = g + 1 < g1;
     const Item nxt = make_item(g + 1);
-    Inputs in_nxt;
+    // ---- 0. everything the NEXT item needs is requested here, ahead of this item's gathers (~2k clocks of cover): its
+    // inputs (the query list was fetched an item ago), the rows entering its windows (first pass; the piece list was
+    // fetched an item ago; after the last tile of the range the same rows are written once more: identical data, nobody
+    // reads them), its header, and the lists of the item after it.  Issued behind a level's gather instead, the last
+    // slice would be waited for at the barrier a few hundred clocks later.
+    RawInputs raw_nxt;
+    load_raw(nxt, qg_nxt, raw_nxt);
+    load_rows(rows, nxt, 0);
     int hdv_nxt = 0, qg_n2 = 0;
     s5u3 rows_n2 = {0u, 0u, 0u};
+    __builtin_amdgcn_sched_barrier(0);
 
     t3v4 acc[4];   // my sample's 16 channels, chunk slot j = channel chunk j ^ rot4; summed over the levels
 #pragma unroll
@@ -233,42 +254,54 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
 
 #pragma unroll
     for (int kk = 0; kk < L; ++kk) {
+      if (kk == L - 1) {   // (ahead of the last level's gather: ~700 clocks of cover, L2 hits)
+        hdv_nxt = header(nxt);
+        const Item nn = make_item(g + 2);
+        qg_n2 = my_query(nn);
+        rows_n2 = piece_list(nn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- A. my sample's record at this level (msda_strips_geom.h: s5_record, shared with the host emulator)
-      const S5Rec rec = s5_record(in_cur.x[kk], in_cur.y[kk], in_cur.a[kk], Hf[kk], Wf[kk], hfield(hdv, HD_WX0 + kk),
-                                  hfield(hdv, HD_WY0 + kk), hfield(hdv, HD_WW + kk), hfield(hdv, HD_WH + kk),
-                                  hfield(hdv, HD_PAR + kk), hfield(hdv, HD_ROT + kk), lv.nsr[kk], lv.pitch[kk],
+      const S5Rec rec = s5_record(in_cur.x[kk], in_cur.y[kk], in_cur.a[kk], Hf[kk], Wf[kk], (unsigned)hfield(hdv, HD_P0 + kk),
+                                  (unsigned)hfield(hdv, HD_P1 + kk), lv.nsr[kk], lv.pitch[kk], lv.next_d[kk], lv.wrap_d[kk],
                                   lds_base + (unsigned)lv.reg[kk], (unsigned)lane & 15u);
-      const bool miss = rec.miss;
 
-      // ---- B. gather: 4 corners x 4 chunks
-#define S5_CORNER(ADDR, WGT)                                                                      \
+      // ---- B. gather: 4 corners x 4 chunks, two corners per trip.  The 4 reads of a corner are one asm statement: left to hipcc at
+      // this register budget (four waves per SIMD) every read is waited for before the next is issued (same destination
+      // registers), and fully unrolled it issues all 16 reads of the level first (64 data registers: spills).
+#define S5_FMA4(D, WGT, J)                                                                        \
   {                                                                                               \
     const t3v2 w2_ = {WGT, WGT};                                                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-      const t3v4 d = *(const T3_LDS t3v4*)(unsigned long long)((ADDR) ^ (unsigned)(j << 4));      \
-      const t3v2 lo = __builtin_elementwise_fma(w2_, (t3v2){d.x, d.y}, (t3v2){acc[j].x, acc[j].y}); \
-      const t3v2 hi = __builtin_elementwise_fma(w2_, (t3v2){d.z, d.w}, (t3v2){acc[j].z, acc[j].w}); \
-      acc[j] = (t3v4){lo.x, lo.y, hi.x, hi.y};                                                    \
-    }                                                                                             \
+    const t3v2 lo = __builtin_elementwise_fma(w2_, (t3v2){D.x, D.y}, (t3v2){acc[J].x, acc[J].y}); \
+    const t3v2 hi = __builtin_elementwise_fma(w2_, (t3v2){D.z, D.w}, (t3v2){acc[J].z, acc[J].w}); \
+    acc[J] = (t3v4){lo.x, lo.y, hi.x, hi.y};                                                      \
   }
-      // (a real two-trip loop: fully unrolled, hipcc issues all 16 reads of the level before the first FMA -- 64 data
-      // registers in flight, which the 128-register budget of four waves per SIMD does not have)
       {
         unsigned ca = rec.a[0], cb = rec.a[1];
         float wa = rec.w[0], wb = rec.w[1];
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) {
-          S5_CORNER(ca, wa)
-          S5_CORNER(cb, wb)
+#define S5_READ4(A, D0, D1, D2, D3)                                                                                      \
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)" \
+               : "=&v"(D0), "=&v"(D1), "=&v"(D2), "=&v"(D3)                                                              \
+               : "v"(A), "v"((A) ^ 16u), "v"((A) ^ 32u), "v"((A) ^ 48u)                                                   \
+               : "memory")
+          t3v4 d0, d1, d2, d3;
+          S5_READ4(ca, d0, d1, d2, d3);
+          S5_FMA4(d0, wa, 0) S5_FMA4(d1, wa, 1) S5_FMA4(d2, wa, 2) S5_FMA4(d3, wa, 3)
+          S5_READ4(cb, d0, d1, d2, d3);
+          S5_FMA4(d0, wb, 0) S5_FMA4(d1, wb, 1) S5_FMA4(d2, wb, 2) S5_FMA4(d3, wb, 3)
+#undef S5_READ4
           ca = rec.a[2]; cb = rec.a[3]; wa = rec.w[2]; wb = rec.w[3];
         }
       }
-#undef S5_CORNER
+#undef S5_FMA4
 
       // ---- C. rare: samples whose footprint leaves the tile's window -> the whole wave fetches the four corners from
       // global memory (lane = corner lane >> 4, channel lane & 15), sums them over the corners and hands the 16 channels
       // to the owning lane
-      unsigned long long mm = __ballot(miss);
+      unsigned long long mm = __ballot(!rec.inwin);
+      if (mm != 0) mm = __ballot(!rec.inwin && in_cur.a[kk] != 0.f && s5_inband(in_cur.x[kk], in_cur.y[kk], Hf[kk], Wf[kk]));
       if (mm != 0) {
         const float* vl = a.vhm + ((long long)cur.hd * S + lv.start[kk]) * DH + (lane & 15);
 #pragma unroll 1
@@ -297,23 +330,10 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
           }
         }
       }
-      // ---- requests, one slice per level (fenced: the scheduler would hoist the loads to the top of the item)
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk == 0) {
-        load_inputs(nxt, qg_nxt, in_nxt);   // the next item's inputs (its query list was fetched an item ago)
-      }
-      if (kk == (L > 1 ? 1 : 0)) {
-        // the rows entering the next tile's windows (first pass; their piece list was fetched an item ago).  After the
-        // last tile of the range the same rows are written once more: identical data, and nobody reads them.
-        load_rows(rows, nxt, 0);
-      }
-      if (kk == L - 1) {
-        hdv_nxt = header(nxt);              // the next item's header; the lists of the item after it
-        const Item nn = make_item(g + 2);
-        qg_n2 = my_query(nn);
-        rows_n2 = piece_list(nn, 0);
-      }
     }
+    // the next item's locations and weights from its raw projections (loaded at the top of this item)
+    Inputs in_nxt;
+    finish_inputs(raw_nxt, in_nxt);
 
     __syncthreads();   // A: nobody reads the rows that are about to be replaced any more
     // Every load of this item -- the next tile's rows, inputs, header, the lists of the tile after it -- is waited for
@@ -347,9 +367,9 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
         const t3u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s8[f]), __float_as_uint(s8[f + 4]), false, false);
         t4[f] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
       }
-      float* orow = a.out + (((long long)cur.n * S + qg_cur) * M + cur.m) * 32 + cur.half * DH;
-      const unsigned ca = (unsigned)pt ^ rot4;
-      *reinterpret_cast<t3v4*>(orow + ca * 4) = (t3v4){t4[0], t4[1], t4[2], t4[3]};
+      char* ob = reinterpret_cast<char*>(a.out + ((long long)cur.n * S * M + cur.m) * 32 + cur.half * DH);   // uniform
+      const unsigned oo = (unsigned)qg_cur * (unsigned)(M * 128) + (((unsigned)pt ^ rot4) << 4);               // < 2^32 (host-checked)
+      *reinterpret_cast<t3v4*>(ob + oo) = (t3v4){t4[0], t4[1], t4[2], t4[3]};
     }
     __syncthreads();   // B: the next tile's rows are in place
     if (!has_next) break;
@@ -445,7 +465,9 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
                             long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
                             hipStream_t st) {
   if (D != 32 || P != 4 || L < 1 || L > 4 || Lq != S || M < 1) return 0;
-  if ((long long)S * S5_DH * 4 >= (1LL << 31) || (long long)N * M * 2 >= (1LL << 30)) return 0;
+  if ((long long)S * S5_DH * 4 >= (1LL << 31) || (long long)N * M * 2 >= (1LL << 30) || (long long)S * M * 128 >= (1LL << 32) ||
+      (long long)S * P * 3 * L * 4 >= (1LL << 32))
+    return 0;
   long long expect = 0;
   int fine = 0;
   for (int l = 0; l < L; ++l) {
@@ -478,7 +500,7 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
     }
     n_cu = v;
   }
-  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", 2 * n_cu), 1));
+  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", 4 * n_cu), 1));
   S5Args a{vhm, qhm, ref, ref_batch_stride, out, N, S, M};
   switch (L) {
     case 1: launch_strips<1>(grid, (unsigned)nb, st, g, a); break;

@@ -38,18 +38,28 @@ constexpr int S5_LDS_MAX = 80 * 1024;   // two workgroups per CU
 struct S5Levels {
   int H[S5_LMAX], W[S5_LMAX], start[S5_LMAX], l[S5_LMAX];
   int pitch[S5_LMAX], reg[S5_LMAX], nsr[S5_LMAX];   // LDS row pitch (pixels, even), region byte offset, super-rows
+  float rW[S5_LMAX], rH[S5_LMAX];                   // 1 / W, 1 / H correctly rounded (exact division by two FMAs)
+  int next_d[S5_LMAX], wrap_d[S5_LMAX];             // byte distance from a sample's top row in the ODD half of a super-row to
+                                                    // the row below it, minus 64: pitch * 128 - 128, and the same when the
+                                                    // next super-row wraps to super-row 0: -(nsr - 1) * pitch * 128 - 128
 };
-// Per tile, workgroup-uniform; 32 dwords, fetched with one vector load (lane k = dword k).
+// Per tile, workgroup-uniform; 16 dwords, fetched with one vector load (lane k = dword k & 15).
 struct S5Tile {
-  int wx0[S5_LMAX], wy0[S5_LMAX], ww[S5_LMAX], wh[S5_LMAX];   // the tile's windows (with the zero ring)
-  int rot[S5_LMAX];   // ((wy0 + 1) >> 1) mod nsr: LDS super-row of the window's first row
-  int par[S5_LMAX];   // (wy0 + 1) & 1: half of that super-row the first row lives in
+  // p0: (wx0 + 1) | (wy0 + 1) << 12 | rot << 24 | par << 30 -- first column / row of the tile's window (zero ring included:
+  // >= -1), rot = ((wy0 + 1) >> 1) mod nsr = LDS super-row of the window's first row, par = (wy0 + 1) & 1 = the half of
+  // that super-row it lives in;  p1: (ww - 2) | (wh - 2) << 8 -- the upper-left corner of a footprint may sit in window
+  // columns [0, ww - 2], rows [0, wh - 2]
+  unsigned p0[S5_LMAX], p1[S5_LMAX];
   int total;          // queries of the tile
   int n_cold;         // pieces per wave of this tile's "whole windows" list
   int n_enter_next;   // pieces per wave of the NEXT tile's "entering rows" list (next in the sequence, wrapping)
   int pad[5];
 };
-static_assert(sizeof(S5Tile) == 128, "32 dwords");
+static_assert(sizeof(S5Tile) == 64, "16 dwords");
+__host__ __device__ __forceinline__ int s5_wx0(unsigned p0) { return (int)(p0 & 0xfffu) - 1; }
+__host__ __device__ __forceinline__ int s5_wy0(unsigned p0) { return (int)((p0 >> 12) & 0xfffu) - 1; }
+__host__ __device__ __forceinline__ int s5_rot(unsigned p0) { return (int)((p0 >> 24) & 0x3fu); }
+__host__ __device__ __forceinline__ int s5_par(unsigned p0) { return (int)((p0 >> 30) & 1u); }
 // One (row, 16-pixel column block) of one level's window: what one wave instruction moves (4 lanes x 16 B per pixel).
 struct S5Piece {
   unsigned a;   // S5_PX_BIAS + pixel index (start + y * W + x) of the block's first pixel within the frame (24 bits) |
@@ -60,57 +70,85 @@ struct S5Piece {
 };
 
 // ---- a lane's sample record at one level: shared by the kernel and the host emulator (tools/strips_emulate.cpp).
-// Inputs: the sample's normalised location (x, y) and attention weight, the level's size as floats, the tile's window
-// (wx0, wy0, ww, wh; zero ring included), par / rot of the window's first row (S5Tile), the level's nsr / pitch and the byte
-// address of its LDS region, and the lane's low four bits.  Outputs: the LDS byte addresses of the four corners in the
-// lane's visiting order (chunk rotation already in bits 4-5: read chunk slot j at a[k] ^ (j << 4)) with their weights, and
-// whether the footprint leaves the window (then all weights are 0 and the caller adds the sample from global memory).
+// Inputs: the sample's normalised location (x, y) and attention weight (FINITE: like the split-bf16 Linears that produce
+// them, this path does not define results for inf / NaN activations), the level's size as floats, the tile's packed window
+// words p0 / p1 (S5Tile), the level's nsr / pitch / next_d / wrap_d and the byte address of its LDS region, and the lane's
+// low four bits.  Outputs: the LDS byte addresses of the four corners in the lane's visiting order (chunk rotation
+// already in bits 4-5: read chunk slot j at a[k] ^ (j << 4)) with their weights, and `inwin`: the footprint lies inside
+// the window (otherwise all weights are 0, the addresses point at the window's first pixel, and the caller checks whether
+// the sample is inside the band and adds it from global memory).
 struct S5Rec {
   unsigned a[4];
   float w[4];
-  bool miss;
+  bool inwin;
 };
-__host__ __device__ __forceinline__ S5Rec s5_record(float x, float y, float awt, float Hf, float Wf, int wx0, int wy0, int ww,
-                                                    int wh, int par, int rot, int nsr, int pitch, unsigned region, unsigned lane4) {
+__host__ __device__ __forceinline__ int s5_floor_to_int(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));   // floor and convert in one (saturating)
+  return r;
+#else
+  return (int)floorf(fminf(fmaxf(v, -1e6f), 1e6f));
+#endif
+}
+__host__ __device__ __forceinline__ unsigned s5_mul24(unsigned a, unsigned b) {   // both < 2^24
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+__host__ __device__ __forceinline__ float s5_fract(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fractf(v);                      // v - floor(v), kept below 1
+#else
+  return v - floorf(v);
+#endif
+}
+__host__ __device__ __forceinline__ S5Rec s5_record(float x, float y, float awt, float Hf, float Wf, unsigned p0, unsigned p1,
+                                                    int nsr, int pitch, int next_d, int wrap_d, unsigned region, unsigned lane4) {
   // reference arithmetic: ms_deform_im2col_cuda.cuh:285-293 and :38-89; the window includes the one-pixel zero ring around
   // the level, so out-of-level corners simply read zeros
-  const float him = y * Hf - 0.5f, wim = x * Wf - 0.5f;
-  const float hf = floorf(him), wf = floorf(wim);
-  // the band (-1, H) x (-1, W) as |v - centre| < radius; false for NaN / inf like the reference's four compares
-  const bool inband = fabsf(fmaf(Hf, -0.5f, him) + 0.5f) < fmaf(Hf, 0.5f, 0.5f) && fabsf(fmaf(Wf, -0.5f, wim) + 0.5f) < fmaf(Wf, 0.5f, 0.5f);
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (v_cvt_i32_f32 saturates and maps NaN to 0; out-of-band samples never use the result)
-  const int r0 = (int)hf - wy0, c0 = (int)wf - wx0;
-#else
-  const int r0 = (int)fminf(fmaxf(hf, -4.f), Hf + 4.f) - wy0, c0 = (int)fminf(fmaxf(wf, -4.f), Wf + 4.f) - wx0;
-#endif
-  const bool inwin = (unsigned)r0 < (unsigned)(wh - 1) && (unsigned)c0 < (unsigned)(ww - 1);
-  const bool use = inband && inwin;
+  const float him = fmaf(y, Hf, -0.5f), wim = fmaf(x, Wf, -0.5f);
+  const int r0 = s5_floor_to_int(him) - s5_wy0(p0), c0 = s5_floor_to_int(wim) - s5_wx0(p0);
+  const float lh = s5_fract(him), lw = s5_fract(wim);
+  // Footprint inside the window?  A window never leaves the ring-extended level, so an in-window sample is inside the
+  // reference's band (-1, H) x (-1, W) -- except exactly on its open edge (him == -1), where the bilinear weights of the
+  // only in-level row are 0 anyway: the band test of cuh:293 is implied.
   S5Rec rec;
-  rec.miss = inband && !inwin && awt != 0.f;
-  // (a sample that must not contribute still reads: it points at the window's first pixel, which is always staged; its
-  // weights are exact zeros -- selects, not products, so that a NaN location contributes nothing)
-  const float lh = use ? him - hf : 0.f, lw = use ? wim - wf : 0.f, aw = use ? awt : 0.f;
+  rec.inwin = (unsigned)r0 <= ((p1 >> 8) & 0xffu) && (unsigned)c0 <= (p1 & 0xffu);
+  // (a sample that must not contribute still reads: everything is masked to the window's first pixel, which is always
+  // staged; its attention weight becomes an exact 0)
+  const unsigned m = rec.inwin ? 0xffffffffu : 0u;
+  const float aw = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, awt) & m);
   // window row r0 -> (super-row, half): rows are paired by the parity of y + 1
-  const int yrel = (use ? r0 : 0) + par;
-  int srl = (yrel >> 1) + rot;
-  srl -= srl >= nsr ? nsr : 0;
-  const unsigned hy = (unsigned)yrel & 1u;
-  const unsigned tl = region + (unsigned)((srl * pitch + (use ? c0 : 0)) * 128) + hy * 64u;
-  // the row below: the other half of the same super-pixel, or the first half of the next super-row (circular)
-  const unsigned nextsr = (srl + 1 == nsr) ? (unsigned)(-(nsr - 1) * pitch * 128 - 64) : (unsigned)(pitch * 128 - 64);
-  const unsigned below = hy ? nextsr : 64u;
-  const unsigned lb0 = lane4 & 1u, lb1 = (lane4 >> 1) & 1u, r4 = ((lane4 >> 2) & 3u) << 4;
+  const unsigned yrel = ((unsigned)r0 & m) + (unsigned)s5_par(p0);
+  const unsigned hy = yrel & 1u;
+  unsigned srl = (yrel >> 1) + (unsigned)s5_rot(p0);
+  const unsigned srw = srl - (unsigned)nsr;
+  srl = srl < srw ? srl : srw;                   // circular: srl - nsr underflows to a huge number unless srl >= nsr
+  const unsigned idx = s5_mul24(srl, (unsigned)pitch) + ((unsigned)c0 & m);
+  const unsigned r4 = ((lane4 >> 2) & 3u) << 4;
+  const unsigned tl = ((idx << 7) + region) | (hy << 6) | r4;
+  // the row below: the other half of the same super-pixel (+64), or the first half of the next super-row (circular)
+  const int nd = (srl + 1u == (unsigned)nsr) ? wrap_d : next_d;
+  const unsigned below = 64u + ((unsigned)nd & (0u - hy));
+  const unsigned lb0 = lane4 & 1u, lb1 = (lane4 >> 1) & 1u;
   const unsigned fs = ((tl >> 7) ^ lb0) & 1u;   // which corner column I read first
-  const unsigned ft = (hy ^ lb1) & 1u;          // which corner row I read first
-  const unsigned c00 = tl + fs * 128u, c01 = tl + 128u - fs * 128u;
-  const unsigned rowd = ft ? below : 0u, rowd2 = ft ? 0u : below;
-  rec.a[0] = (c00 + rowd) | r4; rec.a[1] = (c01 + rowd) | r4; rec.a[2] = (c00 + rowd2) | r4; rec.a[3] = (c01 + rowd2) | r4;
+  const unsigned ft = hy ^ lb1;                 // which corner row I read first
+  const unsigned c00 = tl + (fs << 7), c01 = tl + ((fs ^ 1u) << 7);
+  const unsigned rowd = below & (0u - ft), rowd2 = below - rowd;
+  rec.a[0] = c00 + rowd; rec.a[1] = c01 + rowd; rec.a[2] = c00 + rowd2; rec.a[3] = c01 + rowd2;
   const float f0 = fs ? lw : 1.f - lw;          // column weight of the corner column read first
   const float g0 = ft ? lh : 1.f - lh;          // row weight of the corner row read first
   const float wr0 = aw * g0, wr1 = aw - wr0;
   rec.w[0] = wr0 * f0; rec.w[1] = wr0 - rec.w[0]; rec.w[2] = wr1 * f0; rec.w[3] = wr1 - rec.w[2];
   return rec;
+}
+// inside the reference's band (-1, H) x (-1, W)?  (only evaluated for samples outside the window: the rare path)
+__host__ __device__ __forceinline__ bool s5_inband(float x, float y, float Hf, float Wf) {
+  const float him = fmaf(y, Hf, -0.5f), wim = fmaf(x, Wf, -0.5f);
+  return him > -1.f && wim > -1.f && him < Hf && wim < Wf;
 }
 
 struct S5Host {
@@ -165,6 +203,8 @@ static bool s5_build_host(const LevelTable& lv, int L, int fine, int TH, int TW,
     const int l = ord[kk];
     g.lv.H[kk] = lv.H[l]; g.lv.W[kk] = lv.W[l]; g.lv.start[kk] = lv.start[l]; g.lv.l[kk] = l;
     g.lv.pitch[kk] = pitch[l]; g.lv.nsr[kk] = nsr[l]; g.lv.reg[kk] = (int)lds;
+    g.lv.rW[kk] = 1.0f / (float)lv.W[l]; g.lv.rH[kk] = 1.0f / (float)lv.H[l];
+    g.lv.next_d[kk] = pitch[l] * 128 - 128; g.lv.wrap_d[kk] = -(nsr[l] - 1) * pitch[l] * 128 - 128;
     lds += (size_t)nsr[l] * pitch[l] * 128;
   }
   g.lds = lds;
@@ -197,9 +237,11 @@ static bool s5_build_host(const LevelTable& lv, int L, int fine, int TH, int TW,
         for (int kk = 0; kk < L; ++kk) {
           const int l = ord[kk];
           const int4 gx = ax[(size_t)l * tiles_x + tx], gy = ay[(size_t)l * tiles_y + ty];
-          t.wx0[kk] = gx.z; t.wy0[kk] = gy.z; t.ww[kk] = gx.w; t.wh[kk] = gy.w;
-          t.rot[kk] = s5_pos_mod((gy.z + 1) >> 1, nsr[l]);
-          t.par[kk] = (gy.z + 1) & 1;
+          if (gx.z + 1 < 0 || gx.z + 1 > 0xfff || gy.z + 1 < 0 || gy.z + 1 > 0xfff || nsr[l] > 63 || gx.w < 2 || gy.w < 2 ||
+              gx.w - 2 > 0xff || gy.w - 2 > 0xff) g.ok = false;
+          t.p0[kk] = (unsigned)(gx.z + 1) | ((unsigned)(gy.z + 1) << 12) | ((unsigned)s5_pos_mod((gy.z + 1) >> 1, nsr[l]) << 24) |
+                     ((unsigned)((gy.z + 1) & 1) << 30);
+          t.p1[kk] = (unsigned)(gx.w - 2) | ((unsigned)(gy.w - 2) << 8);
           if (gy.z < -1 || gx.z < -1) g.ok = false;   // (axis_entry clips windows to the zero ring)
           int y0 = gy.z, n = gy.w;
           if (which == 0 && ty > 0) {
