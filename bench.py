@@ -299,13 +299,14 @@ def main():
 
     t_msda = OpTimer(ops, "ms_deform_attn_forward", after=ops.msda_last_tiled_generation)
     t_msdaf = OpTimer(ops, "msda_forward_fused")
+    t_msdas = OpTimer(ops, "msda_forward_strips")
     t_mdec = OpTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)
     t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
     t_res = OpTimer(ops, "bilinear_resample",
                     key=lambda x, size, addend=None: ("fpn" if addend is not None else "maskfeat",) + tuple(int(v) for v in size))
     t_win = OpTimer(ops, "window_attention_image",
                     key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale: (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
-    timers = [t_msda, t_msdaf, t_mdec, t_mattn, t_res, t_win]
+    timers = [t_msda, t_msdaf, t_msdas, t_mdec, t_mattn, t_res, t_win]
     PROF_STEPS = 5
     for t_ in timers:
         t_.enabled = True
@@ -317,15 +318,18 @@ def main():
 
     S = 23 * 40 + 46 * 80 + 92 * 160
     alg = 3200.0 * S * T   # bytes per launch (one launch = T frames of one encoder layer)
-    sec, n = t_msda.seconds()
-    fused = False
+    sec, n = t_msdas.seconds()
+    fused, strips = bool(n), bool(n)
+    if not n:
+        sec, n = t_msda.seconds()
     if not n:
         sec, n = t_msdaf.seconds()
         fused = True
     if n:
         gens = set(t_msda.notes.get("all", []))
-        gen = (4 if os.environ.get("UNIVS_MSDA_TILED", "") == "4" else 3) if fused else (max(gens) if gens else 0)
-        kname = {4: "msda_fwd_tiled4 (MSDeformAttn forward: strips with resident row-circular windows, a lane owns a sample)",
+        gen = 5 if strips else 3 if fused else (max(gens) if gens else 0)
+        kname = {5: "msda_fwd_strips<3> (MSDeformAttn core on head-major operands: strips with resident row-circular windows at half a "
+                    "head per workgroup, two workgroups per CU, a lane owns a sample)",
                  3: "msda_fwd_tiled3 (MSDeformAttn forward: LDS-tiled, register records + DPP gathers, fill waves)",
                  2: "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)",
                  1: "msda_fwd_tiled<3> (MSDeformAttn forward: LDS-tiled, single window)"}.get(gen, "msda_fwd_vec4 (generic)")
@@ -343,7 +347,7 @@ def main():
                                                      "achieved": (alg + prep) / sec / 1e9, "frac": (alg + prep) / sec / HBM_PEAK}
         # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
         # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
-        for fn in ("r02_msda_traffic.json", "r01_msda_traffic.json"):
+        for fn in ("r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tr = json.load(f)

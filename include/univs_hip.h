@@ -93,21 +93,12 @@ int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const f
                            long long ref_batch_stride, const int64_t* spatial_shapes, int N, int Lq, int M,
                            int L, int P, float* loc, float* attn, void* stream);
 
-/* MSDeformAttn core fed with the RAW projections (fusion of univs_msda_prepare_f32 and univs_msda_forward_f32):
+/* MSDeformAttn core fed with the RAW projections -- the fusion of univs_msda_prepare_f32 and univs_msda_forward_f32:
  *   out = ms_deform_attn_forward(value, ..., loc, attn)   with
- *   loc  = ref_points[:, :, None, :, None, :] + offsets / (W_l, H_l)          (ms_deform_attn.py:106-109)
+ *   loc  = ref_points + offsets / (W_l, H_l)                                  (ms_deform_attn.py:106-109)
  *   attn = softmax(logits.view(N, Lq, M, L*P), -1)                            (ms_deform_attn.py:103)
- * `proj` [N, Lq, row_stride]: sampling offsets in columns [0, M*L*P*2), attention logits in columns
- * [n_off, n_off + M*L*P) (the two Linears of ms_deform_attn.py:101-102 as one GEMM); `ref_points` [N or 1, Lq, L, 2]
- * with ref_batch_stride = Lq*L*2 or 0.  The [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] tensors are never materialised.
- * Covered: D == 32, P == 4, 2 <= L <= 4, Lq == S (the encoder geometry); otherwise UNIVS_ERR_NOT_IMPLEMENTED and the
- * caller runs the two operators one after the other. */
-int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                 const float* proj, int row_stride, int n_off, const float* ref_points,
-                                 long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
-                                 void* stream);
-
-/* The same core on HEAD-MAJOR operands, half a head per workgroup (csrc/msda_strips.hip, generation 5: resident
+ * the [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] tensors are never materialised -- on HEAD-MAJOR operands, half a head per
+ * workgroup (csrc/msda_strips.hip: resident
  * row-circular windows, a lane owns a sample, two workgroups per CU):
  *   value_hm [N][M][2][S][16]   value_proj's output in blocks of 16 channels: univs_linear_blocked_f32(..., S, 16);
  *   proj_hm  [N][M][S][P][3 L]  per (query, head, point): L offset pairs (x, y) then L attention logits, levels ordered by
@@ -122,9 +113,33 @@ int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_
                                   const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S,
                                   int M, int D, int L, int Lq, int P, float* out, void* stream);
 
-/* Selects the MSDA forward implementation: 0 = auto (default), 1 = generic direct-gather kernel,
- * 2 = LDS-tiled encoder kernel (falls back to generic when its preconditions do not hold).
- * Used by the parity tests and bench to exercise each path explicitly. */
+/* ---------------------------------------------------------------------------------------------
+ * Process-wide settings.  The library reads NO environment variable: everything that selects an implementation or a
+ * tuning parameter is set here (0 / negative = the default).  univs_configure(NULL) restores the defaults.  Settings
+ * apply to calls that start afterwards; they are read once per call (a consistent snapshot), so changing them from
+ * another thread never tears a call -- but it does change what concurrent callers run, so tests and benchmarks that
+ * select kernels do it from one thread.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct UnivsConfig {
+  int size;               /* sizeof(UnivsConfig) of the caller (versioning) */
+  int msda_impl;          /* 0 auto, 1 generic direct-gather kernel, 2 LDS-tiled kernels where they apply */
+  int msda_strip_w;       /* msda_strips: tile width in pixels of the finest level (default 12) */
+  int msda_strip_h;       /* msda_strips: tile height (default 8; lowered until the windows fit 80 KB of LDS) */
+  int msda_halo;          /* LDS-tiled kernels: sampling offsets covered by the windows, pixels (default 6) */
+  int msda_grid;          /* LDS-tiled kernels: workgroups launched (default: 4 x CUs for msda_strips, 1 x CUs for msda_tiled2) */
+  int mask_decode_impl;   /* 0 by size, 1 exact-f32 MFMA kernel, 2 split-bf16 kernel wherever its preconditions hold */
+  int mask_decode_ct;     /* split-bf16 mask decode: 4 = the 64-column kernel (default 2: 32 columns) */
+  int mask_decode_ablate; /* timing experiments: 1 memory side only, 2 compute side only (results are then meaningless) */
+  int linear_wide_kmin;   /* Linears with K >= this take the x-stationary kernel (default 768) */
+  int linear_wide_nfeat;  /* x-stationary Linear: output features per pass (default: by shape) */
+  int window_attn_v1;     /* 1: the first 7x7 window-attention kernel (kernel benchmarks) */
+  int reserved[8];
+} UnivsConfig;
+int univs_configure(const UnivsConfig* cfg);
+int univs_get_config(UnivsConfig* out);
+
+/* Shorthand for UnivsConfig.msda_impl: 0 = auto (default), 1 = generic direct-gather kernel, 2 = LDS-tiled encoder kernel
+ * (falls back to generic when its preconditions do not hold). */
 int univs_msda_set_impl(int impl);
 /* Which implementation the last univs_msda_forward_f32 call on this thread launched: 1 generic,
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
@@ -134,22 +149,18 @@ int univs_msda_last_impl(void);
  * 0 = none (generic kernel). */
 int univs_msda_last_tiled_generation(void);
 
-/* y[M, N] = x[M, K] * W[N, K]^T + bias[N] (+ ReLU): torch.nn.functional.linear for contiguous float32 operands, as the
- * token projections of MSDeformAttn use it (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113:
- * value_proj, sampling_offsets + attention_weights, output_proj).  fp32 emulated on the bf16 matrix cores from an exact
- * 3-way split of both operands (error <= 3 * 2^-24 per product, i.e. fp32 rounding level).
- * Covered: K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31, at
- * least 16 output features of K fit the LDS (K <= 1664); anything else returns UNIVS_ERR_NOT_IMPLEMENTED without touching
- * y (the caller keeps its library GEMM).  bias may be NULL.  Finite inputs only: the 3-way split of +-Inf is Inf - Inf,
- * so an infinite operand yields NaN where an fp32 GEMM yields Inf. */
-int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
-                           int relu, float* y, void* stream);
-
-/* The same Linear with a fused epilogue, for the Swin block's MLP (mask2former/modeling/backbone/swin.py:35-58 Mlp.forward:
- * fc1 -> nn.GELU() -> fc2, and :291-293 `x = shortcut + self.mlp(...)`) and its qkv / proj projections (:137-141, :163):
+/* y[M, N] = act(x[M, K] * W[N, K]^T + bias[N]) (+ residual): torch.nn.functional.linear for contiguous float32 operands --
+ * the token projections of MSDeformAttn (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113: value_proj,
+ * sampling_offsets + attention_weights, output_proj), the encoder FFN, and the Swin block's MLP and qkv / proj projections
+ * (mask2former/modeling/backbone/swin.py:35-58 Mlp.forward: fc1 -> nn.GELU() -> fc2, :291-293 `x = shortcut + self.mlp(...)`,
+ * :137-141, :163).  fp32 emulated on the bf16 matrix cores from an exact 3-way split of both operands (error <= 3 * 2^-24
+ * per product, i.e. fp32 rounding level).
  *   act = 0: none, 1: ReLU, 2: exact GELU  x * 0.5 * (1 + erf(x / sqrt 2))  (nn.GELU(approximate='none'));
  *   residual (NULL or [M, N], contiguous): y = x W^T + bias + residual.  act != 0 together with a residual is rejected.
- * Same coverage rules and return codes as univs_linear_split_f32. */
+ * Covered: K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31, at
+ * least 16 output features of K fit the LDS (K <= 1664, beyond: the x-stationary variant for K % 128 == 0); anything else
+ * returns UNIVS_ERR_NOT_IMPLEMENTED without touching y (the caller keeps its library GEMM).  bias may be NULL.  Finite
+ * inputs only: the 3-way split of +-Inf is Inf - Inf, so an infinite operand yields NaN where an fp32 GEMM yields Inf. */
 int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
                            int K, int act, float* y, void* stream);
 
@@ -158,7 +169,7 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
  * -- the head-major operand layouts of univs_msda_forward_strips_f32, written by the producing Linear's epilogue at no
  * extra cost (ms_deform_attn.py:95-102: value_proj with col_block = 16, the merged offset / logit projection with
  * col_block = 3 L P).  Covered: K == 256, N % col_block == 0, col_block % 4 == 0, M % rows_per_batch == 0 and the
- * coverage rules of univs_linear_split_f32; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
+ * coverage rules of univs_linear_fused_f32; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
 int univs_linear_blocked_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                              int rows_per_batch, int col_block, float* y, void* stream);
 
@@ -166,7 +177,7 @@ int univs_linear_blocked_f32(const float* x, const float* weight, const float* b
  * x [T, Cin, H, W], y [T, Cout, H, W]; `w_tap_major` [Cout, 9 * Cin] is the weight [Cout, Cin, 3, 3] permuted to
  * [Cout, ky, kx, Cin] (w.permute(0, 2, 3, 1)).  The FPN output convolution of the pixel decoder
  * (mask2former/modeling/pixel_decoder/msdeformattn.py:227-232, :352; its GroupNorm + ReLU stay separate).  fp32 emulated on
- * the bf16 matrix cores from an exact 3-way split, like univs_linear_split_f32.
+ * the bf16 matrix cores from an exact 3-way split, like univs_linear_fused_f32.
  * Covered: Cin % 128 == 0, Cout = 128 or a multiple of 256 up to what one or more 256-feature passes cover, T*H*W >= 4096,
  * 16-byte aligned pointers, tensors < 2^31 bytes; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps its library
  * convolution). */
@@ -179,7 +190,7 @@ int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, 
  * keeps its own permuted copy). */
 int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, void* stream);
 
-/* Selects the mask-decode contraction kernel (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
+/* Shorthand for UnivsConfig.mask_decode_impl (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel
  * (v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fp32 fmaf chain), 2 = fp32 emulated on the bf16 matrix
  * cores from an exact 3-way split of both operands ("bf16 x 6", error <= 3 * 2^-24 per product) wherever its

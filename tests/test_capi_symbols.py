@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from univs_amd import _lib, build
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,3 +76,20 @@ def test_config_surface_loads_reference_style_yaml(tmp_path):
     assert cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES == 100 and cfg.INPUT.MIN_SIZE_TEST == 720
     assert cfg.INPUT.CROP.SIZE == (600, 1024) and cfg.INPUT.SAMPLING_FRAME_NUM == 4
     assert cfg.MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME == "MSDeformAttnPixelDecoder"   # default kept
+
+
+def test_configure_round_trip_without_a_gpu():
+    """UnivsConfig (include/univs_hip.h): the settings object is plain host state -- set by name, read back, validated."""
+    from univs_amd import ops
+    base = ops.get_config()
+    try:
+        prev = ops.configure(msda_impl=1, msda_halo=5)
+        assert prev == base and ops.get_config()["msda_impl"] == 1 and ops.get_config()["msda_halo"] == 5
+        with pytest.raises(RuntimeError):
+            ops.configure(mask_decode_ct=3)
+        with pytest.raises(KeyError):
+            ops.configure(nope=1)
+        assert ops.get_config()["msda_impl"] == 1
+    finally:
+        ops.configure()
+    assert all(v == 0 for v in ops.get_config().values())

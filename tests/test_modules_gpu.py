@@ -45,7 +45,7 @@ def test_pixel_decoder_matches_reference(cuda, golden_dir):
     pd = helpers.build_pixel_decoder(cases.HEAD_CASE["shapes"], cuda)
     with torch.no_grad():
         mf, mf_bfe, enc0, ms = pd.forward_features(_to(cases.backbone_features(), cuda))
-    assert ops.msda_last_impl() == 2, "the LDS-tiled MSDA kernel must be the one that ran"
+    assert ops.msda_last_impl() == 2, "an LDS-tiled MSDA kernel must be the one that ran"
     got = dict(mask_features=mf, mask_features_bfe_conv=mf_bfe, enc0=enc0, ms0=ms[0], ms1=ms[1], ms2=ms[2])
     for k, v in got.items():
         err = np.abs(v.cpu().numpy() - g[k]).max()
@@ -393,64 +393,61 @@ def test_config5_swinl_1080p_against_reference(cuda, golden_dir):
 def test_config5_full_clip_properties(cuda):
     """BASELINE config 5 at FULL size on the GPU (Swin-L, T=10 @ 1080p, 200 queries; the reference's CPU run of this clip
     needs > 100 GB): size-independent properties of the hot operators on the tensors the model really produces --
-    finite outputs; LDS-tiled MSDA (generations 2 and 3) == generic kernel on every encoder layer's inputs; oracle C on
-    every 37th query of the first layer; full-resolution mask decode == fp64 einsum on a strided subset; the first two
-    frames' features == the T=2 run (frames are independent in the backbone)."""
+    finite outputs; the head-major MSDeformAttn kernel (msda_strips.hip) covers the 1080p geometry and == the generic
+    kernel on the same layer's operands un-packed to the standard layouts; oracle C on every 37th query of the first
+    layer; full-resolution mask decode == fp64 einsum on a strided subset; the first two frames' features == the T=2 run
+    (frames are independent in the backbone)."""
     from oracle import c_ops
     case = cases.CFG5
     swin = helpers.build_swin(cuda, variant=cases.SWIN_L)
     head = helpers.build_head(case, cuda, return_aux=False)
     x = cases.preprocess(cases.cfg5_frames(case["T"])).to(cuda)
     seen = {"msda": [], "dec": []}
-    orig_msda, orig_dec, orig_fused = ops.ms_deform_attn_forward, ops.mask_decode, ops.msda_forward_fused
+    orig_strips, orig_dec = ops.msda_forward_strips, ops.mask_decode
 
-    def msda_hook(value, shapes, lsi, loc, attn, step=128):
-        out = orig_msda(value, shapes, lsi, loc, attn, step)
-        assert ops.msda_last_impl() == 2, "the LDS-tiled kernel must cover the 1080p geometry"
-        if len(seen["msda"]) < 2:
-            seen["msda"].append((value, shapes, lsi, loc, attn, out))
-        return out
-
-    def fused_hook(value, proj, n_off, ref_pts, shapes, lsi, P):
-        # the default path: MSDeformAttn core fed with the raw projections (UNIVS_MSDA_FUSED=1)
-        out = orig_fused(value, proj, n_off, ref_pts, shapes, lsi, P)
-        assert out is not None and ops.msda_last_impl() == 2, "the fused LDS-tiled kernel must cover the 1080p geometry"
-        if len(seen["msda"]) < 2:
-            loc, attn = ops.msda_prepare(proj, n_off, ref_pts, shapes, value.shape[2], len(shapes), P)
-            seen["msda"].append((value, shapes, lsi, loc, attn, out))
+    def strips_hook(vhm, qhm, ref_q, shapes, lsi, M, P=4):
+        out = orig_strips(vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert out is not None and ops.msda_last_tiled_generation() == 5, "the head-major kernel must cover the 1080p geometry"
+        if not seen["msda"]:
+            seen["msda"].append((vhm, qhm, ref_q, shapes, lsi, out))
         return out
 
     def dec_hook(e, f):
         out = orig_dec(e, f)
         seen["dec"].append((e, f, out, ops.mask_decode_last_impl()))
         return out
-    ops.ms_deform_attn_forward, ops.mask_decode, ops.msda_forward_fused = msda_hook, dec_hook, fused_hook
+    ops.msda_forward_strips, ops.mask_decode = strips_hook, dec_hook
     try:
         with torch.no_grad():
             feats = swin(x)
             out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
     finally:
-        ops.ms_deform_attn_forward, ops.mask_decode, ops.msda_forward_fused = orig_msda, orig_dec, orig_fused
+        ops.msda_forward_strips, ops.mask_decode = orig_strips, orig_dec
     pm = out["pred_masks"]
     assert tuple(pm.shape) == (1, 200, 10, 272, 480) and torch.isfinite(pm).all()
     assert torch.isfinite(out["pred_logits"]).all() and torch.isfinite(out["pred_embds"]).all()
-    # MSDA: S = 34*60 + 68*120 + 136*240 = 42840 tokens per frame
-    value, shapes, lsi, loc, attn, got = seen["msda"][0]
-    assert value.shape[1] == 42840 and value.shape[0] == 10
-    ops.msda_set_impl(1)
-    try:
-        generic = orig_msda(value, shapes, lsi, loc, attn)
-    finally:
-        ops.msda_set_impl(0)
-    assert (got - generic).abs().max().item() < 3e-5
-    os.environ["UNIVS_MSDA_TILED"] = "3"
-    try:
-        g3 = orig_msda(value, shapes, lsi, loc, attn)
-        assert ops.msda_last_tiled_generation() == 3
-    finally:
-        os.environ.pop("UNIVS_MSDA_TILED", None)
-    assert (g3 - generic).abs().max().item() < 2e-5
-    sub = torch.arange(0, loc.shape[1], 37, device=loc.device)
+    # MSDA: S = 34*60 + 68*120 + 136*240 = 42840 tokens per frame.  Un-pack the head-major operands to the standard layouts
+    vhm, qhm, ref_q, shapes, lsi, got = seen["msda"][0]
+    N, M2, S, DH = vhm.shape
+    M, L, P = M2 // 2, len(shapes), 4
+    assert S == 42840 and N == 10
+    value = vhm.view(N, M, 2, S, DH).permute(0, 3, 1, 2, 4).reshape(N, S, M, 2 * DH).contiguous()
+    order = ops.msda_level_order(shapes)
+    q = qhm.view(N, M, S, P, 3 * L)
+    off = torch.empty((N, S, M, L, P, 2), device=cuda)
+    lg = torch.empty((N, S, M, L, P), device=cuda)
+    for kk, l in enumerate(order):
+        off[:, :, :, l] = q[..., 2 * kk:2 * kk + 2].permute(0, 2, 1, 3, 4)
+        lg[:, :, :, l] = q[..., 2 * L + kk].permute(0, 2, 1, 3)
+    norm = torch.tensor([[w_, h_] for (h_, w_) in shapes], dtype=torch.float32, device=cuda).view(1, 1, 1, L, 1, 2)
+    loc = (ref_q.view(-1, S, 1, 1, 1, 2) + off / norm).contiguous()
+    attn = torch.softmax(lg.reshape(N, S, M, L * P), -1).view(N, S, M, L, P).contiguous()
+    with ops.configured(msda_impl=1):
+        generic = ops.ms_deform_attn_forward(value[:3], shapes, lsi, loc[:3], attn[:3])
+    assert (got[:3] - generic).abs().max().item() < 3e-5
+    tiled2 = ops.ms_deform_attn_forward(value[:3], shapes, lsi, loc[:3], attn[:3])
+    assert ops.msda_last_tiled_generation() == 2 and (tiled2 - generic).abs().max().item() < 3e-5
+    sub = torch.arange(0, S, 37, device=cuda)
     ref = c_ops.msda_forward(value[:2].cpu().numpy(), shapes, lsi, loc[:2, sub].contiguous().cpu().numpy(),
                              attn[:2, sub].contiguous().cpu().numpy())
     assert np.abs(got[:2, sub].cpu().numpy() - ref).max() < 3e-5

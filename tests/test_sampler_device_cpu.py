@@ -80,7 +80,7 @@ def test_device_mode_is_seeded_and_uniform():
     assert counts.numel() == n_cand and (counts.float() - expect).abs().max() < 6 * expect ** 0.5 + 1
 
 
-def test_unknown_mode_is_rejected(monkeypatch):
-    monkeypatch.setenv("UNIVS_SAMPLER", "fast")
-    with pytest.raises(ValueError):
+def test_unknown_mode_is_rejected():
+    from univs_amd.switches import override
+    with override(sampler="fast"), pytest.raises(ValueError):
         VisualPromptEncoder(hidden_dim=256, num_frames=2, num_dense_points=R)

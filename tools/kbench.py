@@ -33,7 +33,6 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--locs", default="local", choices=["local", "uniform", "far"])
     ap.add_argument("--only", default="")
-    ap.add_argument("--ablate", action="store_true", help="also time the gen-3 MSDA kernel with phases switched off")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     res = {}
@@ -48,31 +47,19 @@ def main():
     alg = 3200.0 * S * T
     only_strips = args.only == "strips"
     if not args.only or "msda" in args.only or only_strips:
-        ops.msda_set_impl(1)
-        t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
-        res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
-        ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
-        ops.msda_set_impl(2)
-        for gen, variant in (() if only_strips else ((4, 0), (3, 0), (3, 1), (2, 0), (1, 0))):
-            os.environ["UNIVS_MSDA_TILED"] = str(gen)
-            os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
-            for abl in ([0, 4, 16] if (gen == 3 and args.ablate) else [0]):
-                os.environ["UNIVS_MSDA_ABLATE"] = str(abl)
-                t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
-                out = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
-                nm = f"msda_tiled{gen}" + (f"_v{variant}" if gen == 3 else "") + (f"_ablate{abl}" if abl else "")
-                d = (out - ref).abs()
-                res[nm] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
-                               gen=ops.msda_last_tiled_generation(), max_abs_diff_vs_generic=d.max().item(),
-                               mean_abs_diff_vs_generic=d.mean().item())
-            os.environ.pop("UNIVS_MSDA_ABLATE", None)
-        os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
-        os.environ.pop("UNIVS_MSDA_TILED", None)
-        ops.msda_set_impl(0)
-        # the pair msda_prepare + forward against the fused operator (raw projections in)
+        with ops.configured(msda_impl=1):
+            t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
+            res["msda_generic"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
+            ref = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+        with ops.configured(msda_impl=2):
+            t = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn))
+            out = ops.ms_deform_attn_forward(value, shapes, lsi, loc, attn)
+            d = (out - ref).abs()
+            res["msda_tiled2"] = dict(ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+                                      gen=ops.msda_last_tiled_generation(), max_abs_diff_vs_generic=d.max().item())
+        # raw projections that reproduce the benchmark's sampling locations: offsets in pixels of the target level relative to
+        # the query's own pixel centre (the encoder's reference points), logits whose softmax is `attn`
         M_, L_, P_ = 8, 3, 4
-        # raw projections that reproduce the benchmark's sampling locations: offsets in pixels of the target level
-        # relative to the query's own pixel centre (the encoder's reference points), logits whose softmax is `attn`
         refs = []
         for (h, w) in shapes:
             ys = (torch.arange(h, dtype=torch.float32) + 0.5) / h
@@ -86,39 +73,23 @@ def main():
         n_off = M_ * L_ * P_ * 2
         t = timeit(lambda: ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_))
         res["msda_prepare"] = dict(ms=t * 1e3)
-        for gen, variant in (() if only_strips else ((4, 0), (3, 1), (3, 0))):
-            os.environ["UNIVS_MSDA_T3_VARIANT"] = str(variant)
-            os.environ["UNIVS_MSDA_TILED"] = str(gen)
-            def pair():
-                l_, a_ = ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_)
-                return ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
-            t = timeit(pair)
-            res[f"msda_prepare+tiled{gen}_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK)
-            t = timeit(lambda: ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_))
-            d = (ops.msda_forward_fused(value, proj, n_off, refp, shapes, lsi, P_) - pair()).abs()
-            res[f"msda_fused{gen}_v{variant}"] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK, gen=ops.msda_last_tiled_generation(),
-                                                 max_abs_diff_vs_pair=d.max().item())
-        os.environ.pop("UNIVS_MSDA_T3_VARIANT", None)
-        os.environ.pop("UNIVS_MSDA_TILED", None)
         # generation 5: strips on head-major operands (half a head per workgroup, two workgroups per CU)
         vhm, qhm = ops.msda_pack_head_major(value, proj, n_off, shapes, P_)
         refq = refp[:, :, 0].contiguous()
         l_, a_ = ops.msda_prepare(proj, n_off, refp, shapes, M_, L_, P_)
-        ops.msda_set_impl(1)
-        want = ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
-        ops.msda_set_impl(0)
-        variants = (("", {}),) if only_strips else (("", {}), ("_th6", {"UNIVS_MSDA_STRIP_H": "6"}), ("_w8", {"UNIVS_MSDA_STRIP_W": "8"}),
-                                                     ("_grid256", {"UNIVS_MSDA_GRID": "256"}), ("_grid768", {"UNIVS_MSDA_GRID": "768"}),
-                                                     ("_grid1024", {"UNIVS_MSDA_GRID": "1024"}), ("_grid2048", {"UNIVS_MSDA_GRID": "2048"}))
-        for tag, env in variants:
-            os.environ.update(env)
-            got = ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_)
-            if got is not None:
-                t = timeit(lambda: ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_))
-                res["msda_strips" + tag] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK, gen=ops.msda_last_tiled_generation(),
-                                                max_abs_diff_vs_generic=(got - want).abs().max().item())
-            for k in env:
-                os.environ.pop(k, None)
+        with ops.configured(msda_impl=1):
+            want = ops.ms_deform_attn_forward(value, shapes, lsi, l_, a_)
+        variants = (("", {}),) if only_strips else (("", {}), ("_again", {}), ("_th6", dict(msda_strip_h=6)), ("_w8", dict(msda_strip_w=8)),
+                                                     ("_grid256", dict(msda_grid=256)), ("_grid512", dict(msda_grid=512)),
+                                                     ("_grid768", dict(msda_grid=768)), ("_grid2048", dict(msda_grid=2048)))
+        for tag, cfg in variants:
+            with ops.configured(**cfg):
+                got = ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_)
+                if got is not None:
+                    t = timeit(lambda: ops.msda_forward_strips(vhm, qhm, refq, shapes, lsi, M_, P_))
+                    res["msda_strips" + tag] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+                                                    gen=ops.msda_last_tiled_generation(),
+                                                    max_abs_diff_vs_generic=(got - want).abs().max().item())
         x_tok = synth.normal("kb/tok", (T, S, 256)).to(dev)
         w_v, b_v = synth.normal("kb/wv", (256, 256), std=0.05).to(dev), synth.normal("kb/bv", (256,)).to(dev)
         w_q, b_q = synth.normal("kb/wq", (288, 256), std=0.05).to(dev), synth.normal("kb/bq", (288,)).to(dev)
@@ -215,11 +186,8 @@ def main():
             byts = (q.numel() + q.numel() / 3) * 4.0
             for shift in (0, 3):
                 for v1 in ("0", "1"):
-                    os.environ["UNIVS_WINATTN_V1"] = v1
-                    try:
+                    with ops.configured(window_attn_v1=int(v1)):
                         t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5))
-                    finally:
-                        os.environ.pop("UNIVS_WINATTN_V1", None)
                     res[f"window_attn_image_{H_}x{W_}_shift{shift}" + ("_v1" if v1 == "1" else "")] = dict(
                         ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
     if not args.only or "resample" in args.only:

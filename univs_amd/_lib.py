@@ -31,13 +31,13 @@ SIGNATURES = {
     "univs_msda_forward_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_msda_forward_f64": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_msda_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "univs_msda_forward_fused_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_msda_forward_strips_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_linear_blocked_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P, _P]),
+    "univs_configure": (_I, [_P]),
+    "univs_get_config": (_I, [_P]),
     "univs_msda_set_impl": (_I, [_I]),
     "univs_msda_last_impl": (_I, []),
     "univs_msda_last_tiled_generation": (_I, []),
-    "univs_linear_split_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_conv3x3_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univs_transpose_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P]),
     "univs_linear_fused_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),

@@ -3,7 +3,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
+#include "config.h"
 
 namespace univs {
 
@@ -16,7 +19,13 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static int g_msda_impl = 0;  // 0 auto, 1 generic, 2 tiled
+// process-wide settings (include/univs_hip.h: UnivsConfig); a mutex-protected copy, handed out by value
+static std::mutex g_cfg_mu;
+static UnivsConfig g_cfg = {};
+UnivsConfig config() {
+  std::lock_guard<std::mutex> lock(g_cfg_mu);
+  return g_cfg;
+}
 static thread_local int g_msda_last = 0;
 static thread_local int g_msda_gen = 0;   // generation of the LDS-tiled kernel that ran last (0: none)
 
@@ -27,20 +36,9 @@ int msda_forward_generic_f64(const double*, const LevelTable&, const double*, co
 // returns 1 if the tiled kernel was launched, 0 if its preconditions do not hold, <0 on error
 int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
                             int, float*, hipStream_t);
-int msda_forward_tiled3_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
-                            int, float*, hipStream_t);
-int msda_forward_fused_tiled3_f32(const float*, const LevelTable&, const float*, int, int, const float*, long long, int, int,
-                                  int, int, int, int, int, float*, hipStream_t);
-int msda_forward_tiled4_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
-                            int, float*, hipStream_t);
-int msda_forward_fused_tiled4_f32(const float*, const LevelTable&, const float*, int, int, const float*, long long, int, int,
-                                  int, int, int, int, int, float*, hipStream_t);
-int msda_forward_tiled_f32(const float*, const LevelTable&, const float*, const float*, int, int,
-                           int, int, int, int, int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
 int transpose_f32(const float*, float*, long long, int, int, hipStream_t);
 int conv3x3_split_f32(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
-void mask_decode_set_impl(int);
 int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0);
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
@@ -106,12 +104,44 @@ extern "C" {
 const char* univs_version(void) { return "univs_hip 0.1.0 gfx950"; }
 const char* univs_last_error(void) { return g_err; }
 
+int univs_configure(const UnivsConfig* cfg) {
+  UnivsConfig c = {};
+  if (cfg) {
+    if (cfg->size < (int)(2 * sizeof(int)) || cfg->size > (int)sizeof(UnivsConfig)) {
+      set_error("univs_configure: UnivsConfig.size=%d (this library: %d)", cfg->size, (int)sizeof(UnivsConfig));
+      return UNIVS_ERR_INVALID_ARGUMENT;
+    }
+    memcpy(&c, cfg, (size_t)cfg->size);   // fields the caller does not know keep their defaults (0)
+    if (c.msda_impl < 0 || c.msda_impl > 2 || c.mask_decode_impl < 0 || c.mask_decode_impl > 2 || c.msda_halo > 64 ||
+        (c.mask_decode_ct != 0 && c.mask_decode_ct != 2 && c.mask_decode_ct != 4)) {
+      set_error("univs_configure: msda_impl=%d mask_decode_impl=%d msda_halo=%d mask_decode_ct=%d out of range", c.msda_impl,
+                c.mask_decode_impl, c.msda_halo, c.mask_decode_ct);
+      return UNIVS_ERR_INVALID_ARGUMENT;
+    }
+  }
+  c.size = (int)sizeof(UnivsConfig);
+  std::lock_guard<std::mutex> lock(g_cfg_mu);
+  g_cfg = c;
+  return UNIVS_OK;
+}
+
+int univs_get_config(UnivsConfig* out) {
+  if (!out) {
+    set_error("univs_get_config: NULL");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  *out = config();
+  out->size = (int)sizeof(UnivsConfig);
+  return UNIVS_OK;
+}
+
 int univs_msda_set_impl(int impl) {
   if (impl < 0 || impl > 2) {
     set_error("univs_msda_set_impl: impl=%d not in {0,1,2}", impl);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  g_msda_impl = impl;
+  std::lock_guard<std::mutex> lock(g_cfg_mu);
+  g_cfg.msda_impl = impl;
   return UNIVS_OK;
 }
 
@@ -141,10 +171,6 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
   return rc;
 }
 
-int univs_linear_split_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
-                           int relu, float* y, void* stream) {
-  return univs_linear_fused_f32(x, weight, bias, nullptr, M, N, K, relu ? 1 : 0, y, stream);
-}
 
 int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, int Cout, int H, int W, float* y, void* stream) {
   clear_sticky_error();
@@ -185,7 +211,10 @@ int univs_mask_decode_set_impl(int impl) {
     set_error("univs_mask_decode_set_impl: impl=%d not in {0,1,2}", impl);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  univs::mask_decode_set_impl(impl);
+  {
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    g_cfg.mask_decode_impl = impl;
+  }
   return UNIVS_OK;
 }
 
@@ -209,34 +238,13 @@ int univs_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
   int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_f32");
   if (rc != UNIVS_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (g_msda_impl != 1) {
-    // LDS-tiled kernels for the encoder geometry; each returns 0 when its preconditions fail.  Default: the second
-    // generation (msda_tiled2.hip).  UNIVS_MSDA_TILED (read per call: tests and kernel benchmarks flip it) starts at a later
-    // one: 3 = register records + DPP gathers (msda_tiled3.hip), 4 = strips with resident windows, a lane owns a sample
-    // (msda_tiled4.hip); both also take the raw projections (fused input preparation).  On MI355X all three are within 6 %
-    // of each other at the bench geometry (profiles/r02_msda_trace_v5.txt), so the default has not moved; =1 selects the
-    // first generation.
-    const char* e = getenv("UNIVS_MSDA_TILED");
-    const int tiled_gen = (e && *e) ? atoi(e) : 2;
-    g_msda_gen = 0;
-    rc = tiled_gen >= 4 ? msda_forward_tiled4_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
-    if (rc != 0) {
-      if (rc > 0) { g_msda_last = 2; g_msda_gen = 4; }
-      return rc < 0 ? rc : UNIVS_OK;
-    }
-    rc = tiled_gen >= 3 ? msda_forward_tiled3_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
-    if (rc != 0) {
-      if (rc > 0) { g_msda_last = 2; g_msda_gen = 3; }
-      return rc < 0 ? rc : UNIVS_OK;
-    }
-    rc = tiled_gen >= 2 ? msda_forward_tiled2_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st) : 0;
+  g_msda_gen = 0;
+  if (config().msda_impl != 1) {
+    // the LDS-tiled kernel for the encoder geometry on the standard layouts (msda_tiled2.hip: D == 32, P == 4, 3 <= L <= 4,
+    // Lq == S); returns 0 when its preconditions fail.  (The module path uses univs_msda_forward_strips_f32.)
+    rc = msda_forward_tiled2_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
     if (rc != 0) {
       if (rc > 0) { g_msda_last = 2; g_msda_gen = 2; }
-      return rc < 0 ? rc : UNIVS_OK;
-    }
-    rc = msda_forward_tiled_f32(value, lv, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
-    if (rc != 0) {
-      if (rc > 0) { g_msda_last = 2; g_msda_gen = 1; }
       return rc < 0 ? rc : UNIVS_OK;
     }
   }
@@ -460,53 +468,6 @@ int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const f
   return rc;
 }
 
-int univs_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                                 const float* proj, int row_stride, int n_off, const float* ref_points,
-                                 long long ref_batch_stride, int N, int S, int M, int D, int L, int Lq, int P, float* out,
-                                 void* stream) {
-  if (N < 0 || S < 0 || M < 1 || D < 0 || Lq < 0 || P < 1 || L < 1 || L > UNIVS_MAX_LEVELS || row_stride < M * L * P * 3 ||
-      n_off < M * L * P * 2 || n_off + M * L * P > row_stride || ref_batch_stride < 0) {
-    set_error("univs_msda_forward_fused_f32: bad dimensions N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d row_stride=%d n_off=%d", N, S,
-              M, D, L, Lq, P, row_stride, n_off);
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
-  clear_sticky_error();
-  if (!value || !proj || !ref_points || !out) {
-    set_error("univs_msda_forward_fused_f32: NULL data pointer");
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  LevelTable lv;
-  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_fused_f32");
-  if (rc != UNIVS_OK) return rc;
-  g_msda_gen = 0;
-  {
-    const char* e = getenv("UNIVS_MSDA_TILED");
-    const int tiled_gen = (e && *e) ? atoi(e) : 2;
-    rc = tiled_gen >= 4 ? msda_forward_fused_tiled4_f32(value, lv, proj, row_stride, n_off, ref_points, ref_batch_stride, N, S,
-                                                        M, D, L, Lq, P, out, static_cast<hipStream_t>(stream))
-                        : 0;
-    if (rc > 0) {
-      g_msda_last = 2;
-      g_msda_gen = 4;
-      return UNIVS_OK;
-    }
-    if (rc < 0) return rc;
-  }
-  rc = msda_forward_fused_tiled3_f32(value, lv, proj, row_stride, n_off, ref_points, ref_batch_stride, N, S, M, D, L, Lq, P,
-                                     out, static_cast<hipStream_t>(stream));
-  if (rc > 0) {
-    g_msda_last = 2;
-    g_msda_gen = 3;
-    return UNIVS_OK;
-  }
-  if (rc == 0) {
-    set_error("univs_msda_forward_fused_f32: geometry not covered by the fused kernel (D == 32, P == 4, 2 <= L <= 4, Lq == S)");
-    return UNIVS_ERR_NOT_IMPLEMENTED;
-  }
-  return rc;
-}
-
 int univs_linear_blocked_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                              int rows_per_batch, int col_block, float* y, void* stream) {
   if (M < 0 || N < 1 || K < 1 || rows_per_batch < 1 || col_block < 4 || col_block % 4 != 0 || N % col_block != 0 ||
@@ -548,7 +509,7 @@ int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_
   LevelTable lv;
   int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_strips_f32");
   if (rc != UNIVS_OK) return rc;
-  if (g_msda_impl == 1) {   // the generic kernel was forced: it has no head-major variant, the caller takes the two-operator path
+  if (config().msda_impl == 1) {   // the generic kernel was forced: it has no head-major variant, the caller takes the two-operator path
     set_error("univs_msda_forward_strips_f32: generic implementation forced (univs_msda_set_impl(1))");
     return UNIVS_ERR_NOT_IMPLEMENTED;
   }

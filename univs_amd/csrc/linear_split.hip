@@ -20,6 +20,7 @@
 // Everything about pinning the ring (sched_barrier, the opaque split mask, straight-line tile body, unconditional buffer
 // stores) is explained in mask_decode.hip / DESIGN.md "Toolchain hazards".
 #include "common.h"
+#include "config.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -571,7 +572,7 @@ static int linear_split_wide_f32(const float* x, const float* w, const float* bi
   // measured at 5 x 3680 x 1536 -> 384: 164 us against 211 us
   int passes = (N + 255) / 256;
   if (ST * passes < (n_cu * 3) / 2) passes = (N + 127) / 128;
-  if (const char* e = getenv("UNIVS_LSW_NFEAT")) { const int nf = atoi(e); if (nf >= 16) passes = (N + nf - 1) / nf; }
+  if (const int nf = config().linear_wide_nfeat; nf >= 16) passes = (N + nf - 1) / nf;
   const int nfeat = ((N + passes - 1) / passes + 15) / 16 * 16;
   const int NF = nfeat / 16;
   if (NF != 8 && NF != 12 && NF != 16) return 0;
@@ -611,7 +612,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
       (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
     return 0;
-  static const int wide_kmin = [] { const char* e = getenv("UNIVS_LS_WIDE_KMIN"); return e && *e ? atoi(e) : 768; }();
+  const int wide_kmin = config().linear_wide_kmin > 0 ? config().linear_wide_kmin : 768;
   // (... except the one K = 768 shape with many rows and few features, Swin stage 2's fc2 at 73 600 x 768 -> 192: 203 us
   // W-stationary against 221 us)
   if (K >= wide_kmin && !(K == 768 && M >= 32768 && N <= 256) && epi != LS_EPI_BLOCKED) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,

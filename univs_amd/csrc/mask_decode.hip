@@ -17,6 +17,7 @@
 // column tiles.  v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain (k-ordered), so results equal a
 // scalar fp32 loop bit-for-bit -- what the 1e-3 / argmax-identical parity contract needs.
 #include "common.h"
+#include "config.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -545,14 +546,7 @@ __global__ __launch_bounds__(SB_THREADS, 1) void skinny_gemm_bf16x6_n32(const fl
   }
 }
 
-static int maskdec_ablate() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UNIVS_MASKDEC_ABLATE");
-    v = e ? atoi(e) & 3 : 0;
-  }
-  return v;
-}
+static int maskdec_ablate() { return config().mask_decode_ablate & 3; }   // timing experiments (tools/prof_split.sh)
 template <typename Epilogue>
 static void launch_ablation(int abl, dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* A, const float* B,
                             int Q, int K, int N, int rows, Epilogue ep) {
@@ -637,26 +631,16 @@ static int launch_bf16x6(const float* A, const float* B, int T, int Q, int K, lo
 // column tiles per wave tile of the split kernel: UNIVS_MASKDEC_CT = 2 | 4 (default 2 where K allows the ring)
 static int maskdec_ct(int K, long long out_bytes) {
   if (out_bytes >= 0x7FFFFFFFLL) return 4;      // the 32-column kernel stores through a 32-bit buffer range
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UNIVS_MASKDEC_CT");
-    v = (e && atoi(e) == 4) ? 4 : 2;
-  }
+  const int v = config().mask_decode_ct == 4 ? 4 : 2;
   return (v == 2 && K % (32 * SB2_RING) == 0) ? 2 : 4;
 }
 
 // 0 = by size (default), 1 = exact-f32 MFMA kernel, 2 = bf16 x 6 wherever its preconditions hold
-static int g_maskdec_impl = -1;
 static thread_local int g_maskdec_last = 0;
 static int maskdec_impl() {
-  if (g_maskdec_impl < 0) {
-    const char* e = getenv("UNIVS_MASKDEC_IMPL");
-    int v = e ? atoi(e) : 0;
-    g_maskdec_impl = (v < 0 || v > 2) ? 0 : v;
-  }
-  return g_maskdec_impl;
+  const int v = config().mask_decode_impl;
+  return (v < 0 || v > 2) ? 0 : v;
 }
-void mask_decode_set_impl(int impl) { g_maskdec_impl = impl; }
 int mask_decode_last_impl() { return g_maskdec_last; }
 
 static bool bf16x6_eligible(const void* A, const void* B, const void* out, int T, int Q, int K, long long N, int out_align) {

@@ -10,11 +10,6 @@ namespace univs {
 
 constexpr int UNIVS_MSDA_WIN_EDGE_MAX = 64;   // window edge limit (the product ww*wh is bounded by the LDS carve)
 
-static inline int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 static inline long long floor_div(long long a, long long b) {  // b > 0
   return (a >= 0) ? a / b : -((-a + b - 1) / b);
 }

@@ -35,7 +35,8 @@
 #include <type_traits>
 
 #include "msda_strips_geom.h"
-#include "msda_tiled3_dev.h"
+#include "config.h"
+#include "msda_dev.h"
 
 namespace univs {
 
@@ -477,8 +478,9 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
   }
   if (expect != S) return 0;
 
-  const int TW = env_int("UNIVS_MSDA_STRIP_W", 12), R = env_int("UNIVS_MSDA_HALO", 6);
-  int TH = env_int("UNIVS_MSDA_STRIP_H", 8);
+  const UnivsConfig cfg = config();
+  const int TW = cfg.msda_strip_w > 0 ? cfg.msda_strip_w : 12, R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
+  int TH = cfg.msda_strip_h > 0 ? cfg.msda_strip_h : 8;
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
   const S5Geo* g = nullptr;
   for (; TH >= 2; TH -= 2) {   // the windows of two workgroups must fit one CU's LDS
@@ -500,7 +502,7 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
     }
     n_cu = v;
   }
-  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", 4 * n_cu), 1));
+  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(cfg.msda_grid > 0 ? cfg.msda_grid : 4 * n_cu, 1));
   S5Args a{vhm, qhm, ref, ref_batch_stride, out, N, S, M};
   switch (L) {
     case 1: launch_strips<1>(grid, (unsigned)nb, st, g, a); break;

@@ -19,6 +19,7 @@
 // largest.  With an odd number of levels the first step of every other item lands in B, so odd items visit
 // their levels in the order (1, 0, 2, ...) instead of (0, 1, 2, ...) -- the accumulators do not care.
 // Needs L >= 3 (the next item's query list is built two steps before its first sample loads).
+#include "config.h"
 #include "msda_geometry.h"
 
 #ifdef UNIVS_MSDA_TRACE
@@ -411,8 +412,9 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
   }
   if (expect != S) return 0;
 
-  const int TH = env_int("UNIVS_MSDA_TILE2_H", 8), TW = env_int("UNIVS_MSDA_TILE2_W", 16);
-  const int R = env_int("UNIVS_MSDA_HALO", 6);
+  const UnivsConfig cfg = config();
+  const int TH = 8, TW = 16;
+  const int R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
   const long long cap_px = std::min<long long>(T2_WIN_PX, (long long)T2_WR * T2_OCTETS);
   const GeoEntry* ge = geometry(lv, L, fine, TH, TW, R, cap_px);
@@ -423,7 +425,7 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
   Tile2Geom tg{};
   tg.tiles_y = ge->tiles_y;
   tg.tiles_x = ge->tiles_x;
-  tg.ablate = env_int("UNIVS_MSDA_ABLATE", 0);
+  tg.ablate = 0;
   int by_size[UNIVS_MAX_LEVELS];
   for (int l = 0; l < L; ++l) by_size[l] = l;
   std::sort(by_size, by_size + L, [&](int a, int b) { return ge->lvl_px[a] > ge->lvl_px[b]; });
@@ -456,7 +458,7 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
     }
     n_cu = v;
   }
-  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(env_int("UNIVS_MSDA_GRID", n_cu), 1));
+  const unsigned grid = (unsigned)std::min<long long>(nb, std::max(cfg.msda_grid > 0 ? cfg.msda_grid : n_cu, 1));
   switch (L) {
     case 3: launch_tiled2<3>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
     default: launch_tiled2<4>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;

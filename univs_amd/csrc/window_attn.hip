@@ -18,6 +18,7 @@
 //   * the reduction index of both products is summed in a permuted order (lane group g takes
 //     head-dim 8g..8g+7 / keys 4g..4g+3), which is exact up to fp32 re-association.
 #include "common.h"
+#include "config.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -438,8 +439,7 @@ int window_attention_image_f32(const float* qkv, const float* qkv_bias, const fl
   wi.Wp = (W + ws - 1) / ws * ws;
   wi.nWx = wi.Wp / ws;
   const int nW = (wi.Hp / ws) * wi.nWx;
-  const char* ev1 = getenv("UNIVS_WINATTN_V1");   // (read per call: the kernel benchmark flips it)
-  const bool v1 = ev1 && *ev1 == '1';
+  const bool v1 = config().window_attn_v1 != 0;   // the first 7x7 kernel (kernel benchmarks)
   if (ws == 7 && hd == 32 && !v1 && (long long)B * H * W * 3 * nH * hd < 0x7FFFFFFFLL) {
     const int B_ = B * nW;
     if (B_ == 0) return UNIVS_OK;

@@ -3,7 +3,6 @@
 conv / norm work goes to ATen (hipBLASLt / MIOpen) -- host glue around the HIP kernels.
 """
 import math
-import os
 from typing import Optional
 
 import torch
@@ -42,8 +41,7 @@ def fp32_region(fn):
     return wrapper
 
 
-# UNIVS_SPLIT_CONV=0: the 3 x 3 FPN output convolution stays on MIOpen
-_SPLIT_CONV = (os.environ.get("UNIVS_SPLIT_CONV", "1") or "0") != "0"
+from .switches import SWITCHES   # split_conv / split_linear: which implementation the layers route to
 
 
 class Conv2d(nn.Conv2d):
@@ -59,7 +57,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         y = None
-        if (_SPLIT_CONV and x.is_cuda and self.bias is None and self.kernel_size == (3, 3) and self.stride == (1, 1)
+        if (SWITCHES.split_conv and x.is_cuda and self.bias is None and self.kernel_size == (3, 3) and self.stride == (1, 1)
                 and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1):
             from . import ops
             y = ops.conv3x3(x, self.weight)       # None when not covered
@@ -184,15 +182,14 @@ def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
     return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, residual=residual, return_sum=return_sum, post_add=post_add)
 
 
-# UNIVS_SPLIT_LINEAR: 0 = library GEMMs only, 1 (default) = the MSDeformAttn token projections + encoder FFN through the
-# split-bf16 kernels (measured)
-_SPLIT_LINEAR = (os.environ.get("UNIVS_SPLIT_LINEAR", "1") or "0") != "0"
+# SWITCHES.split_linear: False = library GEMMs only, True (default) = the MSDeformAttn token projections + encoder FFN
+# through the split-bf16 kernels (ops.linear_split)
 
 
 def linear(x, weight, bias=None):
     """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 (the MSDeformAttn token projections: 96 600 rows x
     256 -> 256 / 288) take the split-bf16 kernel (fp32-accurate, ~2x hipBLASLt's fp32 rate), everything else ATen."""
-    if _SPLIT_LINEAR and x.is_cuda:
+    if SWITCHES.split_linear and x.is_cuda:
         from . import ops
         y = ops.linear_split(x, weight, bias)
         if y is not None:
@@ -205,7 +202,7 @@ def linear_act(x, linear, activation):
     ATen's `_addmm_activation`: bit-identical to relu(linear(x)), one pass over the [tokens, d_ffn]
     activations less -- 0.17 ms per encoder layer at 720p)."""
     if activation is F.relu and x.is_cuda and x.dtype == torch.float32 and linear.bias is not None:
-        if _SPLIT_LINEAR:
+        if SWITCHES.split_linear:
             from . import ops
             y = ops.linear_split(x, linear.weight, linear.bias, relu=True)
             if y is not None:

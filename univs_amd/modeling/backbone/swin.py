@@ -12,7 +12,6 @@ Interface and state-dict layout follow the reference's `D2SwinTransformer`
     (swin.py:148-155, :413-440);
   * inference only: DropPath / dropout are identities and are not instantiated.
 """
-import os
 
 import numpy as np
 import torch
@@ -28,13 +27,11 @@ def _to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
 
-# UNIVS_SWIN_FUSED_LINEAR=0: the Swin Linears stay on the library GEMM (qkv, proj, fc1 + GELU, fc2 + shortcut)
-_FUSED_LINEAR = os.environ.get("UNIVS_SWIN_FUSED_LINEAR", "1") != "0"
-_FUSED_PARTS = int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7"))   # diagnostic: 1 qkv / proj, 2 fc1 + GELU, 4 fc2 + shortcut
+from ...switches import SWITCHES   # swin_fused_linear / swin_fused_parts: False = the Swin Linears stay on the library GEMM
 
 
 def _linear(mod, x):
-    y = ops.linear_fused(x, mod.weight, mod.bias) if (_FUSED_LINEAR and (_FUSED_PARTS & 1) and x.is_cuda) else None
+    y = ops.linear_fused(x, mod.weight, mod.bias) if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 1) and x.is_cuda) else None
     return y if y is not None else mod(x)
 
 
@@ -51,10 +48,10 @@ class Mlp(nn.Module):
         """fc2(GELU(fc1(x))) (+ residual) (swin.py:35-58; the block's `shortcut + mlp(...)` of :291-293 rides in fc2's
         epilogue).  On the GPU both Linears take the split-bf16 kernel with the GELU / the residual add fused into the
         store where the shape is covered (ops.linear_fused); the library GEMM + elementwise passes otherwise."""
-        h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (_FUSED_LINEAR and (_FUSED_PARTS & 2) and x.is_cuda) else None
+        h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 2) and x.is_cuda) else None
         if h is None:
             h = self.act(self.fc1(x))
-        y = ops.linear_fused(h, self.fc2.weight, self.fc2.bias, residual=residual) if (_FUSED_LINEAR and (_FUSED_PARTS & 4) and x.is_cuda) else None
+        y = ops.linear_fused(h, self.fc2.weight, self.fc2.bias, residual=residual) if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 4) and x.is_cuda) else None
         if y is None:
             y = self.fc2(h)
             if residual is not None:

@@ -15,7 +15,6 @@ work is organised (results are the same):
     msdeformattn.py:62) are dropped: valid_ratio is identically 1;
   * everything stays fp32 regardless of autocast (msdeformattn.py:316,322).
 """
-import os
 from typing import Callable, Dict, List, Optional, Union
 
 import numpy as np
@@ -29,17 +28,10 @@ from ...registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ..position_encoding import PositionEmbeddingSine
 
 
-# UNIVS_MSDA_FUSED (default 1): msda_prepare + ms_deform_attn_forward as ONE operator (register-record kernel fed with the raw
-# projections: the [N, Lq, M, L, P, 2] / [N, Lq, M, L, P] location and weight tensors never exist).  Measured on MI355X: 181 us
-# per 5-frame layer against 48 + 157 us for the two operators; -0.2 ms per config-2 clip in bench.py (A/B on one box,
-# profiles/r02_bench_ab_msda_fused.txt).  0: the two operators.
-_MSDA_FUSED = os.environ.get("UNIVS_MSDA_FUSED", "1") == "1"
-
-
-# UNIVS_MSDA_STRIPS (default 1): the encoder's MSDeformAttn core on head-major operands (csrc/msda_strips.hip, generation 5):
-# value_proj and the merged offset / logit projection store their outputs in the sampling kernel's layouts (blocked Linear
-# epilogue), the kernel handles half a head per workgroup with two workgroups per CU.  0: the standard-layout operators.
-_MSDA_STRIPS = os.environ.get("UNIVS_MSDA_STRIPS", "1") == "1"
+from ...switches import SWITCHES   # msda_strips (default True): the encoder's MSDeformAttn core on head-major operands
+# (csrc/msda_strips.hip): value_proj and the merged offset / logit projection store their outputs in the sampling kernel's
+# layouts (blocked Linear epilogue), the kernel handles half a head per workgroup with two workgroups per CU.  False: the
+# standard-layout operators (msda_prepare + ms_deform_attn_forward).
 
 
 def _shape_list(spatial_shapes):
@@ -101,7 +93,7 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        if (_MSDA_STRIPS and ref_per_query is not None and query.is_cuda and P == 4 and L <= 4 and Len_q == Len_in
+        if (SWITCHES.msda_strips and ref_per_query is not None and query.is_cuda and P == 4 and L <= 4 and Len_q == Len_in
                 and input_padding_mask is None and self.d_model == 32 * M and query.dtype == torch.float32):
             shapes = _shape_list(input_spatial_shapes)
             order = tuple(ops.msda_level_order(shapes))
@@ -121,14 +113,6 @@ class MSDeformAttn(nn.Module):
         # instead of 192 + 96, `query` is read once
         w, b, n_off = self._merged_query_proj()
         qp = linear(query, w, b)
-        if (reference_points.shape[-1] == 2 and P == 4 and L <= 4 and _MSDA_FUSED and Len_q == Len_in
-                and input_padding_mask is None):
-            # the whole core from the raw projections: softmax + reference + offset / (W_l, H_l) happen inside the
-            # sampling kernel, the location / weight tensors (36 % of the operator's bytes) never exist
-            output = ops.msda_forward_fused(value, qp, n_off, reference_points, input_spatial_shapes,
-                                            input_level_start_index, P)
-            if output is not None:
-                return linear(output, self.output_proj.weight, self.output_proj.bias)
         if reference_points.shape[-1] == 2 and P == 4 and L <= 4:
             # softmax over the L*P logits + reference point + offset / (W_l, H_l): one pass (HIP operator)
             sampling_locations, attention_weights = ops.msda_prepare(qp, n_off, reference_points, input_spatial_shapes,

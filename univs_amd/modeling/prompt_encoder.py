@@ -15,12 +15,12 @@ same call order as the reference, so a seeded run reproduces the reference's sam
 Known quirk kept on purpose: the "avoid NaN" block multiplies by `isblank` instead of `~isblank`
 (:836-840), so blank prompt tokens are filled with zeros.
 """
-import os
 
 import torch
 import torch.nn.functional as F
 
 from ..layers import point_sample
+from ..switches import SWITCHES
 from .position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
 
 
@@ -158,9 +158,9 @@ class VisualPromptEncoder:
         # rank per point; uniform R-subset in random order via top-R of random keys), no host round trip; the random
         # stream differs from the reference's, everything that is not random (cyclic fill of small masks, fallbacks of
         # empty ones) is identical.
-        self.sampler_rng = os.environ.get("UNIVS_SAMPLER", "reference")
+        self.sampler_rng = SWITCHES.sampler          # "reference" | "device" (switches.py; settable per encoder)
         if self.sampler_rng not in ("reference", "device"):
-            raise ValueError(f"UNIVS_SAMPLER={self.sampler_rng!r} (expected 'reference' or 'device')")
+            raise ValueError(f"sampler mode {self.sampler_rng!r} (expected 'reference' or 'device')")
         self._dev_gen = {}
         self._replay = None
 

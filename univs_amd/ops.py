@@ -3,6 +3,7 @@ current torch stream.  PyTorch is plumbing here (device memory, streams); the co
 libunivs_hip.so.  Every function raises on non-GPU tensors -- the reference does the same for its
 operator ("Not implemented on the CPU", ops/src/ms_deform_attn.h:43) and there is no CPU fallback.
 """
+import contextlib
 import ctypes
 import os
 
@@ -136,35 +137,6 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [gv, gl, ga]
 
 
-def msda_forward_fused(value, proj, n_off, reference_points, spatial_shapes, level_start_index, num_points):
-    """MSDeformAttn core straight from the raw projections (ms_deform_attn.py:100-116 in one operator): value
-    [N,S,M,D]; `proj` [N,Lq,C] with the sampling offsets in columns [0, M*L*P*2) and the attention logits in columns
-    [n_off, n_off + M*L*P); reference_points [N or 1, Lq, L, 2].  Returns [N, Lq, M*D], or None when the geometry is
-    not covered (the caller then runs `msda_prepare` + `ms_deform_attn_forward`)."""
-    _inference_only("msda_forward_fused", value, proj, reference_points)
-    value, proj, reference_points = value.contiguous(), proj.contiguous(), reference_points.contiguous()
-    _require_gpu("msda_forward_fused", value, proj, reference_points)
-    if value.dtype != torch.float32 or proj.dtype != torch.float32 or reference_points.dtype != torch.float32:
-        return None
-    N, S, M, D = value.shape
-    N2, Lq, C = proj.shape
-    sh, st, L = _host_shapes(spatial_shapes, level_start_index, S)
-    P = int(num_points)
-    if N2 != N or tuple(reference_points.shape[1:]) != (Lq, L, 2) or reference_points.shape[0] not in (1, N):
-        raise RuntimeError("msda_forward_fused: inconsistent shapes")
-    if D != 32 or P != 4 or not (2 <= L <= 4) or Lq != S:
-        return None
-    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
-    rbs = 0 if reference_points.shape[0] == 1 else Lq * L * 2
-    with torch.cuda.device(value.device):
-        rc = _lib.load().univs_msda_forward_fused_f32(_ptr(value), sh, st, _ptr(proj), C, int(n_off), _ptr(reference_points),
-                                                      rbs, N, S, M, D, L, Lq, P, _ptr(out), _stream_ptr(value))
-    if rc == _lib.ERR_NOT_IMPLEMENTED:
-        return None
-    _lib.check(rc, "msda_forward_fused")
-    return out
-
-
 def msda_level_order(spatial_shapes):
     """Slot order of the levels in the head-major projection layout of `msda_forward_strips`: by size, largest first, ties
     by index (csrc/msda_strips_geom.h: s5_build_host)."""
@@ -215,6 +187,46 @@ def msda_forward_strips(value_hm, proj_hm, ref_points, spatial_shapes, level_sta
     return out
 
 
+class UnivsConfig(ctypes.Structure):
+    """include/univs_hip.h: UnivsConfig -- the library's process-wide settings (it reads no environment variable)."""
+    _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
+                                            "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "linear_wide_kmin",
+                                            "linear_wide_nfeat", "window_attn_v1")] + [("reserved", ctypes.c_int * 8)]
+
+
+def get_config() -> dict:
+    c = UnivsConfig()
+    _lib.check(_lib.load().univs_get_config(ctypes.byref(c)), "get_config")
+    return {n: getattr(c, n) for n, _ in UnivsConfig._fields_ if n not in ("size", "reserved")}
+
+
+def configure(**settings):
+    """Set library settings by name (the others keep their current values); `configure()` with no argument restores the
+    defaults.  Returns the previous settings (pass them back to restore)."""
+    prev = get_config()
+    if not settings:
+        _lib.check(_lib.load().univs_configure(None), "configure")
+        return prev
+    c = UnivsConfig()
+    c.size = ctypes.sizeof(UnivsConfig)
+    for n, v in {**prev, **settings}.items():
+        if n not in prev:
+            raise KeyError(f"configure: unknown setting {n!r} (known: {sorted(prev)})")
+        setattr(c, n, int(v))
+    _lib.check(_lib.load().univs_configure(ctypes.byref(c)), "configure")
+    return prev
+
+
+@contextlib.contextmanager
+def configured(**settings):
+    """`with ops.configured(msda_impl=1): ...` -- settings for the duration of a block (tests, kernel benchmarks)."""
+    prev = configure(**settings) if settings else get_config()
+    try:
+        yield
+    finally:
+        configure(**prev)
+
+
 def msda_set_impl(impl: int):
     """0 auto, 1 generic direct-gather kernel, 2 LDS-tiled encoder kernel."""
     _lib.check(_lib.load().univs_msda_set_impl(int(impl)), "msda_set_impl")
@@ -234,7 +246,7 @@ def msda_last_tiled_generation() -> int:
 _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 # widest K routed to the split-bf16 kernels (K <= 768: W-stationary; beyond: the x-stationary variant, which wants
 # N % 16 == 0 and >= 4096 rows and hands anything else back to the library GEMM)
-_LINEAR_KMAX = int(os.environ.get("UNIVS_LINEAR_KMAX", "4096"))
+from .switches import SWITCHES   # linear_kmax: widest K routed to the split-bf16 Linears
 
 
 def linear_fused(x, weight, bias=None, act=None, residual=None):
@@ -253,7 +265,7 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
     if act not in _ACTS:
         raise RuntimeError(f"linear_fused: unknown activation {act!r}")
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.shape[1] != K
-            or (K % 128 != 0 and K % 96 != 0) or K > _LINEAR_KMAX or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1
+            or (K % 128 != 0 and K % 96 != 0) or K > SWITCHES.linear_kmax or N % 4 != 0 or M < 2048 or M * max(N, K) * 4 >= 2 ** 31 - 1
             or (residual is not None and _ACTS[act] != 0)):
         return None
     x2 = x.contiguous().view(M, K)
@@ -304,7 +316,7 @@ def linear_blocked(x, weight, bias, rows_per_batch, col_block):
     return y
 
 
-def linear_split(x, weight, bias=None, relu=False):
+def linear_split(x, weight, bias=None, relu=False):   # (kept name: layers.linear / linear_act)
     """linear_fused with the ReLU switch of the MSDeformAttn encoder's callers."""
     return linear_fused(x, weight, bias, act="relu" if relu else None)
 

@@ -1,0 +1,62 @@
+"""Python-side switches of the hot path (which operator implementation a module routes to).  ONE process-wide object,
+`SWITCHES`; its defaults are read from the environment ONCE, at import (so a launcher can still A/B with `UNIVS_*=...
+python bench.py`), and tests / tools change it programmatically:
+
+    from univs_amd.switches import SWITCHES, override
+    with override(msda_strips=False): ...
+
+The native library has its own settings object (include/univs_hip.h: UnivsConfig, `ops.configure`) and reads no environment
+variable at all.
+"""
+import contextlib
+import dataclasses
+import os
+
+
+def _flag(name, default):
+    v = os.environ.get(name)
+    return default if v is None or v == "" else v != "0"
+
+
+@dataclasses.dataclass
+class Switches:
+    # the encoder's MSDeformAttn core on head-major operands (csrc/msda_strips.hip); False: msda_prepare + the standard-layout
+    # operator (msda_tiled2.hip / generic)
+    msda_strips: bool = True
+    # token Linears on the split-bf16 kernels (False: library GEMMs)
+    split_linear: bool = True
+    # the 3 x 3 FPN output convolution on the split-bf16 kernel (False: MIOpen)
+    split_conv: bool = True
+    # Swin qkv / proj / fc1+GELU / fc2+shortcut on the fused split-bf16 Linears (False: library GEMM + elementwise passes);
+    # `swin_fused_parts`: diagnostic bit set, 1 qkv / proj, 2 fc1 + GELU, 4 fc2 + shortcut
+    swin_fused_linear: bool = True
+    swin_fused_parts: int = 7
+    # widest K routed to the split-bf16 Linears
+    linear_kmax: int = 4096
+    # prompt sampler draws: "reference" (the reference's host-side randperm order, bit-identical sampling) or "device"
+    sampler: str = "reference"
+    # hipGraph replay of the static parts of a clip (backbone, pixel decoder): see univs_amd/graphs.py
+    graphs: bool = False
+
+
+SWITCHES = Switches(
+    msda_strips=_flag("UNIVS_MSDA_STRIPS", True), split_linear=_flag("UNIVS_SPLIT_LINEAR", True),
+    split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
+    swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
+    sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False))
+if SWITCHES.sampler not in ("reference", "device"):
+    raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
+
+
+@contextlib.contextmanager
+def override(**kw):
+    old = {k: getattr(SWITCHES, k) for k in kw}
+    for k, v in kw.items():
+        if not hasattr(SWITCHES, k):
+            raise KeyError(k)
+        setattr(SWITCHES, k, v)
+    try:
+        yield SWITCHES
+    finally:
+        for k, v in old.items():
+            setattr(SWITCHES, k, v)
