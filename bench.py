@@ -298,7 +298,6 @@ def main():
         return tuple(t.shape[-2:])
 
     t_msda = OpTimer(ops, "ms_deform_attn_forward", after=ops.msda_last_tiled_generation)
-    t_msdaf = OpTimer(ops, "msda_forward_fused")
     t_msdas = OpTimer(ops, "msda_forward_strips")
     t_mdec = OpTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)
     t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
@@ -306,7 +305,7 @@ def main():
                     key=lambda x, size, addend=None: ("fpn" if addend is not None else "maskfeat",) + tuple(int(v) for v in size))
     t_win = OpTimer(ops, "window_attention_image",
                     key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale: (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
-    timers = [t_msda, t_msdaf, t_msdas, t_mdec, t_mattn, t_res, t_win]
+    timers = [t_msda, t_msdas, t_mdec, t_mattn, t_res, t_win]
     PROF_STEPS = 5
     for t_ in timers:
         t_.enabled = True
@@ -319,20 +318,15 @@ def main():
     S = 23 * 40 + 46 * 80 + 92 * 160
     alg = 3200.0 * S * T   # bytes per launch (one launch = T frames of one encoder layer)
     sec, n = t_msdas.seconds()
-    fused, strips = bool(n), bool(n)
+    fused = bool(n)          # the head-major operator also does msda_prepare's work
     if not n:
         sec, n = t_msda.seconds()
-    if not n:
-        sec, n = t_msdaf.seconds()
-        fused = True
     if n:
         gens = set(t_msda.notes.get("all", []))
-        gen = 5 if strips else 3 if fused else (max(gens) if gens else 0)
+        gen = 5 if fused else (max(gens) if gens else 0)
         kname = {5: "msda_fwd_strips<3> (MSDeformAttn core on head-major operands: strips with resident row-circular windows at half a "
                     "head per workgroup, two workgroups per CU, a lane owns a sample)",
-                 3: "msda_fwd_tiled3 (MSDeformAttn forward: LDS-tiled, register records + DPP gathers, fill waves)",
-                 2: "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)",
-                 1: "msda_fwd_tiled<3> (MSDeformAttn forward: LDS-tiled, single window)"}.get(gen, "msda_fwd_vec4 (generic)")
+                 2: "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)"}.get(gen, "msda_fwd_vec4 (generic)")
         res["roofline"] = {"kernel": kname + (" + fused msda_prepare" if fused else ""), "bound": "hbm",
                            "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
                            "traffic": None, "avg_launch_us": sec * 1e6, "launches_per_step": n // PROF_STEPS,
