@@ -88,6 +88,8 @@ def test_maskformer_video_is_registered_and_calls_the_head_without_targets():
     from univs_amd.modeling.meta_arch.univs_prompt import MaskFormer_Video
     case = cases.HEAD_CASE
     head = helpers.build_head(case, "cpu", return_aux=False)
+    with cpu_ops(), torch.no_grad(), pytest.raises(ValueError):
+        head(cases.backbone_features(case))          # no targets and no opt-in: raises, as the reference's decoder does
     calls = []
 
     class Backbone(torch.nn.Module):

@@ -17,8 +17,7 @@ static inline long long ceil_div(long long a, long long b) {  // b > 0
   return -floor_div(-a, b);
 }
 
-// ---- host-side geometry: built once per (device, level shapes, tile parameters), kept for the
-// lifetime of the process (a few hundred bytes of device memory per distinct geometry).
+// ---- host-side geometry: built once per (device, level shapes, tile parameters); the 32 most recent are kept.
 struct GeoKey {
   int dev, L, TH, TW, R, ring;
   long long cap_px;
@@ -106,6 +105,12 @@ static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, i
     (void)hipGetLastError();
     delete ge;
     return nullptr;
+  }
+  if (cache.size() >= 32) {   // bounded (image datasets: many resolutions): drop the oldest entry; nobody may still be reading it
+    (void)hipDeviceSynchronize();
+    (void)hipFree(cache.front()->table);
+    delete cache.front();
+    cache.erase(cache.begin());
   }
   cache.push_back(ge);
   return ge;

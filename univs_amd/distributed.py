@@ -33,6 +33,7 @@ class FrameShard:
     def all_gather_frames(self, x: torch.Tensor, dim: int) -> torch.Tensor:
         """Concatenate every rank's block along `dim` in rank order: ONE collective into ONE preallocated tensor
         (`all_gather_into_tensor`; no per-rank temporaries, no concatenation pass when dim == 0)."""
+        dim = dim % x.dim()            # negative axes count from the end
         if self.world == 1:
             return x
         x = x.contiguous()

@@ -118,10 +118,16 @@ class MaskFormer_Video(nn.Module):
     transformer decoder are a different model family, outside SURVEY.md 8a."""
 
     @configurable
-    def __init__(self, *, backbone, sem_seg_head, num_frames, size_divisibility, pixel_mean, pixel_std):
+    def __init__(self, *, backbone, sem_seg_head, num_frames, size_divisibility, pixel_mean, pixel_std,
+                 dataset_name="ytvis_2021_dev"):
         super().__init__()
         self.backbone = backbone
         self.sem_seg_head = sem_seg_head
+        # this meta-architecture calls the head without targets: it names the class vocabulary of the category-specified
+        # first clip the decoder then builds (the decoder raises for a target-less call otherwise)
+        pred = getattr(sem_seg_head, "predictor", None)
+        if pred is not None and hasattr(pred, "default_dataset_name"):
+            pred.default_dataset_name = dataset_name
         self.num_frames = num_frames
         self.size_divisibility = size_divisibility if size_divisibility >= 0 else getattr(backbone, "size_divisibility", 32)
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)

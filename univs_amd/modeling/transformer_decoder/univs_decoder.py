@@ -139,7 +139,9 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         self.semantic_extraction_enable = semantic_extraction_enable
         self.return_aux_outputs = return_aux_outputs
         self.frame_shard = None  # univs_amd.distributed.FrameShard: frames of the clip sharded over ranks
-        self.default_dataset_name = "ytvis_2021_dev"   # class vocabulary when the caller passes no targets (MaskFormer_Video)
+        # `MaskFormer_Video` calls the head WITHOUT targets; the meta-architecture opts in by naming the class vocabulary here.
+        # None (default): a call without targets raises, as the reference's decoder does (it dereferences targets[0], :310)
+        self.default_dataset_name = None
         self._clip_norm_cache = None
         self._sa_mask_cache = {}
         with torch.no_grad():  # the reference's init for the two temperatures (:233-236)
@@ -201,6 +203,10 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             # `MaskFormer_Video`'s call, `self.sem_seg_head(features)` (mask2former_video/video_maskformer_model.py:209):
             # no caller-owned state -> a category-specified first clip (the reference's UniVS decoder dereferences
             # `targets[0]` unconditionally, :310-333, so this combination raises there)
+            if self.default_dataset_name is None:
+                raise ValueError("VideoMultiScaleMaskedTransformerDecoderUniVS.forward needs `targets` (task, dataset_name, "
+                                 "prompt_type, frame indices); a meta-architecture that calls the head without them sets "
+                                 "`predictor.default_dataset_name` first")
             targets = [{"task": "detection", "dataset_name": self.default_dataset_name, "prompt_type": "visual",
                         "num_frames": t_total, "first_frame_idx": 0, "frame_indices": torch.arange(t_total, device=dev)}]
         if "frame_indices" in targets[0]:

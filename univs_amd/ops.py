@@ -276,8 +276,9 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
         raise RuntimeError("linear_fused: bias must be float32 [N] on the GPU")
     r = None
     if residual is not None:
-        if residual.dtype != torch.float32 or not residual.is_cuda or residual.numel() != M * N:
-            raise RuntimeError("linear_fused: residual must be float32 of the output's shape on the GPU")
+        if residual.dtype != torch.float32 or not residual.is_cuda or tuple(residual.shape) != tuple(x.shape[:-1]) + (N,):
+            raise RuntimeError("linear_fused: residual must be float32 of the output's shape on the GPU "
+                               f"(got {tuple(residual.shape)}, output {tuple(x.shape[:-1]) + (N,)})")
         r = residual.contiguous()
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
