@@ -53,7 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (default: min(cores, 32))")
-    ap.add_argument("--no-frame-sharded", action="store_true", help="N>1: skip the config-3 frame-sharded measurement")
+    ap.add_argument("--no-frame-sharded", action="store_true", help="skip the config-3 frame-sharded measurement (N>1: one clip "
+                    "of 5*N frames over the ranks; N=1: the 40-frame anchor under a one-rank RCCL group)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo plumbing check (tests): launcher, rendezvous, barrier-bracketed timing, max over "
                          "ranks, JSON line -- with a trivial step instead of the model")
@@ -275,6 +276,69 @@ def main():
                         "the query states per decoder layer (all_gather_into_tensor)",
             "value": T * world * steps_s / dts, "unit": "frames/s", "frames_per_clip": T * world, "steps": steps_s,
             "ms_per_step": dts / steps_s * 1e3, "scaling": "weak"}
+
+    # ---- N = 1 anchor of the frame-sharded path: ONE 40-frame 720p clip (config 3's single-clip reading: position_encoding.py:123
+    # allows 128 frames) through FrameShard under a ONE-rank RCCL group, collectives issued for real -- the denominator a
+    # later 8-GPU number of `frame_sharded` needs, and the sharded code path on hardware at all
+    if world == 1 and not args.no_frame_sharded:
+        try:
+            import socket
+            from univs_amd.distributed import FrameShard
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+            T40 = 40
+            head.predictor.frame_shard = FrameShard(always_collective=True)
+            fr40 = synth.synthetic_frames(T40, case["H"], case["W"], "frames/t40").to(dev)
+            fidx40 = torch.arange(T40, device=dev)
+            sa_events = []
+            hooks = []
+            for layer in head.predictor.transformer_self_attention_layers:
+                def pre(m, a, k=None, _e=sa_events):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _e.append([e0, None])
+
+                def post(m, a, o, _e=sa_events):
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    _e[-1][1] = e1
+                hooks += [layer.register_forward_pre_hook(pre), layer.register_forward_hook(post)]
+
+            @torch.no_grad()
+            def step40():
+                x40 = torch.nn.functional.pad((fr40 - mean) / std, (0, 0, 0, 16))
+                return head(swin(x40), targets=targets(fidx40))
+            step40()
+            sync()
+            torch.cuda.reset_peak_memory_stats(dev)
+            sa_events.clear()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                o40 = step40()
+            sync()
+            dt40 = (time.perf_counter() - t0) / 3
+            sa_ms = sum(a_.elapsed_time(b_) for a_, b_ in sa_events) / 3
+            for h_ in hooks:
+                h_.remove()
+            head.predictor.frame_shard = None
+            res["frame_sharded_n1"] = {
+                "workload": "ONE clip of 40 frames @ 720p on ONE GPU through FrameShard(world=1) under a one-rank RCCL group "
+                            "(all_gather_into_tensor / all_reduce issued per decoder layer)",
+                "ms_per_clip": dt40 * 1e3, "frames_per_s": T40 / dt40, "frames_per_clip": T40,
+                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                "self_attention_ms_per_clip": sa_ms, "self_attention_share": sa_ms / (dt40 * 1e3),
+                "self_attention_tokens": int(o40["pred_masks"].shape[1]) * T40,
+                "rccl": {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                         "version": ".".join(str(v) for v in torch.cuda.nccl.version())}}
+            del o40, fr40
+            dist.destroy_process_group()
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            res["frame_sharded_n1"] = {"error": repr(e)[:300]}
+            head.predictor.frame_shard = None
 
     if rank != 0:
         if world > 1:

@@ -165,3 +165,35 @@ def test_frame_sharded_box_and_point_prompts():
 def test_frame_sharded_decoder_matches_single_process(scenario):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), scenario), nprocs=world, join=True)
+
+
+def test_one_rank_group_with_collectives_issued():
+    """bench.py's `frame_sharded_n1`: FrameShard(always_collective=True) in a ONE-rank group runs the collectives for real
+    and must reproduce the unsharded result exactly (a gather of one block and a sum of one term are identities)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from oracle.cpu_path import cpu_ops
+        from tests import cases, helpers
+        from univs_amd.distributed import FrameShard
+
+        shard = FrameShard(always_collective=True)
+        x = torch.arange(24.0).view(2, 3, 4)
+        for dim in (0, 1, -1):
+            y = shard.all_gather_frames(x, dim)
+            assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)
+        assert torch.equal(shard.all_reduce_sum(x.clone()), x)
+        assert FrameShard().all_gather_frames(x, 1) is x          # default: a one-rank shard returns its input
+
+        case = dict(cases.HEAD_CASE, name="head_dist1", T=4)
+        feats = cases.backbone_features(case)
+        head = helpers.build_head(case, "cpu", return_aux=False)
+        with cpu_ops(), torch.no_grad():
+            ref = head(feats, targets=cases.targets_first_clip(case))
+            head.predictor.frame_shard = shard
+            out = head(feats, targets=cases.targets_first_clip(case))
+        for k in ("pred_masks", "pred_logits", "pred_embds"):
+            assert torch.equal(out[k], ref[k]), k
+    finally:
+        dist.destroy_process_group()

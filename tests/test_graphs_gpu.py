@@ -1,0 +1,46 @@
+"""GPU: hipGraph replay of the shape-static parts of a clip (univs_amd/graphs.py) == the eager call, bit for bit, with
+fresh output tensors per call."""
+import pytest
+import torch
+
+from tests import cases, helpers
+from univs_amd.switches import override
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backbone_and_pixel_decoder_graph_replay_is_bitwise_eager(cuda):
+    swin = helpers.build_swin(cuda)
+    pd = helpers.build_pixel_decoder(cases.SWINT_SHAPES, cuda)
+    xs = [cases.swin_input().to(cuda), (cases.swin_input() * 0.5 + 0.1).to(cuda)]
+    with torch.no_grad():
+        eager = []
+        for x in xs:
+            f = swin(x)
+            eager.append((f, pd.forward_features(f)))
+        with override(graphs=True):
+            graphed = []
+            for rep in range(2):                      # second round: pure replays
+                for x in xs:
+                    f = swin(x)
+                    graphed.append((f, pd.forward_features(f)))
+            assert swin._graphed.replays == 4 and pd._graphed.replays == 4 and len(swin._graphed.entries) == 1
+            # another shape: its own graph, the first one stays valid
+            x3 = cases.swin_input(dict(cases.SWIN_CASE, H=64, W=96)).to(cuda)
+            f3 = swin(x3)
+            assert len(swin._graphed.entries) == 2
+            f_again = swin(xs[0])
+        f3_eager = swin(x3)
+    for i, (fe, pe) in enumerate(eager):
+        for rep in range(2):
+            fg, pg = graphed[2 * rep + i]
+            for k in fe:
+                assert torch.equal(fe[k], fg[k]), (i, rep, k)
+            flat_e = [pe[0], pe[1], pe[2], *pe[3]]
+            flat_g = [pg[0], pg[1], pg[2], *pg[3]]
+            for a, b in zip(flat_e, flat_g):
+                assert torch.equal(a, b), (i, rep)
+    # fresh tensors per call: the outputs of the first call were not overwritten by the later replays
+    assert graphed[0][0]["res2"].data_ptr() != graphed[2][0]["res2"].data_ptr()
+    for k in f3:
+        assert torch.equal(f3[k], f3_eager[k]) and torch.equal(f_again[k], eager[0][0][k])

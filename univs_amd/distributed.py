@@ -18,11 +18,14 @@ import torch.distributed as dist
 class FrameShard:
     """Equal contiguous blocks of frames per rank (T_total = world * T_loc)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        """`always_collective`: issue the collectives even in a one-rank group (bench.py's N = 1 anchor runs the very code
+        path of N ranks, RCCL calls included; by default a one-rank shard returns its inputs)."""
         assert dist.is_available() and dist.is_initialized(), "init torch.distributed first"
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.always_collective = always_collective
 
     def total(self, t_local: int) -> int:
         return t_local * self.world
@@ -34,7 +37,7 @@ class FrameShard:
         """Concatenate every rank's block along `dim` in rank order: ONE collective into ONE preallocated tensor
         (`all_gather_into_tensor`; no per-rank temporaries, no concatenation pass when dim == 0)."""
         dim = dim % x.dim()            # negative axes count from the end
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return x
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -46,7 +49,7 @@ class FrameShard:
         return out.movedim(0, dim).reshape(tuple(x.shape[:dim]) + (self.world * x.shape[dim],) + tuple(x.shape[dim + 1:]))
 
     def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return x
         x = x.contiguous()
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)

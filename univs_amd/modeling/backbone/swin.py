@@ -265,6 +265,16 @@ class SwinTransformer(nn.Module):
 
     @fp32_region
     def forward(self, x):
+        if SWITCHES.graphs and x.is_cuda and not self.training:
+            # hipGraph replay per input shape (univs_amd/graphs.py): one launch instead of ~250
+            g = self.__dict__.get("_graphed")
+            if g is None:
+                from ...graphs import GraphedCallable
+                g = self.__dict__["_graphed"] = GraphedCallable(self._forward)
+            return g(x)
+        return self._forward(x)
+
+    def _forward(self, x):
         x = self.patch_embed(x)
         Wh, Ww = x.size(2), x.size(3)
         if self.ape:

@@ -303,6 +303,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def forward_features(self, features):
         with torch.autocast(device_type=next(iter(features.values())).device.type, enabled=False):
+            if SWITCHES.graphs and not self.training and all(f.is_cuda for f in features.values()):
+                # hipGraph replay per input signature (univs_amd/graphs.py): one launch instead of ~200
+                g = self.__dict__.get("_graphed")
+                if g is None:
+                    from ...graphs import GraphedCallable
+                    g = self.__dict__["_graphed"] = GraphedCallable(self._forward_features)
+                return g({k: features[k] for k in self.in_features})
             return self._forward_features(features)
 
     def _forward_features(self, features):
