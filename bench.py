@@ -171,19 +171,37 @@ def dry_run(args, world, rank):
         return a @ a
 
     dt, _ = timed_loop(step, args.steps, args.warmup, world, lambda: None, torch.device("cpu"))
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": "dry-run (launcher / rendezvous / timing plumbing only)", "value": world * args.steps / dt,
-                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}))
+        line = json.dumps({"metric": "dry-run (launcher / rendezvous / timing plumbing only)", "value": world * args.steps / dt,
+                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                           "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"})
     if world > 1:
         dist.destroy_process_group()
+    return line
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_torchrun(args))
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 on their own (RCCL's
+    # version banner at communicator creation, hipcc when the library is rebuilt on first use) are sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     world, rank, local_rank = init_distributed(args)
     if args.dry_run:
         return dry_run(args, world, rank)
@@ -344,7 +362,7 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return None
 
     # ---- parity of the timed path against the reference's own CPU run (tests/golden/g12)
     try:
@@ -524,10 +542,10 @@ def main():
                                          "plain-C MSDA): 1 warm-up + 3 timed, median",
                                "seconds_per_clip": runs, "warmup_seconds_by_threads": {str(k): v for k, v in sweep.items()}}
         res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]   # reported, not a quality measure
-    print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return json.dumps(res)
 
 
 if __name__ == "__main__":

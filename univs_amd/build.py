@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
            "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(HERE, "..", "include"), *srcs, "-o", LIB + ".tmp"]
     if verbose:
-        print("[univs_amd.build]", " ".join(cmd), flush=True)
+        print("[univs_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB + ".tmp", LIB)
     return LIB
