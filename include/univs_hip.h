@@ -258,6 +258,21 @@ int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, co
                                      const float* shift_mask, int B, int H, int W, int ws, int shift,
                                      int nH, int hd, float scale, float* out, void* stream);
 
+/* The same operator with the operand precision of its two matrix products chosen by the caller (BASELINE config 5: the
+ * reference runs the backbone under autocast, train_net.py:334, so swin.py:141-168 multiplies in fp16).
+ *   UNIVS_MMA_F32  exact fp32 products (v_mfma_f32_16x16x4_f32): identical to univs_window_attention_image_f32
+ *   UNIVS_MMA_F16  q*scale, k, v and the un-normalised probabilities exp(s - max) are rounded to fp16 (RNE) as MFMA
+ *                  operands (v_mfma_f32_16x16x32_f16 / 16x16x16_f16); accumulation, bias, shift mask, softmax and the
+ *                  1/sum normalisation stay fp32, as do the input and output tensors.  ws <= 12, hd = 32,
+ *                  B*H*W*3*nH*hd < 2^31.  Tolerance against the fp32 result: tests/test_ops_gpu.py
+ *                  (test_window_attention_fp16_operands).
+ * Any other value of `mma` returns UNIVS_ERR_INVALID_ARGUMENT. */
+#define UNIVS_MMA_F32 0
+#define UNIVS_MMA_F16 1
+int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, const float* bias,
+                                     const float* shift_mask, int B, int H, int W, int ws, int shift,
+                                     int nH, int hd, float scale, int mma, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bilinear resampling of image planes, align_corners = false (PyTorch semantics).
  * Replaces: F.interpolate(x, size=(Hout, Wout), mode="bilinear", align_corners=False) on the path of the

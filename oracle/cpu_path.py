@@ -41,9 +41,23 @@ def mask_decode_attn(mask_embed, feat_lowres):
     return m
 
 
-def window_attention(qkv, bias, shift_mask, num_windows, scale):
+def window_attention(qkv, bias, shift_mask, num_windows, scale, mma="f32"):
+    """swin.py:137-168 between the two Linears.  mma="f16" restates UNIVS_MMA_F16 (include/univs_hip.h): q * scale, k, v
+    and the un-normalised probabilities rounded to fp16 as operands of fp32-accumulating products, everything else
+    fp32 (scores in the exp2 domain, normalisation applied to the output, as the kernel orders it)."""
     B_, N, _, nH, hd = qkv.shape
     q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)  # each [B_, nH, N, hd]
+    if mma == "f16":
+        log2e = 1.4426950408889634
+        r16 = lambda t: t.half().float()            # noqa: E731
+        attn = r16(q * (torch.tensor(scale, dtype=torch.float32) * torch.tensor(log2e, dtype=torch.float32))) @ r16(k).transpose(-2, -1) + (bias * log2e).unsqueeze(0)
+        if shift_mask is not None:
+            nW = shift_mask.shape[0]
+            attn = (attn.view(B_ // nW, nW, nH, N, N) + (shift_mask * log2e).unsqueeze(1).unsqueeze(0)).view(-1, nH, N, N)
+        e = torch.exp2(attn - attn.amax(-1, keepdim=True))
+        out = (r16(e) @ r16(v)) / e.sum(-1, keepdim=True)
+        return out.transpose(1, 2).reshape(B_, N, nH * hd)
+    assert mma == "f32", mma
     attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
     if shift_mask is not None:
         nW = shift_mask.shape[0]
@@ -78,7 +92,7 @@ def masked_softmax_(scores, mask=None):
     return scores
 
 
-def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale):
+def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale, mma="f32"):
     """The reference's data movement around the core (swin.py:252-284): pad (padded pixels carry the qkv bias =
     Linear(0)), roll, window_partition -> core -> window_reverse, roll back, crop."""
     B, L, _, nH, hd = qkv.shape
@@ -95,7 +109,7 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
         x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
     xw = x.view(B, Hp // ws, ws, Wp // ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3, nH, hd)
     nW = (Hp // ws) * (Wp // ws)
-    o = window_attention(xw, bias, shift_mask if shift else None, nW, scale)          # [B*nW, ws*ws, C]
+    o = window_attention(xw, bias, shift_mask if shift else None, nW, scale, mma)         # [B*nW, ws*ws, C]
     o = o.view(B, Hp // ws, Wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, -1)
     if shift:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))

@@ -390,6 +390,46 @@ def test_config5_swinl_1080p_against_reference(cuda, golden_dir):
     assert np.abs(out["pred_embds"][:, :, :, ::4].cpu().numpy() - g["pred_embds"]).max() < 3e-3
 
 
+# Tolerances of BASELINE config 5 with the fp16-operand window attention (SwinTransformer.set_attention_mma("f16")) against
+# the reference's fp32 CPU run (g19).  24 Swin-L blocks each add an operand-rounding error of ~2^-11 relative to the
+# attention output; measured on the GPU: backbone features 4.2e-4 (6.5e-4 against the fp32 model), mask logits 1.44e-3
+# (|logit| reaches 14; the fp32 model: 3.7e-4), class logits 3.5e-5, no mask sign differs where |reference logit| > 5e-3.
+# The bounds keep a factor ~3-4 over the measurement.
+CFG5_F16_FEATURE_ATOL = 2e-3
+CFG5_F16_MASK_ATOL = 5e-3
+CFG5_F16_LOGIT_ATOL = 1e-3
+
+
+def test_config5_fp16_window_attention_against_reference(cuda, golden_dir):
+    """BASELINE config 5 as it is named ("MFMA window-attn, fp16"): Swin-L with the window-attention products on fp16
+    operands (window_attn_img_f16<9>), everything else fp32, first two frames at 1080p against the reference's fp32 run (g19)
+    under the variant's own tolerance; the fp32 model on the same input bounds what the variant changed."""
+    g = _g(golden_dir, "g19_cfg5_swinl_1080p")
+    case = dict(cases.CFG5, T=cases.CFG5_GOLDEN_T)
+    swin = helpers.build_swin(cuda, variant=cases.SWIN_L, attn_mma="f16")
+    assert all(m.mma == "f16" for m in swin.modules() if hasattr(m, "mma"))
+    head = helpers.build_head(case, cuda, return_aux=False)
+    x = cases.preprocess(cases.cfg5_frames(case["T"])).to(cuda)
+    with torch.no_grad():
+        feats = swin(x)
+        out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
+        feats32 = swin.set_attention_mma("f32")(x)
+    ferr = {k: float(np.abs(v[:, ::16, ::4, ::4].cpu().numpy() - g["feat_" + k + "_s"]).max()) for k, v in feats.items()}
+    fdiff = {k: float((feats[k] - feats32[k]).abs().max()) for k in feats}
+    ref_s = g["pred_masks_s"]
+    got_s = out["pred_masks"][0, :, :, ::16, ::16].cpu().numpy()
+    err = np.abs(got_s - ref_s).max()
+    flips = ((got_s > 0) != (ref_s > 0)) & (np.abs(ref_s) > CFG5_F16_MASK_ATOL)
+    lerr = np.abs(out["pred_logits"].cpu().numpy() - g["pred_logits"]).max()
+    print(f"cfg5 fp16 window attention (T=2): features vs reference {ferr}, vs the fp32 model {fdiff}; pred_masks max-abs-err "
+          f"{err:.3e} (|ref| max {np.abs(ref_s).max():.2f}), sign flips beyond the tolerance {flips.sum()}, pred_logits {lerr:.3e}")
+    assert max(fdiff.values()) > 0, "the fp16 variant must be the kernel that ran"
+    assert max(ferr.values()) < CFG5_F16_FEATURE_ATOL, ferr
+    assert err < CFG5_F16_MASK_ATOL, err
+    assert flips.sum() == 0
+    assert lerr < CFG5_F16_LOGIT_ATOL, lerr
+
+
 def test_config5_full_clip_properties(cuda):
     """BASELINE config 5 at FULL size on the GPU (Swin-L, T=10 @ 1080p, 200 queries; the reference's CPU run of this clip
     needs > 100 GB): size-independent properties of the hot operators on the tensors the model really produces --

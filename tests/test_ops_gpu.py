@@ -499,13 +499,7 @@ def test_masked_softmax_matches_torch(cuda, N, h, L, S):
     assert torch.equal(got3, got.cpu())
 
 
-@pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 0, 3), (2, 14, 21, 7, 3, 3), (1, 23, 40, 7, 3, 2), (1, 24, 36, 12, 6, 4),
-                                                (2, 9, 11, 12, 0, 1), (1, 7, 7, 7, 0, 2)], ids=lambda v: str(v))
-def test_window_attention_image_matches_reference_data_movement(cuda, B, H, W, ws, shift, nH):
-    """Image-mode window attention == pad -> roll -> window_partition -> core -> window_reverse -> roll -> crop
-    (the oracle's restatement of swin.py:252-284 around the already-pinned core), incl. padded pixels (qkv = bias),
-    shifted windows with the 0/-100 mask, windows larger than the image, and both window sizes."""
-    from oracle import cpu_path
+def _window_image_inputs(B, H, W, ws, shift, nH):
     hd, n = 32, ws * ws
     tag = f"wai/{B}/{H}/{W}/{ws}/{shift}/{nH}"
     qkv = synth.normal(tag + "/qkv", (B, H * W, 3, nH, hd))
@@ -526,11 +520,56 @@ def test_window_attention_image_matches_reference_data_movement(cuda, B, H, W, w
         am = mw.unsqueeze(1) - mw.unsqueeze(2)
         mask = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
         assert mask.shape[0] == nW
-    ref = cpu_path.window_attention_image(qkv, qb, bias, mask, H, W, ws, shift, hd ** -0.5)
+    return qkv, qb, bias, mask
+
+
+@pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 0, 3), (2, 14, 21, 7, 3, 3), (1, 23, 40, 7, 3, 2), (1, 24, 36, 12, 6, 4),
+                                                (2, 9, 11, 12, 0, 1), (1, 7, 7, 7, 0, 2)], ids=lambda v: str(v))
+def test_window_attention_image_matches_reference_data_movement(cuda, B, H, W, ws, shift, nH):
+    """Image-mode window attention == pad -> roll -> window_partition -> core -> window_reverse -> roll -> crop
+    (the oracle's restatement of swin.py:252-284 around the already-pinned core), incl. padded pixels (qkv = bias),
+    shifted windows with the 0/-100 mask, windows larger than the image, and both window sizes."""
+    from oracle import cpu_path
+    qkv, qb, bias, mask = _window_image_inputs(B, H, W, ws, shift, nH)
+    ref = cpu_path.window_attention_image(qkv, qb, bias, mask, H, W, ws, shift, 32 ** -0.5)
     got = ops.window_attention_image(qkv.to(cuda), qb.to(cuda), bias.to(cuda), mask.to(cuda) if mask is not None else None,
-                                     H, W, ws, shift, hd ** -0.5).cpu()
+                                     H, W, ws, shift, 32 ** -0.5).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-5
+
+
+# Tolerance of the fp16-operand window attention (UNIVS_MMA_F16) against the fp32 operator, on unit-normal q, k, v, bias:
+# each operand carries a relative rounding error of 2^-11, which over 32 channels and up to 144 keys gives errors of a few
+# 1e-4 of the output scale; 4e-3 absolute leaves a factor ~4 over the largest error measured on these cases.
+WINDOW_F16_ATOL = 4e-3
+# against the restatement that rounds at the SAME points (oracle/cpu_path.py: window_attention(mma="f16")) only the
+# summation order and the last bit of exp2 differ; an exp2 off by one ulp can flip the fp16 rounding of ONE probability p,
+# which moves the output by 2^-11 p |v| (2.1e-4 measured; |v| reaches 4 on these inputs)
+WINDOW_F16_ATOL_SAME_ROUNDING = 5e-4
+
+
+@pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 0, 3), (2, 14, 21, 7, 3, 3), (1, 23, 40, 7, 3, 2), (1, 24, 36, 12, 6, 4),
+                                                (2, 9, 11, 12, 0, 1), (1, 7, 7, 7, 0, 2), (1, 20, 31, 9, 4, 2), (1, 13, 26, 8, 0, 3),
+                                                (2, 68, 120, 12, 6, 6)], ids=lambda v: str(v))
+def test_window_attention_fp16_operands(cuda, B, H, W, ws, shift, nH):
+    """ops.window_attention_image(mma="f16") (BASELINE config 5's fp16 MFMA window attention) -- against the oracle's
+    restatement with the same rounding points (tight: layout, padding, masks, every tile size 4 / 6 / 9 blocks) and
+    against the fp32 operator (the stated tolerance of the variant)."""
+    from oracle import cpu_path
+    qkv, qb, bias, mask = _window_image_inputs(B, H, W, ws, shift, nH)
+    args = (H, W, ws, shift, 32 ** -0.5)
+    dev = [t.to(cuda) if t is not None else None for t in (qkv, qb, bias, mask)]
+    got = ops.window_attention_image(*dev, *args, mma="f16")
+    f32 = ops.window_attention_image(*dev, *args, mma="f32")
+    assert torch.equal(f32, ops.window_attention_image(*dev, *args))            # "f32" is the default operator
+    same = cpu_path.window_attention_image(qkv, qb, bias, mask, *args, mma="f16")
+    e_same = (got.cpu() - same).abs().max().item()
+    e_f32 = (got - f32).abs().max().item()
+    print(f"fp16 window attention {B, H, W, ws, shift, nH}: vs same-rounding oracle {e_same:.2e}, vs fp32 operator {e_f32:.2e}")
+    assert e_same < WINDOW_F16_ATOL_SAME_ROUNDING
+    assert 0 < e_f32 < WINDOW_F16_ATOL
+    with pytest.raises(ValueError):
+        ops.window_attention_image(*dev, *args, mma="bf16")
 
 
 @pytest.mark.parametrize("N,Lq,M,shapes,bcast", [(2, 37, 8, [(8, 14), (16, 28), (32, 56)], True), (1, 5, 2, [(3, 4)], False),

@@ -190,6 +190,21 @@ def main():
                         t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5))
                     res[f"window_attn_image_{H_}x{W_}_shift{shift}" + ("_v1" if v1 == "1" else "")] = dict(
                         ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+    if not args.only or "win12" in args.only:
+        # config 5: Swin-L at 1080p (1088 x 1920 padded), 12 x 12 windows, the four stages, 2 frames; exact-f32 vs fp16 operands
+        hd, ws, Tw = 32, 12, 2
+        for (H_, W_, nh) in ((272, 480, 6), (136, 240, 12), (68, 120, 24), (34, 60, 48)):
+            q = synth.normal(f"kb/qkv12/{H_}", (Tw, H_ * W_, 3, nh, hd)).to(dev)
+            qb = synth.normal(f"kb/qb12/{nh}", (3 * nh * hd,)).to(dev)
+            bi = synth.normal(f"kb/bias12/{nh}", (nh, ws * ws, ws * ws)).to(dev)
+            nWi = ((H_ + ws - 1) // ws) * ((W_ + ws - 1) // ws)
+            mk = torch.zeros(nWi, ws * ws, ws * ws, device=dev)
+            byts = (q.numel() + q.numel() / 3) * 4.0
+            for shift in (0, 6):
+                for mma in ("f32", "f16"):
+                    t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5, mma=mma))
+                    res[f"window12_{H_}x{W_}_shift{shift}_{mma}"] = dict(
+                        ms=t * 1e3, us_per_frame=t * 1e6 / Tw, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
     if not args.only or "resample" in args.only:
         f = synth.normal("kb/f", (T, 256, 184, 320)).to(dev)
         for (h, w) in ((92, 160), (46, 80), (23, 40)):

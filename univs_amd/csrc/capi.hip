@@ -58,6 +58,8 @@ int group_norm_f32(const float*, const float*, const float*, int, int, long long
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
+int window_attention_image_f16mma(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
+                                  int, float, float*, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -435,6 +437,30 @@ int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, co
   }
   return window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out,
                                     static_cast<hipStream_t>(stream));
+}
+
+int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, const float* bias,
+                                     const float* shift_mask, int B, int H, int W, int ws, int shift, int nH,
+                                     int hd, float scale, int mma, float* out, void* stream) {
+  if (mma == UNIVS_MMA_F32)
+    return univs_window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out, stream);
+  clear_sticky_error();
+  if (mma != UNIVS_MMA_F16) {
+    set_error("univs_window_attention_image_mma: mma=%d (UNIVS_MMA_F32 = 0 or UNIVS_MMA_F16 = 1)", mma);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (B < 0 || H < 1 || W < 1 || ws < 1 || shift < 0 || shift >= ws || nH < 1 || hd < 1) {
+    set_error("univs_window_attention_image_mma: bad dimensions B=%d H=%d W=%d ws=%d shift=%d nH=%d hd=%d", B, H, W,
+              ws, shift, nH, hd);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return UNIVS_OK;
+  if (!qkv || !bias || !out) {
+    set_error("univs_window_attention_image_mma: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return window_attention_image_f16mma(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out,
+                                       static_cast<hipStream_t>(stream));
 }
 
 int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const float* ref_points,

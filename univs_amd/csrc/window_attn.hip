@@ -19,6 +19,7 @@
 //     head-dim 8g..8g+7 / keys 4g..4g+3), which is exact up to fp32 re-association.
 #include "common.h"
 #include "config.h"
+#include "window_attn.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -29,15 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WA_WAVES = 4;
 constexpr int WA_VSTRIDE = 36;  // floats per staged V row (32 + 4 pad): groups g, g+1 hit disjoint banks
-
-// Image mode (IMG): qkv / out are in TOKEN order [B, H*W, ...] and the kernel does the reference's
-// pad -> roll(-shift) -> window_partition on the way in and window_reverse -> roll(+shift) -> crop on
-// the way out (swin.py:252-284) by index arithmetic: window b = (image, wy, wx), position j = (py, px)
-// maps to pixel ((wy*ws + py + shift) mod Hp, (wx*ws + px + shift) mod Wp); pixels beyond (H, W) are the
-// zero padding, whose q/k/v are the qkv Linear's bias (Linear(0) = bias) and which are not written back.
-struct WinImage {
-  int H, W, ws, shift, nWx, Hp, Wp;
-};
 
 template <bool IMG>
 __device__ __forceinline__ long long win_token(const WinImage& wi, long long b, int nW, int Ntok, int j) {
@@ -433,11 +425,7 @@ int window_attention_f32(const float* qkv, const float* bias, const float* shift
 int window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask,
                                int B, int H, int W, int ws, int shift, int nH, int hd, float scale, float* out,
                                hipStream_t st) {
-  WinImage wi;
-  wi.H = H; wi.W = W; wi.ws = ws; wi.shift = shift;
-  wi.Hp = (H + ws - 1) / ws * ws;
-  wi.Wp = (W + ws - 1) / ws * ws;
-  wi.nWx = wi.Wp / ws;
+  const WinImage wi = win_image(H, W, ws, shift);
   const int nW = (wi.Hp / ws) * wi.nWx;
   const bool v1 = config().window_attn_v1 != 0;   // the first 7x7 kernel (kernel benchmarks)
   if (ws == 7 && hd == 32 && !v1 && (long long)B * H * W * 3 * nH * hd < 0x7FFFFFFFLL) {

@@ -1,0 +1,299 @@
+// Swin window attention core with fp16 MFMA operands (BASELINE config 5: the reference runs the backbone under autocast,
+// train_net.py:334, so WindowAttention.forward -- mask2former/modeling/backbone/swin.py:131-171 -- multiplies in fp16).
+//
+// What is fp16 here and what is not (UNIVS_MMA_F16 in include/univs_hip.h):
+//   * q * scale, k, v and the un-normalised softmax probabilities exp(s - max) are ROUNDED to fp16 (RNE) as MFMA operands;
+//   * both products accumulate in fp32 (v_mfma_f32_16x16x32_f16 for K (Q scale)^T over the 32 head channels in ONE
+//     instruction, v_mfma_f32_16x16x16_f16 for P V);
+//   * the relative-position bias, the shift mask, the softmax (max, exp2, sum) and the 1/sum normalisation (applied to the
+//     fp32 output) are fp32; inputs and outputs are the fp32 tensors of the fp32 path.
+// The reference's autocast rounds MORE (qkv and the scores themselves are fp16 tensors there), so this variant sits between
+// the fp32 path and the reference's fp16 run; its tolerance against the fp32 result is stated in tests/test_ops_gpu.py.
+//
+// Organisation (image mode only: tokens in image order, pad / roll / partition / reverse / crop by index arithmetic):
+//   * a workgroup = 8 waves = ONE head, persistent over a range of windows; the head's bias table (times log2 e) sits in
+//     LDS in fp32 once per workgroup, row stride NP + 4 floats (a lane's four consecutive keys are one conflict-free
+//     16-byte read and are the accumulator's initial value);
+//   * a wave = one window at a time.  Scores are computed transposed, S^T = K (Q scale)^T, so that a lane holds
+//     S[query n][keys jb*16 + 4g .. + 3]: softmax runs over registers and the four 16-lane groups, and the fp16
+//     probabilities are already the A operand of P V;
+//   * V is staged per wave in LDS as fp16, TRANSPOSED ([head channel][key], row stride NP + 8 halves: conflict-free 8-byte
+//     reads): the B operand of P V is V[keys 4g .. 4g+3][channel n], four keys of ONE channel per lane.  The transpose is
+//     done in registers on the way in: a lane loads 4 keys x 4 channels (four 16-byte loads) and writes four 8-byte rows;
+//   * with 12 x 12 windows (config 5) every tile is full: 144 tokens = 9 blocks of 16, no padded key or query exists.
+//     LDS: 144 x 148 x 4 (bias) + 8 x 32 x 152 x 2 (V) = 163 072 B of the CU's 163 840: one workgroup per CU.
+#include "common.h"
+#include "config.h"
+#include "window_attn.h"
+
+#include <algorithm>
+
+namespace univs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WH_WAVES = 8;
+
+template <int NB, bool MASK4>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
+__global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float* __restrict__ qkv,
+                                                                      const float* __restrict__ qkv_bias,
+                                                                      const float* __restrict__ bias,
+                                                                      const float* __restrict__ shift_mask, int B_, int nW,
+                                                                      int nH, float scale, float* __restrict__ out,
+                                                                      WinImage wi, int magic) {
+  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + 8;
+  constexpr int VR = (NB + 1) / 2;   // V staging rounds: lanes 0-31 take key block r, lanes 32-63 block r + VR
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int Ntok = wi.ws * wi.ws;
+  extern __shared__ __attribute__((aligned(16))) float lds_wh[];
+  float* bias_lds = lds_wh;                                   // [NP][BS]: log2e * bias of head h, -inf for keys >= Ntok
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  _Float16* vt = reinterpret_cast<_Float16*>(lds_wh + NP * BS) + wave * (HD * VS);   // [HD][VS]
+  const int h = blockIdx.y;
+  const int g = lane >> 4, n = lane & 15;
+
+  for (int idx = threadIdx.x; idx < NP * NP; idx += 64 * WH_WAVES) {
+    const int i = idx / NP, j = idx - i * NP;
+    float v = j < Ntok ? 0.f : -INFINITY;
+    if (i < Ntok && j < Ntok) v = bias[((long long)h * Ntok + i) * Ntok + j] * LOG2E;
+    bias_lds[i * BS + j] = v;
+  }
+  __syncthreads();
+
+  const int tok_stride = 3 * nH * HD, part = nH * HD;
+  const float* qkvb = qkv_bias ? qkv_bias + h * HD : nullptr;
+  const int nWy = wi.Hp / wi.ws;
+  const float qscale = scale * LOG2E;    // scores in the exp2 domain
+  // V staging roles: key group kgl (4 keys) of the half-wave's block, channel group hg (4 channels)
+  const int half = lane >> 5, kgl = (lane >> 3) & 3, hg = lane & 7;
+
+#pragma unroll 1
+  for (int b = blockIdx.x * WH_WAVES + wave; b < B_; b += gridDim.x * WH_WAVES) {   // scalar
+    const int w = b % nW, img = b / nW;
+    const int wy = w / wi.nWx, wx = w - wy * wi.nWx;
+    const int y0 = wy * wi.ws + wi.shift, x0 = wx * wi.ws + wi.shift;
+    const bool masked = shift_mask && (wy == nWy - 1 || wx == wi.nWx - 1);   // scalar
+    // token of row j: >= 0 its index, -1 a zero-padded pixel (q/k/v = the qkv bias), -2 beyond Ntok
+    auto token = [&](int j) __attribute__((always_inline)) -> int {
+      const int py = (j * magic) >> 16, px = j - py * wi.ws;
+      int y = y0 + py, x = x0 + px;
+      y -= (y >= wi.Hp) ? wi.Hp : 0;
+      x -= (x >= wi.Wp) ? wi.Wp : 0;
+      const int t = (y < wi.H && x < wi.W) ? (img * wi.H + y) * wi.W + x : -1;
+      return j < Ntok ? t : -2;
+    };
+    int tok[NB];                     // of my rows j = 16 jb + n
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) tok[jb] = token(jb * 16 + n);
+    auto row_ptr = [&](int t) __attribute__((always_inline)) -> const float* {
+      return t >= 0 ? qkv + (long long)t * tok_stride + h * HD : (t == -1 ? qkvb : nullptr);
+    };
+
+    // ---- V: 4 keys x 4 channels per lane and round, transposed into LDS as fp16
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      const bool hi_ok = r + VR < NB;                          // compile time
+      const int src = hi_ok ? (half ? tok[hi_ok ? r + VR : r] : tok[r]) : tok[r];
+      float4 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = __shfl(src, half * 32 + kgl * 4 + e, 64);
+        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* rp = row_ptr(t);
+        if (rp && (hi_ok || half == 0)) v[e] = *reinterpret_cast<const float4*>(rp + 2 * part + 4 * hg);
+      }
+      if (hi_ok || half == 0) {
+        const int jb = r + half * VR;
+        _Float16* dst = vt + (4 * hg) * VS + jb * 16 + kgl * 4;
+        f16x4 c0 = {(_Float16)v[0].x, (_Float16)v[1].x, (_Float16)v[2].x, (_Float16)v[3].x};
+        f16x4 c1 = {(_Float16)v[0].y, (_Float16)v[1].y, (_Float16)v[2].y, (_Float16)v[3].y};
+        f16x4 c2 = {(_Float16)v[0].z, (_Float16)v[1].z, (_Float16)v[2].z, (_Float16)v[3].z};
+        f16x4 c3 = {(_Float16)v[0].w, (_Float16)v[1].w, (_Float16)v[2].w, (_Float16)v[3].w};
+        *reinterpret_cast<f16x4*>(dst) = c0;
+        *reinterpret_cast<f16x4*>(dst + VS) = c1;
+        *reinterpret_cast<f16x4*>(dst + 2 * VS) = c2;
+        *reinterpret_cast<f16x4*>(dst + 3 * VS) = c3;
+      }
+    }
+
+    // ---- K fragments: lane holds K[jb*16 + n][8g .. 8g+7] as 8 halves
+    f16x8 kf[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+      const float* rp = row_ptr(tok[jb]);
+      if (rp) {
+        const float4* p = reinterpret_cast<const float4*>(rp + part + 8 * g);
+        a = p[0];
+        c = p[1];
+      }
+      kf[jb] = f16x8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                     (_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
+    }
+    // Q of the first query block (the loop below requests block ib + 1 while it computes block ib)
+    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qc = qa;
+    {
+      const float* rp = row_ptr(tok[0]);
+      if (rp) {
+        const float4* pq = reinterpret_cast<const float4*>(rp + 8 * g);
+        qa = pq[0];
+        qc = pq[1];
+      }
+    }
+    const float* mask_w = masked ? shift_mask + (long long)w * Ntok * Ntok : nullptr;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    __builtin_amdgcn_wave_barrier();
+
+    // the query loop stays rolled: unrolled, hipcc hoists the 81 bias reads and the addresses of all nine blocks to the
+    // top and spills 600 registers
+#pragma unroll 1
+    for (int ib = 0; ib < NB; ++ib) {
+      const int i = ib * 16 + n;        // this lane's query (column of S^T)
+      const int tok_i = token(i);
+      const f16x8 qf = {(_Float16)(qa.x * qscale), (_Float16)(qa.y * qscale), (_Float16)(qa.z * qscale), (_Float16)(qa.w * qscale),
+                        (_Float16)(qc.x * qscale), (_Float16)(qc.y * qscale), (_Float16)(qc.z * qscale), (_Float16)(qc.w * qscale)};
+      if (ib + 1 < NB) {                // scalar
+        qa = make_float4(0.f, 0.f, 0.f, 0.f);
+        qc = qa;
+        const float* rp = row_ptr(token(i + 16));
+        if (rp) {
+          const float4* pq = reinterpret_cast<const float4*>(rp + 8 * g);
+          qa = pq[0];
+          qc = pq[1];
+        }
+      }
+      f32x4 s[NB];
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        // bias (and the -inf of the padded keys) is the accumulator's initial value
+        const f32x4 acc = *reinterpret_cast<const f32x4*>(bias_lds + i * BS + jb * 16 + 4 * g);
+        s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qf, acc, 0, 0, 0);
+      }
+      if (mask_w) {   // scalar: last row / column of windows only
+        // unconditional loads at clamped indices + a select (see window_attn.hip: a load behind a lane condition made
+        // hipcc 7.2 restore stale AGPR copies of s[] in the lanes that skip it)
+        const float* mrow = mask_w + min(i, Ntok - 1) * Ntok;
+        if (MASK4) {                    // rows are 16-byte aligned: a lane's four keys are one load
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) {
+            const int j0 = jb * 16 + 4 * g;
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(mrow + min(j0, Ntok - 4));
+            const float keep = (i < Ntok && j0 < Ntok) ? LOG2E : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[jb][r] += mv[r] * keep;
+          }
+        } else {
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = jb * 16 + 4 * g + r;
+              const float mv = mrow[min(j, Ntok - 1)];
+              s[jb][r] += (i < Ntok && j < Ntok) ? mv * LOG2E : 0.f;
+            }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[jb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+      f16x4 p[NB];
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = __builtin_amdgcn_exp2f(s[jb][r] - mx);   // exp2(-inf) = 0 for padded keys
+          sum += e[r];
+        }
+        p[jb] = f16x4{(_Float16)e[0], (_Float16)e[1], (_Float16)e[2], (_Float16)e[3]};
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;     // of query n (the same value in the four lane groups)
+
+      // out[ib] (16 queries x 32 channels) = P[ib, :] @ V : two 16-channel halves
+      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const f16x4 b0 = *reinterpret_cast<const f16x4*>(vt + n * VS + jb * 16 + 4 * g);
+        const f16x4 b1 = *reinterpret_cast<const f16x4*>(vt + (16 + n) * VS + jb * 16 + 4 * g);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b0, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b1, o1, 0, 0, 0);
+      }
+      // C layout: row = 4g + r -> query ib*16 + 4g + r (token and 1/sum: lane 4g + r); col = n -> channel n / 16 + n
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = __shfl(tok_i, 4 * g + r, 64);
+        const float invr = __shfl(inv, 4 * g + r, 64);
+        if (t >= 0) {
+          float* op = out + ((long long)t * nH + h) * HD;
+          op[n] = o0[r] * invr;
+          op[16 + n] = o1[r] * invr;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the next window's V staging overwrites vt
+  }
+}
+
+template <int NB, bool MASK4>
+static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B_, int nW,
+                      int nH, float scale, float* out, const WinImage& wi, int n_cu, hipStream_t st) {
+  constexpr int NP = 16 * NB;
+  const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * 32 * (NP + 8) * sizeof(_Float16);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+  // workgroups = resident slots rounded DOWN to a multiple of the head count: one extra workgroup would double the tail
+  int gx = std::max(1, n_cu * per_cu / nH);
+  gx = std::min(gx, (B_ + WH_WAVES - 1) / WH_WAVES);
+  const void* fn = reinterpret_cast<const void*>(&window_attn_img_f16<NB, MASK4>);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((window_attn_img_f16<NB, MASK4>), dim3(gx, nH), dim3(64 * WH_WAVES), lds, st, qkv, qkv_bias, bias, shift_mask,
+                     B_, nW, nH, scale, out, wi, (65536 + wi.ws - 1) / wi.ws);
+  return check_launch("window_attn_img_f16");
+}
+
+// qkv [B, H*W, 3, nH, hd] in token order; out [B, H*W, nH*hd]
+int window_attention_image_f16mma(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B,
+                                  int H, int W, int ws, int shift, int nH, int hd, float scale, float* out, hipStream_t st) {
+  if (hd != 32) {
+    set_error("window_attention_image (fp16 operands): head_dim=%d (only 32, the Swin-T/B/L value)", hd);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (ws > 12) {
+    set_error("window_attention_image (fp16 operands): %d x %d windows (max 12 x 12)", ws, ws);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)B * H * W * 3 * nH * hd >= 0x7FFFFFFFLL || nH > 65535) {
+    set_error("window_attention_image (fp16 operands): qkv of %lld elements (32-bit offsets inside the kernel)",
+              (long long)B * H * W * 3 * nH * hd);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const WinImage wi = win_image(H, W, ws, shift);
+  const int nW = (wi.Hp / ws) * wi.nWx;
+  const int B_ = B * nW;
+  if (B_ == 0) return UNIVS_OK;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n_cu = v;
+  }
+  const int ntok = ws * ws;
+  if (ntok <= 64) return launch_f16<4, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  if (ntok <= 96) return launch_f16<6, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  if (ntok % 4 == 0) return launch_f16<9, true>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  return launch_f16<9, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+}
+
+}  // namespace univs

@@ -98,6 +98,7 @@ class WindowAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
         self._bias_cache = None
+        self.mma = "f32"             # operand precision of the attention products (SwinTransformer.set_attention_mma)
 
     def _bias(self):
         t = self.relative_position_bias_table
@@ -116,7 +117,7 @@ class WindowAttention(nn.Module):
         B, L, C = x.shape
         qkv = _linear(self.qkv, x).view(B, L, 3, self.num_heads, C // self.num_heads)
         out = ops.window_attention_image(qkv, self.qkv.bias, self._bias(), mask, H, W, self.window_size[0], shift,
-                                         self.scale)
+                                         self.scale, mma=self.mma)
         return _linear(self.proj, out)
 
     def forward(self, x, mask=None):
@@ -273,6 +274,18 @@ class SwinTransformer(nn.Module):
                 g = self.__dict__["_graphed"] = GraphedCallable(self._forward)
             return g(x)
         return self._forward(x)
+
+    def set_attention_mma(self, mma):
+        """Operand precision of every block's window-attention products: "f32" (default, exact) or "f16" (fp16 MFMA
+        operands, fp32 accumulation / softmax -- what BASELINE config 5 names; the reference gets there through autocast,
+        train_net.py:334).  An explicit choice of the caller: nothing switches it on by itself."""
+        if mma not in ops.MMA_DTYPES:
+            raise ValueError(f"set_attention_mma: {mma!r} (one of {sorted(ops.MMA_DTYPES)})")
+        for m in self.modules():
+            if isinstance(m, WindowAttention):
+                m.mma = mma
+        self._graphed = None         # captured graphs hold the old kernels
+        return self
 
     def _forward(self, x):
         x = self.patch_embed(x)

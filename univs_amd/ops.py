@@ -554,11 +554,17 @@ def masked_softmax_(scores, mask=None):
     return scores
 
 
-def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale):
+MMA_DTYPES = {"f32": 0, "f16": 1}      # UNIVS_MMA_F32 / UNIVS_MMA_F16 (include/univs_hip.h)
+
+
+def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale, mma="f32"):
     """Swin window attention on tokens in image order: qkv [B, H*W, 3, nH, hd] (the qkv Linear applied to the
     un-padded tokens) -> [B, H*W, nH*hd]; pad / roll / window_partition / window_reverse / crop of
     swin.py:252-284 happen inside the kernel.  `qkv_bias` [3*nH*hd] or None supplies q/k/v of the padded
-    pixels; `shift_mask` [nW, ws*ws, ws*ws] is required when shift > 0."""
+    pixels; `shift_mask` [nW, ws*ws, ws*ws] is required when shift > 0.  `mma`: operand precision of the two
+    matrix products, "f32" (exact) or "f16" (fp16 operands, fp32 accumulation and softmax: BASELINE config 5)."""
+    if mma not in MMA_DTYPES:
+        raise ValueError(f"window_attention_image: mma={mma!r} (one of {sorted(MMA_DTYPES)})")
     _inference_only("window_attention_image", qkv, qkv_bias, bias)
     _require_gpu("window_attention_image", qkv, bias)
     if qkv.dtype != torch.float32 or qkv.dim() != 5:
@@ -583,10 +589,10 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
             raise RuntimeError("window_attention_image: bad qkv_bias shape")
     out = torch.empty((B, L, nH * hd), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        rc = _lib.load().univs_window_attention_image_f32(
+        rc = _lib.load().univs_window_attention_image_mma(
             _ptr(qkv), _ptr(qkv_bias) if qkv_bias is not None else None, _ptr(bias),
             _ptr(shift_mask) if shift_mask is not None else None, B, int(H), int(W), ws, int(shift), nH, hd,
-            float(scale), _ptr(out), _stream_ptr(qkv))
+            float(scale), MMA_DTYPES[mma], _ptr(out), _stream_ptr(qkv))
     _lib.check(rc, "window_attention_image")
     return out
 

@@ -111,14 +111,14 @@ def preprocess(frames, divisibility=32):
 # ---------------------------------------------------------------------------------------------------
 # product modules with the closed-form weights
 # ---------------------------------------------------------------------------------------------------
-def build_swin(device="cpu", variant=None):
+def build_swin(device="cpu", variant=None, attn_mma="f32"):
     from .modeling.backbone.swin import SwinTransformer
     k = dict(variant or SWIN_T)
     m = SwinTransformer(k["pretrain_img_size"], k["patch_size"], k["in_chans"], k["embed_dim"], k["depths"],
                         k["num_heads"], k["window_size"], k["mlp_ratio"], k["qkv_bias"], k["qk_scale"], k["ape"],
                         k["patch_norm"]).eval()
     synth.load_synthetic(m, prefix="backbone.")
-    return m.to(device)
+    return m.set_attention_mma(attn_mma).to(device)
 
 
 def build_pixel_decoder(shapes, device="cpu"):
