@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (default: min(cores, 32))")
     ap.add_argument("--no-frame-sharded", action="store_true", help="skip the config-3 frame-sharded measurement (N>1: one clip "
                     "of 5*N frames over the ranks; N=1: the 40-frame anchor under a one-rank RCCL group)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (Swin-L, 1080p) clip measurement at N = 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo plumbing check (tests): launcher, rendezvous, barrier-bracketed timing, max over "
                          "ranks, JSON line -- with a trivial step instead of the model")
@@ -357,6 +358,50 @@ def run(args):
         except Exception as e:  # pragma: no cover
             res["frame_sharded_n1"] = {"error": repr(e)[:300]}
             head.predictor.frame_shard = None
+
+    # ---- BASELINE config 5 (Swin-L, T=10 @ 1080p, 200 queries, "MFMA window-attn, fp16"): one clip with the window-attention
+    # products on fp16 operands (the variant the config names) and one with the exact-f32 products, on rank 0 at N = 1
+    if world == 1 and not args.no_config5:
+        try:
+            c5 = cases.CFG5
+            swin5 = helpers.build_swin(dev, variant=cases.SWIN_L)
+            head5 = helpers.build_head(c5, dev, return_aux=False)
+            fr5 = cases.cfg5_frames(c5["T"]).to(dev)
+            tg5 = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(c5)[0].items()}
+            wa = OpTimer(ops, "window_attention_image")
+
+            @torch.no_grad()
+            def step5():
+                x5 = torch.nn.functional.pad((fr5 - mean) / std, (0, 0, 0, 8))     # 1080 -> 1088 rows
+                return head5(swin5(x5), targets=[dict(tg5)])
+            c5res = {"workload": "BASELINE config 5: Swin-L (12 x 12 windows), T=10 @ 1080p (1088x1920 padded), 200 queries, "
+                                 "first clip; 2 warm-up + 3 timed clips per variant", "frames_per_clip": c5["T"]}
+            for mma in ("f16", "f32"):
+                swin5.set_attention_mma(mma)
+                for _ in range(2):
+                    step5()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step5()
+                sync()
+                dt5 = (time.perf_counter() - t0) / 3
+                wa.enabled = True
+                step5()
+                sync()
+                wa.enabled = False
+                c5res[f"window_attention_{mma}"] = {"ms_per_clip": dt5 * 1e3, "frames_per_s": c5["T"] / dt5,
+                                                    "window_attention_ms_per_clip": wa.total_seconds() * 1e3,
+                                                    "window_attention_launches": sum(len(v) for v in wa.events.values())}
+                wa.events.clear()
+            setattr(ops, "window_attention_image", wa.orig)
+            res["config5_swinl_1080p"] = c5res
+            del swin5, head5, fr5
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            res["config5_swinl_1080p"] = {"error": repr(e)[:300]}
+            if "wa" in locals():
+                setattr(ops, "window_attention_image", wa.orig)
 
     if rank != 0:
         if world > 1:

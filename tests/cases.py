@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from univs_amd import synth
-from univs_amd.workloads import (CFG2, HEAD_CASE, PIXDEC, R50_SHAPES, SWIN_B, SWIN_L, SWIN_T, SWINL_SHAPES,  # noqa: F401
+from univs_amd.workloads import (CFG2, CFG5, CFG5_GOLDEN_T, cfg5_frames, HEAD_CASE, PIXDEC, R50_SHAPES, SWIN_B, SWIN_L, SWIN_T, SWINL_SHAPES,  # noqa: F401
                                  SWINT_SHAPES, backbone_features, cfg2_frames, clip_table, decoder_kwargs, preprocess, sampler_kwargs,
                                  targets_first_clip, targets_with_entities)
 
@@ -163,17 +163,6 @@ def targets_grounding(case=HEAD_CASE, n_exp=3):
 # Swin-B (configs/univs_inf/vids/refvos/univs_swinb_refvos_davis_c1+univs.yaml:5-9): window 12 -> 144-token
 # windows, the second instantiation of the window-attention kernel
 SWINB_CASE = dict(name="swin_b", N=1, H=96, W=160)
-
-
-# Swin-L (configs/univs_inf/vids/vis/univs_swinl_yt21_c1+univs.yaml:5-13) -- BASELINE config 5: T=10 @ 1080p (padded to
-# 1088x1920), 200 queries.  The reference's CPU run of the full clip needs > 100 GB, so the golden (g19) is the same
-# network on the first TWO frames; the T=10 run is checked through size-independent properties on the GPU.
-CFG5 = dict(name="cfg5", T=10, H=1080, W=1920, Q=200, shapes=SWINL_SHAPES)
-CFG5_GOLDEN_T = 2
-
-
-def cfg5_frames(T):
-    return synth.synthetic_frames(T, CFG5["H"], CFG5["W"], "cfg5/frames")
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -98,6 +98,17 @@ def cfg2_frames(case=CFG2):
     return synth.synthetic_frames(case["T"], case["H"], case["W"], "frames/seed0")
 
 
+# Swin-L (configs/univs_inf/vids/vis/univs_swinl_yt21_c1+univs.yaml:5-13) -- BASELINE config 5: T=10 @ 1080p (padded to
+# 1088x1920), 200 queries.  The reference's CPU run of the full clip needs > 100 GB, so the golden (g19) is the same
+# network on the first TWO frames; the T=10 run is checked through size-independent properties on the GPU.
+CFG5 = dict(name="cfg5", T=10, H=1080, W=1920, Q=200, shapes=SWINL_SHAPES)
+CFG5_GOLDEN_T = 2
+
+
+def cfg5_frames(T):
+    return synth.synthetic_frames(T, CFG5["H"], CFG5["W"], "cfg5/frames")
+
+
 def preprocess(frames, divisibility=32):
     """normalise + zero-pad to a multiple of 32 (univs/inference/inference_video_entity.py:251-260)."""
     mean = torch.tensor(synth.PIXEL_MEAN).view(1, 3, 1, 1)
