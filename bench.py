@@ -31,6 +31,7 @@ clip over the summed time of every kernel the fused implementation runs for them
 stage), and `cpu_baseline` (rank 0, N=1 only: the CPU oracle path on the host cores, 1 warm-up + 3 timed clips, median).
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -196,6 +197,7 @@ def main():
         line = run(args)
     finally:
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)         # C stdio buffers too (RCCL prints its banner with printf)
         os.dup2(json_fd, 1)
         os.close(json_fd)
     if line is not None:
@@ -431,7 +433,7 @@ def run(args):
     t_res = OpTimer(ops, "bilinear_resample",
                     key=lambda x, size, addend=None: ("fpn" if addend is not None else "maskfeat",) + tuple(int(v) for v in size))
     t_win = OpTimer(ops, "window_attention_image",
-                    key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale: (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
+                    key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale, mma="f32": (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
     timers = [t_msda, t_msdas, t_mdec, t_mattn, t_res, t_win]
     PROF_STEPS = 5
     for t_ in timers:
