@@ -74,6 +74,38 @@ def test_head_matches_reference(cuda, golden_dir, name, dec_over, targets_fn, se
         helpers.check_head_outputs(out3, g, "clip3_", tol=1e-3)
 
 
+def test_prompt_prefetch_on_a_side_stream_equals_the_inline_sampler(cuda, monkeypatch):
+    """The head starts the annotation-only part of the visual-prompt sampler on a side stream before the pixel decoder
+    (VisualPromptSampler.prefetch: candidate pixels, feature-resolution masks, the sizes of the reference's randperm
+    draws in ONE host round trip); the same clip with that work done inline must give identical outputs and pool."""
+    head = helpers.build_head(cases.HEAD_CASE, cuda)
+    feats = _to(cases.backbone_features(), cuda)
+    sampler = head.predictor.visual_prompt_sampler
+    calls = []
+    orig = sampler.prefetch
+    monkeypatch.setattr(sampler, "prefetch", lambda tv, nf: (calls.append(nf), orig(tv, nf))[1])
+    res = []
+    for use in (True, False, False):
+        targets = _targets_to(cases.targets_with_entities(), cuda)
+        if not use:
+            monkeypatch.setattr(head.predictor, "prefetch_prompts", lambda *a: None)
+        with torch.no_grad():
+            torch.manual_seed(3)
+            out = head(feats, targets=targets)
+        assert "_prompt_prefetch" not in targets[0]
+        res.append((out, targets[0]))
+    assert calls == [cases.HEAD_CASE["T"]], "the prefetch must have run exactly once, for the first of the three calls"
+    # the sampler's own products are deterministic: identical pools; the decoder behind them is compared at the run-to-run
+    # spread of two inline runs (library GEMMs with split reductions are not bitwise repeatable)
+    for k in ("prompt_feats", "prompt_pe", "prompt_attn_masks"):
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for k in ("pred_masks", "pred_logits", "pred_embds"):
+        d_pf = (res[0][0][k] - res[1][0][k]).abs().max().item()
+        d_rr = (res[1][0][k] - res[2][0][k]).abs().max().item()
+        print(f"{k}: prefetch vs inline {d_pf:.2e}, inline vs inline {d_rr:.2e}")
+        assert d_pf <= max(2 * d_rr, 1e-5), (k, d_pf, d_rr)
+
+
 def test_g4_g5_prediction_heads_and_teacher_forced_layer(cuda, golden_dir):
     """SURVEY.md Appendix B G4 / G5 through the HIP operators: prediction heads (mask decode + fused attention mask) and
     one teacher-forced decoder layer against tensors captured inside the reference decoder."""

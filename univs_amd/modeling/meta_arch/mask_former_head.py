@@ -73,6 +73,9 @@ class MaskFormerHead(nn.Module):
     def layers(self, features, mask=None, targets=None):
         if self.pixel_decoder_name != "MSDeformAttnPixelDecoder":
             raise ValueError(f"pixel decoder {self.pixel_decoder_name} is outside the hot path (SURVEY.md section 2)")
+        if targets is not None and hasattr(self.predictor, "prefetch_prompts"):
+            # the annotation-only part of the visual-prompt sampler, on a side stream, ahead of the pixel decoder
+            self.predictor.prefetch_prompts(targets, next(iter(features.values())).shape[0])
         mask_features, mask_features_bfe_conv, enc_features, multi_scale_features = \
             self.pixel_decoder.forward_features(features)
         if self.transformer_in_feature != "multi_scale_pixel_decoder":

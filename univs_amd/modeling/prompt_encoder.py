@@ -232,24 +232,46 @@ class VisualPromptEncoder:
         return point_coords, pd, fd, masks_
 
     @torch.no_grad()
+    def annotation_prefix(self, masks, boxes, h_img, w_img, mask_thresh=0.5):
+        """The part of `get_mask_prompt` that depends on the annotations only -- not on the image features -- for F key
+        frames at once: masks [F, n, h, w], boxes [F, n, 4] or None -> tensors with a leading frame axis: `valid` / `visible` [F, n] (some pixel above the threshold / above 0),
+        `feat_masks` / `feat_masks_binary` [F, n, h_img, w_img], the point candidates `sel` [F, n, h, w] with their row
+        counts `rowcnt` [F, n, h], and `counts` [F, 2 n] int32 = the sizes of the reference's randperm draws of one call
+        (points of the n entities, then dense tokens of the n entities).  Every quantity is per entity except the
+        threshold of `feat_masks_binary`, which is per frame (prompt_encoder.py:198-200 takes the max over the call)."""
+        Fk, n, h, w = masks.shape
+        s = self.img_feats_scale
+        assert (h_img * s == h) and (w_img * s == w), \
+            f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
+        flat = masks.reshape(Fk * n, h, w)
+        mx = flat.amax(2).amax(1)                             # two short reductions
+        valid = mx > mask_thresh                              # some pixel above the threshold
+        feat_masks = F.interpolate(flat.float().unsqueeze(1), (h_img, w_img), mode="nearest").squeeze(1)
+        thr = feat_masks.reshape(Fk, -1).amax(1).clamp(max=mask_thresh)
+        feat_masks_binary = feat_masks >= thr.view(Fk, 1, 1, 1).expand(Fk, n, 1, 1).reshape(-1, 1, 1)
+        sel, rowcnt = self._select_candidates(flat, None if boxes is None else boxes.reshape(Fk * n, 4))
+        counts = torch.cat([rowcnt.sum(1, dtype=torch.int32).view(Fk, n),
+                            feat_masks_binary.flatten(1).sum(1, dtype=torch.int32).view(Fk, n)], dim=1)
+        return {"valid": valid.view(Fk, n), "visible": (mx > 0).view(Fk, n), "feat_masks": feat_masks.view(Fk, n, h_img, w_img),
+                "feat_masks_binary": feat_masks_binary.view(Fk, n, h_img, w_img), "sel": sel.view(Fk, n, h, w),
+                "rowcnt": rowcnt.view(Fk, n, h), "counts": counts}
+
+    @torch.no_grad()
     def get_mask_prompt(self, img_features, img_pos, masks, boxes=None, mask_thresh=0.5, key_fid=None,
-                        key_fid_original=None, is_train=False, enable_dense_prompt=True):
+                        key_fid_original=None, is_train=False, enable_dense_prompt=True, _pre=None, _counts=None):
+        """`_pre`: this call's slice of `annotation_prefix` (computed ahead for all key frames of a clip by
+        VisualPromptSampler.prefetch); `_counts`: its `counts` row already on the host (list of 2 n ints)."""
         key_fid = self.key_fid if key_fid is None else key_fid
         key_fid_original = key_fid if key_fid_original is None else key_fid_original
         h_img, w_img = img_features.shape[-2:]
         device = img_features.device
         assert masks.dim() == 3, f"Mask shape shoule be num_instsxHxW, but get {masks.shape}"
-        valid = masks.amax(2).amax(1) > mask_thresh          # some pixel above the threshold (two short reductions)
         n, h, w = masks.shape
         s = self.img_feats_scale
-        img_masks = torch.zeros((n, h_img * s, w_img * s), device=masks.device)
-        img_masks[:, :h, :w] = masks.float()
-        feat_masks = F.interpolate(img_masks.unsqueeze(1), (h_img, w_img), mode="nearest").squeeze(1)
-        feat_masks_binary = feat_masks >= feat_masks.max().clamp(max=mask_thresh)
-        # ONE host round trip per call: the pixel counts that size the reference's randperm calls (point selection,
-        # then dense tokens -- generated on the host in exactly that order)
-        assert (h_img * s == h) and (w_img * s == w), \
-            f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
+        if _pre is None:
+            _pre = self.annotation_prefix(masks[None], None if boxes is None else boxes[None], h_img, w_img, mask_thresh)
+            _pre = {k: v[0] for k, v in _pre.items()}
+        valid, feat_masks, feat_masks_binary = _pre["valid"], _pre["feat_masks"], _pre["feat_masks_binary"]
         replay_feat_idx = None
         if self._replay is not None:
             assert self._replay, "sampler replay: more get_mask_prompt calls than recorded draws"
@@ -259,18 +281,16 @@ class VisualPromptEncoder:
             replay_feat_idx = _to_device_async(replay_feat_idx.to(torch.int64), device)
             counts = [None] * (2 * n)
             point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
-        else:
-            sel, rowcnt = self._select_candidates(masks, boxes)
-        if self._replay is not None:
-            pass
         elif self.sampler_rng == "device":
             counts = [None] * (2 * n)                        # sizes stay on the device
             point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
-                                                            _prepared=(sel, rowcnt, None))
+                                                            _prepared=(_pre["sel"], _pre["rowcnt"], None))
         else:
-            counts = torch.cat([rowcnt.sum(1), feat_masks_binary.flatten(1).sum(1).to(torch.int32)]).tolist()
+            # the pixel counts that size the reference's randperm calls (point selection, then dense tokens -- generated
+            # on the host in exactly that order): ONE host round trip per call unless the caller fetched them ahead
+            counts = _pre["counts"].tolist() if _counts is None else _counts
             point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
-                                                            _prepared=(sel, rowcnt, counts[:n]))
+                                                            _prepared=(_pre["sel"], _pre["rowcnt"], counts[:n]))
         query_pe = self._point_pe(h_img, w_img, point_coords, key_fid, key_fid_original)
         fw = feat_masks * feat_masks_binary
         pf = torch.einsum("qn,nc->qc", fw.flatten(-2).float(), img_features.flatten(-2).t())
@@ -495,6 +515,90 @@ class VisualPromptSampler:
         prompt_feats_dense = torch.where(isblank.unsqueeze(-1), mean, prompt_feats_dense)
         return prompt_pe_dense, prompt_feats_dense, prompt_attn_masks
 
+    # ---- annotation-only work of a clip's `get_mask_prompt` calls, ahead of the image features ---------------------------
+    def _needs_prev_frame(self, tv):
+        return tv["first_frame_idx"] != 0 and ((self.num_frames == 1) or ("prompt_feats" not in tv))
+
+    def _update_frames(self, tv, num_frames):
+        # Important (reference comment): first clip encodes frame 0 only (none for grounding); later
+        # clips re-encode all but the last `clip_stride` frames
+        if tv["first_frame_idx"] == 0:
+            return 1 - int(tv["task"] == "grounding")
+        return num_frames - self.clip_stride
+
+    @torch.no_grad()
+    def _annotation_jobs(self, tv, num_frames, device, prompt_type="masks"):
+        """Everything the `get_mask_prompt` calls of this clip compute from the annotations alone (candidate pixels,
+        feature-resolution masks, the sizes of the random draws), for all key frames at once and on the CURRENT stream:
+        {"prev": (ha, prefix, counts) | None, "clip": (prefix, counts) | None}; `counts` = per key frame the host list of
+        draw sizes ("reference" sampler without replay: ONE host round trip for the whole clip) or None."""
+        enc = self.visual_prompt_encoder
+        cs, T = self.clip_stride, num_frames
+        masks_all, boxes_all = tv["masks"], tv["boxes"]
+        h, w = masks_all.shape[-2:]
+        sc = enc.img_feats_scale
+        h_img, w_img = h // sc, w // sc
+        jobs = {"prev": None, "clip": None}
+        if self._needs_prev_frame(tv):
+            prev_frame_idx = max(0, tv["first_frame_idx"] - 1)
+            fa = tv["first_appear_frame_idxs"]
+            ha = torch.nonzero((fa <= prev_frame_idx) & (fa != -1)).flatten()      # the one extra host round trip
+            if ha.numel() > 0:
+                ha = ha.to(device)
+                m = masks_all[:, -(T + cs):-T].to(device)[ha].transpose(0, 1)
+                b = boxes_all[:, -(T + cs):-T].to(device)[ha].transpose(0, 1)
+                jobs["prev"] = [ha, enc.annotation_prefix(m, b, h_img, w_img), None]
+        U = self._update_frames(tv, T)
+        if U > 0 and prompt_type == "masks":
+            m = masks_all[:, -T:][:, :U].to(device).transpose(0, 1)
+            b = boxes_all[:, -T:][:, :U].to(device).transpose(0, 1)
+            jobs["clip"] = [enc.annotation_prefix(m, b, h_img, w_img), None]
+        if enc.sampler_rng == "reference" and enc._replay is None:
+            parts = [j[-2]["counts"].flatten() for j in (jobs["prev"], jobs["clip"]) if j is not None]
+            if parts:
+                host = torch.cat(parts).tolist()                                   # ONE host round trip for the clip
+                for j in (jobs["prev"], jobs["clip"]):
+                    if j is not None:
+                        Fk, n2 = j[-2]["counts"].shape
+                        j[-1] = [host[k * n2:(k + 1) * n2] for k in range(Fk)]
+                        host = host[Fk * n2:]
+        return jobs
+
+    @torch.no_grad()
+    def prefetch(self, tv, num_frames):
+        """Run `_annotation_jobs` for the NEXT `process_per_video_inference(..., tv)` on a side stream and hand its results
+        over through `tv`.  Call it BEFORE the backbone of the clip is enqueued: the side stream then waits only for the
+        work that produced the annotations (the previous clip), its kernels overlap the backbone, and the host round trip
+        for the draw sizes waits for the side stream alone -- inside `get_mask_prompt` it would wait for the backbone and
+        the pixel decoder, and the GPU would drain five times per clip (profiles/r03_prompted_clip_breakdown_v0.txt:
+        21 ms of 55 idle).  Without this call the same work runs inline, once per clip."""
+        if "masks" not in tv or tv["masks"].nelement() == 0 or not tv["masks"].is_cuda:
+            return
+        device = tv["masks"].device
+        main = torch.cuda.current_stream(device)
+        side = self.__dict__.setdefault("_side_streams", {}).get(str(device))
+        if side is None:
+            side = self._side_streams[str(device)] = torch.cuda.Stream(device=device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            jobs = self._annotation_jobs(tv, num_frames, device)
+            ev = side.record_event()
+        tv["_prompt_prefetch"] = {"jobs": jobs, "event": ev, "key": (tv["first_frame_idx"], num_frames, id(tv["masks"]))}
+
+    def _take_jobs(self, tv, num_frames, device, prompt_type):
+        pf = tv.pop("_prompt_prefetch", None)
+        if pf is not None and pf["key"] == (tv["first_frame_idx"], num_frames, id(tv["masks"])) and prompt_type == "masks":
+            main = torch.cuda.current_stream(device)
+            main.wait_event(pf["event"])
+            for j in (pf["jobs"]["prev"], pf["jobs"]["clip"]):
+                if j is not None:
+                    for t in j[-2].values():
+                        t.record_stream(main)
+                    if len(j) == 3:
+                        j[0].record_stream(main)
+            return pf["jobs"]
+        return self._annotation_jobs(tv, num_frames, device, prompt_type)
+
     @torch.no_grad()
     def process_per_video_inference(self, img_emb, pos_emb, tv, prompt_type="masks", use_all_prev_frames=False):
         device = img_emb.device
@@ -502,14 +606,13 @@ class VisualPromptSampler:
         first_frame_idx = tv["first_frame_idx"]
         frame_indices = tv["frame_indices"]
         is_first_clip = first_frame_idx == 0
+        jobs = self._take_jobs(tv, num_frames, device, prompt_type)
         if not is_first_clip:
             self.zero_pad_prompt(tv)
-            self.process_per_video_inference_prev_frame(tv, prompt_type="masks")
+            self.process_per_video_inference_prev_frame(tv, prompt_type="masks", _job=jobs["prev"])
         gt_boxes = tv["boxes"][:, -num_frames:].to(device)
         gt_masks = tv["masks"][:, -num_frames:].to(device)
-        # Important (reference comment): first clip encodes frame 0 only (none for grounding); later
-        # clips re-encode all but the last `clip_stride` frames
-        update_frames = 1 - int(tv["task"] == "grounding") if is_first_clip else num_frames - self.clip_stride
+        update_frames = self._update_frames(tv, num_frames)
         enc = self.visual_prompt_encoder
         for key_fid in range(update_frames):
             kfo = frame_indices[key_fid]
@@ -519,8 +622,11 @@ class VisualPromptSampler:
                 tup = enc.get_box_prompt(x_key, x_pos, gt_boxes[:, key_fid], is_train=False, key_fid=key_fid,
                                          key_fid_original=kfo)
             else:
+                pre, counts = jobs["clip"]
                 tup = enc.get_mask_prompt(x_key, x_pos, masks=gt_masks[:, key_fid], boxes=gt_boxes[:, key_fid],
-                                          is_train=False, key_fid=key_fid, key_fid_original=kfo)
+                                          is_train=False, key_fid=key_fid, key_fid_original=kfo,
+                                          _pre={k: v[key_fid] for k, v in pre.items()},
+                                          _counts=None if counts is None else counts[key_fid])
             pe_d, f_d, m_d = tup[1], tup[2], tup[3]
             tv["prompt_obj_ids"] = tv["ids"]
             if is_first_clip:
@@ -529,7 +635,8 @@ class VisualPromptSampler:
                 s_idx = -num_frames + key_fid
                 # entities visible in this frame overwrite their pool rows (select, not boolean-mask indexing:
                 # that would cost a host round trip per frame)
-                valid = (gt_masks[:, key_fid].amax(2).amax(1) > 0).view(-1, 1, 1, 1)
+                valid = pre["visible"][key_fid].view(-1, 1, 1, 1) if prompt_type == "masks" else \
+                    (gt_masks[:, key_fid].amax(2).amax(1) > 0).view(-1, 1, 1, 1)
                 tv["prompt_pe"][:, :, s_idx:] = torch.where(valid, pe_d[:, :, key_fid:], tv["prompt_pe"][:, :, s_idx:])
                 tv["prompt_feats"][:, :, s_idx:] = torch.where(valid, f_d[:, :, key_fid:], tv["prompt_feats"][:, :, s_idx:])
                 tv["prompt_attn_masks"][s_idx:] = m_d[key_fid:]
@@ -539,19 +646,17 @@ class VisualPromptSampler:
                 tv["prompt_attn_masks"][-num_frames:])
 
     @torch.no_grad()
-    def process_per_video_inference_prev_frame(self, tv, prompt_type="masks"):
+    def process_per_video_inference_prev_frame(self, tv, prompt_type="masks", _job=None):
         device = tv["img_emb_per_video"].device
         n_inst = tv["masks"].shape[0]
         num_frames = tv["img_emb_per_video"].shape[0]
-        prev_frame_idx = max(0, tv["first_frame_idx"] - 1)
-        fa = tv["first_appear_frame_idxs"]
-        has_appeared = (fa <= prev_frame_idx) & (fa != -1)
-        update_prev_frame = (self.num_frames == 1) or ("prompt_feats" not in tv)
-        if not update_prev_frame:
+        if not self._needs_prev_frame(tv):
             return
-        ha = torch.nonzero(has_appeared).flatten()      # the one host round trip of this function
-        if ha.numel() == 0:
+        if _job is None:
+            _job = self._annotation_jobs(tv, num_frames, device)["prev"]
+        if _job is None:                                          # no entity has appeared yet
             return
+        ha, pre, counts = _job
         cs = self.clip_stride
         for key_fid in range(cs):
             gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[ha]
@@ -560,7 +665,9 @@ class VisualPromptSampler:
             x_key, x_pos = tv["img_emb_per_video"][key_fid], tv["pos_emb_per_video"][key_fid]
             assert prompt_type == "masks"
             tup = self.visual_prompt_encoder.get_mask_prompt(x_key, x_pos, masks=gt_masks, boxes=gt_boxes,
-                                                             is_train=False, key_fid=key_fid, key_fid_original=kfo)
+                                                             is_train=False, key_fid=key_fid, key_fid_original=kfo,
+                                                             _pre={k: v[key_fid] for k, v in pre.items()},
+                                                             _counts=None if counts is None else counts[key_fid])
             pe_d, f_d, m_d = tup[1], tup[2], tup[3]
             if "prompt_feats" not in tv:
                 _, R, T, C = pe_d.shape

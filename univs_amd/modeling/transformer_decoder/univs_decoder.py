@@ -391,6 +391,17 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
 
     # ---------------------------------------------------------------------------------------------
     @fp32_region
+    def prefetch_prompts(self, targets, num_frames):
+        """Called by the head BEFORE it enqueues the pixel decoder: starts the annotation-only work of the visual-prompt
+        sampler for this clip on a side stream (VisualPromptSampler.prefetch).  A no-op where `forward_prompt_encoder`
+        would not sample visual prompts from `targets[0]`, for CPU tensors and for frame-sharded clips."""
+        if (not self.prompt_as_queries or self.visual_prompt_sampler is None or self.frame_shard is not None
+                or len(targets) != 1 or torch.is_grad_enabled()):
+            return
+        tv = targets[0]
+        if tv.get("task") == "sot" or tv.get("prompt_type") == "visual":
+            self.visual_prompt_sampler.prefetch(tv, num_frames)
+
     def forward_prompt_encoder(self, src, pos, size_list, targets, num_frames=None, prompt_type=None,
                                use_all_prev_frames=False):
         """:599-758 (inference branches)."""
