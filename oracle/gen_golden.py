@@ -373,6 +373,11 @@ def _capture_sampler_draws(enc, store):
     `get_dense_features` (:471-481: all pixels cyclically for small masks, `randperm(count)[:R]` otherwise) as flat indices
     (-1 = empty mask).  The draw SIZES are pixel counts, so a fp32 implementation whose mask differs in one near-threshold
     pixel cannot reproduce the draws from the seed; replaying the sampled pixels removes that discontinuity."""
+    if hasattr(enc, "draw_log"):
+        # the build's encoder (tests/test_b1_dropin_cpu.py drives OUR modules with the reference's loop): it samples all key
+        # frames of a clip in one pass and keeps its own record in the same format
+        enc.draw_log = store
+        return
     orig_gmp, orig_sel, orig_gdf = enc.get_mask_prompt, enc.select_points_from_box_mask, enc.get_dense_features
     state = {}
 

@@ -163,6 +163,9 @@ class VisualPromptEncoder:
             raise ValueError(f"sampler mode {self.sampler_rng!r} (expected 'reference' or 'device')")
         self._dev_gen = {}
         self._replay = None
+        # a list: every get_mask_prompt call (or key frame of get_mask_prompts) appends the pixels it sampled, in the format
+        # of `set_replay` -- (point_idx [n] int32, feat_idx [n, R] int32 with -1 rows for empty masks), on the host
+        self.draw_log = None
 
     def set_replay(self, draws):
         """Replay recorded draws instead of drawing: `draws` = a sequence of (point_idx [n], feat_idx [n, R]) per
@@ -312,11 +315,121 @@ class VisualPromptEncoder:
                                              _replay_idx=replay_feat_idx)
         if self.feature_reduce is not None:
             fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
+        if self.draw_log is not None and enable_dense_prompt:
+            px = torch.round(point_coords[:, 0] * w - 0.5).long()
+            py = torch.round(point_coords[:, 1] * h - 0.5).long()
+            self._log_draws((py * w + px)[None], self._last_dense[0][None], self._last_dense[1][None])
         # invalid (empty) entities: zero tokens, nothing masked (unconditional: no host round trip for `.any()`)
         pd = pd * valid.view(-1, 1, 1, 1).float()
         fd = fd * valid.view(-1, 1, 1, 1).float()
         attn = attn & valid.view(1, 1, -1, 1)
         return point_coords, pd, fd, attn
+
+    def _log_draws(self, point_idx, dense_idx, empty):
+        """[F, n], [F, n, R], [F, n] -> one (point_idx, feat_idx) record per key frame"""
+        pi = point_idx.to(torch.int32).cpu()
+        di = torch.where(empty[..., None], torch.full_like(dense_idx, -1), dense_idx).to(torch.int32).cpu()
+        for f in range(pi.shape[0]):
+            self.draw_log.append((pi[f], di[f]))
+
+    @torch.no_grad()
+    def get_mask_prompts(self, img_features, img_pos, masks, boxes, key_fids, key_fids_original, pre, counts=None,
+                         mask_thresh=0.5):
+        """`get_mask_prompt` for F key frames in ONE pass over the device (a prompted clip re-encodes T - clip_stride key
+        frames: ~110 launches each when called one by one).  img_features / img_pos [F, C, h_img, w_img] = the key frames'
+        maps, masks [F, n, h, w], boxes [F, n, 4], key_fids / key_fids_original = F clip-relative / absolute frame
+        indices, `pre` = annotation_prefix(masks, boxes), `counts` = its `counts` rows on the host (F lists of 2 n ints;
+        "reference" sampler only).  Returns (point_coords [F, n, 2], pd, fd [F, n, R, T, C], attn [F, T, 1, n, h_img*w_img]):
+        slice f is what the f-th separate call returns.  The host draws are generated frame by frame -- points of frame
+        0, dense tokens of frame 0, points of frame 1, ... -- i.e. in the order of F separate calls (and of the
+        reference's loop, prompt_encoder.py:463-474 / :236-251), so a seeded run samples the same pixels."""
+        assert self.feature_reduce is None, "frame-sharded clips go through get_mask_prompt (one reduction per key frame)"
+        Fk, n, h, w = masks.shape
+        C = img_features.shape[1]
+        h_img, w_img = img_features.shape[-2:]
+        HW, T, R = h_img * w_img, self.num_frames, self.num_dense_points
+        device = img_features.device
+        N = Fk * n
+        valid, feat_masks, fmb = pre["valid"].reshape(N), pre["feat_masks"], pre["feat_masks_binary"]
+        m = fmb.reshape(N, HW)
+        # ---- the draws: a rank among the candidate pixels per entity, R ranks among the mask's feature pixels per entity
+        dense_idx = None
+        if self._replay is not None:
+            assert len(self._replay) >= Fk, "sampler replay: more get_mask_prompt calls than recorded draws"
+            rec = [self._replay.popleft() for _ in range(Fk)]
+            assert all(r[0].shape[0] == n and tuple(r[1].shape) == (n, R) for r in rec), \
+                "sampler replay: entity count differs from the recording"
+            point_idx = _to_device_async(torch.cat([r[0].to(torch.int64) for r in rec]), device)
+            dense_idx = _to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
+            empty = (dense_idx[:, :1] < 0).view(-1, 1, 1)
+            dense_idx = dense_idx.clamp(min=0)
+        elif self.sampler_rng == "device":
+            rowcnt = pre["rowcnt"].reshape(N, h)
+            cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
+            u = torch.rand((N, 1), device=device, generator=self._generator(device))
+            ranks = (u * cnt[:, None]).long().clamp(max=cnt[:, None] - 1)
+            point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), ranks, rowcnt)[:, 0]
+            dcnt = m.sum(1)
+            cyc = torch.arange(R, device=device)[None] % dcnt.clamp(min=1)[:, None]
+            idx_small = _kth_true(m, cyc)
+            keys = torch.rand(m.shape, device=device, generator=self._generator(device)).masked_fill(~m.bool(), -1.0)
+            idx_big = keys.topk(min(R, HW), dim=1).indices
+            if idx_big.shape[1] < R:
+                idx_big = torch.cat([idx_big, idx_big[:, :1].expand(-1, R - idx_big.shape[1])], dim=1)
+            dense_idx = torch.where((dcnt >= R)[:, None], idx_big, idx_small)
+            empty = (dcnt == 0).view(-1, 1, 1)
+        else:
+            assert counts is not None and len(counts) == Fk
+            rows_p, rows_d = [], []
+            for f in range(Fk):
+                rows_p += [torch.randperm(int(c))[:1] for c in counts[f][:n]]
+                for c in counts[f][n:]:
+                    c = int(c)
+                    if c == 0:
+                        rows_d.append(torch.zeros(R + 1, dtype=torch.int64))
+                        rows_d[-1][R] = 1                                       # last column: the entity is empty
+                    elif c < R:
+                        rows_d.append(torch.cat([torch.arange(c).repeat(int(R / c) + 1)[:R], torch.zeros(1, dtype=torch.int64)]))
+                    else:
+                        rows_d.append(torch.cat([torch.randperm(c)[:R], torch.zeros(1, dtype=torch.int64)]))
+            tab = _to_device_async(torch.cat([torch.stack(rows_d), torch.stack(rows_p)], dim=1), device)   # one transfer
+            point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), tab[:, R + 1:], pre["rowcnt"].reshape(N, h))[:, 0]
+            dense_idx = _kth_true(m, tab[:, :R])
+            empty = (tab[:, R] != 0).view(-1, 1, 1)
+        if self.draw_log is not None:
+            self._log_draws(point_idx.view(Fk, n), dense_idx.view(Fk, n, R), empty.view(Fk, n))
+        point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
+        # ---- position token of the sampled point at its key frame, replicated over the clip's frames
+        kf = torch.as_tensor(key_fids, device=device)
+        size = (T, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
+        if self.position_embedding_sin3d_type == "FixedT":
+            pe = self.pe_layer.forward_points_with_size(size, point_coords)                        # [T, N, C]
+            query_pe = pe.view(T, Fk, n, -1)[kf, torch.arange(Fk, device=device)]                 # [F, n, C]
+        else:
+            kfo = torch.stack([torch.as_tensor(k, device=device).reshape(()) for k in key_fids_original])
+            z = kfo / self.pe_layer.num_max_frames * self.pe_layer.scale
+            ar = torch.arange(Fk, device=device)
+            query_pe = self.pe_layer._points(z, point_coords).view(Fk, Fk, n, -1)[ar, ar]
+        query_pe = query_pe.reshape(N, 1, -1).repeat(1, T, 1)                                      # [N, T, C]
+        # ---- mask-pooled feature token
+        fw = feat_masks * fmb                                                                       # [F, n, h_img, w_img]
+        feats = img_features.flatten(-2).transpose(1, 2)                                            # [F, HW, C]
+        pf = torch.bmm(fw.flatten(-2).float(), feats) / fw.sum((-2, -1)).clamp(min=mask_thresh)[..., None]
+        query_feats = pf.reshape(N, 1, C).repeat(1, T, 1)
+        # ---- cross-attention mask: everything outside the box, at the key frame only
+        attn = torch.zeros((Fk, T, 1, n, HW), dtype=torch.bool, device=device)
+        attn[torch.arange(Fk, device=device), kf, 0] = torch.logical_not(convert_box_to_mask(boxes, h_img, w_img).flatten(-2))
+        # ---- dense tokens: features / position embeddings at the R sampled pixels of the key frame's map
+        off = (torch.arange(Fk, device=device) * HW).repeat_interleave(n)[:, None]
+        gidx = dense_idx + off
+        fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats.reshape(Fk * HW, C)[gidx])
+        pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1),
+                         img_pos.flatten(-2).transpose(1, 2).reshape(Fk * HW, -1)[gidx])
+        vf = valid.view(-1, 1, 1, 1).float()
+        fd = (fd[:, :, None].repeat(1, 1, T, 1) * vf).view(Fk, n, R, T, -1)
+        pd = (pd[:, :, None].repeat(1, 1, T, 1) * vf).view(Fk, n, R, T, -1)
+        attn = attn & valid.view(Fk, 1, 1, n, 1)
+        return point_coords.view(Fk, n, 2), pd, fd, attn
 
     @torch.no_grad()
     def get_box_prompt(self, img_features, img_pos, boxes, key_fid=None, key_fid_original=None, is_train=False,
@@ -421,6 +534,7 @@ class VisualPromptEncoder:
             assert tuple(_replay_idx.shape) == (m.shape[0], R), "sampler replay: dense-token table has the wrong shape"
             empty = (_replay_idx[:, :1] < 0).view(-1, 1, 1)
             idx = _replay_idx.clamp(min=0)
+            self._last_dense = (idx, empty.view(-1))
             fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
             pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
             return (fd[:, :, None].repeat(1, 1, self.num_frames, 1), pd[:, :, None].repeat(1, 1, self.num_frames, 1))
@@ -437,6 +551,7 @@ class VisualPromptEncoder:
                 idx_big = torch.cat([idx_big, idx_big[:, :1].expand(-1, R - idx_big.shape[1])], dim=1)
             idx = torch.where((cnt >= R)[:, None], idx_big, idx_small)
             empty = (cnt == 0).view(-1, 1, 1)
+            self._last_dense = (idx, empty.view(-1))
             fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
             pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
             return (fd[:, :, None].repeat(1, 1, self.num_frames, 1), pd[:, :, None].repeat(1, 1, self.num_frames, 1))
@@ -456,6 +571,7 @@ class VisualPromptEncoder:
         dev_tab = _to_device_async(host, m.device)
         idx = _kth_true(m, dev_tab[:, :R])                        # [n, R] flat feature-map indices
         empty = (dev_tab[:, R] != 0).view(-1, 1, 1)
+        self._last_dense = (idx, empty.view(-1))
         fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
         pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
         fd = fd[:, :, None].repeat(1, 1, self.num_frames, 1)
@@ -614,15 +730,25 @@ class VisualPromptSampler:
         gt_masks = tv["masks"][:, -num_frames:].to(device)
         update_frames = self._update_frames(tv, num_frames)
         enc = self.visual_prompt_encoder
+        assert prompt_type in {"boxes", "masks"}, "point prompts at inference are not supported"
+        batched = None
+        if prompt_type == "masks" and update_frames > 0:
+            pre, counts = jobs["clip"]
+            if enc.feature_reduce is None:
+                # all key frames of the clip in one pass (same draws, in the same order, as one call per frame)
+                U = update_frames
+                batched = enc.get_mask_prompts(img_emb[:U], pos_emb[:U], gt_masks[:, :U].transpose(0, 1),
+                                               gt_boxes[:, :U].transpose(0, 1), list(range(U)),
+                                               [frame_indices[k] for k in range(U)], pre, counts)
         for key_fid in range(update_frames):
             kfo = frame_indices[key_fid]
             x_key, x_pos = img_emb[key_fid], pos_emb[key_fid]
-            assert prompt_type in {"boxes", "masks"}, "point prompts at inference are not supported"
             if prompt_type == "boxes":
                 tup = enc.get_box_prompt(x_key, x_pos, gt_boxes[:, key_fid], is_train=False, key_fid=key_fid,
                                          key_fid_original=kfo)
+            elif batched is not None:
+                tup = tuple(b[key_fid] for b in batched)
             else:
-                pre, counts = jobs["clip"]
                 tup = enc.get_mask_prompt(x_key, x_pos, masks=gt_masks[:, key_fid], boxes=gt_boxes[:, key_fid],
                                           is_train=False, key_fid=key_fid, key_fid_original=kfo,
                                           _pre={k: v[key_fid] for k, v in pre.items()},
@@ -658,16 +784,27 @@ class VisualPromptSampler:
             return
         ha, pre, counts = _job
         cs = self.clip_stride
+        enc = self.visual_prompt_encoder
+        assert prompt_type == "masks"
+        batched = None
+        if enc.feature_reduce is None:
+            T = num_frames
+            batched = enc.get_mask_prompts(tv["img_emb_per_video"][:cs], tv["pos_emb_per_video"][:cs],
+                                           tv["masks"][:, -(T + cs):-T].to(device)[ha].transpose(0, 1),
+                                           tv["boxes"][:, -(T + cs):-T].to(device)[ha].transpose(0, 1), list(range(cs)),
+                                           [tv["frame_indices"][0] - (cs - k) for k in range(cs)], pre, counts)
         for key_fid in range(cs):
-            gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[ha]
-            gt_masks = tv["masks"][:, -(num_frames + cs) + key_fid].to(device)[ha]
-            kfo = tv["frame_indices"][0] - (cs - key_fid)
-            x_key, x_pos = tv["img_emb_per_video"][key_fid], tv["pos_emb_per_video"][key_fid]
-            assert prompt_type == "masks"
-            tup = self.visual_prompt_encoder.get_mask_prompt(x_key, x_pos, masks=gt_masks, boxes=gt_boxes,
-                                                             is_train=False, key_fid=key_fid, key_fid_original=kfo,
-                                                             _pre={k: v[key_fid] for k, v in pre.items()},
-                                                             _counts=None if counts is None else counts[key_fid])
+            if batched is not None:
+                tup = tuple(b[key_fid] for b in batched)
+            else:
+                gt_boxes = tv["boxes"][:, -(num_frames + cs) + key_fid].to(device)[ha]
+                gt_masks = tv["masks"][:, -(num_frames + cs) + key_fid].to(device)[ha]
+                kfo = tv["frame_indices"][0] - (cs - key_fid)
+                x_key, x_pos = tv["img_emb_per_video"][key_fid], tv["pos_emb_per_video"][key_fid]
+                tup = enc.get_mask_prompt(x_key, x_pos, masks=gt_masks, boxes=gt_boxes,
+                                          is_train=False, key_fid=key_fid, key_fid_original=kfo,
+                                          _pre={k: v[key_fid] for k, v in pre.items()},
+                                          _counts=None if counts is None else counts[key_fid])
             pe_d, f_d, m_d = tup[1], tup[2], tup[3]
             if "prompt_feats" not in tv:
                 _, R, T, C = pe_d.shape
