@@ -545,16 +545,19 @@ def run(args):
             tvd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in tv0.items()}
             x_p = torch.nn.functional.pad((frames - mean) / std, (0, 0, 0, 16))
             with torch.no_grad():
-                for _ in range(2):
+                def prompted_clip():
                     torch.manual_seed(0)
-                    head(swin(x_p), targets=[dict(tvd)])
+                    tg = [dict(tvd)]
+                    head.prefetch_prompts(tg, T)          # sampler work that needs the annotations only, ahead of the backbone
+                    return head(swin(x_p), targets=tg)
+                for _ in range(2):
+                    prompted_clip()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(3):
-                    torch.manual_seed(0)
-                    head(swin(x_p), targets=[dict(tvd)])
+                for _ in range(5):
+                    prompted_clip()
                 torch.cuda.synchronize()
-            dtp = (time.perf_counter() - t0) / 3
+            dtp = (time.perf_counter() - t0) / 5
             res["steady_state_with_prompts"] = {"ms_per_clip": dtp * 1e3, "frames_per_s": T / dtp, "entities": 10,
                                                 "queries": 110, "note": "second clip of a video, visual prompts"}
         except Exception as e:  # pragma: no cover

@@ -37,14 +37,18 @@ def main():
         for name, tg in (("first clip", first), (f"prompted clip ({args.entities} entities)", prompted)):
             for _ in range(2):
                 torch.manual_seed(0)
-                head(swin(x), targets=[dict(tg)])
+                tgl = [dict(tg)]
+                head.prefetch_prompts(tgl, x.shape[0])
+                head(swin(x), targets=tgl)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             enq = 0.0
             for _ in range(args.clips):
                 torch.manual_seed(0)
                 h0 = time.perf_counter()
-                out = head(swin(x), targets=[dict(tg)])
+                tgl = [dict(tg)]
+                head.prefetch_prompts(tgl, x.shape[0])
+                out = head(swin(x), targets=tgl)
                 enq += time.perf_counter() - h0
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.clips

@@ -70,6 +70,13 @@ class MaskFormerHead(nn.Module):
     def forward(self, features, mask=None, targets=None):
         return self.layers(features, mask, targets)
 
+    def prefetch_prompts(self, targets, num_frames):
+        """Optional, for callers that run the backbone and the head back to back on one clip: called BEFORE the backbone is
+        enqueued, the annotation-only part of the visual-prompt sampler (and its one host round trip) overlaps the backbone
+        instead of the pixel decoder.  `forward` starts it itself when the caller did not."""
+        if targets is not None and hasattr(self.predictor, "prefetch_prompts"):
+            self.predictor.prefetch_prompts(targets, num_frames)
+
     def layers(self, features, mask=None, targets=None):
         if self.pixel_decoder_name != "MSDeformAttnPixelDecoder":
             raise ValueError(f"pixel decoder {self.pixel_decoder_name} is outside the hot path (SURVEY.md section 2)")

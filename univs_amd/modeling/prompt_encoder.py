@@ -71,6 +71,16 @@ def _to_device_async(t, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def _ints_to_device(vals, device):
+    """python ints / 0-dim tensors -> int64 [len] on `device` without a blocking copy (a pageable H2D copy waits for the
+    whole stream; `int()` of a device tensor does too)."""
+    if all(isinstance(v, torch.Tensor) and v.device == device for v in vals):
+        return torch.stack([v.reshape(()) for v in vals]).to(torch.int64)
+    if all(not (isinstance(v, torch.Tensor) and v.is_cuda) for v in vals):
+        return _to_device_async(torch.tensor([int(v) for v in vals], dtype=torch.int64), device)
+    return torch.stack([torch.as_tensor(v).reshape(()).to(device, non_blocking=True) for v in vals]).to(torch.int64)
+
+
 def _kth_true(mask, ranks):
     """mask [n, L] bool, ranks [n, R] int64 (0-based, < row count) -> flat index of the rank-th True of every
     row, in raster order -- `nonzero(mask[k])[rank]` for all rows at once, without the host round trip of
@@ -400,13 +410,13 @@ class VisualPromptEncoder:
             self._log_draws(point_idx.view(Fk, n), dense_idx.view(Fk, n, R), empty.view(Fk, n))
         point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
         # ---- position token of the sampled point at its key frame, replicated over the clip's frames
-        kf = torch.as_tensor(key_fids, device=device)
+        kf = torch.arange(Fk, device=device) if list(key_fids) == list(range(Fk)) else _ints_to_device(key_fids, device)
         size = (T, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
         if self.position_embedding_sin3d_type == "FixedT":
             pe = self.pe_layer.forward_points_with_size(size, point_coords)                        # [T, N, C]
             query_pe = pe.view(T, Fk, n, -1)[kf, torch.arange(Fk, device=device)]                 # [F, n, C]
         else:
-            kfo = torch.stack([torch.as_tensor(k, device=device).reshape(()) for k in key_fids_original])
+            kfo = _ints_to_device(key_fids_original, device)
             z = kfo / self.pe_layer.num_max_frames * self.pe_layer.scale
             ar = torch.arange(Fk, device=device)
             query_pe = self.pe_layer._points(z, point_coords).view(Fk, Fk, n, -1)[ar, ar]

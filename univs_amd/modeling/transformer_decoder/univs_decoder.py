@@ -256,7 +256,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         def heads(out_tokens, target_size, last):
             cls_, msk_, attn_, reid_ = self.forward_prediction_heads(
                 out_tokens, mf, feat_lowres[target_size], task, targets, t, need_masks=(last or want_full),
-                t_total=t_total)
+                t_total=t_total, need_class=(last or want_full))
             predictions_class.append(cls_)
             predictions_mask.append(msk_)
             predictions_embds.append(out_tokens.view(out_tokens.shape[0], bs, t, -1).permute(1, 0, 2, 3))
@@ -345,7 +345,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return c
 
     def forward_prediction_heads(self, output, mask_features, feat_lowres, task, targets, t, need_masks,
-                                 t_total=None):
+                                 t_total=None, need_class=True):
         """:498-567.  output [Q', T, C] (batch 1); mask_features [T, C, H, W]; feat_lowres [T, C, h, w].
         Returns (class logits [1,Q',K], mask logits [1,Q',T,H,W] or None, attn mask bool [T,Q',hw], reid)."""
         bs = 1
@@ -358,8 +358,12 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             return fs.all_reduce_sum(x.sum(0, keepdim=True)) / float(t_total)
 
         decoder_output = self.decoder_norm(output).transpose(0, 1)  # [T, Q', C]
-        outputs_class = self.vis2text_projection(decoder_output)
-        if task != "grounding":
+        # class logits of the intermediate layers are only ever returned as aux outputs (the attention mask of the next
+        # layer depends on the mask embedding alone): the 8 launches of this head run where their result is used
+        outputs_class = self.vis2text_projection(decoder_output) if need_class else None
+        if not need_class:
+            pass
+        elif task != "grounding":
             clip = self._clip_normalized(outputs_class)
             outputs_class = F.normalize(outputs_class, p=2, dim=-1)
             outputs_class = torch.einsum("bqc,kc->bqk", outputs_class, clip)
@@ -399,6 +403,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 or len(targets) != 1 or torch.is_grad_enabled()):
             return
         tv = targets[0]
+        if "_prompt_prefetch" in tv:       # the caller already started it (before the backbone)
+            return
         if tv.get("task") == "sot" or tv.get("prompt_type") == "visual":
             self.visual_prompt_sampler.prefetch(tv, num_frames)
 
