@@ -133,7 +133,12 @@ typedef struct UnivsConfig {
   int linear_wide_kmin;   /* Linears with K >= this take the x-stationary kernel (default 768) */
   int linear_wide_nfeat;  /* x-stationary Linear: output features per pass (default: by shape) */
   int window_attn_v1;     /* 1: the first 7x7 window-attention kernel (kernel benchmarks) */
-  int reserved[8];
+  int linear_terms;       /* fp32 Linears on the matrix cores (W-stationary kernel): 0 / 3 = two row-scaled fp16 parts per operand,
+                             three products (linear_f16x3.hip; the default), 6 = three bf16 parts per operand, six products
+                             (linear_split.hip) */
+  int linear_ablate;      /* timing experiments on linear_f16x3 (results then only valid for inputs already in fp16's range):
+                             1 = no row-maximum pass over x (scale 1) */
+  int reserved[6];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);

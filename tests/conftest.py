@@ -23,3 +23,18 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu test started without a visible GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def linear_terms():
+    """`linear_terms(3)`: select the fp16 three-product Linear (6: the bf16 six-product one) for the rest of the test."""
+    from univs_amd import ops
+    prev = {}
+
+    def select(terms):
+        if not prev:
+            prev.update(ops.get_config())
+        ops.configure(linear_terms=int(terms))
+    yield select
+    if prev:
+        ops.configure(**prev)

@@ -177,9 +177,11 @@ def test_msda_strips_cfg2_and_cfg5_size(cuda):
 
 
 @pytest.mark.parametrize("N,S,CB", [(5, 19320, 16), (5, 19320, 36), (2, 4200, 48), (3, 2352, 16)], ids=str)
-def test_linear_blocked_matches_standard_layout(cuda, N, S, CB):
+@pytest.mark.parametrize("terms", [6, 3], ids=["bf16x6", "f16x3"])
+def test_linear_blocked_matches_standard_layout(cuda, linear_terms, terms, N, S, CB):
     """The Linear with the column-blocked epilogue (head-major operands of the strips kernel) == the standard-layout Linear,
     permuted: bit for bit (same arithmetic, different store addresses)."""
+    linear_terms(terms)
     K = 256
     Nf = 256 if CB == 16 else 8 * CB
     x = synth.normal("linblk/x", (N, S, K)).to(cuda)
@@ -594,9 +596,12 @@ def test_msda_prepare_matches_reference_expressions(cuda, N, Lq, M, shapes, bcas
                                              (5000, 256, 1024, True, True), (4099, 128, 100, False, False),
                                              (2048, 384, 4, False, True), (3000, 256, 108, True, True)],
                          ids=lambda v: str(v))
-def test_linear_split_matches_torch(cuda, M, K, N, relu, bias):
-    """ops.linear_split (fp32 from an exact 3-way bf16 split on the bf16 matrix cores) == F.linear to fp32 rounding:
-    within a few ulp, same order as the error of ATen's own fp32 GEMM against the fp64 result."""
+@pytest.mark.parametrize("terms", [6, 3], ids=["bf16x6", "f16x3"])
+def test_linear_split_matches_torch(cuda, linear_terms, terms, M, K, N, relu, bias):
+    """ops.linear_split (fp32 from an exact 3-way bf16 split on the bf16 matrix cores: six products; or from two row-scaled
+    fp16 parts: three products) == F.linear to fp32 rounding: within a few ulp, same order as the error of ATen's own fp32
+    GEMM against the fp64 result."""
+    linear_terms(terms)
     F = torch.nn.functional
     x = synth.normal(f"ls/x/{M}x{K}", (M, K), std=1.0)
     w = synth.normal(f"ls/w/{N}x{K}", (N, K), std=K ** -0.5)
@@ -623,9 +628,11 @@ def test_linear_split_matches_torch(cuda, M, K, N, relu, bias):
                                             (19320, 1024, 256, None, False), (4600, 1536, 384, None, True), (4613, 3072, 768, "gelu", False),
                                             (5000, 1024, 128, "relu", False)],
                          ids=lambda v: str(v))
-def test_linear_fused_matches_torch(cuda, M, K, N, act, res):
+@pytest.mark.parametrize("terms", [6, 3], ids=["bf16x6", "f16x3"])
+def test_linear_fused_matches_torch(cuda, linear_terms, terms, M, K, N, act, res):
     """ops.linear_fused at the Swin-T widths (K = 96 / 192: register ring of three k-steps; 384 / 768: ring of four) with
     the fused epilogues (exact GELU, residual add) == F.linear + F.gelu / + residual to fp32 rounding."""
+    linear_terms(terms)
     F = torch.nn.functional
     x = synth.normal(f"lf/x/{M}x{K}", (M, K), std=1.0)
     w = synth.normal(f"lf/w/{N}x{K}", (N, K), std=K ** -0.5)
@@ -648,6 +655,42 @@ def test_linear_fused_matches_torch(cuda, M, K, N, act, res):
     with pytest.raises(RuntimeError):
         ops.linear_fused(xd, wd, bd, act="tanh")
     assert ops.linear_fused(xd, wd, bd, act="gelu", residual=torch.zeros(M, N, device=cuda)) is None   # not both
+
+
+def test_linear_f16x3_row_scaling(cuda, linear_terms):
+    """The three-product Linear (linear_f16x3.hip) scales every row of x and of W into fp16's range by a power of two: rows
+    of wildly different magnitude, rows with outliers, zero rows and tiny / huge rows keep the accuracy of the fp32 GEMM
+    relative to THEIR OWN sum of |x||w| (the quantity a GEMM's rounding error scales with); Inf / NaN stay in their row."""
+    linear_terms(3)
+    M, K, N = 4096, 256, 288
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g)
+    x *= torch.exp2(torch.randint(-40, 40, (M, 1), generator=g).float())          # rows over 80 binades
+    x[5] = 0
+    x[6] = torch.randn(K, generator=g) * 1e-30
+    x[7] = torch.randn(K, generator=g) * 1e30
+    x[8, 3] = 1e4 * x[8].abs().max()                                                # an outlier 10^4 above its row
+    w = torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-12, 12, (N, 1), generator=g).float()) / 16
+    w[9] = 0
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    y = ops.linear_split(xd, wd, bd)
+    assert y is not None
+    ref64 = torch.nn.functional.linear(xd.double(), wd.double(), bd.double())
+    ref32 = torch.nn.functional.linear(xd, wd, bd)
+    scale = xd.double().abs() @ wd.double().abs().t() + bd.double().abs()[None] + 1e-300
+    e3 = ((y.double() - ref64).abs() / scale).max().item()
+    e32 = ((ref32.double() - ref64).abs() / scale).max().item()
+    print(f"f16x3 row scaling: max error / sum|x||w| {e3:.2e} (ATen fp32 GEMM: {e32:.2e})")
+    assert e3 < max(2.0 * e32, 3e-7), (e3, e32)
+    assert torch.equal(y[5], bd.expand(1, -1)[0]) and torch.isfinite(y).all()
+    xd2 = xd.clone()
+    xd2[100, 17] = float("inf")
+    xd2[200, 5] = float("nan")
+    y2 = ops.linear_split(xd2, wd, bd)
+    bad = torch.zeros(M, dtype=torch.bool, device=cuda)
+    bad[100] = bad[200] = True
+    assert torch.equal(y2[~bad], y[~bad]) and not torch.isfinite(y2[100]).any() and torch.isnan(y2[200]).all()
 
 
 def test_linear_split_uncovered_shapes_return_none(cuda):

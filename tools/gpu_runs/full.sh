@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-full}
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -x > $O/pytest.log 2>&1
+timeout 1500 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo "smoke rc $?" >> $O/smoke.log

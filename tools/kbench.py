@@ -126,6 +126,12 @@ def main():
             t = timeit(lambda: ops.linear_split(xs, w_, b_, relu=relu))
             fl = 2.0 * Mr * 256 * N_
             res[f"linear_split_{N_}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, GBps=(Mr * (256 + N_) * 4.0) / t / 1e9)
+            with ops.configured(linear_terms=3):
+                t = timeit(lambda: ops.linear_split(xs, w_, b_, relu=relu))
+            res[f"linear_f16x3_{N_}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, GBps=(Mr * (256 + N_) * 4.0) / t / 1e9)
+            with ops.configured(linear_terms=3, linear_ablate=1):
+                t = timeit(lambda: ops.linear_split(xs, w_, b_, relu=relu))
+            res[f"linear_f16x3_{N_}_no_row_pass"] = dict(ms=t * 1e3)
             if relu:
                 t = timeit(lambda: torch._addmm_activation(b_, xs, w_.t(), use_gelu=False))
             else:
@@ -150,6 +156,9 @@ def main():
                 if y is not None:
                     t2 = timeit(lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs))
                     res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["fused_us"] = t2 * 1e6
+                    with ops.configured(linear_terms=3):
+                        t2 = timeit(lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs))
+                    res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["fused_f16x3_us"] = t2 * 1e6
                     if act:
                         t3 = timeit(lambda: torch.nn.functional.gelu(torch.nn.functional.linear(xs, w_, b_)))
                         res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["library_plus_gelu_us"] = t3 * 1e6

@@ -599,6 +599,9 @@ static int linear_split_wide_f32(const float* x, const float* w, const float* bi
   return rc == UNIVS_OK ? 1 : rc;
 }
 
+int linear_f16x3_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
+                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols);   // linear_f16x3.hip
+
 // returns 1 if launched, 0 if the shape is not covered (the caller uses the library GEMM), < 0 on error
 int linear_split_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
                      int K, int epi, hipStream_t st, int blk_rows, int blk_cols) {
@@ -620,6 +623,7 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
     const int rc = linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);
     if (rc != 0 || K > 768) return rc;
   }
+  if (config().linear_terms != 6) return linear_f16x3_f32(x, w, bias, residual, y, M, N, K, epi, st, blk_rows, blk_cols);   // default: three products
   const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + the zeroed tail (see the staging loop)
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);
   r_cap -= r_cap % 4;

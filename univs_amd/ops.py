@@ -191,7 +191,7 @@ class UnivsConfig(ctypes.Structure):
     """include/univs_hip.h: UnivsConfig -- the library's process-wide settings (it reads no environment variable)."""
     _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
                                             "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "linear_wide_kmin",
-                                            "linear_wide_nfeat", "window_attn_v1")] + [("reserved", ctypes.c_int * 8)]
+                                            "linear_wide_nfeat", "window_attn_v1", "linear_terms", "linear_ablate")] + [("reserved", ctypes.c_int * 6)]
 
 
 def get_config() -> dict:
