@@ -236,6 +236,24 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Pre-split weights for the three-product fp16 GEMM kernels whose W streams through LDS (gemm_f16x3_stream.hip): wide-K
+ * Linears (K >= 768) and the 3 x 3 convolution.  The split of W -- row maxima, power-of-two row scales, two fp16 parts in
+ * the kernels' LDS order -- is done ONCE per weight tensor; the caller keeps the result (4 bytes per element + N floats)
+ * for as long as the weights do not change.
+ *   w      [N, K] fp32 (conv = 0), or a convolution weight [N, Cin, 3, 3] with conv = 1 (then K = 9 * Cin, tap-major)
+ *   wp     N * K * 4 bytes, 16-byte aligned (out);  winv [N] fp32 (out)
+ * univs_linear_presplit_f32 : y = act(x W^T + bias) (+ residual), arguments as univs_linear_fused_f32 with (wp, winv) in place
+ *   of w; K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048.  UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.
+ * univs_conv3x3_presplit_f32: as univs_conv3x3_f32 with (wp, winv) in place of w2.
+ * Replaces: the same call sites as univs_linear_fused_f32 / univs_conv3x3_f32 (swin.py:35-58, msdeformattn.py:87-91, :227-232).
+ * ------------------------------------------------------------------------------------------- */
+int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp, float* winv, void* stream);
+int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,
+                              long long M, int N, int K, int act, float* y, void* stream);
+int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
+                               float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Swin window attention core.
  * Replaces: WindowAttention.forward between the qkv and proj linears
  *           (mask2former/modeling/backbone/swin.py:137-168):

@@ -696,7 +696,7 @@ def test_linear_f16x3_row_scaling(cuda, linear_terms):
 def test_linear_split_uncovered_shapes_return_none(cuda):
     x = torch.zeros(4096, 80, device=cuda)
     assert ops.linear_split(x, torch.zeros(96, 80, device=cuda)) is None                      # K % 96 and K % 128
-    assert ops.linear_split(torch.zeros(4096, 1024, device=cuda), torch.zeros(8, 1024, device=cuda)) is None   # K > 768: N % 16
+    assert ops.linear_split(torch.zeros(4096, 1024, device=cuda), torch.zeros(6, 1024, device=cuda)) is None   # wide K: N % 4 too
     assert ops.linear_split(torch.zeros(4096, 256, device=cuda), torch.zeros(6, 256, device=cuda)) is None     # N % 4
     assert ops.linear_split(torch.zeros(100, 256, device=cuda), torch.zeros(8, 256, device=cuda)) is None      # few rows
     assert ops.linear_split(torch.zeros(4096, 256), torch.zeros(8, 256)) is None                               # CPU tensors
@@ -715,9 +715,17 @@ def test_transpose_last2_is_exact(cuda, shape):
 
 
 @pytest.mark.parametrize("T,Cin,Cout,H,W", [(2, 256, 256, 48, 44), (1, 128, 128, 70, 64), (3, 256, 256, 17, 83), (1, 384, 256, 64, 64)], ids=str)
-def test_conv3x3_matches_torch(cuda, T, Cin, Cout, H, W):
-    """ops.conv3x3 (3 x 3, stride 1, padding 1, no bias: the split-bf16 x-stationary GEMM with tap addressing) ==
-    F.conv2d to fp32 rounding, borders and ragged row tiles included."""
+@pytest.mark.parametrize("presplit", [768, 0], ids=["f16x3-presplit", "bf16x6"])
+def test_conv3x3_matches_torch(cuda, presplit, T, Cin, Cout, H, W):
+    """ops.conv3x3 (3 x 3, stride 1, padding 1, no bias: the x-stationary GEMM with tap addressing -- three fp16 products on
+    weights split once per tensor, or six bf16 products splitting W in the kernel) == F.conv2d to fp32 rounding, borders
+    and ragged row tiles included."""
+    from univs_amd.switches import override
+    with override(presplit_kmin=presplit):
+        _conv3x3_case(cuda, T, Cin, Cout, H, W)
+
+
+def _conv3x3_case(cuda, T, Cin, Cout, H, W):
     F = torch.nn.functional
     x = synth.normal(f"cv/x/{T}/{Cin}/{H}/{W}", (T, Cin, H, W)).to(cuda)
     w = synth.normal(f"cv/w/{Cout}/{Cin}", (Cout, Cin, 3, 3), std=(9 * Cin) ** -0.5).to(cuda)
@@ -730,6 +738,42 @@ def test_conv3x3_matches_torch(cuda, T, Cin, Cout, H, W):
     assert err < max(4.0 * err32, 5e-6), (err, err32)
     assert ops.conv3x3(torch.zeros(1, 96, 64, 64, device=cuda), torch.zeros(64, 96, 3, 3, device=cuda)) is None   # Cin % 128
     assert ops.conv3x3(torch.zeros(1, 128, 16, 16, device=cuda), torch.zeros(128, 128, 3, 3, device=cuda)) is None  # < 4096 pixels
+
+
+def test_presplit_weights_cache_and_wide_linear(cuda):
+    """ops.presplit_weights: one split per weight tensor, redone after an in-place update; the wide-K Linear on the
+    streamed three-product kernel == the six-product kernel to fp32 rounding, all epilogues, ragged rows, a short last pass."""
+    from univs_amd.switches import override
+    F = torch.nn.functional
+    M, K, N = 5003, 1024, 208
+    x = synth.normal("ps/x", (M, K)).to(cuda)
+    w = synth.normal("ps/w", (N, K), std=K ** -0.5).to(cuda)
+    b = synth.normal("ps/b", (N,)).to(cuda)
+    r = synth.normal("ps/r", (M, N)).to(cuda)
+    wp1, winv1 = ops.presplit_weights(w)
+    wp2, _ = ops.presplit_weights(w)
+    assert wp1 is wp2 and wp1.numel() == N * K and winv1.shape == (N,)
+    ref64 = F.linear(x.double(), w.double(), b.double())
+    ref32 = F.linear(x, w, b)
+    e32 = (ref32.double() - ref64).abs().max().item()
+    for act, res in ((None, None), ("relu", None), ("gelu", None), (None, r)):
+        y = ops.linear_fused(x, w, b, act=act, residual=res)
+        with override(presplit_kmin=0):
+            y6 = ops.linear_fused(x, w, b, act=act, residual=res)
+        want = ref64
+        want = want.relu() if act == "relu" else F.gelu(want) if act == "gelu" else want
+        want = want + res.double() if res is not None else want
+        assert y is not None and (y.double() - want).abs().max().item() < max(4 * e32, 5e-6), act
+        assert y6 is None or (y - y6).abs().max().item() < 2e-5      # (the six-product wide kernel covers 128 / 192 / 256 features per pass)
+    with torch.no_grad():
+        w.mul_(2.0)                                                  # in-place: the version counter moves
+    wp3, winv3 = ops.presplit_weights(w)
+    assert wp3 is not wp1
+    assert torch.equal(winv3, 2.0 * winv1) and torch.equal(wp3, wp1)  # a power of two only changes the row scales
+    y2 = ops.linear_fused(x, w, None)
+    assert (y2.double() - 2.0 * F.linear(x.double(), w.double() / 2)).abs().max().item() < max(8 * e32, 1e-5)
+    with pytest.raises(RuntimeError):
+        ops.presplit_weights(torch.zeros(4, 4, 3, 2, device=cuda), conv=True)
 
 
 def test_layer_norm_second_output(cuda):

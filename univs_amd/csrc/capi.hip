@@ -58,6 +58,10 @@ int group_norm_f32(const float*, const float*, const float*, int, int, long long
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
+int presplit_f16x3(const float*, int, int, int, void*, float*, hipStream_t);
+int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
+                            hipStream_t);
+int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
 int window_attention_image_f16mma(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                   int, float, float*, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
@@ -189,6 +193,57 @@ int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, 
   const int rc = univs::conv3x3_split_f32(x, w_tap_major, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_conv3x3_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout = 128 or a multiple of 256 ..., >= 4096 pixels)", T, Cin, Cout, H, W);
+  return rc;
+}
+
+int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp, float* winv, void* stream) {
+  clear_sticky_error();
+  if (N < 0 || K < 32 || K % 32 != 0 || (conv != 0 && conv != 1) || (conv == 1 && K % 9 != 0)) {
+    set_error("univs_presplit_weights_f32: bad arguments N=%d K=%d conv=%d (K a multiple of 32; conv: K = 9 Cin)", N, K, conv);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (N == 0) return UNIVS_OK;
+  if (!w || !wp || !winv || (reinterpret_cast<uintptr_t>(wp) & 15)) {
+    set_error("univs_presplit_weights_f32: NULL or unaligned pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return univs::presplit_f16x3(w, N, K, conv ? K / 9 : 0, wp, winv, static_cast<hipStream_t>(stream));
+}
+
+int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,
+                              long long M, int N, int K, int act, float* y, void* stream) {
+  clear_sticky_error();
+  if (M < 0 || N < 0 || K < 1 || act < 0 || act > 2 || (act != 0 && residual)) {
+    set_error("univs_linear_presplit_f32: bad arguments M=%lld N=%d K=%d act=%d%s", M, N, K, act,
+              (act != 0 && residual) ? " (an activation and a residual exclude each other)" : "");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0 || N == 0) return UNIVS_OK;
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_linear_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::linear_f16x3_stream_f32(x, wp, winv, bias, residual, y, M, N, K, residual ? 3 : act,
+                                                static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_linear_presplit_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
+  return rc;
+}
+
+int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
+                               float* y, void* stream) {
+  clear_sticky_error();
+  if (T < 0 || Cin < 1 || Cout < 0 || H < 0 || W < 0) {
+    set_error("univs_conv3x3_presplit_f32: bad dimensions T=%d Cin=%d Cout=%d H=%d W=%d", T, Cin, Cout, H, W);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0 || Cout == 0 || H == 0 || W == 0) return UNIVS_OK;
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_conv3x3_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::conv3x3_f16x3_f32(x, wp, winv, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_conv3x3_presplit_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout %% 16, >= 4096 pixels)", T, Cin, Cout, H, W);
   return rc;
 }
 

@@ -1,0 +1,46 @@
+// Shared by the three-product fp16 GEMM kernels (linear_f16x3.hip: W resident in LDS; gemm_f16x3_stream.hip: W pre-split in
+// global memory and streamed through LDS -- wide-K Linears and the 3 x 3 convolution).
+#pragma once
+#include "common.h"
+
+namespace univs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// power of two that brings a row whose largest magnitude has the bit pattern `maxbits` into [2^t, 2^(t+1)), and its inverse.
+// Zero rows and rows below 2^-100 keep a finite scale (2^(t+100)); an infinite maximum gives 2^(t-128).
+__device__ __forceinline__ void l3_scale(unsigned maxbits, int t, float& s, float& inv) {
+  int e = (int)((maxbits >> 23) & 255u) - 127;            // 2^e <= max < 2^(e+1)
+  e = max(-100, min(e, 128));
+  s = __builtin_bit_cast(float, (unsigned)(127 + t - e) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(127 - t + e) << 23);
+}
+
+// 8 consecutive k of one row, scaled -> the two fp16x8 parts (round to nearest even)
+__device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h, f16x8& m) {
+  const float x[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 hh = (_Float16)x[e];
+    h[e] = hh;
+    m[e] = (_Float16)(x[e] - (float)hh);                   // exact difference, then rounded
+  }
+}
+
+__device__ __forceinline__ unsigned l3_absmax8(f32x4 v0, f32x4 v1) {
+  const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+  const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+  return __builtin_bit_cast(unsigned, fmaxf(a, b));        // non-negative floats order like their bit patterns
+}
+
+// maximum over the four lanes (k-groups, lane >> 4) that hold one row of the B operand
+__device__ __forceinline__ unsigned l3_row_max(unsigned v) {
+  const auto s1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  const unsigned r1 = max(s1[0], s1[1]);
+  const auto s2 = __builtin_amdgcn_permlane16_swap(r1, r1, false, false);
+  return max(s2[0], s2[1]);
+}
+
+}  // namespace univs

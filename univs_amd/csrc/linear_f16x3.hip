@@ -24,46 +24,17 @@
 // epilogues ReLU / GELU / residual / column-blocked output.
 #include "common.h"
 #include "config.h"
+#include "f16x3.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace univs {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int L3_THREADS = 512;   // 8 waves, two per SIMD
 constexpr int L3_TILE_M = 32;     // rows of x per wave tile (two 16-column MFMA tiles)
 constexpr int L3_MAX_RB = 8;
 enum { L3_EPI_NONE = 0, L3_EPI_RELU = 1, L3_EPI_GELU = 2, L3_EPI_RESIDUAL = 3, L3_EPI_BLOCKED = 4 };   // = LS_EPI_*
-
-// power of two that brings a row whose largest magnitude has the bit pattern `maxbits` into [2^t, 2^(t+1)), and its inverse.
-// Zero rows and rows below 2^-100 keep a finite scale (2^(t+100)); an infinite maximum gives 2^(t-128).
-__device__ __forceinline__ void l3_scale(unsigned maxbits, int t, float& s, float& inv) {
-  int e = (int)((maxbits >> 23) & 255u) - 127;            // 2^e <= max < 2^(e+1)
-  e = max(-100, min(e, 128));
-  s = __builtin_bit_cast(float, (unsigned)(127 + t - e) << 23);
-  inv = __builtin_bit_cast(float, (unsigned)(127 - t + e) << 23);
-}
-
-// 8 consecutive k of one row, scaled -> the two fp16x8 parts (round to nearest even)
-__device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h, f16x8& m) {
-  const float x[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const _Float16 hh = (_Float16)x[e];
-    h[e] = hh;
-    m[e] = (_Float16)(x[e] - (float)hh);                   // exact difference, then rounded
-  }
-}
-
-__device__ __forceinline__ unsigned l3_absmax8(f32x4 v0, f32x4 v1) {
-  const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
-  const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
-  return __builtin_bit_cast(unsigned, fmaxf(a, b));        // non-negative floats order like their bit patterns
-}
 
 // LDS: Wsp [K/32][4 k-groups][2 parts][16 RB features] 16 B | bias[R] | winv[R] | zero tail (16 x 16 B) | wmax[R]
 template <int RB, int RING>   // RING: register stages of x (K / 32 is a multiple)
@@ -94,7 +65,6 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
   const int wg0 = (int)((long long)WT * blockIdx.x / gridDim.x), wg1 = (int)((long long)WT * (blockIdx.x + 1) / gridDim.x);
   const int wt0 = wg0 + wave;
   const int ntiles = wt0 < wg1 ? (wg1 - wt0 + NWV - 1) / NWV : 0;
-  const int nsteps = max(ntiles, 1) * KS;                        // a multiple of RING (idle waves: one dummy tile)
 
   // x through buffer loads: the lane's byte offset (row, k-group) is computed once per tile, the k-step is the scalar
   // offset -- no vector arithmetic per load.  Rows past the end repeat the last row (their results are not stored).
@@ -234,14 +204,6 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
   };
-  // maximum over the four lanes (k-groups) that hold one row
-  auto row_max = [&](unsigned v) __attribute__((always_inline)) -> unsigned {
-    const auto s1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    const unsigned r1 = max(s1[0], s1[1]);
-    const auto s2 = __builtin_amdgcn_permlane16_swap(r1, r1, false, false);
-    return max(s2[0], s2[1]);
-  };
-
   auto group = [&](int ks0, bool last_group) __attribute__((always_inline)) {
     unsigned vo_ref[2];                                           // rows of the k-steps requested in this group
 #pragma unroll
@@ -254,7 +216,7 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
       int enew[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const unsigned mk = row_max(l3_absmax8(raw[u][c][0], raw[u][c][1]));
+        const unsigned mk = l3_row_max(l3_absmax8(raw[u][c][0], raw[u][c][1]));
         enew[c] = max(-100, min((int)((mk >> 23) & 255u) - 127, 128));      // 2^e <= max < 2^(e+1)
         need = need || (enew[c] > eset[c] + 2);
       }

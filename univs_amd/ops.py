@@ -4,6 +4,7 @@ libunivs_hip.so.  Every function raises on non-GPU tensors -- the reference does
 operator ("Not implemented on the CPU", ops/src/ms_deform_attn.h:43) and there is no CPU fallback.
 """
 import contextlib
+import weakref
 import ctypes
 import os
 
@@ -249,6 +250,36 @@ _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 from .switches import SWITCHES   # linear_kmax: widest K routed to the split-bf16 Linears
 
 
+_PRESPLIT = {}      # id(weight tensor) -> (weak reference to it, (version, data_ptr, device), wp, winv); dropped with the tensor
+
+
+def presplit_weights(weight, conv=False):
+    """The split of a weight tensor for the three-product fp16 GEMM kernels (include/univs_hip.h:
+    univs_presplit_weights_f32): `weight` [N, K] (a Linear) or [N, Cin, 3, 3] with `conv=True` -> (wp [N * K] int32 = two fp16
+    parts per element in the kernels' LDS order, winv [N]).  Done once per tensor and cached on the tensor object; an
+    in-place update (load_state_dict, optimizer step), a move to another device or a new storage invalidates the entry."""
+    key = (weight._version, weight.data_ptr(), weight.device)
+    e = _PRESPLIT.get(id(weight))
+    if e is not None and e[0]() is weight and e[1] == key:
+        return e[2], e[3]
+    _require_gpu("presplit_weights", weight)
+    if weight.dtype != torch.float32:
+        raise RuntimeError("presplit_weights: float32 only")
+    N = weight.shape[0]
+    K = weight.numel() // max(N, 1)
+    if conv and (weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3)):
+        raise RuntimeError("presplit_weights: conv=True takes a [N, Cin, 3, 3] weight")
+    w = weight.detach().contiguous()
+    wp = torch.empty(N * K, dtype=torch.int32, device=weight.device)
+    winv = torch.empty(N, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.load().univs_presplit_weights_f32(_ptr(w), N, K, int(bool(conv)), _ptr(wp), _ptr(winv), _stream_ptr(w)),
+                   "presplit_weights")
+    wid = id(weight)
+    _PRESPLIT[wid] = (weakref.ref(weight, lambda _r, _i=wid: _PRESPLIT.pop(_i, None)), key, wp, winv)
+    return wp, winv
+
+
 def linear_fused(x, weight, bias=None, act=None, residual=None):
     """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [exact, erf]) or `residual`
     (a tensor of the output's shape that is added) -- for float32 on the GPU through the split-bf16 kernel (fp32-accurate:
@@ -282,9 +313,16 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
         r = residual.contiguous()
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().univs_linear_fused_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None,
-                                                _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
-                                                _stream_ptr(x2))
+        rc = _lib.ERR_NOT_IMPLEMENTED
+        if 0 < SWITCHES.presplit_kmin <= K:
+            wp, winv = presplit_weights(weight)
+            rc = _lib.load().univs_linear_presplit_f32(_ptr(x2), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None,
+                                                       _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
+                                                       _stream_ptr(x2))
+        if rc == _lib.ERR_NOT_IMPLEMENTED:
+            rc = _lib.load().univs_linear_fused_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None,
+                                                    _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
+                                                    _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "linear_fused")
@@ -431,10 +469,15 @@ def conv3x3(x, weight):
     T, Cin, H, W = x.shape
     Cout = weight.shape[0]
     x = x.contiguous()
-    w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()      # [Cout, ky, kx, Cin]: a k-step = 32 channels of a tap
     y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().univs_conv3x3_f32(_ptr(x), _ptr(w2), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
+        rc = _lib.ERR_NOT_IMPLEMENTED
+        if SWITCHES.presplit_kmin > 0:
+            wp, winv = presplit_weights(weight, conv=True)
+            rc = _lib.load().univs_conv3x3_presplit_f32(_ptr(x), _ptr(wp), _ptr(winv), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
+        if rc == _lib.ERR_NOT_IMPLEMENTED:
+            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()   # [Cout, ky, kx, Cin]: a k-step = 32 channels of a tap
+            rc = _lib.load().univs_conv3x3_f32(_ptr(x), _ptr(w2), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "conv3x3")

@@ -33,6 +33,10 @@ class Switches:
     swin_fused_parts: int = 7
     # widest K routed to the split-bf16 Linears
     linear_kmax: int = 4096
+    # Linears with K >= presplit_kmin and the 3 x 3 convolution run on the three-product fp16 kernel with weights split once
+    # per tensor (csrc/gemm_f16x3_stream.hip; ops.presplit_weights caches the split); 0: the six-product kernels that
+    # split W in every workgroup
+    presplit_kmin: int = 768
     # prompt sampler draws: "reference" (the reference's host-side randperm order, bit-identical sampling) or "device"
     sampler: str = "reference"
     # hipGraph replay of the static parts of a clip (backbone, pixel decoder): see univs_amd/graphs.py
@@ -43,7 +47,8 @@ SWITCHES = Switches(
     msda_strips=_flag("UNIVS_MSDA_STRIPS", True), split_linear=_flag("UNIVS_SPLIT_LINEAR", True),
     split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
-    sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False))
+    sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
+    presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
