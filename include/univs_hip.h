@@ -130,15 +130,13 @@ typedef struct UnivsConfig {
   int mask_decode_impl;   /* 0 by size, 1 exact-f32 MFMA kernel, 2 split-bf16 kernel wherever its preconditions hold */
   int mask_decode_ct;     /* split-bf16 mask decode: 4 = the 64-column kernel (default 2: 32 columns) */
   int mask_decode_ablate; /* timing experiments: 1 memory side only, 2 compute side only (results are then meaningless) */
-  int linear_wide_kmin;   /* Linears with K >= this take the x-stationary kernel (default 768) */
-  int linear_wide_nfeat;  /* x-stationary Linear: output features per pass (default: by shape) */
   int window_attn_v1;     /* 1: the first 7x7 window-attention kernel (kernel benchmarks) */
   int linear_terms;       /* fp32 Linears on the matrix cores (W-stationary kernel): 0 / 3 = two row-scaled fp16 parts per operand,
                              three products (linear_f16x3.hip; the default), 6 = three bf16 parts per operand, six products
                              (linear_split.hip) */
   int linear_ablate;      /* timing experiments on linear_f16x3 (results then only valid for inputs already in fp16's range):
                              1 = no row-maximum pass over x (scale 1) */
-  int reserved[6];
+  int reserved[8];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);
@@ -158,14 +156,17 @@ int univs_msda_last_tiled_generation(void);
  * the token projections of MSDeformAttn (mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:95-113: value_proj,
  * sampling_offsets + attention_weights, output_proj), the encoder FFN, and the Swin block's MLP and qkv / proj projections
  * (mask2former/modeling/backbone/swin.py:35-58 Mlp.forward: fc1 -> nn.GELU() -> fc2, :291-293 `x = shortcut + self.mlp(...)`,
- * :137-141, :163).  fp32 emulated on the bf16 matrix cores from an exact 3-way split of both operands (error <= 3 * 2^-24
- * per product, i.e. fp32 rounding level).
+ * :137-141, :163).  fp32 emulated on the fp16 matrix cores: both operands are scaled per row by a power of two into fp16's
+ * range and split into two fp16 parts, three of the four part products are accumulated in fp32 (error <= 2^-21.7 per
+ * product, below the rounding error of an fp32 FMA chain over K terms; linear_f16x3.hip).  UnivsConfig.linear_terms = 6
+ * selects the older six-product split into three bf16 parts (error <= 3 * 2^-24 per product; linear_split.hip).
  *   act = 0: none, 1: ReLU, 2: exact GELU  x * 0.5 * (1 + erf(x / sqrt 2))  (nn.GELU(approximate='none'));
  *   residual (NULL or [M, N], contiguous): y = x W^T + bias + residual.  act != 0 together with a residual is rejected.
- * Covered: K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048, 16-byte aligned pointers, M * max(N, K) * 4 < 2^31, at
- * least 16 output features of K fit the LDS (K <= 1664, beyond: the x-stationary variant for K % 128 == 0); anything else
- * returns UNIVS_ERR_NOT_IMPLEMENTED without touching y (the caller keeps its library GEMM).  bias may be NULL.  Finite
- * inputs only: the 3-way split of +-Inf is Inf - Inf, so an infinite operand yields NaN where an fp32 GEMM yields Inf. */
+ * Covered: K % 128 == 0 or K % 96 == 0, K <= 768 (this entry splits W inside every workgroup: wider K goes through
+ * univs_presplit_weights_f32 + univs_linear_presplit_f32), N % 4 == 0, M >= 2048, 16-byte aligned pointers,
+ * M * max(N, K) * 4 < 2^31; anything else returns UNIVS_ERR_NOT_IMPLEMENTED without touching y (the caller keeps its library
+ * GEMM).  bias may be NULL.  Inf / NaN inputs make the results of their own row Inf / NaN (as in a GEMM; with
+ * linear_terms = 6 an infinite operand yields NaN where an fp32 GEMM yields Inf). */
 int univs_linear_fused_f32(const float* x, const float* weight, const float* bias, const float* residual, long long M, int N,
                            int K, int act, float* y, void* stream);
 
@@ -173,20 +174,10 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
  *   y[M / rows_per_batch][N / col_block][rows_per_batch][col_block],  y[b][c][s][i] = (x W^T + bias)[b * rows_per_batch + s][c * col_block + i]
  * -- the head-major operand layouts of univs_msda_forward_strips_f32, written by the producing Linear's epilogue at no
  * extra cost (ms_deform_attn.py:95-102: value_proj with col_block = 16, the merged offset / logit projection with
- * col_block = 3 L P).  Covered: K == 256, N % col_block == 0, col_block % 4 == 0, M % rows_per_batch == 0 and the
+ * col_block = 3 L P).  Covered: N % col_block == 0, col_block % 4 == 0, M % rows_per_batch == 0 and the
  * coverage rules of univs_linear_fused_f32; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
 int univs_linear_blocked_f32(const float* x, const float* weight, const float* bias, long long M, int N, int K,
                              int rows_per_batch, int col_block, float* y, void* stream);
-
-/* y = conv2d(x, w, bias=None, stride=1, padding=1) for a 3 x 3 kernel on contiguous float32 NCHW tensors:
- * x [T, Cin, H, W], y [T, Cout, H, W]; `w_tap_major` [Cout, 9 * Cin] is the weight [Cout, Cin, 3, 3] permuted to
- * [Cout, ky, kx, Cin] (w.permute(0, 2, 3, 1)).  The FPN output convolution of the pixel decoder
- * (mask2former/modeling/pixel_decoder/msdeformattn.py:227-232, :352; its GroupNorm + ReLU stay separate).  fp32 emulated on
- * the bf16 matrix cores from an exact 3-way split, like univs_linear_fused_f32.
- * Covered: Cin % 128 == 0, Cout = 128 or a multiple of 256 up to what one or more 256-feature passes cover, T*H*W >= 4096,
- * 16-byte aligned pointers, tensors < 2^31 bytes; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps its library
- * convolution). */
-int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, int Cout, int H, int W, float* y, void* stream);
 
 /* out[b][c][r] = x[b][r][c]: contiguous float32 [B, R, C] -> [B, C, R].  The layout changes at the edges of the Swin
  * backbone: stage outputs tokens [B, H*W, C] -> NCHW (mask2former/modeling/backbone/swin.py:676-683
@@ -244,8 +235,13 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
  *   wp     N * K * 4 bytes, 16-byte aligned (out);  winv [N] fp32 (out)
  * univs_linear_presplit_f32 : y = act(x W^T + bias) (+ residual), arguments as univs_linear_fused_f32 with (wp, winv) in place
  *   of w; K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048.  UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.
- * univs_conv3x3_presplit_f32: as univs_conv3x3_f32 with (wp, winv) in place of w2.
- * Replaces: the same call sites as univs_linear_fused_f32 / univs_conv3x3_f32 (swin.py:35-58, msdeformattn.py:87-91, :227-232).
+ * univs_conv3x3_presplit_f32: y = conv2d(x, w, bias=None, stride=1, padding=1) for a 3 x 3 kernel on contiguous float32 NCHW
+ *   tensors, x [T, Cin, H, W] -> y [T, Cout, H, W], as a GEMM with tap addressing of x (the FPN output convolution of the
+ *   pixel decoder, mask2former/modeling/pixel_decoder/msdeformattn.py:227-232, :352; its GroupNorm + ReLU stay separate).
+ *   Covered: Cin % 128 == 0, Cout % 16 == 0, T*H*W >= 4096, 16-byte aligned pointers, tensors < 2^31 bytes; otherwise
+ *   UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps its library convolution).
+ * Replaces: the Linear call sites of univs_linear_fused_f32 with K >= 768 (swin.py:35-58, msdeformattn.py:87-91) and
+ *   F.conv2d at msdeformattn.py:227-232.
  * ------------------------------------------------------------------------------------------- */
 int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp, float* winv, void* stream);
 int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,

@@ -38,7 +38,6 @@ SIGNATURES = {
     "univs_msda_set_impl": (_I, [_I]),
     "univs_msda_last_impl": (_I, []),
     "univs_msda_last_tiled_generation": (_I, []),
-    "univs_conv3x3_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univs_transpose_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P]),
     "univs_linear_fused_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_mask_decode_set_impl": (_I, [_I]),

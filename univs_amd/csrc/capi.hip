@@ -38,7 +38,6 @@ int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const
                             int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
 int transpose_f32(const float*, float*, long long, int, int, hipStream_t);
-int conv3x3_split_f32(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0);
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
@@ -178,23 +177,6 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
   return rc;
 }
 
-
-int univs_conv3x3_f32(const float* x, const float* w_tap_major, int T, int Cin, int Cout, int H, int W, float* y, void* stream) {
-  clear_sticky_error();
-  if (T < 0 || Cin < 1 || Cout < 0 || H < 0 || W < 0) {
-    set_error("univs_conv3x3_f32: bad dimensions T=%d Cin=%d Cout=%d H=%d W=%d", T, Cin, Cout, H, W);
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  if (T == 0 || Cout == 0 || H == 0 || W == 0) return UNIVS_OK;
-  if (!x || !w_tap_major || !y) {
-    set_error("univs_conv3x3_f32: NULL data pointer");
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  const int rc = univs::conv3x3_split_f32(x, w_tap_major, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
-  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
-    set_error("univs_conv3x3_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout = 128 or a multiple of 256 ..., >= 4096 pixels)", T, Cin, Cout, H, W);
-  return rc;
-}
 
 int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp, float* winv, void* stream) {
   clear_sticky_error();

@@ -247,358 +247,6 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
   }
 }
 
-// ---- wide-K variant: x-stationary.
-// The kernel above keeps a slab of W (all of K for <= 112 output features) in LDS and makes one pass over x per slab: right
-// for K <= 768, hopeless beyond (K = 1024 leaves room for 24 features: eleven passes over x).  Here a wave keeps its 16
-// rows of x for ALL of K in flight and owns a [16 rows x NF * 16 features] block of accumulators; W streams through LDS in
-// k-steps of 32 (all NF * 16 features x 32 k = 49 KB at 256 features), double-buffered, split to bf16 x 3 by the whole
-// workgroup while the previous k-step is multiplied; one barrier per k-step.  Used for the encoder's second FFN Linear
-// (K = 1024 -> 256, msdeformattn.py:87-91) and the fc2 of the deeper Swin stages (K = 1536).
-template <int NF, int EPI>
-__global__ __launch_bounds__(LS_THREADS, NF <= 8 ? 2 : 1) void linear_bf16x6_wide(const float* __restrict__ X,      // [M, K]
-                                                                     const float* __restrict__ W,      // [N, K]
-                                                                     const float* __restrict__ bias,   // [N] or null
-                                                                     const float* __restrict__ Res,    // [M, N]
-                                                                     float* __restrict__ Y, int M, int N, int K) {
-  constexpr int RING = 4;
-  constexpr int NFEAT = NF * 16;
-  extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];   // [2 buffers][4 k-groups][NFEAT][3 parts]
-  const int n0 = blockIdx.y * NFEAT;
-  const int R = min(NFEAT, N - n0);                              // a multiple of 4
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KS = K >> 5;
-  const int j = lane & 15, g = lane >> 4;
-  constexpr int NWV = LS_THREADS / 64;
-  const int WT = (M + 15) / 16;                                  // 16-row wave tiles
-  const int ST = (WT + NWV - 1) / NWV;                           // super-tiles of 8 wave tiles
-
-  // W staging, two phases a k-step apart so that the global latency hides behind a whole k-step of MFMAs:
-  //   fetch_w(ks): this pass's k-step `ks` of W -> registers (8 consecutive k of one feature per work item, <= 2 items);
-  //   commit_w(buf): registers -> split -> LDS buffer `buf` (fragment order)
-  constexpr int WITEMS = (NFEAT * 4 + LS_THREADS - 1) / LS_THREADS;
-  f32x4 wraw[WITEMS][2];
-  auto fetch_w = [&](int ks) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < WITEMS; ++it) {
-      const int idx = tid + it * LS_THREADS;
-      const int r = idx >> 2, kg = idx & 3;
-      wraw[it][0] = wraw[it][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (idx < NFEAT * 4 && r < R) {
-        const float* src = W + (size_t)(n0 + r) * K + min(ks, KS - 1) * 32 + kg * 8;
-        wraw[it][0] = *reinterpret_cast<const f32x4*>(src);
-        wraw[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-    }
-  };
-  auto commit_w = [&](int buf) __attribute__((always_inline)) {
-    u32x4* dst0 = Wst + (size_t)buf * 4 * NFEAT * 3;
-#pragma unroll
-    for (int it = 0; it < WITEMS; ++it) {
-      const int idx = tid + it * LS_THREADS;
-      const int r = idx >> 2, kg = idx & 3;
-      if (idx < NFEAT * 4) {
-        bf16x8 h, m, l;
-        ls_split8(wraw[it][0], wraw[it][1], 0xFFFF0000u, h, m, l);
-        u32x4* dst = dst0 + (kg * NFEAT + r) * 3;
-        dst[0] = __builtin_bit_cast(u32x4, h);
-        dst[1] = __builtin_bit_cast(u32x4, m);
-        dst[2] = __builtin_bit_cast(u32x4, l);
-      }
-    }
-  };
-
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * N * 4), 0x00020000);
-  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == LS_EPI_RESIDUAL ? Res : X), 0, (int)((long long)M * N * 4), 0x00020000);
-  const char* Xb = reinterpret_cast<const char*>(X);
-
-#pragma unroll 1
-  for (int st = blockIdx.x; st < ST; st += gridDim.x) {
-    const int m = (st * NWV + wave) * 16 + j;                    // my row (lanes j; the 4 k-groups g share it)
-    const int mc = min(m, M - 1);
-    f32x4 raw[RING][2];
-    auto load_x = [&](f32x4 (&buf)[2], int ks) __attribute__((always_inline)) {
-      const char* p = Xb + ((unsigned)mc * (unsigned)K + (unsigned)(min(ks, KS - 1) * 32 + 8 * g)) * 4u;
-      buf[0] = *reinterpret_cast<const f32x4*>(p);
-      buf[1] = *reinterpret_cast<const f32x4*>(p + 16);
-    };
-#pragma unroll
-    for (int u = 0; u < RING; ++u) load_x(raw[u], u);
-    f32x4 acc[NF];
-#pragma unroll
-    for (int rb = 0; rb < NF; ++rb) {
-      const int f = rb * 16 + 4 * g;
-      acc[rb] = (bias && f < R) ? *reinterpret_cast<const f32x4*>(bias + n0 + f) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();                                             // the previous super-tile's last k-step is done with the buffers
-    fetch_w(0);
-    commit_w(0);
-    fetch_w(1);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int ks0 = 0; ks0 < KS; ks0 += RING) {
-#pragma unroll
-      for (int u = 0; u < RING; ++u) {
-        const int ks = ks0 + u;
-        commit_w((ks + 1) & 1);                                  // W of k-step ks + 1 (fetched a k-step ago) -> the free buffer
-        fetch_w(ks + 2);                                         // ... and the one after it -> registers
-        bf16x8 bh, bm, bl;
-        ls_split8(raw[u][0], raw[u][1], 0xFFFF0000u, bh, bm, bl);
-        load_x(raw[u], ks + RING);
-        const u32x4* ap = Wst + (size_t)(ks & 1) * 4 * NFEAT * 3 + (g * NFEAT + j) * 3;
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (see above)
-#pragma unroll
-        for (int rb = 0; rb < NF; ++rb) {
-          bf16x8 a3[3];
-#pragma unroll
-          for (int p3 = 0; p3 < 3; ++p3) a3[p3] = __builtin_bit_cast(bf16x8, ap[rb * 48 + p3]);
-#pragma unroll
-          for (int term = 0; term < 6; ++term) {
-            const bf16x8 b = TB[term] == 0 ? bh : TB[term] == 1 ? bm : bl;
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[TA[term]], b, acc[rb], 0, 0, 0);
-          }
-        }
-        __syncthreads();                                         // buffer (ks + 1) & 1 is staged; buffer ks & 1 is free
-      }
-    }
-    // ---- epilogue: D[i = feature][j = row]: a lane holds four consecutive features of its row
-#pragma unroll
-    for (int rb = 0; rb < NF; ++rb) {
-      const int f = rb * 16 + 4 * g;
-      f32x4 v = acc[rb];
-      const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
-      const unsigned offc = (m < M && f < R) ? off : 0xFFFFFFF0u;
-      if (EPI == LS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-      if (EPI == LS_EPI_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
-      }
-      if (EPI == LS_EPI_RESIDUAL) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
-    }
-  }
-}
-
-// ---- 3 x 3 convolution (stride 1, padding 1, no bias) on NCHW tensors as the x-stationary GEMM above with tap addressing:
-//   y[t][co][p] = sum over (tap, ci) of W2[co][tap * Cin + ci] * x[t][ci][p + tap offset]      (zero outside the image)
-// i.e. M = T * H * W rows (pixels), K = 9 * Cin, N = Cout; a k-step of 32 is 32 input channels of one tap.  The FPN output
-// convolution of the pixel decoder (msdeformattn.py:227-232, :352: 256 -> 256 at 1/4 resolution, 347 GFLOP per 5-frame clip,
-// the single largest kernel of the clip at 2.7 ms in MIOpen's fp32 implicit GEMM).  A lane's B fragment is 8 input channels
-// of its pixel: 8 dword loads a channel plane apart (16 consecutive pixels = 64 contiguous bytes per load and k-group);
-// the output is stored NCHW, 4 dword stores per feature block.
-template <int NF>
-__global__ __launch_bounds__(LS_THREADS, 1) void conv3x3_bf16x6(const float* __restrict__ X,     // [T, Cin, H, W]
-                                                                 const float* __restrict__ W2,    // [Cout, 9 * Cin], tap-major
-                                                                 float* __restrict__ Y,           // [T, Cout, H, W]
-                                                                 int T, int Cin, int Cout, int H, int Wd) {
-  constexpr int RING = 4;
-  constexpr int NFEAT = NF * 16;
-  extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];   // [2 buffers][4 k-groups][NFEAT][3 parts]
-  const int n0 = blockIdx.y * NFEAT;
-  const int R = min(NFEAT, Cout - n0);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = 9 * Cin, KS = K >> 5, kspt = Cin >> 5;           // k-steps per tap
-  const int j = lane & 15, g = lane >> 4;
-  constexpr int NWV = LS_THREADS / 64;
-  const int HW = H * Wd;
-  const int M = T * HW;
-  const int WT = (M + 15) / 16;
-  const int ST = (WT + NWV - 1) / NWV;
-
-  constexpr int WITEMS = (NFEAT * 4 + LS_THREADS - 1) / LS_THREADS;
-  f32x4 wraw[WITEMS][2];
-  auto fetch_w = [&](int ks) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < WITEMS; ++it) {
-      const int idx = tid + it * LS_THREADS;
-      const int r = idx >> 2, kg = idx & 3;
-      wraw[it][0] = wraw[it][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (idx < NFEAT * 4 && r < R) {
-        const float* src = W2 + (size_t)(n0 + r) * K + min(ks, KS - 1) * 32 + kg * 8;
-        wraw[it][0] = *reinterpret_cast<const f32x4*>(src);
-        wraw[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-    }
-  };
-  auto commit_w = [&](int buf) __attribute__((always_inline)) {
-    u32x4* dst0 = Wst + (size_t)buf * 4 * NFEAT * 3;
-#pragma unroll
-    for (int it = 0; it < WITEMS; ++it) {
-      const int idx = tid + it * LS_THREADS;
-      const int r = idx >> 2, kg = idx & 3;
-      if (idx < NFEAT * 4) {
-        bf16x8 h, m, l;
-        ls_split8(wraw[it][0], wraw[it][1], 0xFFFF0000u, h, m, l);
-        u32x4* dst = dst0 + (kg * NFEAT + r) * 3;
-        dst[0] = __builtin_bit_cast(u32x4, h);
-        dst[1] = __builtin_bit_cast(u32x4, m);
-        dst[2] = __builtin_bit_cast(u32x4, l);
-      }
-    }
-  };
-
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)((long long)T * Cin * HW * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)T * Cout * HW * 4), 0x00020000);
-
-#pragma unroll 1
-  for (int st = blockIdx.x; st < ST; st += gridDim.x) {
-    const int m = (st * NWV + wave) * 16 + j;                    // my pixel (lanes j; the 4 k-groups g share it)
-    const bool valid = m < M;
-    const int mc = min(m, M - 1);
-    const int t = mc / HW, rem = mc - t * HW;
-    const int py = rem / Wd, px = rem - py * Wd;
-    float raw[RING][8];
-    // 8 input channels of tap (ks / kspt) at my pixel; out-of-image taps and rows past M read 0 (offset out of the buffer)
-    auto load_x = [&](float (&buf)[8], int ks) __attribute__((always_inline)) {
-      const int kk = min(ks, KS - 1);
-      const int tap = kk / kspt, cb = (kk - tap * kspt) * 32;    // uniform
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int yy = py + dy, xx = px + dx;
-      const bool inb = valid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)Wd;
-      const unsigned base = (unsigned)(((t * Cin + cb + 8 * g) * H + yy) * Wd + xx) * 4u;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        buf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, inb ? base + (unsigned)(e * HW) * 4u : 0xFFFFFFF0u, 0, 0));
-    };
-#pragma unroll
-    for (int u = 0; u < RING; ++u) load_x(raw[u], u);
-    f32x4 acc[NF];
-#pragma unroll
-    for (int rb = 0; rb < NF; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    fetch_w(0);
-    commit_w(0);
-    fetch_w(1);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int ks0 = 0; ks0 < KS; ks0 += RING) {
-#pragma unroll
-      for (int u = 0; u < RING; ++u) {
-        const int ks = ks0 + u;
-        commit_w((ks + 1) & 1);
-        fetch_w(ks + 2);
-        bf16x8 bh, bm, bl;
-        ls_split8((f32x4){raw[u][0], raw[u][1], raw[u][2], raw[u][3]}, (f32x4){raw[u][4], raw[u][5], raw[u][6], raw[u][7]},
-                  0xFFFF0000u, bh, bm, bl);
-        load_x(raw[u], ks + RING);
-        const u32x4* ap = Wst + (size_t)(ks & 1) * 4 * NFEAT * 3 + (g * NFEAT + j) * 3;
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int rb = 0; rb < NF; ++rb) {
-          bf16x8 a3[3];
-#pragma unroll
-          for (int p3 = 0; p3 < 3; ++p3) a3[p3] = __builtin_bit_cast(bf16x8, ap[rb * 48 + p3]);
-#pragma unroll
-          for (int term = 0; term < 6; ++term) {
-            const bf16x8 b = TB[term] == 0 ? bh : TB[term] == 1 ? bm : bl;
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[TA[term]], b, acc[rb], 0, 0, 0);
-          }
-        }
-        __syncthreads();
-      }
-    }
-    // ---- epilogue: a lane holds four consecutive output channels of its pixel -> NCHW
-#pragma unroll
-    for (int rb = 0; rb < NF; ++rb) {
-      const int f = rb * 16 + 4 * g;
-      // (R is a multiple of 16: one predicate per feature block; out-of-range lanes move their offset out of the buffer)
-      const unsigned off0 = (valid && f < R) ? (unsigned)((t * Cout + n0 + f) * HW + rem) * 4u : 0xFFFFFFF0u - 3u * (unsigned)HW * 4u;
-      // (each element through an opaque register: hipcc 7.2 otherwise emits all four stores with the FIRST element as data)
-      float vx = acc[rb].x, vy = acc[rb].y, vz = acc[rb].z, vw = acc[rb].w;
-      asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(vw));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), yrs, off0, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), yrs, off0 + (unsigned)HW * 4u, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vz), yrs, off0 + 2u * (unsigned)HW * 4u, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vw), yrs, off0 + 3u * (unsigned)HW * 4u, 0, 0);
-    }
-  }
-}
-
-// K % (32 * 4) == 0 <=> (9 * Cin) % 128 == 0 <=> Cin % 128 == 0.  returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED
-int conv3x3_split_f32(const float* x, const float* w2, float* y, int T, int Cin, int Cout, int H, int W, hipStream_t st) {
-  if (T <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UNIVS_OK;
-  const long long M = (long long)T * H * W;
-  if (Cin % 128 != 0 || Cout % 16 != 0 || M < 4096 || M * std::max(Cin, Cout) * 4 >= 0x7FFFFFFFLL ||
-      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w2) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
-    return UNIVS_ERR_NOT_IMPLEMENTED;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
-      (void)hipGetLastError();
-      v = 256;
-    }
-    n_cu = v;
-  }
-  const long long ST = ((M + 15) / 16 + 7) / 8;
-  const int passes = (Cout + 255) / 256;
-  const int nfeat = ((Cout + passes - 1) / passes + 15) / 16 * 16;
-  if (nfeat != 256 && nfeat != 128) return UNIVS_ERR_NOT_IMPLEMENTED;
-  const unsigned gx = (unsigned)std::min<long long>(ST, std::max(1, n_cu / passes));
-  const size_t lds = (size_t)2 * 4 * nfeat * 3 * 16;
-  dim3 grid(gx, (unsigned)((Cout + nfeat - 1) / nfeat)), block(LS_THREADS);
-  if (nfeat == 256) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_bf16x6<16>), grid, block, lds, st, x, w2, y, T, Cin, Cout, H, W);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_bf16x6<8>), grid, block, lds, st, x, w2, y, T, Cin, Cout, H, W);
-  }
-  return check_launch("conv3x3_split_f32");
-}
-
-// returns 1 if launched, 0 if not covered
-static int linear_split_wide_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M,
-                                 int N, int K, int epi, hipStream_t st) {
-  if (K % 128 != 0 || N % 16 != 0 || M < 4096) return 0;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
-      (void)hipGetLastError();
-      v = 256;
-    }
-    n_cu = v;
-  }
-  const long long ST = ((M + 15) / 16 + 7) / 8;
-  // features per pass: 256 (one workgroup per CU, x read once) when the row super-tiles alone give every CU several
-  // rounds of work; otherwise 128 (two workgroups per CU, x read once per pass from L2 / the memory-side cache) --
-  // measured at 5 x 3680 x 1536 -> 384: 164 us against 211 us
-  int passes = (N + 255) / 256;
-  if (ST * passes < (n_cu * 3) / 2) passes = (N + 127) / 128;
-  if (const int nf = config().linear_wide_nfeat; nf >= 16) passes = (N + nf - 1) / nf;
-  const int nfeat = ((N + passes - 1) / passes + 15) / 16 * 16;
-  const int NF = nfeat / 16;
-  if (NF != 8 && NF != 12 && NF != 16) return 0;
-  const unsigned gx = (unsigned)std::min<long long>(ST, std::max(1, n_cu / ((N + nfeat - 1) / nfeat)));
-  const size_t lds = (size_t)2 * 4 * nfeat * 3 * 16;
-  dim3 grid(gx, (unsigned)((N + nfeat - 1) / nfeat)), block(LS_THREADS);
-#define UNIVS_LSW(nf, ep)                                                                                       \
-  do {                                                                                                          \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16x6_wide<nf, ep>),                       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-    hipLaunchKernelGGL((linear_bf16x6_wide<nf, ep>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K); \
-  } while (0)
-#define UNIVS_LSW_EPI(nf)                                        \
-  switch (epi) {                                                 \
-    case LS_EPI_RELU: UNIVS_LSW(nf, LS_EPI_RELU); break;         \
-    case LS_EPI_GELU: UNIVS_LSW(nf, LS_EPI_GELU); break;         \
-    case LS_EPI_RESIDUAL: UNIVS_LSW(nf, LS_EPI_RESIDUAL); break; \
-    default: UNIVS_LSW(nf, LS_EPI_NONE); break;                  \
-  }
-  if (NF == 8) { UNIVS_LSW_EPI(8) } else if (NF == 12) { UNIVS_LSW_EPI(12) } else { UNIVS_LSW_EPI(16) }
-#undef UNIVS_LSW_EPI
-#undef UNIVS_LSW
-  const int rc = check_launch("linear_split_wide_f32");
-  return rc == UNIVS_OK ? 1 : rc;
-}
-
 int linear_f16x3_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
                      int K, int epi, hipStream_t st, int blk_rows, int blk_cols);   // linear_f16x3.hip
 
@@ -615,14 +263,9 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
       (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
     return 0;
-  const int wide_kmin = config().linear_wide_kmin > 0 ? config().linear_wide_kmin : 768;
-  // (... except the one K = 768 shape with many rows and few features, Swin stage 2's fc2 at 73 600 x 768 -> 192: 203 us
-  // W-stationary against 221 us)
-  if (K >= wide_kmin && !(K == 768 && M >= 32768 && N <= 256) && epi != LS_EPI_BLOCKED) {   // x-stationary variant (measured against the W-stationary one at the Swin-T widths: a tie at K = 384,
-                    // 133 / 47 / 167 us against 159 / 61 / 228 us for the stage-4 qkv / proj / fc1 at K = 768)
-    const int rc = linear_split_wide_f32(x, w, bias, residual, y, M, N, K, epi, st);
-    if (rc != 0 || K > 768) return rc;
-  }
+  // K >= 768: the weights are split once per tensor and streamed (gemm_f16x3_stream.hip: univs_linear_presplit_f32); this
+  // entry splits W in every workgroup and only pays while the whole K of a useful number of features fits LDS
+  if (K > 768) return 0;
   if (config().linear_terms != 6) return linear_f16x3_f32(x, w, bias, residual, y, M, N, K, epi, st, blk_rows, blk_cols);   // default: three products
   const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + the zeroed tail (see the staging loop)
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);

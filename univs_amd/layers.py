@@ -122,8 +122,8 @@ class MultiheadAttention(nn.Module):
         S = key.shape[0]
         h, d = self.num_heads, self.head_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        lin = F.linear   # (the split-bf16 kernel was measured for these in-projections -- cross-attention K / V of tall memories --
-        #                  and is no faster than the tuned library GEMM: profiles/r02_bench_ab_split_linear.txt)
+        lin = linear     # tall projections (cross-attention K / V of the 1/8-resolution memory: 73 600 rows) take the fp16
+        #                  three-product kernel (62 vs 90 us in the tuned library GEMM); short ones stay on the library
         if query is key and key is value:
             q, k, v = lin(query, w, b).chunk(3, dim=-1)
         else:
@@ -187,8 +187,9 @@ def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
 
 
 def linear(x, weight, bias=None):
-    """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 (the MSDeformAttn token projections: 96 600 rows x
-    256 -> 256 / 288) take the split-bf16 kernel (fp32-accurate, ~2x hipBLASLt's fp32 rate), everything else ATen."""
+    """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 or K % 96 == 0 (the MSDeformAttn token projections:
+    96 600 rows x 256 -> 256 / 288) take the split kernels on the matrix cores (fp32-accurate: ops.linear_fused),
+    everything else ATen."""
     if SWITCHES.split_linear and x.is_cuda:
         from . import ops
         y = ops.linear_split(x, weight, bias)

@@ -191,8 +191,8 @@ def msda_forward_strips(value_hm, proj_hm, ref_points, spatial_shapes, level_sta
 class UnivsConfig(ctypes.Structure):
     """include/univs_hip.h: UnivsConfig -- the library's process-wide settings (it reads no environment variable)."""
     _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
-                                            "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "linear_wide_kmin",
-                                            "linear_wide_nfeat", "window_attn_v1", "linear_terms", "linear_ablate")] + [("reserved", ctypes.c_int * 6)]
+                                            "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "window_attn_v1",
+                                            "linear_terms", "linear_ablate")] + [("reserved", ctypes.c_int * 8)]
 
 
 def get_config() -> dict:
@@ -475,9 +475,6 @@ def conv3x3(x, weight):
         if SWITCHES.presplit_kmin > 0:
             wp, winv = presplit_weights(weight, conv=True)
             rc = _lib.load().univs_conv3x3_presplit_f32(_ptr(x), _ptr(wp), _ptr(winv), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
-        if rc == _lib.ERR_NOT_IMPLEMENTED:
-            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()   # [Cout, ky, kx, Cin]: a k-step = 32 channels of a tap
-            rc = _lib.load().univs_conv3x3_f32(_ptr(x), _ptr(w2), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "conv3x3")
