@@ -11,7 +11,7 @@ WHAT=${2:-mask}
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python tools/kbench.py --only $WHAT"
-FILT="bf16x6,skinny_gemm"
+FILT="bf16x6,f16x3,skinny_gemm"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
