@@ -160,7 +160,8 @@ int univs_msda_last_tiled_generation(void);
  * range and split into two fp16 parts, three of the four part products are accumulated in fp32 (error <= 2^-21.7 per
  * product, below the rounding error of an fp32 FMA chain over K terms; linear_f16x3.hip).  UnivsConfig.linear_terms = 6
  * selects the older six-product split into three bf16 parts (error <= 3 * 2^-24 per product; linear_split.hip).
- *   act = 0: none, 1: ReLU, 2: exact GELU  x * 0.5 * (1 + erf(x / sqrt 2))  (nn.GELU(approximate='none'));
+ *   act = 0: none, 1: ReLU, 2: GELU  x * 0.5 * (1 + erf(x / sqrt 2))  (nn.GELU(approximate='none'); erf by Abramowitz & Stegun
+ *         7.1.26, branch-free: within 4.7e-7 absolute of the exact value in fp32, ATen's fp32 GELU is within 1.2e-6);
  *   residual (NULL or [M, N], contiguous): y = x W^T + bias + residual.  act != 0 together with a residual is rejected.
  * Covered: K % 128 == 0 or K % 96 == 0, K <= 768 (this entry splits W inside every workgroup: wider K goes through
  * univs_presplit_weights_f32 + univs_linear_presplit_f32), N % 4 == 0, M >= 2048, 16-byte aligned pointers,

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
           if (epi == GS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
           if (epi == GS_EPI_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            for (int e = 0; e < 4; ++e) v[e] = l3_gelu(v[e]);
           }
           if (epi == GS_EPI_RESIDUAL) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
