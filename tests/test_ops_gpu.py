@@ -767,6 +767,30 @@ def test_presplit_weights_cache_and_wide_linear(cuda):
         ops.presplit_weights(torch.zeros(4, 4, 3, 2, device=cuda), conv=True)
 
 
+@pytest.mark.parametrize("M,K,N,act", [(4100, 960, 72, None), (3000, 864, 136, "relu"), (2500, 2304, 264, "gelu"), (70000, 768, 192, None)],
+                         ids=lambda v: str(v))
+def test_streamed_linear_ring_of_three_and_ragged_shapes(cuda, M, K, N, act):
+    """gemm_f16x3_stream beyond the model's own shapes: K a multiple of 96 but not of 128 (register ring / W groups of three
+    k-steps), feature counts that leave a short last pass or a partial 16-feature block, ragged row tiles, idle waves."""
+    F = torch.nn.functional
+    x = synth.normal(f"sl/x/{M}x{K}", (M, K))
+    x *= torch.exp2(torch.arange(M).remainder(9).float() - 4.0)[:, None]                  # rows over eight binades
+    w = synth.normal(f"sl/w/{N}x{K}", (N, K), std=K ** -0.5)
+    b = synth.normal(f"sl/b/{N}", (N,), std=0.5)
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    y = ops.linear_fused(xd, wd, bd, act=act)
+    assert y is not None and tuple(y.shape) == (M, N)
+    ref64 = F.linear(xd.double(), wd.double(), bd.double())
+    ref32 = F.linear(xd, wd, bd)
+    if act == "relu":
+        ref64, ref32 = ref64.relu(), ref32.relu()
+    if act == "gelu":
+        ref64, ref32 = F.gelu(ref64), F.gelu(ref32)
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+
+
 def test_layer_norm_second_output(cuda):
     """ops.layer_norm(..., post_add=p) == (LayerNorm(x + r), LayerNorm(x + r) + p): the encoder's norm2 and the next layer's
     `src + pos` from one pass."""
