@@ -453,9 +453,10 @@ def run(args):
     t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
     t_res = OpTimer(ops, "bilinear_resample",
                     key=lambda x, size, addend=None: ("fpn" if addend is not None else "maskfeat",) + tuple(int(v) for v in size))
+    t_pyr = OpTimer(ops, "bilinear_pyramid3")          # the three mask-feature resamplings of the prediction heads in one pass
     t_win = OpTimer(ops, "window_attention_image",
                     key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale, mma="f32": (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
-    timers = [t_msda, t_msdas, t_mdec, t_mattn, t_res, t_win]
+    timers = [t_msda, t_msdas, t_mdec, t_mattn, t_res, t_pyr, t_win]
     PROF_STEPS = 5
     for t_ in timers:
         t_.enabled = True
@@ -546,7 +547,7 @@ def run(args):
         # the ten prediction-head calls of a clip: un-fused op-boundary bytes over everything we run for them
         fam = {"full_res_decode": t_mdec.total_seconds() / PROF_STEPS,
                "attn_mask": t_mattn.total_seconds() / PROF_STEPS,
-               "mask_feature_resample": t_res.total_seconds(lambda kk: kk[0] == "maskfeat") / PROF_STEPS}
+               "mask_feature_resample": (t_res.total_seconds(lambda kk: kk[0] == "maskfeat") + t_pyr.total_seconds()) / PROF_STEPS}
         calls = n_md // PROF_STEPS + sum(len(v) for v in t_mattn.events.values()) // PROF_STEPS
         fam_t = sum(fam.values())
         unfused = 10.0 * algb
@@ -557,7 +558,7 @@ def run(args):
                                              "impl": sorted(set(t_mattn.notes.get(kk, [])))}
         res["roofline_mask_decode_family"] = {
             "what": "10 prediction-head calls per clip (1 full-resolution decode + 9 attention masks at 3 resolutions incl. "
-                    "the row reset, + 3 resamplings of the mask features), SURVEY.md 8d un-fused accounting",
+                    "the row reset, + the resampling of the mask features to the 3 resolutions: one pass), SURVEY.md 8d un-fused accounting",
             "bound": "hbm", "unfused_bytes_per_clip": unfused, "seconds_per_clip": fam_t, "achieved": unfused / fam_t / 1e9,
             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": unfused / fam_t / HBM_PEAK, "head_calls_per_clip": calls,
             "ms_per_clip": {k: v * 1e3 for k, v in fam.items()}, "attn_mask_per_level": per_level,

@@ -308,6 +308,13 @@ int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, co
 int univs_bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes,
                                 int Hin, int Win, int Hout, int Wout, void* stream);
 
+/* The three attention-mask resolutions of the decoder in one pass: out2 / out4 / out8 = univs_bilinear_resample_f32(in) to
+ * (H/2, W/2), (H/4, W/4), (H/8, W/8) -- bit-identical to the three separate calls, the input is read once
+ * (...decoder_univs.py:555-558 resizes to the sizes of the three feature levels, strides 8 / 16 / 32 against mask features
+ * at stride 4).  H and W multiples of 8, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
+int univs_bilinear_pyramid3_f32(const float* in, long long planes, int H, int W, float* out2, float* out4, float* out8,
+                                void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm with an optional fused residual add.
  * Replaces: nn.LayerNorm(C)(x) and nn.LayerNorm(C)(x + residual) on the token tensors of the path --

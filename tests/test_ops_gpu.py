@@ -791,6 +791,22 @@ def test_streamed_linear_ring_of_three_and_ragged_shapes(cuda, M, K, N, act):
     assert err < max(4.0 * err32, 5e-6), (err, err32)
 
 
+@pytest.mark.parametrize("shape", [(5, 256, 184, 320), (3, 7, 16, 24), (1, 1, 8, 8), (2, 3, 272, 480)], ids=lambda v: str(v))
+def test_bilinear_pyramid3_equals_three_resamplings(cuda, shape):
+    """ops.bilinear_pyramid3 == three ops.bilinear_resample calls, bit for bit (and hence F.interpolate to rounding); sizes that
+    are not multiples of 8 return None."""
+    x = synth.normal(f"pyr/{shape}", shape).to(cuda)
+    H, W = shape[-2:]
+    pyr = ops.bilinear_pyramid3(x)
+    assert pyr is not None and len(pyr) == 3
+    for k, got in zip((2, 4, 8), pyr):
+        want = ops.bilinear_resample(x, (H // k, W // k))
+        assert torch.equal(got, want), k
+        ref = torch.nn.functional.interpolate(x, size=(H // k, W // k), mode="bilinear", align_corners=False)
+        assert (got - ref).abs().max().item() < 1e-6
+    assert ops.bilinear_pyramid3(torch.zeros(2, 3, 12, 16, device=cuda)) is None
+
+
 def test_layer_norm_second_output(cuda):
     """ops.layer_norm(..., post_add=p) == (LayerNorm(x + r), LayerNorm(x + r) + p): the encoder's norm2 and the next layer's
     `src + pos` from one pass."""

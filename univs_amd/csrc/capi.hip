@@ -50,6 +50,7 @@ int msda_backward_f32(const float*, const LevelTable&, const float*, const float
 int msda_prepare_f32(const float*, int, int, const float*, long long, const LevelTable&, int, int, int, int, int,
                      float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
+int bilinear_pyramid3_f32(const float*, float*, float*, float*, long long, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
                    long long, hipStream_t);
 int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
@@ -402,6 +403,23 @@ int univs_bilinear_resample_f32(const float* in, const float* addend, float* out
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return bilinear_resample_f32(in, addend, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
+}
+
+int univs_bilinear_pyramid3_f32(const float* in, long long planes, int H, int W, float* out2, float* out4, float* out8,
+                                void* stream) {
+  clear_sticky_error();
+  if (planes < 0 || H < 8 || W < 8) {
+    set_error("univs_bilinear_pyramid3_f32: bad dimensions planes=%lld in=%dx%d", planes, H, W);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (planes == 0) return UNIVS_OK;
+  if (!in || !out2 || !out4 || !out8) {
+    set_error("univs_bilinear_pyramid3_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = bilinear_pyramid3_f32(in, out2, out4, out8, planes, H, W, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_bilinear_pyramid3_f32: %dx%d is not a multiple of 8 (or unaligned pointers)", H, W);
+  return rc;
 }
 
 int univs_layer_norm_add_f32(const float* x, const float* residual, const float* gamma, const float* beta, const float* addend,

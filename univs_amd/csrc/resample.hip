@@ -77,6 +77,59 @@ __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float*
   }
 }
 
+// ---- the three attention-mask resolutions of the decoder (1/2, 1/4, 1/8 of the mask-feature resolution) in ONE pass.
+// For an exact 2x / 4x / 8x reduction the taps of make_tap() are fixed: source index s * (dst + 0.5) - 0.5 = s * dst + s / 2 -
+// 0.5, i.e. rows / columns (2 d, 2 d + 1), (4 d + 1, 4 d + 2), (8 d + 3, 8 d + 4) with weights (0.5, 0.5) -- every output is the
+// same expression as in the kernel above (the multiplications by 0.5 are exact, so the results are bit-identical to three
+// separate calls).  One thread owns an 8 x 8 block of the input (sixteen 16-byte loads) and writes its 4 x 4, 2 x 2 and 1 x 1
+// outputs: the 301-MB feature tensor of a config-2 clip is read once instead of three times.
+__global__ __launch_bounds__(256) void bilinear_pyramid3_f32_kernel(const float* __restrict__ in, float* __restrict__ out2,
+                                                                    float* __restrict__ out4, float* __restrict__ out8, int H,
+                                                                    int W, long long planes) {
+  const int bw = W >> 3, bh = H >> 3;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= bh * bw) return;
+  const int by = q / bw, bx = q - by * bw;
+  auto avg = [](float a, float b, float c, float d) __attribute__((always_inline)) {
+    return 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * c + 0.5f * d);      // l0 * (l0 a + l1 b) + l1 * (l0 c + l1 d)
+  };
+  for (long long p = blockIdx.y; p < planes; p += gridDim.y) {
+    const float* src = in + (p * H + 8 * by) * (long long)W + 8 * bx;
+    float r[8][8];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const float4 u = *reinterpret_cast<const float4*>(src + (long long)y * W);
+      const float4 v = *reinterpret_cast<const float4*>(src + (long long)y * W + 4);
+      r[y][0] = u.x; r[y][1] = u.y; r[y][2] = u.z; r[y][3] = u.w;
+      r[y][4] = v.x; r[y][5] = v.y; r[y][6] = v.z; r[y][7] = v.w;
+    }
+    float* d2 = out2 + (p * (H >> 1) + 4 * by) * (long long)(W >> 1) + 4 * bx;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+      *reinterpret_cast<float4*>(d2 + (long long)y * (W >> 1)) =
+          make_float4(avg(r[2 * y][0], r[2 * y][1], r[2 * y + 1][0], r[2 * y + 1][1]), avg(r[2 * y][2], r[2 * y][3], r[2 * y + 1][2], r[2 * y + 1][3]),
+                      avg(r[2 * y][4], r[2 * y][5], r[2 * y + 1][4], r[2 * y + 1][5]), avg(r[2 * y][6], r[2 * y][7], r[2 * y + 1][6], r[2 * y + 1][7]));
+    float* d4 = out4 + (p * (H >> 2) + 2 * by) * (long long)(W >> 2) + 2 * bx;
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+      *reinterpret_cast<float2*>(d4 + (long long)y * (W >> 2)) =
+          make_float2(avg(r[4 * y + 1][1], r[4 * y + 1][2], r[4 * y + 2][1], r[4 * y + 2][2]),
+                      avg(r[4 * y + 1][5], r[4 * y + 1][6], r[4 * y + 2][5], r[4 * y + 2][6]));
+    out8[(p * bh + by) * (long long)bw + bx] = avg(r[3][3], r[3][4], r[4][3], r[4][4]);
+  }
+}
+
+// H and W multiples of 8 (and W / 2 a multiple of 4 for the 16-byte stores): UNIVS_ERR_NOT_IMPLEMENTED otherwise
+int bilinear_pyramid3_f32(const float* in, float* out2, float* out4, float* out8, long long planes, int H, int W, hipStream_t st) {
+  if (H % 8 != 0 || W % 8 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out2) & 15) ||
+      (reinterpret_cast<uintptr_t>(out4) & 7))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
+  const unsigned gx = (unsigned)(((long long)(H >> 3) * (W >> 3) + 255) / 256);
+  hipLaunchKernelGGL(bilinear_pyramid3_f32_kernel, dim3(gx, gy), dim3(256), 0, st, in, out2, out4, out8, H, W, planes);
+  return check_launch("bilinear_pyramid3_f32");
+}
+
 int bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes, int Hin, int Win,
                           int Hout, int Wout, hipStream_t st) {
   const float rh = (float)Hin / (float)Hout, rw = (float)Win / (float)Wout;

@@ -247,8 +247,14 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         # mask features resampled once per clip to the three attention-mask resolutions
         mf = mask_features.float().contiguous()
         feat_lowres = {}
+        h_m2, w_m2 = mf.shape[-2] >> 1, mf.shape[-1] >> 1
+        if mf.is_cuda and set(size_list) == {(h_m2, w_m2), (h_m2 >> 1, w_m2 >> 1), (h_m2 >> 2, w_m2 >> 2)}:
+            pyr = ops.bilinear_pyramid3(mf)            # strides 8 / 16 / 32 against stride 4: one pass over the features
+            if pyr is not None:
+                feat_lowres = {tuple(int(v) for v in p_.shape[-2:]): p_ for p_ in pyr}
         for sz in set(size_list):
-            feat_lowres[sz] = ops.bilinear_resample(mf, sz)
+            if sz not in feat_lowres:
+                feat_lowres[sz] = ops.bilinear_resample(mf, sz)
 
         predictions_class, predictions_mask, predictions_embds, predictions_reid = [], [], [], []
         want_full = self.return_aux_outputs

@@ -433,6 +433,28 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
     return out
 
 
+def bilinear_pyramid3(x):
+    """(bilinear_resample(x, (H/2, W/2)), (H/4, W/4), (H/8, W/8)) for float32 [..., H, W] on the GPU in ONE pass over x
+    (bit-identical to the three calls): the mask features at the decoder's three attention-mask resolutions.  None when H
+    or W is not a multiple of 8."""
+    _inference_only("bilinear_pyramid3", x)
+    x = x.contiguous()
+    _require_gpu("bilinear_pyramid3", x)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise RuntimeError("bilinear_pyramid3: float32 [..., H, W] only")
+    H, W = x.shape[-2:]
+    if H % 8 or W % 8 or H < 8 or W < 8:
+        return None
+    planes = x.numel() // (H * W)
+    outs = [torch.empty(tuple(x.shape[:-2]) + (H >> k, W >> k), dtype=torch.float32, device=x.device) for k in (1, 2, 3)]
+    with torch.cuda.device(x.device):
+        rc = _lib.load().univs_bilinear_pyramid3_f32(_ptr(x), planes, H, W, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "bilinear_pyramid3")
+    return tuple(outs)
+
+
 def bilinear_resample(x, size, addend=None):
     """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for float32 [..., Hin, Win] on the
     GPU (decoder attention-mask path, ...decoder_univs.py:555-558); with `addend` [..., Hout, Wout] the FPN
