@@ -26,6 +26,24 @@ def _interleaved_sincos(v, dim_t):
     return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), dim=-1).flatten(-2)
 
 
+class _ShapeCache:
+    """The embeddings are pure functions of the shape: one tensor per (shape, device), at most `cap` of them (callers only
+    read them: they add them to features or slice views).  Skipped while autograd records."""
+
+    def __init__(self, cap=8):
+        self.cap, self.d = cap, {}
+
+    def get(self, key, make):
+        if torch.is_grad_enabled():
+            return make()
+        v = self.d.get(key)
+        if v is None:
+            if len(self.d) >= self.cap:
+                self.d.pop(next(iter(self.d)))
+            v = self.d[key] = make()
+        return v
+
+
 def _axis(n, scale, device, normalize=True):
     """cumsum of ones (1..n), normalised like the reference: k / (n + eps) * scale."""
     k = torch.arange(1, n + 1, dtype=torch.float32, device=device)
@@ -41,11 +59,14 @@ class PositionEmbeddingSine(nn.Module):
             raise ValueError("normalize should be True if scale is passed")
         self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
         self.scale = 2 * math.pi if scale is None else scale
+        self._cache = _ShapeCache()
 
     def forward(self, x, mask=None):
         assert mask is None, "padding masks are not used on the inference hot path"
         N, _, H, W = x.shape
-        dev = x.device
+        return self._cache.get((N, H, W, str(x.device)), lambda: self._make(N, H, W, x.device))
+
+    def _make(self, N, H, W, dev):
         dim_t = _dim_t(self.num_pos_feats, self.temperature, dev)
         pos_y = _interleaved_sincos(_axis(H, self.scale, dev, self.normalize), dim_t)  # [H, F]
         pos_x = _interleaved_sincos(_axis(W, self.scale, dev, self.normalize), dim_t)  # [W, F]
@@ -95,7 +116,10 @@ class PositionEmbeddingSine3D(_Sine3DBase):
         b, t, _, h, w = x.shape
         dev = x.device
         assert self.normalize
-        pos = self._compose(_axis(t, self.scale, dev), _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev)
+        if not hasattr(self, "_cache"):
+            self._cache = _ShapeCache()
+        pos = self._cache.get((t, h, w, str(dev)), lambda: self._compose(
+            _axis(t, self.scale, dev), _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev))
         return pos[None].expand(b, -1, -1, -1, -1)
 
     def forward_points_with_size(self, size, xy_embed_normalized):
