@@ -576,7 +576,11 @@ def run(args):
             stages[f"{Hs}x{Ws}x{nH}h"] = {"avg_launch_us": s_ * 1e6, "launches_per_step": n_ // PROF_STEPS,
                                           "algorithmic_bytes_per_launch": byts, "achieved_GBps": byts / s_ / 1e9,
                                           "frac": byts / s_ / HBM_PEAK}
-        res["roofline_window_attn"] = {"kernel": "window_attn_img7_f32 (Swin window attention in image order, 7x7 windows: persistent per head, bias table in LDS, f32 MFMA 16x16x4)",
+        wa_kernel = {"f16x3": "window_attn_img_f16<4,false,3> (Swin window attention in image order, 7x7 windows: persistent per head, bias table "
+                              "in LDS, two fp16 parts per operand and three products on the fp16 matrix cores: fp32-accurate)",
+                     "f32": "window_attn_img7_f32 (Swin window attention in image order, 7x7 windows: persistent per head, bias table in LDS, "
+                            "f32 MFMA 16x16x4)"}.get(next((m.mma for m in swin.modules() if hasattr(m, "mma")), "f32"), "window attention")
+        res["roofline_window_attn"] = {"kernel": wa_kernel,
                                        "bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "per_stage": stages,
                                        "ms_per_clip": t_win.total_seconds() / PROF_STEPS * 1e3}
 

@@ -286,9 +286,14 @@ int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, co
  *                  1/sum normalisation stay fp32, as do the input and output tensors.  ws <= 12, hd = 32,
  *                  B*H*W*3*nH*hd < 2^31.  Tolerance against the fp32 result: tests/test_ops_gpu.py
  *                  (test_window_attention_fp16_operands).
+ *   UNIVS_MMA_F16X3  fp32-accurate on the fp16 matrix cores: every operand (q*scale, k, the probabilities, v) as TWO fp16 parts,
+ *                  three of the four part products (error <= 2^-21.7 per product, the class of univs_linear_fused_f32), at
+ *                  3/16 of the exact-f32 MFMA time.  No scaling is applied: |q*scale*log2(e)|, |k|, |v| < 65504.  Windows up to
+ *                  9 x 9; larger windows run the UNIVS_MMA_F32 kernel.
  * Any other value of `mma` returns UNIVS_ERR_INVALID_ARGUMENT. */
 #define UNIVS_MMA_F32 0
 #define UNIVS_MMA_F16 1
+#define UNIVS_MMA_F16X3 2
 int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, const float* bias,
                                      const float* shift_mask, int B, int H, int W, int ws, int shift,
                                      int nH, int hd, float scale, int mma, float* out, void* stream);

@@ -224,6 +224,9 @@ def main():
                         t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5))
                     res[f"window_attn_image_{H_}x{W_}_shift{shift}" + ("_v1" if v1 == "1" else "")] = dict(
                         ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
+                t = timeit(lambda: ops.window_attention_image(q, qb, bi, mk if shift else None, H_, W_, ws, shift, hd ** -0.5, mma="f16x3"))
+                res[f"window_attn_image_{H_}x{W_}_shift{shift}_f16x3"] = dict(
+                    ms=t * 1e3, us_per_frame=t * 1e6 / T, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
     if not args.only or "win12" in args.only:
         # config 5: Swin-L at 1080p (1088 x 1920 padded), 12 x 12 windows, the four stages, 2 frames; exact-f32 vs fp16 operands
         hd, ws, Tw = 32, 12, 2

@@ -63,7 +63,7 @@ int linear_f16x3_stream_f32(const float*, const void*, const float*, const float
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
 int window_attention_image_f16mma(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
-                                  int, float, float*, hipStream_t);
+                                  int, float, int, float*, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
                          float*, hipStream_t);
 
@@ -501,8 +501,8 @@ int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, co
   if (mma == UNIVS_MMA_F32)
     return univs_window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out, stream);
   clear_sticky_error();
-  if (mma != UNIVS_MMA_F16) {
-    set_error("univs_window_attention_image_mma: mma=%d (UNIVS_MMA_F32 = 0 or UNIVS_MMA_F16 = 1)", mma);
+  if (mma != UNIVS_MMA_F16 && mma != UNIVS_MMA_F16X3) {
+    set_error("univs_window_attention_image_mma: mma=%d (UNIVS_MMA_F32 = 0, UNIVS_MMA_F16 = 1 or UNIVS_MMA_F16X3 = 2)", mma);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (B < 0 || H < 1 || W < 1 || ws < 1 || shift < 0 || shift >= ws || nH < 1 || hd < 1) {
@@ -515,8 +515,11 @@ int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, co
     set_error("univs_window_attention_image_mma: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  return window_attention_image_f16mma(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out,
-                                       static_cast<hipStream_t>(stream));
+  const int rc = window_attention_image_f16mma(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale,
+                                               mma == UNIVS_MMA_F16X3 ? 3 : 1, out, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED && mma == UNIVS_MMA_F16X3)      // windows beyond 9 x 9: the exact kernel (same accuracy class)
+    return univs_window_attention_image_f32(qkv, qkv_bias, bias, shift_mask, B, H, W, ws, shift, nH, hd, scale, out, stream);
+  return rc;
 }
 
 int univs_msda_prepare_f32(const float* proj, int row_stride, int n_off, const float* ref_points,

@@ -36,7 +36,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WH_WAVES = 8;
 
-template <int NB, bool MASK4>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
+// TERMS = 1: fp16 operands (UNIVS_MMA_F16).  TERMS = 3: every operand as TWO fp16 parts (h = fp16(x), m = fp16(x - h)) and three
+// of the four part products -- fp32-accurate (<= 2^-21.7 per product, see linear_f16x3.hip) at 3/16 of the exact-f32 MFMA time
+// (UNIVS_MMA_F16X3; no scaling is applied: operands must lie within fp16's range, |x| < 65504).
+template <int NB, bool MASK4, int TERMS>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
 __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float* __restrict__ qkv,
                                                                       const float* __restrict__ qkv_bias,
                                                                       const float* __restrict__ bias,
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
   extern __shared__ __attribute__((aligned(16))) float lds_wh[];
   float* bias_lds = lds_wh;                                   // [NP][BS]: log2e * bias of head h, -inf for keys >= Ntok
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  _Float16* vt = reinterpret_cast<_Float16*>(lds_wh + NP * BS) + wave * (HD * VS);   // [HD][VS]
+  constexpr int PL = TERMS == 3 ? 2 : 1;                      // planes of V (h, m)
+  _Float16* vt = reinterpret_cast<_Float16*>(lds_wh + NP * BS) + wave * (PL * HD * VS);   // [PL][HD][VS]
   const int h = blockIdx.y;
   const int g = lane >> 4, n = lane & 15;
 
@@ -107,19 +111,24 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       if (hi_ok || half == 0) {
         const int jb = r + half * VR;
         _Float16* dst = vt + (4 * hg) * VS + jb * 16 + kgl * 4;
-        f16x4 c0 = {(_Float16)v[0].x, (_Float16)v[1].x, (_Float16)v[2].x, (_Float16)v[3].x};
-        f16x4 c1 = {(_Float16)v[0].y, (_Float16)v[1].y, (_Float16)v[2].y, (_Float16)v[3].y};
-        f16x4 c2 = {(_Float16)v[0].z, (_Float16)v[1].z, (_Float16)v[2].z, (_Float16)v[3].z};
-        f16x4 c3 = {(_Float16)v[0].w, (_Float16)v[1].w, (_Float16)v[2].w, (_Float16)v[3].w};
-        *reinterpret_cast<f16x4*>(dst) = c0;
-        *reinterpret_cast<f16x4*>(dst + VS) = c1;
-        *reinterpret_cast<f16x4*>(dst + 2 * VS) = c2;
-        *reinterpret_cast<f16x4*>(dst + 3 * VS) = c3;
+        const float vv[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                                {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                          // channel 4 hg + c: four keys
+          f16x4 ch, cm;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ch[e] = (_Float16)vv[c][e];
+            cm[e] = (_Float16)(vv[c][e] - (float)ch[e]);
+          }
+          *reinterpret_cast<f16x4*>(dst + c * VS) = ch;
+          if (TERMS == 3) *reinterpret_cast<f16x4*>(dst + HD * VS + c * VS) = cm;
+        }
       }
     }
 
-    // ---- K fragments: lane holds K[jb*16 + n][8g .. 8g+7] as 8 halves
-    f16x8 kf[NB];
+    // ---- K fragments: lane holds K[jb*16 + n][8g .. 8g+7] as 8 halves (TERMS = 3: two parts)
+    f16x8 kf[NB], kfm[TERMS == 3 ? NB : 1];
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
@@ -129,8 +138,12 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
         a = p[0];
         c = p[1];
       }
-      kf[jb] = f16x8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
-                     (_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
+      const float kk[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        kf[jb][e] = (_Float16)kk[e];
+        if (TERMS == 3) kfm[jb][e] = (_Float16)(kk[e] - (float)kf[jb][e]);
+      }
     }
     // Q of the first query block (the loop below requests block ib + 1 while it computes block ib)
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qc = qa;
@@ -152,8 +165,23 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
     for (int ib = 0; ib < NB; ++ib) {
       const int i = ib * 16 + n;        // this lane's query (column of S^T)
       const int tok_i = token(i);
-      const f16x8 qf = {(_Float16)(qa.x * qscale), (_Float16)(qa.y * qscale), (_Float16)(qa.z * qscale), (_Float16)(qa.w * qscale),
-                        (_Float16)(qc.x * qscale), (_Float16)(qc.y * qscale), (_Float16)(qc.z * qscale), (_Float16)(qc.w * qscale)};
+      f16x8 qf, qfm;
+      {
+        float qq[8] = {qa.x * qscale, qa.y * qscale, qa.z * qscale, qa.w * qscale,
+                       qc.x * qscale, qc.y * qscale, qc.z * qscale, qc.w * qscale};
+        if (TERMS == 3) {
+          // BOTH parts must come from the fp32-ROUNDED product: left alone, hipcc forms h with v_cvt_pk_f16_f32 of the rounded
+          // product and m = fma(q, scale, -h') with h' = the UNROUNDED product rounded once (v_fma_mixlo_f16): where the fp32
+          // product is an fp16 tie the two roundings differ by one fp16 ulp and h + m is off by 2^-11 (one query in ~3 000)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(qq[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          qf[e] = (_Float16)qq[e];
+          qfm[e] = (_Float16)(qq[e] - (float)qf[e]);
+        }
+      }
       if (ib + 1 < NB) {                // scalar
         qa = make_float4(0.f, 0.f, 0.f, 0.f);
         qc = qa;
@@ -169,7 +197,12 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       for (int jb = 0; jb < NB; ++jb) {
         // bias (and the -inf of the padded keys) is the accumulator's initial value
         const f32x4 acc = *reinterpret_cast<const f32x4*>(bias_lds + i * BS + jb * 16 + 4 * g);
-        s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qf, acc, 0, 0, 0);
+        f32x4 sc = acc;
+        if (TERMS == 3) {                                      // smallest terms first
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfm[jb], qf, sc, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qfm, sc, 0, 0, 0);
+        }
+        s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qf, sc, 0, 0, 0);
       }
       if (mask_w) {   // scalar: last row / column of windows only
         // unconditional loads at clamped indices + a select (see window_attn.hip: a load behind a lane condition made
@@ -203,16 +236,16 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       float sum = 0.f;
-      f16x4 p[NB];
+      f16x4 p[NB], pm[TERMS == 3 ? NB : 1];
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
-        float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          e[r] = __builtin_amdgcn_exp2f(s[jb][r] - mx);   // exp2(-inf) = 0 for padded keys
-          sum += e[r];
+          const float e = __builtin_amdgcn_exp2f(s[jb][r] - mx);   // exp2(-inf) = 0 for padded keys
+          sum += e;
+          p[jb][r] = (_Float16)e;
+          if (TERMS == 3) pm[jb][r] = (_Float16)(e - (float)p[jb][r]);
         }
-        p[jb] = f16x4{(_Float16)e[0], (_Float16)e[1], (_Float16)e[2], (_Float16)e[3]};
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
@@ -224,6 +257,14 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       for (int jb = 0; jb < NB; ++jb) {
         const f16x4 b0 = *reinterpret_cast<const f16x4*>(vt + n * VS + jb * 16 + 4 * g);
         const f16x4 b1 = *reinterpret_cast<const f16x4*>(vt + (16 + n) * VS + jb * 16 + 4 * g);
+        if (TERMS == 3) {
+          const f16x4 b0m = *reinterpret_cast<const f16x4*>(vt + HD * VS + n * VS + jb * 16 + 4 * g);
+          const f16x4 b1m = *reinterpret_cast<const f16x4*>(vt + HD * VS + (16 + n) * VS + jb * 16 + 4 * g);
+          o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(pm[jb], b0, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(pm[jb], b1, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b0m, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b1m, o1, 0, 0, 0);
+        }
         o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b0, o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p[jb], b1, o1, 0, 0, 0);
       }
@@ -243,25 +284,29 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
   }
 }
 
-template <int NB, bool MASK4>
+template <int NB, bool MASK4, int TERMS>
 static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B_, int nW,
                       int nH, float scale, float* out, const WinImage& wi, int n_cu, hipStream_t st) {
   constexpr int NP = 16 * NB;
-  const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * 32 * (NP + 8) * sizeof(_Float16);
+  const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * (TERMS == 3 ? 2 : 1) * 32 * (NP + 8) * sizeof(_Float16);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
   // workgroups = resident slots rounded DOWN to a multiple of the head count: one extra workgroup would double the tail
   int gx = std::max(1, n_cu * per_cu / nH);
   gx = std::min(gx, (B_ + WH_WAVES - 1) / WH_WAVES);
-  const void* fn = reinterpret_cast<const void*>(&window_attn_img_f16<NB, MASK4>);
+  const void* fn = reinterpret_cast<const void*>(&window_attn_img_f16<NB, MASK4, TERMS>);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((window_attn_img_f16<NB, MASK4>), dim3(gx, nH), dim3(64 * WH_WAVES), lds, st, qkv, qkv_bias, bias, shift_mask,
+  hipLaunchKernelGGL((window_attn_img_f16<NB, MASK4, TERMS>), dim3(gx, nH), dim3(64 * WH_WAVES), lds, st, qkv, qkv_bias, bias, shift_mask,
                      B_, nW, nH, scale, out, wi, (65536 + wi.ws - 1) / wi.ws);
   return check_launch("window_attn_img_f16");
 }
 
 // qkv [B, H*W, 3, nH, hd] in token order; out [B, H*W, nH*hd]
+// terms = 1: fp16 operands; terms = 3: two fp16 parts per operand, three products (windows up to 9 x 9: returns
+// UNIVS_ERR_NOT_IMPLEMENTED beyond, the caller then runs the exact-f32 kernel)
 int window_attention_image_f16mma(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B,
-                                  int H, int W, int ws, int shift, int nH, int hd, float scale, float* out, hipStream_t st) {
+                                  int H, int W, int ws, int shift, int nH, int hd, float scale, int terms, float* out,
+                                  hipStream_t st) {
+  if (terms == 3 && (ws > 9 || hd != 32)) return UNIVS_ERR_NOT_IMPLEMENTED;
   if (hd != 32) {
     set_error("window_attention_image (fp16 operands): head_dim=%d (only 32, the Swin-T/B/L value)", hd);
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -290,10 +335,14 @@ int window_attention_image_f16mma(const float* qkv, const float* qkv_bias, const
     n_cu = v;
   }
   const int ntok = ws * ws;
-  if (ntok <= 64) return launch_f16<4, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
-  if (ntok <= 96) return launch_f16<6, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
-  if (ntok % 4 == 0) return launch_f16<9, true>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
-  return launch_f16<9, false>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  if (terms == 3) {
+    if (ntok <= 64) return launch_f16<4, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+    return launch_f16<6, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  }
+  if (ntok <= 64) return launch_f16<4, false, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  if (ntok <= 96) return launch_f16<6, false, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  if (ntok % 4 == 0) return launch_f16<9, true, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  return launch_f16<9, false, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
 }
 
 }  // namespace univs

@@ -98,7 +98,10 @@ class WindowAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
         self._bias_cache = None
-        self.mma = "f32"             # operand precision of the attention products (SwinTransformer.set_attention_mma)
+        # how the two attention products run (SwinTransformer.set_attention_mma): "f16x3" = fp32-accurate on the fp16 matrix
+        # cores (two fp16 parts per operand, three products; windows up to 9 x 9, larger ones take the exact kernel),
+        # "f32" = exact f32 MFMA, "f16" = fp16 operands (BASELINE config 5; an explicit choice only)
+        self.mma = "f16x3"
 
     def _bias(self):
         t = self.relative_position_bias_table
@@ -276,9 +279,10 @@ class SwinTransformer(nn.Module):
         return self._forward(x)
 
     def set_attention_mma(self, mma):
-        """Operand precision of every block's window-attention products: "f32" (default, exact) or "f16" (fp16 MFMA
-        operands, fp32 accumulation / softmax -- what BASELINE config 5 names; the reference gets there through autocast,
-        train_net.py:334).  An explicit choice of the caller: nothing switches it on by itself."""
+        """How every block's window-attention products run: "f16x3" (default: fp32-accurate, two fp16 parts per operand),
+        "f32" (exact f32 MFMA) or "f16" (fp16 MFMA operands, fp32 accumulation / softmax -- what BASELINE config 5 names; the
+        reference gets there through autocast, train_net.py:334).  "f16" is an explicit choice of the caller: nothing
+        switches it on by itself."""
         if mma not in ops.MMA_DTYPES:
             raise ValueError(f"set_attention_mma: {mma!r} (one of {sorted(ops.MMA_DTYPES)})")
         for m in self.modules():

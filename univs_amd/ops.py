@@ -616,7 +616,7 @@ def masked_softmax_(scores, mask=None):
     return scores
 
 
-MMA_DTYPES = {"f32": 0, "f16": 1}      # UNIVS_MMA_F32 / UNIVS_MMA_F16 (include/univs_hip.h)
+MMA_DTYPES = {"f32": 0, "f16": 1, "f16x3": 2}      # UNIVS_MMA_F32 / _F16 / _F16X3 (include/univs_hip.h)
 
 
 def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, shift, scale, mma="f32"):
@@ -624,7 +624,8 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
     un-padded tokens) -> [B, H*W, nH*hd]; pad / roll / window_partition / window_reverse / crop of
     swin.py:252-284 happen inside the kernel.  `qkv_bias` [3*nH*hd] or None supplies q/k/v of the padded
     pixels; `shift_mask` [nW, ws*ws, ws*ws] is required when shift > 0.  `mma`: operand precision of the two
-    matrix products, "f32" (exact) or "f16" (fp16 operands, fp32 accumulation and softmax: BASELINE config 5)."""
+    matrix products, "f32" (exact), "f16x3" (fp32-accurate: two fp16 parts per operand, three products) or "f16" (fp16
+    operands, fp32 accumulation and softmax: BASELINE config 5)."""
     if mma not in MMA_DTYPES:
         raise ValueError(f"window_attention_image: mma={mma!r} (one of {sorted(MMA_DTYPES)})")
     _inference_only("window_attention_image", qkv, qkv_bias, bias)

@@ -122,7 +122,7 @@ def preprocess(frames, divisibility=32):
 # ---------------------------------------------------------------------------------------------------
 # product modules with the closed-form weights
 # ---------------------------------------------------------------------------------------------------
-def build_swin(device="cpu", variant=None, attn_mma="f32"):
+def build_swin(device="cpu", variant=None, attn_mma="f16x3"):
     from .modeling.backbone.swin import SwinTransformer
     k = dict(variant or SWIN_T)
     m = SwinTransformer(k["pretrain_img_size"], k["patch_size"], k["in_chans"], k["embed_dim"], k["depths"],
