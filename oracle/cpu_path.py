@@ -57,7 +57,7 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale, mma="f32"):
         e = torch.exp2(attn - attn.amax(-1, keepdim=True))
         out = (r16(e) @ r16(v)) / e.sum(-1, keepdim=True)
         return out.transpose(1, 2).reshape(B_, N, nH * hd)
-    assert mma == "f32", mma
+    assert mma in ("f32", "f16x3"), mma      # "f16x3" is fp32-accurate (three fp16 products per fp32 product): the exact restatement
     attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
     if shift_mask is not None:
         nW = shift_mask.shape[0]
