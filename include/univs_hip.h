@@ -136,7 +136,11 @@ typedef struct UnivsConfig {
                              (linear_split.hip) */
   int linear_ablate;      /* timing experiments on linear_f16x3 (results then only valid for inputs already in fp16's range):
                              1 = no row-maximum pass over x (scale 1) */
-  int reserved[8];
+  int mask_decode_chunked;/* 1: the exact-f32 mask kernel always in its chunked form (kernel benchmarks; default 0: small maps with
+                             C == 256 request every row of their columns at once, skinny_gemm_f32_oneshot) */
+  int mask_decode_wave_tiles; /* split-bf16 mask decode: column tiles a wave should get before a workgroup is added (default 1;
+                             the split of A is per workgroup, larger values trade balance for fewer splits) */
+  int reserved[6];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);

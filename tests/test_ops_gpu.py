@@ -349,6 +349,28 @@ def test_mask_decode_attn_matches_rule(cuda, case, impl):
     assert bad.sum() == 0
 
 
+@pytest.mark.parametrize("T,Q,h,w", [(5, 100, 23, 40), (5, 100, 46, 80), (3, 37, 23, 41), (2, 110, 46, 80)], ids=str)
+def test_mask_decode_small_maps_one_shot_is_bit_identical(cuda, T, Q, h, w):
+    """The attention masks of the coarse levels (config 2: 23x40 and 46x80, two column tiles per workgroup at 46x80) run the
+    one-shot form of the exact-f32 kernel (every k-row of a wave's columns requested at once): same fmaf chain as the chunked
+    form, so logits and masks are bit-identical to it (and the masks follow the oracle's rule)."""
+    e = synth.normal(f"md1s/e{T}{Q}{h}", (T, Q, 256), std=0.5).to(cuda)
+    f = synth.normal(f"md1s/f{T}{Q}{h}", (T, 256, h, w), std=0.5).to(cuda)
+    with ops.configured(mask_decode_impl=1):
+        lg1 = ops.mask_decode(e, f)
+        m1 = ops.mask_decode_attn(e, f)
+        with ops.configured(mask_decode_chunked=1):
+            lg0 = ops.mask_decode(e, f)
+            m0 = ops.mask_decode_attn(e, f)
+    m_default = ops.mask_decode_attn(e, f)                      # by size: the exact-f32 kernel at these sizes
+    assert ops.mask_decode_last_impl() == 1
+    assert torch.equal(lg1, lg0) and torch.equal(m1, m0) and torch.equal(m_default, m1)
+    ref = torch.einsum("tqc,tchw->qthw", e.double(), f.double())
+    assert (lg1.double() - ref).abs().max().item() < 1e-4
+    want = c_ops.attn_mask_from_logits(np.ascontiguousarray(lg1.cpu().numpy().transpose(1, 0, 2, 3)).reshape(T, Q, -1))
+    assert np.array_equal(m1.cpu().numpy(), want)
+
+
 def test_mask_decode_attn_row_reset(cuda):
     T, Q, C, h, w = 1, 3, 64, 4, 5
     f = torch.ones(T, C, h, w, device=cuda)
@@ -769,6 +791,27 @@ def test_presplit_weights_cache_and_wide_linear(cuda):
     assert (y2.double() - 2.0 * F.linear(x.double(), w.double() / 2)).abs().max().item() < max(8 * e32, 1e-5)
     with pytest.raises(RuntimeError):
         ops.presplit_weights(torch.zeros(4, 4, 3, 2, device=cuda), conv=True)
+
+
+def test_presplit_weights_made_on_another_stream(cuda):
+    """A weight split on a side stream (the prompt sampler's annotation work runs Linears there) and used right away on the
+    current stream: the cache orders the consumer behind the split (an event per entry, waited for once per stream)."""
+    F = torch.nn.functional
+    M, K, N = 4096, 1024, 256
+    x = synth.normal("pss/x", (M, K)).to(cuda)
+    w = synth.normal("pss/w", (N, K), std=K ** -0.5).to(cuda)
+    ref64 = F.linear(x.double(), w.double())
+    e32 = (F.linear(x, w).double() - ref64).abs().max().item()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(side):
+        big = torch.empty(64 << 20, device=cuda).normal_()          # work in front of the split on the side stream
+        wp, _ = ops.presplit_weights(w)
+    y = ops.linear_fused(x, w, None)
+    wp2, _ = ops.presplit_weights(w)
+    torch.cuda.synchronize()
+    assert wp2 is wp and y is not None and (y.double() - ref64).abs().max().item() < max(4 * e32, 5e-6)
+    del big
 
 
 @pytest.mark.parametrize("M,K,N,act", [(4100, 960, 72, None), (3000, 864, 136, "relu"), (2500, 2304, 264, "gelu"), (70000, 768, 192, None)],

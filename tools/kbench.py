@@ -110,6 +110,23 @@ def main():
                 fl = torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False).contiguous()
                 t = timeit(lambda: ops.mask_decode_attn(e, fl))
                 res[f"{nm}_attn_{h}x{w}"] = dict(ms=t * 1e3, impl=ops.mask_decode_last_impl())
+        ops.mask_decode_set_impl(0)
+        lows = {(h, w): torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+                for (h, w) in shapes}
+        for (h, w) in shapes:       # what the model runs (dispatch by size), and the chunked form of the exact-f32 kernel beside it
+            fl = lows[(h, w)]
+            t = timeit(lambda: ops.mask_decode_attn(e, fl))
+            res[f"mask_decode_attn_default_{h}x{w}"] = dict(us=t * 1e6, impl=ops.mask_decode_last_impl())
+            with ops.configured(mask_decode_impl=1, mask_decode_chunked=1):
+                t = timeit(lambda: ops.mask_decode_attn(e, fl))
+                res[f"mask_decode_attn_f32_chunked_{h}x{w}"] = dict(us=t * 1e6, impl=ops.mask_decode_last_impl())
+            with ops.configured(mask_decode_impl=1):
+                t = timeit(lambda: ops.mask_decode_attn(e, fl))
+                res[f"mask_decode_attn_f32_oneshot_{h}x{w}"] = dict(us=t * 1e6, impl=ops.mask_decode_last_impl())
+            for wt in (2, 3):
+                with ops.configured(mask_decode_impl=2, mask_decode_wave_tiles=wt):
+                    t = timeit(lambda: ops.mask_decode_attn(e, fl))
+                    res[f"mask_decode_attn_bf16x6_wave_tiles{wt}_{h}x{w}"] = dict(us=t * 1e6, impl=ops.mask_decode_last_impl())
         e110 = synth.normal("kb/e110", (T, 110, C)).to(dev)
         t = timeit(lambda: ops.mask_decode(e110, f))
         res["mask_decode_bf16x6_q110"] = dict(ms=t * 1e3, impl=ops.mask_decode_last_impl())

@@ -120,7 +120,7 @@ int univs_configure(const UnivsConfig* cfg) {
     memcpy(&c, cfg, (size_t)cfg->size);   // fields the caller does not know keep their defaults (0)
     if (c.msda_impl < 0 || c.msda_impl > 2 || c.mask_decode_impl < 0 || c.mask_decode_impl > 2 || c.msda_halo > 64 ||
         (c.mask_decode_ct != 0 && c.mask_decode_ct != 2 && c.mask_decode_ct != 4) ||
-        (c.linear_terms != 0 && c.linear_terms != 3 && c.linear_terms != 6)) {
+        (c.linear_terms != 0 && c.linear_terms != 3 && c.linear_terms != 6) || c.mask_decode_wave_tiles > 64) {
       set_error("univs_configure: msda_impl=%d mask_decode_impl=%d msda_halo=%d mask_decode_ct=%d linear_terms=%d out of range",
                 c.msda_impl, c.mask_decode_impl, c.msda_halo, c.mask_decode_ct, c.linear_terms);
       return UNIVS_ERR_INVALID_ARGUMENT;

@@ -156,6 +156,77 @@ __global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32(const float* __
 }
 
 
+// The same arithmetic for SMALL maps (the attention masks of the coarse levels: 23x40 and 46x80 pixels, K = 256, 100 rows:
+// 5-19 MB per launch), where the chunked kernel above is a chain of latencies -- stage A, barrier, then eight times
+// "request 16 rows, run 16 MFMAs": 29 / 44 us for what the memory system delivers in a few.  ONE SHOT: a wave requests all
+// 128 k-row pairs of its 32 columns at once (128 registers), A is requested in front of them and committed to LDS while
+// they fly, and the 128 MFMAs then run back to back as the rows arrive (the hardware returns loads in order; every MFMA
+// waits for exactly its own row).  Same k order, same fmaf chain: bit-identical to skinny_gemm_f32<1>.
+template <typename Epilogue>
+__global__ __launch_bounds__(MD_THREADS, 1) void skinny_gemm_f32_oneshot(const float* __restrict__ A,  // [T,Q,256]
+                                                                          const float* __restrict__ B,  // [T,256,N]
+                                                                          int Q, int N, int tiles_per_block, Epilogue ep) {
+  constexpr int K = 256, QP = 32, LDP = QP + 1, NL = K / 2;
+  extern __shared__ __attribute__((aligned(16))) float At[];  // [K][LDP]
+  const int t = blockIdx.z;
+  const int q0 = blockIdx.y * QP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(B + (long long)t * K * N), 0, (int)((long long)K * N * 4), 0x00020000);
+
+  // ---- A^T of rows q0 .. q0+31: requested first (16 loads per thread, coalesced along k) ...
+  constexpr int NA = QP * K / MD_THREADS;
+  float areg[NA];
+  {
+    const float* At_src = A + ((long long)t * Q) * K;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + i * MD_THREADS, k = idx & (K - 1), q = idx >> 8;
+      areg[i] = At_src[(long long)min(q0 + q, Q - 1) * K + k];     // rows past Q: a copy of the last row, never stored
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float b[NL];
+  auto request = [&](int tile) __attribute__((always_inline)) {
+    const int col = min((blockIdx.x * tiles_per_block + tile) * MD_BLOCK_N + wave * MD_WAVE_N + l31, N - 1);
+    const int voff = (col + khalf * N) * 4;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (2 * u) * N * 4, 0));
+  };
+  // ... then the first tile's rows of B, then A goes to LDS (waits for the A loads only: they are the oldest)
+  request(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int idx = tid + i * MD_THREADS, k = idx & (K - 1), q = idx >> 8;
+    At[k * LDP + q] = areg[i];
+  }
+  __syncthreads();
+
+  const float* arow = At + khalf * LDP + l31;
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const int col0 = (blockIdx.x * tiles_per_block + tile) * MD_BLOCK_N + wave * MD_WAVE_N;
+    if (col0 >= N) break;                    // wave-uniform
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * u * LDP], b[u], acc, 0, 0, 0);
+    const int col = col0 + l31;
+    if (tile + 1 < tiles_per_block) request(tile + 1);   // (uniform) the next tile's rows fly under this tile's stores
+    if (col < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (q < Q) ep(t, q, col, N, acc[r]);
+      }
+    }
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Second generation: fp32 emulated on the bf16 matrix cores ("bf16 x 6").
 //
@@ -590,9 +661,13 @@ static int launch_bf16x6(const float* A, const float* B, int T, int Q, int K, lo
     }
     n_cu = v;
   }
-  // one workgroup per CU over (frames x passes); at least 2 tiles per wave so that the A split is amortised
+  // one workgroup per CU over (frames x passes), as long as every wave has a tile (`wave_tiles` = 1).  Measured on the
+  // attention-mask maps (T = 5, 100 rows; tools/kbench.py --only mask): 92 x 160 = 460 tiles: 51 workgroups 39.8 us, 29
+  // workgroups (two tiles per wave) 44.4 us, and the round-2 rule (floor(460 / 16) = 28 workgroups of 16-17 tiles, i.e. a
+  // THIRD tile for one wave of twelve of them) 56 us: the per-workgroup split of A costs less than an unbalanced tail.
+  const int wave_tiles = config().mask_decode_wave_tiles > 0 ? config().mask_decode_wave_tiles : 1;
   long long gx = std::max<long long>(1, n_cu / std::max(1, T * passes));
-  gx = std::min(gx, std::max<long long>(1, WT / (2 * (SB_THREADS / 64))));
+  gx = std::min(gx, std::max<long long>(1, (WT + wave_tiles * (SB_THREADS / 64) - 1) / (wave_tiles * (SB_THREADS / 64))));
   const size_t lds = (size_t)K * rows * 6;
   dim3 grid((unsigned)gx, (unsigned)passes, (unsigned)T), block(SB_THREADS);
 #define UNIVS_LAUNCH_RB(rb)                                                                                       \
@@ -688,6 +763,12 @@ static int launch_skinny(const float* A, const float* B, int T, int Q, int K, lo
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   dim3 grid((unsigned)gx, (unsigned)qtiles, (unsigned)T), block(MD_THREADS);
+  if (MI == 1 && K == 256 && config().mask_decode_chunked == 0) {   // small maps: every row of B requested at once
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_f32_oneshot<Epilogue>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((skinny_gemm_f32_oneshot<Epilogue>), grid, block, lds, st, A, B, Q, (int)N, (int)tpb, ep);
+    return check_launch(what);
+  }
 #define UNIVS_LAUNCH_MI(mi)                                                                         \
   do {                                                                                              \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_f32<mi, Epilogue>),            \

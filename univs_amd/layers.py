@@ -183,7 +183,7 @@ def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
 
 
 # SWITCHES.split_linear: False = library GEMMs only, True (default) = the MSDeformAttn token projections + encoder FFN
-# through the split-bf16 kernels (ops.linear_split)
+# through the hand-written fp32-accurate GEMM kernels (ops.linear_fused: three fp16 products, csrc/linear_f16x3.hip)
 
 
 def linear(x, weight, bias=None):

@@ -46,7 +46,7 @@ class Mlp(nn.Module):
 
     def forward(self, x, residual=None):
         """fc2(GELU(fc1(x))) (+ residual) (swin.py:35-58; the block's `shortcut + mlp(...)` of :291-293 rides in fc2's
-        epilogue).  On the GPU both Linears take the split-bf16 kernel with the GELU / the residual add fused into the
+        epilogue).  On the GPU both Linears take the three-product fp16 kernel with the GELU / the residual add fused into the
         store where the shape is covered (ops.linear_fused); the library GEMM + elementwise passes otherwise."""
         h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 2) and x.is_cuda) else None
         if h is None:

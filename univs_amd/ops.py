@@ -192,7 +192,7 @@ class UnivsConfig(ctypes.Structure):
     """include/univs_hip.h: UnivsConfig -- the library's process-wide settings (it reads no environment variable)."""
     _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
                                             "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "window_attn_v1",
-                                            "linear_terms", "linear_ablate")] + [("reserved", ctypes.c_int * 8)]
+                                            "linear_terms", "linear_ablate", "mask_decode_chunked", "mask_decode_wave_tiles")] + [("reserved", ctypes.c_int * 6)]
 
 
 def get_config() -> dict:
@@ -245,12 +245,13 @@ def msda_last_tiled_generation() -> int:
 
 
 _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
-# widest K routed to the split-bf16 kernels (K <= 768: W-stationary; beyond: the x-stationary variant, which wants
-# N % 16 == 0 and >= 4096 rows and hands anything else back to the library GEMM)
-from .switches import SWITCHES   # linear_kmax: widest K routed to the split-bf16 Linears
+# K <= 768: the W-resident kernel (csrc/linear_f16x3.hip); K >= SWITCHES.presplit_kmin: the streamed kernel on weights split once
+# per tensor (csrc/gemm_f16x3_stream.hip); anything neither covers goes back to the library GEMM
+from .switches import SWITCHES   # linear_kmax: widest K routed to the hand-written Linears
 
 
-_PRESPLIT = {}      # id(weight tensor) -> (weak reference to it, (version, data_ptr, device), wp, winv); dropped with the tensor
+_PRESPLIT = {}      # id(weight tensor) -> (weak reference to it, (version, data_ptr, device), wp, winv, event recorded behind the
+                    # split, ids of the streams already ordered behind it); dropped with the tensor
 
 
 def presplit_weights(weight, conv=False):
@@ -261,6 +262,11 @@ def presplit_weights(weight, conv=False):
     key = (weight._version, weight.data_ptr(), weight.device)
     e = _PRESPLIT.get(id(weight))
     if e is not None and e[0]() is weight and e[1] == key:
+        # made on another stream (the prompt sampler's side stream, a caller's own): order this stream behind the split, once
+        sid = torch.cuda.current_stream(weight.device).cuda_stream
+        if sid not in e[5] and not torch.cuda.is_current_stream_capturing():   # (a capture follows eager warm-up calls: graphs.py)
+            torch.cuda.current_stream(weight.device).wait_event(e[4])
+            e[5].add(sid)
         return e[2], e[3]
     _require_gpu("presplit_weights", weight)
     if weight.dtype != torch.float32:
@@ -275,15 +281,18 @@ def presplit_weights(weight, conv=False):
     with torch.cuda.device(weight.device):
         _lib.check(_lib.load().univs_presplit_weights_f32(_ptr(w), N, K, int(bool(conv)), _ptr(wp), _ptr(winv), _stream_ptr(w)),
                    "presplit_weights")
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(weight.device))
     wid = id(weight)
-    _PRESPLIT[wid] = (weakref.ref(weight, lambda _r, _i=wid: _PRESPLIT.pop(_i, None)), key, wp, winv)
+    _PRESPLIT[wid] = (weakref.ref(weight, lambda _r, _i=wid: _PRESPLIT.pop(_i, None)), key, wp, winv, done,
+                      {torch.cuda.current_stream(weight.device).cuda_stream})
     return wp, winv
 
 
 def linear_fused(x, weight, bias=None, act=None, residual=None):
-    """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [exact, erf]) or `residual`
-    (a tensor of the output's shape that is added) -- for float32 on the GPU through the split-bf16 kernel (fp32-accurate:
-    an exact 3-way bf16 split of both operands, six MFMA terms): the token projections of MSDeformAttn
+    """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [the erf form; erf to 4.7e-7 absolute]) or `residual`
+    (a tensor of the output's shape that is added) -- for float32 on the GPU through the three-product fp16 kernels (fp32-accurate:
+    two fp16 parts per operand, three MFMA products; `configure(linear_terms=6)`: six bf16 products): the token projections of MSDeformAttn
     (ms_deform_attn.py:95-113) and of the Swin blocks (swin.py:35-58, :137-141, :163, :291-293).
     Returns None when the shape is not covered or the library GEMM is the better choice (K not a multiple of 96 / 128 or
     above 768, N % 4, fewer than 2048 rows, ranges beyond 2^31 bytes, autograd needed): the caller then keeps its own
@@ -482,8 +491,8 @@ def bilinear_resample(x, size, addend=None):
 
 
 def conv3x3(x, weight):
-    """F.conv2d(x, weight, None, stride=1, padding=1) for a 3 x 3 kernel, float32 NCHW on the GPU, through the split-bf16
-    x-stationary GEMM with tap addressing (the FPN output convolution, msdeformattn.py:227-232).  Returns None when the
+    """F.conv2d(x, weight, None, stride=1, padding=1) for a 3 x 3 kernel, float32 NCHW on the GPU, through the three-product fp16
+    streamed GEMM with tap addressing on weights split once per tensor (the FPN output convolution, msdeformattn.py:227-232).  Returns None when the
     shape is not covered: the caller keeps the library convolution."""
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or x.dim() != 4
             or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x.shape[1] or needs_grad(x, weight)):

@@ -23,19 +23,19 @@ class Switches:
     # the encoder's MSDeformAttn core on head-major operands (csrc/msda_strips.hip); False: msda_prepare + the standard-layout
     # operator (msda_tiled2.hip / generic)
     msda_strips: bool = True
-    # token Linears on the split-bf16 kernels (False: library GEMMs)
+    # token Linears on the hand-written fp32-accurate GEMM kernels (False: library GEMMs)
     split_linear: bool = True
-    # the 3 x 3 FPN output convolution on the split-bf16 kernel (False: MIOpen)
+    # the 3 x 3 FPN output convolution on the three-product fp16 kernel (False: MIOpen)
     split_conv: bool = True
-    # Swin qkv / proj / fc1+GELU / fc2+shortcut on the fused split-bf16 Linears (False: library GEMM + elementwise passes);
+    # Swin qkv / proj / fc1+GELU / fc2+shortcut on the fused hand-written Linears (False: library GEMM + elementwise passes);
     # `swin_fused_parts`: diagnostic bit set, 1 qkv / proj, 2 fc1 + GELU, 4 fc2 + shortcut
     swin_fused_linear: bool = True
     swin_fused_parts: int = 7
-    # widest K routed to the split-bf16 Linears
+    # widest K routed to the hand-written Linears
     linear_kmax: int = 4096
     # Linears with K >= presplit_kmin and the 3 x 3 convolution run on the three-product fp16 kernel with weights split once
-    # per tensor (csrc/gemm_f16x3_stream.hip; ops.presplit_weights caches the split); 0: the six-product kernels that
-    # split W in every workgroup
+    # per tensor (csrc/gemm_f16x3_stream.hip; ops.presplit_weights caches the split); 0: only the W-resident kernels (K <= 768), which
+    # split W in every workgroup; wider Linears and the convolution then go to the libraries
     presplit_kmin: int = 768
     # prompt sampler draws: "reference" (the reference's host-side randperm order, bit-identical sampling) or "device"
     sampler: str = "reference"
