@@ -197,3 +197,38 @@ def test_one_rank_group_with_collectives_issued():
             assert torch.equal(out[k], ref[k]), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pre_norm", [False, True], ids=["post_norm", "pre_norm"])
+def test_self_attention_rows_equal_rows_of_the_full_attention(pre_norm):
+    """The row-sharded form of the spatio-temporal self-attention (…decoder_univs.py:408-414 evaluated per rank only for the
+    query rows of its own frames): rows [Q' T_loc] against all [Q' T] keys == the same rows of the full
+    attention, with the 'sep-blocked' mask sliced by rows; and the layer really only projects / attends Q' T_loc query rows."""
+    from oracle.cpu_path import cpu_ops
+    from univs_amd import synth
+    from univs_amd.modeling.transformer_decoder.transformer_layers import SelfAttentionLayer
+    Qn, T, C, nq = 7, 6, 32, 4
+    layer = SelfAttentionLayer(C, 4, normalize_before=pre_norm).eval()
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            p.copy_(synth.normal(f"sa_rows/{n}", tuple(p.shape), std=0.2))
+    x = synth.normal("sa_rows/x", (Qn, T, C))
+    pos = synth.normal("sa_rows/pos", (Qn, T, C))
+    mask = torch.ones(Qn * T, Qn * T, dtype=torch.bool)
+    mask[:nq * T, :nq * T] = False
+    for j in range(Qn - nq):
+        s = (nq + j) * T
+        mask[s:s + T, s:s + T] = False
+    seen = []
+    attn_forward = layer.self_attn.forward
+    layer.self_attn.forward = lambda q, k, v, **kw: (seen.append((q.shape[0], k.shape[0])), attn_forward(q, k, v, **kw))[1]
+    with cpu_ops(), torch.no_grad():
+        full = layer(x.reshape(Qn * T, 1, C), tgt_mask=mask, query_pos=pos.reshape(Qn * T, 1, C)).reshape(Qn, T, C)
+        for lo, hi in ((0, 2), (2, 4), (4, 6), (1, 2)):
+            sl = slice(lo, hi)
+            rows_mask = mask.view(Qn, T, Qn * T)[:, sl].reshape(-1, Qn * T)
+            got = layer(x[:, sl].reshape(-1, 1, C), tgt_mask=rows_mask, query_pos=pos[:, sl].reshape(-1, 1, C),
+                        kv=x.reshape(Qn * T, 1, C), kv_pos=pos.reshape(Qn * T, 1, C)).reshape(Qn, hi - lo, C)
+            assert (got - full[:, sl]).abs().max().item() < 2e-6
+            assert seen[-1] == (Qn * (hi - lo), Qn * T)
+    assert seen[0] == (Qn * T, Qn * T)

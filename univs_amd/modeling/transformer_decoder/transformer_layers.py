@@ -21,14 +21,25 @@ class SelfAttentionLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def forward(self, tgt, tgt_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
-                query_pos: Optional[Tensor] = None):
+                query_pos: Optional[Tensor] = None, kv: Optional[Tensor] = None, kv_pos: Optional[Tensor] = None):
+        """`kv` / `kv_pos` (frame-sharded decoding, univs_amd/distributed.py): `tgt` then holds only SOME of the tokens -- this
+        rank's query rows -- and attends to the keys / values of ALL tokens in `kv`; `tgt_mask` is [rows, all].  Row r of the
+        result equals row r of the full self-attention (…decoder_univs.py:408-414): softmax rows are independent."""
         assert tgt_key_padding_mask is None
+        if kv is None:
+            kv, kv_pos = tgt, query_pos
+            full = True
+        else:
+            full = False
         if self.normalize_before:
             t2 = layer_norm(self.norm, tgt)
-            q = k = _with_pos(t2, query_pos)
-            return tgt + self.self_attn(q, k, t2, attn_mask=tgt_mask)[0]
-        q = k = _with_pos(tgt, query_pos)
-        return layer_norm(self.norm, self.self_attn(q, k, tgt, attn_mask=tgt_mask)[0], residual=tgt)
+            kv2 = t2 if full else layer_norm(self.norm, kv)
+            q = _with_pos(t2, query_pos)
+            k = q if full else _with_pos(kv2, kv_pos)
+            return tgt + self.self_attn(q, k, kv2, attn_mask=tgt_mask)[0]
+        q = _with_pos(tgt, query_pos)
+        k = q if full else _with_pos(kv, kv_pos)
+        return layer_norm(self.norm, self.self_attn(q, k, kv, attn_mask=tgt_mask)[0], residual=tgt)
 
 
 class CrossAttentionLayer(nn.Module):

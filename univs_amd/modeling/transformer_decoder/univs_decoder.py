@@ -292,14 +292,19 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 o = self.transformer_self_attention_layers[i](o, tgt_mask=self_attn_mask, query_pos=qe)
                 output = o.reshape(Qn, bs * t, -1)
             else:
-                # the one collective of the layer: every rank gets the query states of all frames
-                # ([Q', T_loc, C] -> [Q', T, C]); the (tiny) self-attention is then evaluated redundantly
-                # on every rank and the local frames are sliced back out.
+                # the one collective of the layer: every rank gets the query states of all frames ([Q', T_loc, C] -> [Q', T, C]);
+                # each rank then evaluates the self-attention ONLY for the query rows of its own frames (Q' T_loc rows against
+                # all Q' T keys): the term shrinks with the number of ranks instead of being repeated on each
+                # (6.7 ms of a 179-ms 40-frame clip on one GPU; evaluated redundantly it capped 8 GPUs at ~6.2x).
                 full = fs.all_gather_frames(output, dim=1)
-                o = full.reshape(Qn * t_total, bs, -1)
-                qe = query_embed_all.reshape(Qn * t_total, bs, -1)
-                o = self.transformer_self_attention_layers[i](o, tgt_mask=self_attn_mask, query_pos=qe)
-                output = o.reshape(Qn, t_total, -1)[:, fs.local_slice(t)].contiguous()
+                kv = full.reshape(Qn * t_total, bs, -1)
+                kv_pos = query_embed_all.reshape(Qn * t_total, bs, -1)
+                rows_mask = None
+                if self_attn_mask is not None:
+                    rows_mask = self._sa_mask_rows(self_attn_mask, Qn, t_total, fs.local_slice(t))
+                o = self.transformer_self_attention_layers[i](output.reshape(Qn * t, bs, -1), tgt_mask=rows_mask,
+                                                              query_pos=query_embed.reshape(Qn * t, bs, -1), kv=kv, kv_pos=kv_pos)
+                output = o.reshape(Qn, t, -1)
             output = self.transformer_ffn_layers[i](output)
             attn_mask = heads(output, size_list[(i + 1) % self.num_feature_levels], i == self.num_layers - 1)
 
@@ -548,6 +553,16 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return out[1], out[0]
 
     @torch.no_grad()
+    def _sa_mask_rows(self, mask, Qn, t_total, sl):
+        """Rows of the [Q' T, Q' T] self-attention mask that belong to the frames `sl` (token order (q, t)): [Q' T_loc, Q' T]."""
+        key = ("rows", id(mask), Qn, t_total, sl.start, sl.stop)
+        m = self._sa_mask_cache.get(key)
+        if m is None or m[0] is not mask:
+            rows = mask.view(Qn, t_total, Qn * t_total)[:, sl].reshape(-1, Qn * t_total).contiguous()
+            m = (mask, rows)           # (the full mask is kept alive with its rows: id() keys must not be reused)
+            self._sa_mask_cache[key] = m
+        return m[1]
+
     def generate_self_attn_mask(self, bs, t, num_queries_lp, device, dataset_name, task):
         """:824-848: bool [QT, QT] (True = blocked), identical for every head (broadcast)."""
         tp = self.maskdec_self_attn_mask_type
