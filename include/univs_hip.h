@@ -135,7 +135,9 @@ typedef struct UnivsConfig {
                              three products (linear_f16x3.hip; the default), 6 = three bf16 parts per operand, six products
                              (linear_split.hip) */
   int linear_ablate;      /* timing experiments on linear_f16x3 (results then only valid for inputs already in fp16's range):
-                             1 = no row-maximum pass over x (scale 1) */
+                             1 = no row-maximum pass over x (scale 1); 2 / 3 / 4 = univs_mlp_presplit_f32 (encoder FFN and Swin stage-1
+                             shapes) without its MFMAs / without the LDS reads of the weight fragments / without the activation
+                             and split of the hidden activations: results are then WRONG, kernel benchmarks only */
   int mask_decode_chunked;/* 1: the exact-f32 mask kernel always in its chunked form (kernel benchmarks; default 0: small maps with
                              C == 256 request every row of their columns at once, skinny_gemm_f32_oneshot) */
   int mask_decode_wave_tiles; /* split-bf16 mask decode: column tiles a wave should get before a workgroup is added (default 1;
@@ -236,7 +238,9 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
  * Linears (K >= 768) and the 3 x 3 convolution.  The split of W -- row maxima, power-of-two row scales, two fp16 parts in
  * the kernels' LDS order -- is done ONCE per weight tensor; the caller keeps the result (4 bytes per element + N floats)
  * for as long as the weights do not change.
- *   w      [N, K] fp32 (conv = 0), or a convolution weight [N, Cin, 3, 3] with conv = 1 (then K = 9 * Cin, tap-major)
+ *   w      [N, K] fp32 (conv = 0), or a convolution weight [N, Cin, 3, 3] with conv = 1 (then K = 9 * Cin, tap-major), or
+ *          [N, K] fp32 with conv = 2: the SECOND Linear of univs_mlp_presplit_f32 (inside every 32-wide k-step the k-order is
+ *          (4 g + e, 16 + 4 g + e), g = 0..3, e = 0..3: the order in which that kernel holds its hidden activations)
  *   wp     N * K * 4 bytes, 16-byte aligned (out);  winv [N] fp32 (out)
  * univs_linear_presplit_f32 : y = act(x W^T + bias) (+ residual), arguments as univs_linear_fused_f32 with (wp, winv) in place
  *   of w; K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048.  UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.
@@ -253,6 +257,22 @@ int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv,
                               long long M, int N, int K, int act, float* y, void* stream);
 int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
                                float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y[M, C] = act(x[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16
+ * arithmetic of univs_linear_fused_f32 in both products; the [M, Hd] hidden activations stay in registers (they are neither
+ * written to nor read from memory).
+ *   w1p, w1inv   univs_presplit_weights_f32(W1 [Hd, C], Hd, C, 0, ...)
+ *   w2p, w2inv   univs_presplit_weights_f32(W2 [C, Hd], C, Hd, 2, ...)     (mode 2: the MLP k-order)
+ *   b1 [Hd], b2 [C], residual [M, C]: optional (NULL);  act: 1 ReLU, 2 GELU (erf form, as univs_linear_fused_f32)
+ * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 130 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
+ * aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps two univs_linear_* calls).
+ * Replaces: linear2(dropout(activation(linear1(src)))) of the MSDeformAttn encoder layer
+ *   (mask2former/modeling/pixel_decoder/msdeformattn.py:87-91) and Mlp.forward + the block's shortcut add of the Swin stages
+ *   with C <= 256 (mask2former/modeling/backbone/swin.py:35-58, :291-293).
+ * ------------------------------------------------------------------------------------------- */
+int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
+                           const float* b2, const float* residual, long long M, int C, int Hd, int act, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.

@@ -566,6 +566,42 @@ def test_window_attention_image_matches_reference_data_movement(cuda, mma, B, H,
     assert err < (4e-6 if mma == "f16x3" else 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 3, 3), (1, 20, 31, 9, 4, 2), (1, 23, 40, 7, 0, 2)], ids=lambda v: str(v))
+def test_window_attention_f16x3_out_of_range_operands(cuda, B, H, W, ws, shift, nH):
+    """The three-product window attention (the Swin default) on operands OUTSIDE fp16's range: windows whose k, v or scaled q
+    hold magnitudes >= 2^15 are brought into range by a wave-uniform power of two inside the kernel (undone on the fp32
+    scores / the normaliser), so the result stays that of the exact-f32 kernel instead of Inf - Inf = NaN -- large v (1e6),
+    large k with small q, large q with small k, and everything large but scores still finite in fp32."""
+    qkv, qb, bias, mask = _window_image_inputs(B, H, W, ws, shift, nH)
+    args = (H, W, ws, shift, 32 ** -0.5)
+    dev = lambda t: t.to(cuda) if t is not None else None  # noqa: E731
+    base = [dev(t) for t in (qkv, qb, bias, mask)]
+    ok = ops.window_attention_image(*base, *args, mma="f16x3")
+    assert torch.isfinite(ok).all()
+    for name, sq, sk, sv in (("large v", 1.0, 1.0, 1.0e6), ("large k, small q", 1.0e-5, 1.0e5, 1.0), ("large q, small k", 3.0e5, 2.0e-6, 1.0),
+                             ("k and v beyond 65504", 1.0e-2, 7.0e4, 7.0e4), ("one huge channel", 1.0, 1.0, 1.0)):
+        q2 = qkv.clone()
+        q2[:, :, 0] *= sq
+        q2[:, :, 1] *= sk
+        q2[:, :, 2] *= sv
+        qb2 = qb.clone().view(3, -1)
+        qb2[0] *= sq
+        qb2[1] *= sk
+        qb2[2] *= sv
+        if name == "one huge channel":       # a single outlier in one token of one window: only that window is rescaled
+            q2[0, 5, 1, 0, 3] = 9.0e4
+        a2 = [dev(q2), dev(qb2.reshape(-1)), base[2], base[3]]
+        got = ops.window_attention_image(*a2, *args, mma="f16x3")
+        ref = ops.window_attention_image(*a2, *args, mma="f32")
+        assert torch.isfinite(got).all(), name
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item() / scale
+        print(f"f16x3 window attention, {name} {B, H, W, ws, shift, nH}: relative max error {err:.2e}")
+        assert err < 2e-5, (name, err)
+        if name == "one huge channel":       # windows without the outliers are untouched (bit-identical to the plain run)
+            assert (got == ok).float().mean().item() > 0.5
+
+
 # Tolerance of the fp16-operand window attention (UNIVS_MMA_F16) against the fp32 operator, on unit-normal q, k, v, bias:
 # each operand carries a relative rounding error of 2^-11, which over 32 channels and up to 144 keys gives errors of a few
 # 1e-4 of the output scale; 4e-3 absolute leaves a factor ~4 over the largest error measured on these cases.
@@ -681,6 +717,86 @@ def test_linear_fused_matches_torch(cuda, linear_terms, terms, M, K, N, act, res
     with pytest.raises(RuntimeError):
         ops.linear_fused(xd, wd, bd, act="tanh")
     assert ops.linear_fused(xd, wd, bd, act="gelu", residual=torch.zeros(M, N, device=cuda)) is None   # not both
+
+
+@pytest.mark.parametrize("M,C,Hd,act,res", [(19320, 256, 1024, "relu", False), (58880, 96, 384, "gelu", True), (14720, 192, 768, "gelu", True),
+                                             (5000, 128, 512, "gelu", True), (4099, 96, 384, "gelu", False), (2049, 256, 32, "relu", True),
+                                             (3000, 256, 2048, "gelu", False), (2048, 192, 96, "relu", False)], ids=lambda v: str(v))
+def test_mlp_fused_matches_torch(cuda, M, C, Hd, act, res):
+    """ops.mlp_fused (csrc/mlp_f16x3.hip: both Linears of an MLP in one kernel, hidden activations in registers, W2 pre-split
+    in the k-order of the first product's accumulators) == linear -> activation -> linear (+ residual) to fp32 rounding:
+    against fp64 the error is of the order of ATen's own fp32 path (msdeformattn.py:87-91, swin.py:35-58, :291-293)."""
+    F = torch.nn.functional
+    x = synth.normal(f"mlp/x/{M}x{C}", (M, C), std=1.0)
+    w1 = synth.normal(f"mlp/w1/{Hd}x{C}", (Hd, C), std=C ** -0.5)
+    b1 = synth.normal(f"mlp/b1/{Hd}", (Hd,), std=0.5)
+    w2 = synth.normal(f"mlp/w2/{C}x{Hd}", (C, Hd), std=Hd ** -0.5)
+    b2 = synth.normal(f"mlp/b2/{C}", (C,), std=0.5)
+    r = synth.normal(f"mlp/r/{M}x{C}", (M, C), std=1.0) if res else None
+    xd, w1d, b1d, w2d, b2d = (t.to(cuda) for t in (x, w1, b1, w2, b2))
+    rd = r.to(cuda) if res else None
+    y = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, act, residual=rd)
+    assert y is not None and tuple(y.shape) == (M, C)
+    fn = F.relu if act == "relu" else F.gelu
+    ref64 = F.linear(fn(F.linear(xd.double(), w1d.double(), b1d.double())), w2d.double(), b2d.double())
+    ref32 = F.linear(fn(F.linear(xd, w1d, b1d)), w2d, b2d)
+    if res:
+        ref64, ref32 = ref64 + rd.double(), ref32 + rd
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+    # the two-kernel path it replaces computes the same thing with the same arithmetic: equal to rounding
+    two = ops.linear_fused(ops.linear_fused(xd, w1d, b1d, act=act), w2d, b2d, residual=rd)
+    if two is not None:
+        assert (two - y).abs().max().item() < max(4.0 * err32, 5e-6)
+    # leading dimensions are kept; no biases; scaling x by a power of two under ReLU is exact
+    y3 = ops.mlp_fused(xd.view(1, M, C), w1d, None, w2d, None, act)
+    assert tuple(y3.shape) == (1, M, C)
+    if act == "relu":
+        assert torch.equal(ops.mlp_fused(4.0 * xd, w1d, None, w2d, None, act), 4.0 * y3.view(M, C))
+
+
+def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):
+    """Rows of x over 80 binades, zero rows, hidden rows whose magnitude jumps between chunks (the running scale of the hidden
+    activations is lowered with an exact rescaling of the output accumulators), Inf / NaN confined to their row; shapes the
+    kernel does not cover return None."""
+    F = torch.nn.functional
+    M, C, Hd = 4096, 256, 512
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, C, generator=g) * torch.exp2(torch.randint(-30, 30, (M, 1), generator=g).float())
+    x[5] = 0
+    x[8, 3] = 1e4 * x[8].abs().max()
+    w1 = torch.randn(Hd, C, generator=g) / 16
+    w1[:32] *= 2.0 ** -20                 # first chunk tiny, later chunks large: the hidden scale must be lowered on the way
+    w1[320:352] *= 2.0 ** 12
+    b1 = torch.randn(Hd, generator=g) * 0.1
+    w2 = torch.randn(C, Hd, generator=g) * torch.exp2(torch.randint(-6, 6, (C, 1), generator=g).float()) / 22
+    b2 = torch.randn(C, generator=g)
+    xd, w1d, b1d, w2d, b2d = (t.to(cuda) for t in (x, w1, b1, w2, b2))
+    for act, fn in (("relu", F.relu), ("gelu", F.gelu)):
+        y = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, act)
+        assert y is not None and torch.isfinite(y).all()
+        h64 = fn(F.linear(xd.double(), w1d.double(), b1d.double()))
+        ref64 = F.linear(h64, w2d.double(), b2d.double())
+        ref32 = F.linear(fn(F.linear(xd, w1d, b1d)), w2d, b2d)
+        scale = h64.abs() @ w2d.double().abs().t() + b2d.double().abs()[None] + 1e-300
+        e3 = ((y.double() - ref64).abs() / scale).max().item()
+        e32 = ((ref32.double() - ref64).abs() / scale).max().item()
+        print(f"mlp_fused {act}: max error / sum|h||w2| {e3:.2e} (ATen fp32: {e32:.2e})")
+        assert e3 < max(3.0 * e32, 5e-7), (act, e3, e32)
+        xd2 = xd.clone()
+        xd2[100, 17] = float("inf")
+        xd2[200, 5] = float("nan")
+        y2 = ops.mlp_fused(xd2, w1d, b1d, w2d, b2d, act)
+        bad = torch.zeros(M, dtype=torch.bool, device=cuda)
+        bad[100] = bad[200] = True
+        assert torch.equal(y2[~bad], y[~bad]) and not torch.isfinite(y2[100]).any() and torch.isnan(y2[200]).all()
+    assert ops.mlp_fused(torch.zeros(4096, 384, device=cuda), torch.zeros(1536, 384, device=cuda), None,
+                         torch.zeros(384, 1536, device=cuda), None, "gelu") is None                              # C = 384
+    assert ops.mlp_fused(xd[:100], w1d, b1d, w2d, b2d, "relu") is None                                           # few rows
+    assert ops.mlp_fused(xd, w1d[:500], b1d[:500], w2d[:, :500].contiguous(), b2d, "relu") is None               # Hd % 32
+    assert ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "tanh") is None
+    assert ops.mlp_fused(xd.cpu(), w1d.cpu(), None, w2d.cpu(), None, "relu") is None
 
 
 def test_linear_f16x3_row_scaling(cuda, linear_terms):

@@ -191,6 +191,27 @@ def main():
                     if rs is not None:
                         t3 = timeit(lambda: rs + torch.nn.functional.linear(xs, w_, b_))
                         res[f"swin_s{stage}_{nm}_{K_}x{N_}"]["library_plus_add_us"] = t3 * 1e6
+    if args.only and "mlp" in args.only:
+        # two-Linear MLPs in one kernel (csrc/mlp_f16x3.hip) against the two fused Linears they replace: the encoder FFN and the
+        # Swin Mlp + shortcut of the stages with C <= 256, at 720p x T frames
+        for nm, Mr, C, Hd, act, with_res in (("encoder_ffn", T * 19320, 256, 1024, "relu", False), ("swin_s1_mlp", T * 184 * 320, 96, 384, "gelu", True),
+                                           ("swin_s2_mlp", T * 92 * 160, 192, 768, "gelu", True)):
+            xs = synth.normal(f"kb/mlp/x{C}/{Mr}", (Mr, C)).to(dev)
+            w1 = synth.normal(f"kb/mlp/w1/{C}", (Hd, C), std=C ** -0.5).to(dev)
+            b1 = synth.normal(f"kb/mlp/b1/{C}", (Hd,), std=0.5).to(dev)
+            w2 = synth.normal(f"kb/mlp/w2/{C}", (C, Hd), std=Hd ** -0.5).to(dev)
+            b2 = synth.normal(f"kb/mlp/b2/{C}", (C,), std=0.5).to(dev)
+            rs = synth.normal(f"kb/mlp/r{C}/{Mr}", (Mr, C)).to(dev) if with_res else None
+            t2 = timeit(lambda: ops.linear_fused(ops.linear_fused(xs, w1, b1, act=act), w2, b2, residual=rs))
+            t1 = timeit(lambda: ops.mlp_fused(xs, w1, b1, w2, b2, act, residual=rs))
+            fl = 4.0 * Mr * C * Hd
+            byts = 4.0 * Mr * C * (3 if with_res else 2)
+            res[nm] = dict(fused_us=t1 * 1e6, two_kernels_us=t2 * 1e6, TFLOPs_fp32_equiv=fl / t1 / 1e12, f16_mfma_frac=3 * fl / t1 / 2.5e15,
+                           hbm_frac=byts / t1 / HBM_PEAK)
+            if C in (96, 256):       # timing experiments (results wrong): what the kernel costs without one of its parts
+                for tag, abl in (("no_mfma_us", 2), ("no_lds_reads_us", 3), ("no_activation_split_us", 4)):
+                    with ops.configured(linear_ablate=abl):
+                        res[nm][tag] = timeit(lambda: ops.mlp_fused(xs, w1, b1, w2, b2, act, residual=rs)) * 1e6
     if args.only and "conv" in args.only:
         from univs_amd.switches import override as _ov
         xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)

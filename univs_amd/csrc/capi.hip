@@ -58,7 +58,9 @@ int group_norm_f32(const float*, const float*, const float*, int, int, long long
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
-int presplit_f16x3(const float*, int, int, int, void*, float*, hipStream_t);
+int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
+int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*, float*,
+                  long long, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -181,8 +183,8 @@ int univs_linear_fused_f32(const float* x, const float* weight, const float* bia
 
 int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp, float* winv, void* stream) {
   clear_sticky_error();
-  if (N < 0 || K < 32 || K % 32 != 0 || (conv != 0 && conv != 1) || (conv == 1 && K % 9 != 0)) {
-    set_error("univs_presplit_weights_f32: bad arguments N=%d K=%d conv=%d (K a multiple of 32; conv: K = 9 Cin)", N, K, conv);
+  if (N < 0 || K < 32 || K % 32 != 0 || conv < 0 || conv > 2 || (conv == 1 && K % 9 != 0)) {
+    set_error("univs_presplit_weights_f32: bad arguments N=%d K=%d mode=%d (K a multiple of 32; mode 1: K = 9 Cin)", N, K, conv);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (N == 0) return UNIVS_OK;
@@ -190,7 +192,26 @@ int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp,
     set_error("univs_presplit_weights_f32: NULL or unaligned pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  return univs::presplit_f16x3(w, N, K, conv ? K / 9 : 0, wp, winv, static_cast<hipStream_t>(stream));
+  return univs::presplit_f16x3(w, N, K, conv == 1 ? K / 9 : 0, conv == 2 ? 1 : 0, wp, winv, static_cast<hipStream_t>(stream));
+}
+
+int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
+                           const float* b2, const float* residual, long long M, int C, int Hd, int act, float* y, void* stream) {
+  clear_sticky_error();
+  if (M < 0 || C < 1 || Hd < 1 || (act != 1 && act != 2)) {
+    set_error("univs_mlp_presplit_f32: bad arguments M=%lld C=%d Hd=%d act=%d (1 ReLU, 2 GELU)", M, C, Hd, act);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return UNIVS_OK;
+  if (!x || !w1p || !w1inv || !w2p || !w2inv || !y) {
+    set_error("univs_mlp_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, y, M, C, Hd, act, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256, Hd %% 32 == 0, "
+              "M >= 2048)", M, C, Hd);
+  return rc;
 }
 
 int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,

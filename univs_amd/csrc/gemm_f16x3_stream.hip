@@ -24,7 +24,9 @@ constexpr int GS_TILE_M = 32;
 enum { GS_EPI_NONE = 0, GS_EPI_RELU = 1, GS_EPI_GELU = 2, GS_EPI_RESIDUAL = 3 };   // = LS_EPI_*
 
 // ---- W [N, K] fp32 -> Wp [(K/32) * 4 * 2][N] 16-byte units + winv [N].  conv: W is [N, Cin, 3, 3] and k = tap * Cin + ci.
-__global__ __launch_bounds__(256) void presplit_f16x3_kernel(const float* __restrict__ W, int N, int K, int conv_cin,
+// kperm: the k-order inside a 32-wide k-step is (4 g + e, 16 + 4 g + e) for k-group g, e = 0..3 -- the order in which the
+// fused MLP (mlp_f16x3.hip) holds its hidden activations when they come out of the first product's accumulators.
+__global__ __launch_bounds__(256) void presplit_f16x3_kernel(const float* __restrict__ W, int N, int K, int conv_cin, int kperm,
                                                              u32x4* __restrict__ Wp, float* __restrict__ winv) {
   __shared__ unsigned smax;
   const int r = blockIdx.x;
@@ -47,8 +49,9 @@ __global__ __launch_bounds__(256) void presplit_f16x3_kernel(const float* __rest
     f32x4 v0, v1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v0[e] = elem(kc * 8 + e);
-      v1[e] = elem(kc * 8 + 4 + e);
+      const int k0 = kperm ? (kc >> 2) * 32 + 4 * (kc & 3) + e : kc * 8 + e;
+      v0[e] = elem(k0);
+      v1[e] = elem(kperm ? k0 + 16 : k0 + 4);
     }
     f16x8 h, m;
     l3_split8(v0, v1, s, h, m);
@@ -57,9 +60,9 @@ __global__ __launch_bounds__(256) void presplit_f16x3_kernel(const float* __rest
   }
 }
 
-int presplit_f16x3(const float* w, int N, int K, int conv_cin, void* wp, float* winv, hipStream_t st) {
+int presplit_f16x3(const float* w, int N, int K, int conv_cin, int kperm, void* wp, float* winv, hipStream_t st) {
   if (N <= 0) return UNIVS_OK;
-  hipLaunchKernelGGL(presplit_f16x3_kernel, dim3(N), dim3(256), 0, st, w, N, K, conv_cin, reinterpret_cast<u32x4*>(wp), winv);
+  hipLaunchKernelGGL(presplit_f16x3_kernel, dim3(N), dim3(256), 0, st, w, N, K, conv_cin, kperm, reinterpret_cast<u32x4*>(wp), winv);
   return check_launch("presplit_f16x3");
 }
 
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
         if (XMODE == 0) {
           const unsigned off = ((unsigned)m * (unsigned)N + (unsigned)(n0 + f)) * 4u;
           const unsigned offc = (row_ok && f < R) ? off : 0xFFFFFFF0u;
-          if (epi == GS_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+          if (epi == GS_EPI_RELU) v = __builtin_elementwise_maximum(v, (f32x4){0.f, 0.f, 0.f, 0.f})   /* NaN-propagating, as torch.relu */;
           if (epi == GS_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = l3_gelu(v[e]);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
           off = (rowpart + cb * (unsigned)blk_rows * (unsigned)blk_cols + (fg - cb * (unsigned)blk_cols)) * 4u;
         }
         const unsigned offc = (m < M && f < R) ? off : 0xFFFFFFF0u;   // out of range: loads return 0, stores are dropped
-        if (epi == L3_EPI_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (epi == L3_EPI_RELU) v = __builtin_elementwise_maximum(v, (f32x4){0.f, 0.f, 0.f, 0.f})   /* NaN-propagating, as torch.relu */;
         if (epi == L3_EPI_GELU) {   // x * 0.5 * (1 + erf(x / sqrt 2)): nn.GELU() (approximate = 'none')
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = l3_gelu(v[e]);

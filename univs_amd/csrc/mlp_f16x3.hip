@@ -1,0 +1,438 @@
+// y[M, C] = act(x[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in ONE kernel, three-product fp16 arithmetic (see
+// linear_f16x3.hip), the hidden activations never leave the CU.
+//   * the encoder FFN 256 -> 1024 (ReLU) -> 256 (msdeformattn.py:87-91: linear2(dropout(activation(linear1(src)))));
+//   * the Swin Mlp C -> 4C (GELU) -> C + shortcut (swin.py:35-58, :291-293) at C = 96 / 128 / 192 / 256.
+// With two kernels the [M, Hd] activations are written and read back (396 MB each way per encoder layer at 720p, 452 MB at Swin
+// stage 1) and split into fp16 parts a second time.  Here a wave owns 16 CT token rows for the whole MLP:
+//   * its x tile is read once, scaled by the exact row maximum and kept as two fp16 parts in registers (the B operand of GEMM 1);
+//   * the hidden dimension is walked in chunks of 32 features: h = act(x W1[chunk]^T + b1) comes out of the matrix cores as
+//     D[i = hidden feature][j = token] -- a lane holds 4 + 4 consecutive features of one token -- which IS a B operand of the
+//     second product if the k-order inside a 32-wide k-step is taken as (4 g + e, 16 + 4 g + e): W2 is pre-split ONCE with that
+//     permutation (presplit mode 2), so h goes from accumulator to operand with no data movement: bias, activation, running
+//     power-of-two row scale (as x in linear_f16x3: set by the first chunk, lowered with an exact rescaling of the output
+//     accumulators), split into two fp16 parts;
+//   * y accumulates over the chunks in registers (C / 16 blocks of 16 features) and is stored once.
+// Both weight matrices stream through LDS in the chunk order, double-buffered: chunk = W1 rows [32 c, 32 c + 32) (all k) and
+// the k-step c of W2 (all rows), 256 C bytes; a thread moves its 16-byte units of the next chunk L2 -> registers -> LDS on a
+// static schedule spread over the chunk's batches (a unit is committed a quarter of a chunk after its fetch), one barrier
+// per chunk.  A workgroup = NW waves (8; 4 for the narrow widths, so that two or three workgroups share a CU and one's
+// load / store / activation phases overlap another's matrix phases), persistent over row groups.
+// A fragments (two 16-row blocks x two parts = four ds_read_b128 per batch of six or twelve MFMAs) are requested TWO batches
+// ahead into a ring of three; the wait before a batch is `s_waitcnt lgkmcnt(n)` with n = the LDS operations issued after
+// that batch's reads (the next batch's four reads + this slot's commits): LDS operations complete in order and the loop
+// holds no scalar memory operation (checked in the ISA), so the count is exact.
+#include "common.h"
+#include "config.h"
+#include "f16x3.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace univs {
+
+enum { ML_ACT_RELU = 1, ML_ACT_GELU = 2 };
+// ABL (timing experiments, UnivsConfig.linear_ablate = 2 / 3 / 4; results are then WRONG): 1 no MFMAs, 2 no LDS reads of the A
+// fragments, 3 no activation / scale / split of the hidden activations
+
+struct MlpArgs {
+  const float* X;       // [M, C]
+  const u32x4* W1p;     // W1 [Hd, C] pre-split, standard k order: unit (kc * 2 + part) * Hd + r
+  const float* w1inv;   // [Hd]
+  const float* b1;      // [Hd] or null
+  const u32x4* W2p;     // W2 [C, Hd] pre-split with the MLP k-permutation: unit (kc * 2 + part) * C + r
+  const float* w2inv;   // [C]
+  const float* b2;      // [C] or null
+  const float* Res;     // [M, C] or null
+  float* Y;             // [M, C]
+  int M, Hd, nwg;
+};
+
+template <int N>
+__device__ __forceinline__ void ml_wait_lgkm(u32x4 (&d)[2][2]) {   // the operands tie the MFMAs behind this wait
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+  else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ml_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ml_static_for<I + 1, N>(f);
+  }
+}
+
+// static schedule of the weight stream: unit v of a thread is fetched in batch slot ml_fs(v) and committed ML_D slots later
+constexpr int ml_dist(int nbat) { return nbat / 4 > 2 ? nbat / 4 : 2; }
+constexpr int ml_fs(int v, int upt, int nbat) { return v * (nbat - ml_dist(nbat)) / upt; }
+constexpr int ml_commits_in(int t, int upt, int nbat) {
+  int n = 0;
+  for (int v = 0; v < upt; ++v) n += (ml_fs(v, upt, nbat) + ml_dist(nbat) == t) ? 1 : 0;
+  return n;
+}
+constexpr int ml_ring(int upt, int nbat) {          // most units in flight at once (after a slot's commits and fetches)
+  int worst = 1;
+  for (int t = 0; t < nbat; ++t) {
+    int n = 0;
+    for (int v = 0; v < upt; ++v) n += (ml_fs(v, upt, nbat) <= t && t < ml_fs(v, upt, nbat) + ml_dist(nbat)) ? 1 : 0;
+    worst = n > worst ? n : worst;
+  }
+  return worst;
+}
+
+// LDS (16-byte units): 2 x { W1 part [C/8 k-chunks][2 parts][32 hidden rows] | W2 part [4 k-groups][2 parts][C rows] } |
+//                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C]
+template <int KS1, int CT, int ACT, int NW, int ABL>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
+  constexpr int THREADS = 64 * NW;
+  constexpr int C = 32 * KS1;
+  constexpr int NOB = C / 16;                                    // output feature blocks
+  constexpr int NBAT = 2 * KS1;                                  // A-fragment batches per chunk: KS1 k-steps of GEMM 1, KS1 block pairs of GEMM 2
+  constexpr int W1U = 8 * C, W2U = 8 * C, CHU = W1U + W2U;       // units per chunk
+  constexpr int UPT = CHU / THREADS;                             // units per thread and chunk
+  constexpr int WR = ml_ring(UPT, NBAT), WD = ml_dist(NBAT);
+  static_assert(CHU % THREADS == 0 && NOB == 2 * KS1 && NBAT >= 4, "chunk geometry");
+  constexpr int RG = NW * 16 * CT;                               // rows per workgroup round
+  const int M = a.M, Hd = a.Hd, NCH = Hd >> 5, nwg = a.nwg;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  float* b1_lds = reinterpret_cast<float*>(Lds + 2 * CHU);
+  float* w1inv_lds = b1_lds + Hd;
+  float* b2_lds = w1inv_lds + Hd;
+  float* w2inv_lds = b2_lds + C;
+  const int ngroups = (M + RG - 1) / RG;
+  if ((int)blockIdx.x >= ngroups) return;
+
+  for (int r = tid; r < Hd; r += THREADS) {
+    b1_lds[r] = a.b1 ? a.b1[r] : 0.f;
+    w1inv_lds[r] = a.w1inv[r];
+  }
+  for (int r = tid; r < C; r += THREADS) {
+    b2_lds[r] = a.b2 ? a.b2[r] : 0.f;
+    w2inv_lds[r] = a.w2inv[r];
+  }
+
+  // ---- weight stream: unit i = tid + THREADS v of the chunk image
+  auto w_src = [&](int c, int v) __attribute__((always_inline)) -> const u32x4* {
+    const int i = tid + THREADS * v;
+    return i < W1U ? a.W1p + ((size_t)(i >> 5) * Hd + 32 * c + (i & 31)) : a.W2p + ((size_t)c * W2U + (i - W1U));
+  };
+  {
+    u32x4 w0[UPT];                                               // chunk 0 -> buffer 0
+#pragma unroll
+    for (int v = 0; v < UPT; ++v) w0[v] = *w_src(0, v);
+#pragma unroll
+    for (int v = 0; v < UPT; ++v) Lds[tid + THREADS * v] = w0[v];
+  }
+  u32x4 wreg[WR];
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+
+  u32x4 afr[3][2][2];                                            // [ring][block][part]
+  if (ABL == 2) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) afr[r][q][0] = afr[r][q][1] = (u32x4){0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+  }
+  auto read_batch = [&](u32x4 (&d)[2][2], unsigned addr, unsigned pstride) __attribute__((always_inline)) {
+    if (ABL == 2) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned ah = addr + (unsigned)(q * 256);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(d[q][0]), "=&v"(d[q][1]) : "v"(ah), "v"(ah + pstride) : "memory");
+    }
+  };
+  // byte addresses inside a chunk image: GEMM 1 (k-step t, block q): ((t*4 + g)*2 + part)*32 + 16 q + j units;
+  // GEMM 2 (blocks 2 t + q): W1U + (g*2 + part)*C + 16 (2 t + q) + j units
+  const unsigned a1_lane = (unsigned)((g * 64 + j) * 16);
+  const unsigned a2_lane = (unsigned)((W1U + g * 2 * C + j) * 16);
+
+  int gq = 0;                                                    // chunks done: chunk gq's image is in buffer gq & 1
+#pragma unroll 1
+  for (int grp = blockIdx.x; grp < ngroups; grp += nwg) {
+    const int row0 = grp * RG + wave * 16 * CT;
+    // ---- x tile: read once, exact row maximum, two fp16 parts in registers
+    f16x8 xh[CT][KS1], xm[CT][KS1];
+    float sx_inv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int m = min(row0 + 16 * ct + j, M - 1);              // rows past the end repeat the last row (not stored)
+      const unsigned vo = ((unsigned)m * (unsigned)C + (unsigned)(8 * g)) * 4u;
+      f32x4 raw[KS1][2];
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        raw[ks][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, ks * 128, 0));
+        raw[ks][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 16u, ks * 128, 0));
+      }
+      unsigned mx = 0u;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) mx = max(mx, l3_absmax8(raw[ks][0], raw[ks][1]));
+      mx = l3_row_max(mx);
+      float s, inv;
+      l3_scale(mx, 14, s, inv);
+      sx_inv[ct] = inv;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) l3_split8(raw[ks][0], raw[ks][1], s, xh[ct][ks], xm[ct][ks]);
+    }
+
+    f32x4 acc2[NOB][CT];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc2[ob][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int eset[CT];                                                 // exponent the hidden rows' scale was set for
+    float sh[CT], sh_inv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      eset[ct] = -1000;
+      sh[ct] = sh_inv[ct] = 1.0f;
+    }
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c, ++gq) {
+      __syncthreads();                                           // chunk gq's image is complete; the other buffer is free
+      const int cn = (c + 1 == NCH) ? 0 : c + 1;
+      const int bufc = gq & 1;
+      const unsigned a1 = a1_lane + (unsigned)(bufc * CHU * 16);
+      const unsigned a2 = a2_lane + (unsigned)(bufc * CHU * 16);
+      u32x4* const wdst = Lds + (bufc ^ 1) * CHU + tid;
+      read_batch(afr[0], a1, 512u);
+      read_batch(afr[1], a1 + 4096u, 512u);
+
+      f32x4 acc1[2][CT];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc1[q][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f16x8 hh[CT], hm[CT];
+
+      // one batch slot: this slot's share of the weight stream, wait for batch T's fragments, request batch T + 2, six CT MFMAs
+      auto slot = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+        ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
+          constexpr int V = decltype(vc)::value;
+          if constexpr (ml_fs(V, UPT, NBAT) + WD == T) wdst[THREADS * V] = wreg[V % WR];
+        });
+        ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
+          constexpr int V = decltype(vc)::value;
+          if constexpr (ml_fs(V, UPT, NBAT) == T) wreg[V % WR] = *w_src(cn, V);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 2) ml_wait_lgkm<(T + 1 < NBAT ? 4 : 0) + ml_commits_in(T, UPT, NBAT)>(afr[T % 3]);
+        if constexpr (T + 2 < NBAT) {
+          if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], a1 + (unsigned)((T + 2) * 4096), 512u);
+          else read_batch(afr[(T + 2) % 3], a2 + (unsigned)((T + 2 - KS1) * 512), (unsigned)(C * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 1) {
+          const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[T % 3][0][0]), am0 = __builtin_bit_cast(f16x8, afr[T % 3][0][1]);
+          const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[T % 3][1][0]), am1 = __builtin_bit_cast(f16x8, afr[T % 3][1][1]);
+          // smallest terms first: m h', h m', h h'; the two blocks alternate (dependent accumulators two issues apart)
+          if constexpr (T < KS1) {                               // GEMM 1: acc1[block][ct] += W1[chunk rows] x^T, k-step T
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, xh[ct][T], acc1[0][ct], 0, 0, 0);
+              acc1[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, xh[ct][T], acc1[1][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xm[ct][T], acc1[0][ct], 0, 0, 0);
+              acc1[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xm[ct][T], acc1[1][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh[ct][T], acc1[0][ct], 0, 0, 0);
+              acc1[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh[ct][T], acc1[1][ct], 0, 0, 0);
+            }
+          } else {                                               // GEMM 2: acc2[blocks 2 t, 2 t + 1][ct] += W2[rows][k-step c] h^T
+            constexpr int B0 = 2 * (T - KS1), B1 = B0 + 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc2[B0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, hh[ct], acc2[B0][ct], 0, 0, 0);
+              acc2[B1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, hh[ct], acc2[B1][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc2[B0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, hm[ct], acc2[B0][ct], 0, 0, 0);
+              acc2[B1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, hm[ct], acc2[B1][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              acc2[B0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, hh[ct], acc2[B0][ct], 0, 0, 0);
+              acc2[B1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, hh[ct], acc2[B1][ct], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+
+      ml_static_for<0, KS1>(slot);
+
+      // ---- hidden activations of this chunk: bias, activation, running row scale, two fp16 parts = the B operand of GEMM 2
+      if (ABL == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(acc1[q][ct]));
+      }
+      if (ABL == 3) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          hh[ct] = __builtin_bit_cast(f16x8, acc1[0][ct]);
+          hm[ct] = __builtin_bit_cast(f16x8, acc1[1][ct]);
+        }
+      } else {
+        const int hf = 32 * c + 4 * g;
+        const f32x4 wi0 = *reinterpret_cast<const f32x4*>(w1inv_lds + hf), wi1 = *reinterpret_cast<const f32x4*>(w1inv_lds + hf + 16);
+        const f32x4 bi0 = *reinterpret_cast<const f32x4*>(b1_lds + hf), bi1 = *reinterpret_cast<const f32x4*>(b1_lds + hf + 16);
+        f32x4 v0[CT], v1[CT];
+        bool need = false;
+        int enew[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          v0[ct] = (acc1[0][ct] * sx_inv[ct]) * wi0 + bi0;          // two exact unscalings, then the bias
+          v1[ct] = (acc1[1][ct] * sx_inv[ct]) * wi1 + bi1;
+          if (ACT == ML_ACT_RELU) {                               // NaN-propagating maximum (v_maximum3_f32), as torch's relu
+            v0[ct] = __builtin_elementwise_maximum(v0[ct], (f32x4){0.f, 0.f, 0.f, 0.f});
+            v1[ct] = __builtin_elementwise_maximum(v1[ct], (f32x4){0.f, 0.f, 0.f, 0.f});
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[ct][e] = l3_gelu(v0[ct][e]);
+              v1[ct][e] = l3_gelu(v1[ct][e]);
+            }
+          }
+          const unsigned mk = l3_row_max(l3_absmax8(v0[ct], v1[ct]));
+          enew[ct] = max(-100, min((int)((mk >> 23) & 255u) - 127, 128));   // 2^e <= max < 2^(e+1)
+          need = need || (enew[ct] > eset[ct] + 2);
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {              // rare after the first chunk
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const bool mine = enew[ct] > eset[ct] + 2;
+            const int en = mine ? enew[ct] : eset[ct];
+            const float ratio = __builtin_bit_cast(float, (unsigned)(127 + max(eset[ct] - en, -126)) << 23);   // 2^(old - new) <= 1
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc2[ob][ct] *= ratio;
+            eset[ct] = en;
+            sh[ct] = __builtin_bit_cast(float, (unsigned)(127 + 12 - en) << 23);
+            sh_inv[ct] = __builtin_bit_cast(float, (unsigned)(127 - 12 + en) << 23);
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) l3_split8(v0[ct], v1[ct], sh[ct], hh[ct], hm[ct]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      ml_static_for<KS1, NBAT>(slot);
+    }
+
+    // ---- y: D[i = feature][j = row]: a lane holds four consecutive features of its rows
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int m = row0 + 16 * ct + j;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int f = ob * 16 + 4 * g;
+        const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
+        f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
+        const unsigned offc = m < M ? ((unsigned)m * (unsigned)C + (unsigned)f) * 4u : 0xFFFFFFF0u;   // out of range: dropped
+        if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+      }
+    }
+  }
+}
+
+static int ml_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n_cu = v;
+  }
+  return n_cu;
+}
+
+template <int KS1, int CT, int ACT, int NW, int ABL>
+static int ml_launch1(MlpArgs a, size_t lds, int ngroups, hipStream_t st) {
+  const void* fn = reinterpret_cast<const void*>(&mlp_f16x3<KS1, CT, ACT, NW, ABL>);
+  static int per_cu = 0;                                          // resident workgroups per CU (LDS and registers)
+  if (per_cu == 0) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NW, lds) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    per_cu = nb;
+  }
+  a.nwg = std::min(ml_cus() * per_cu, ngroups);
+  hipLaunchKernelGGL((mlp_f16x3<KS1, CT, ACT, NW, ABL>), dim3((unsigned)a.nwg), dim3(64 * NW), lds, st, a);
+  return check_launch("mlp_f16x3");
+}
+
+template <int KS1, int CT, int NW>
+static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
+  constexpr int C = 32 * KS1;
+  constexpr int RG = NW * 16 * CT;
+  const int ngroups = (a.M + RG - 1) / RG;
+  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 2 * C) * 4;
+  if (lds > 160 * 1024) return UNIVS_ERR_NOT_IMPLEMENTED;
+  const int abl = config().linear_ablate;                         // 2 / 3 / 4: timing experiments (encoder FFN and Swin stage 1 only)
+  if (abl >= 2 && abl <= 4 && ((KS1 == 8 && act == ML_ACT_RELU) || (KS1 == 3 && act == ML_ACT_GELU))) {
+    if constexpr (KS1 == 8) {
+      if (abl == 2) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 1>(a, lds, ngroups, st);
+      if (abl == 3) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 2>(a, lds, ngroups, st);
+      return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 3>(a, lds, ngroups, st);
+    }
+    if constexpr (KS1 == 3) {
+      if (abl == 2) return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 1>(a, lds, ngroups, st);
+      if (abl == 3) return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 2>(a, lds, ngroups, st);
+      return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 3>(a, lds, ngroups, st);
+    }
+  }
+  if (act == ML_ACT_RELU) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 0>(a, lds, ngroups, st);
+  return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 0>(a, lds, ngroups, st);
+}
+
+// returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
+int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
+                  const float* b2, const float* residual, float* y, long long M, int C, int Hd, int act, hipStream_t st) {
+  if (M <= 0) return UNIVS_OK;
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
+      mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  MlpArgs a{};
+  a.X = x; a.W1p = reinterpret_cast<const u32x4*>(w1p); a.w1inv = w1inv; a.b1 = b1;
+  a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = residual; a.Y = y;
+  a.M = (int)M; a.Hd = Hd;
+  switch (C) {
+    case 96: return ml_launch<3, 2, 4>(a, act, st);
+    case 128: return ml_launch<4, 1, 8>(a, act, st);
+    case 192: return ml_launch<6, 1, 8>(a, act, st);
+    case 256: return ml_launch<8, 1, 8>(a, act, st);
+    default: return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+}
+
+}  // namespace univs

@@ -24,6 +24,7 @@
 //     LDS: 144 x 148 x 4 (bias) + 8 x 32 x 152 x 2 (V) = 163 072 B of the CU's 163 840: one workgroup per CU.
 #include "common.h"
 #include "config.h"
+#include "f16x3.h"
 #include "window_attn.h"
 
 #include <algorithm>
@@ -38,7 +39,23 @@ constexpr int WH_WAVES = 8;
 
 // TERMS = 1: fp16 operands (UNIVS_MMA_F16).  TERMS = 3: every operand as TWO fp16 parts (h = fp16(x), m = fp16(x - h)) and three
 // of the four part products -- fp32-accurate (<= 2^-21.7 per product, see linear_f16x3.hip) at 3/16 of the exact-f32 MFMA time
-// (UNIVS_MMA_F16X3; no scaling is applied: operands must lie within fp16's range, |x| < 65504).
+// (UNIVS_MMA_F16X3).  Range: a window whose k, v or scaled q holds a magnitude >= 2^15 would turn into Inf - Inf = NaN in the
+// split; every wave therefore tests its operands (one max per two elements and a ballot) and, in that rare case only, brings
+// the operand into [2^14, 2^15) by a wave-uniform power of two -- exact, undone on the fp32 scores (bias scaled with them)
+// and on the 1/sum normaliser -- so the result stays what the exact-f32 kernel returns for any finite input.
+// rare path of the range test: the wave's largest magnitude -> (power of two that brings it into [2^14, 2^15), its inverse),
+// the same value in every lane and in scalar registers
+__device__ __forceinline__ void wh_wave_scale(float mx, float& s, float& inv) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  l3_scale(__builtin_bit_cast(unsigned, mx), 14, s, inv);
+  s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+  inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv)));
+}
+__device__ __forceinline__ bool wh_out_of_range(float mx) {       // wave-uniform: some lane holds a magnitude >= 2^15 (or Inf)
+  return __builtin_amdgcn_ballot_w64(!(mx < 32768.0f)) != 0;
+}
+
 template <int NB, bool MASK4, int TERMS>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
 __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float* __restrict__ qkv,
                                                                       const float* __restrict__ qkv_bias,
@@ -96,18 +113,45 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
     };
 
     // ---- V: 4 keys x 4 channels per lane and round, transposed into LDS as fp16
+    float4 vraw[VR][4];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
       const bool hi_ok = r + VR < NB;                          // compile time
       const int src = hi_ok ? (half ? tok[hi_ok ? r + VR : r] : tok[r]) : tok[r];
-      float4 v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int t = __shfl(src, half * 32 + kgl * 4 + e, 64);
-        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vraw[r][e] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* rp = row_ptr(t);
-        if (rp && (hi_ok || half == 0)) v[e] = *reinterpret_cast<const float4*>(rp + 2 * part + 4 * hg);
+        if (rp && (hi_ok || half == 0)) vraw[r][e] = *reinterpret_cast<const float4*>(rp + 2 * part + 4 * hg);
       }
+    }
+    float sv_inv = 1.0f;                                         // TERMS == 3: inverse of the power of two applied to V (rarely != 1)
+    if (TERMS == 3) {
+      float mv = 0.f;
+#pragma unroll
+      for (int r = 0; r < VR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vraw[r][e].x), fabsf(vraw[r][e].y))), fmaxf(fabsf(vraw[r][e].z), fabsf(vraw[r][e].w)));
+      if (wh_out_of_range(mv)) {
+        float sv;
+        wh_wave_scale(mv, sv, sv_inv);
+#pragma unroll
+        for (int r = 0; r < VR; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vraw[r][e].x *= sv;
+            vraw[r][e].y *= sv;
+            vraw[r][e].z *= sv;
+            vraw[r][e].w *= sv;
+          }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+      const bool hi_ok = r + VR < NB;
+      const float4(&v)[4] = vraw[r];
       if (hi_ok || half == 0) {
         const int jb = r + half * VR;
         _Float16* dst = vt + (4 * hg) * VS + jb * 16 + kgl * 4;
@@ -129,21 +173,43 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
 
     // ---- K fragments: lane holds K[jb*16 + n][8g .. 8g+7] as 8 halves (TERMS = 3: two parts)
     f16x8 kf[NB], kfm[TERMS == 3 ? NB : 1];
+    float sk = 1.0f, sk_inv = 1.0f;                              // TERMS == 3: power of two applied to K (rarely != 1)
+    {
+      float kraw[NB][8];
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-      const float* rp = row_ptr(tok[jb]);
-      if (rp) {
-        const float4* p = reinterpret_cast<const float4*>(rp + part + 8 * g);
-        a = p[0];
-        c = p[1];
-      }
-      const float kk[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      for (int jb = 0; jb < NB; ++jb) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        const float* rp = row_ptr(tok[jb]);
+        if (rp) {
+          const float4* p = reinterpret_cast<const float4*>(rp + part + 8 * g);
+          a = p[0];
+          c = p[1];
+        }
+        const float kk[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        kf[jb][e] = (_Float16)kk[e];
-        if (TERMS == 3) kfm[jb][e] = (_Float16)(kk[e] - (float)kf[jb][e]);
+        for (int e = 0; e < 8; ++e) kraw[jb][e] = kk[e];
       }
+      if (TERMS == 3) {
+        float mk = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) mk = fmaxf(mk, fmaxf(fabsf(kraw[jb][e]), fabsf(kraw[jb][e + 1])));
+        if (wh_out_of_range(mk)) {
+          wh_wave_scale(mk, sk, sk_inv);
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kraw[jb][e] *= sk;
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kf[jb][e] = (_Float16)kraw[jb][e];
+          if (TERMS == 3) kfm[jb][e] = (_Float16)(kraw[jb][e] - (float)kf[jb][e]);
+        }
     }
     // Q of the first query block (the loop below requests block ib + 1 while it computes block ib)
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qc = qa;
@@ -166,6 +232,7 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       const int i = ib * 16 + n;        // this lane's query (column of S^T)
       const int tok_i = token(i);
       f16x8 qf, qfm;
+      float ss = 1.0f, ss_inv = 1.0f;                             // wave-uniform (scalar registers)
       {
         float qq[8] = {qa.x * qscale, qa.y * qscale, qa.z * qscale, qa.w * qscale,
                        qc.x * qscale, qc.y * qscale, qc.z * qscale, qc.w * qscale};
@@ -175,6 +242,19 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
           // product is an fp16 tie the two roundings differ by one fp16 ulp and h + m is off by 2^-11 (one query in ~3 000)
 #pragma unroll
           for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(qq[e]));
+        }
+        if (TERMS == 3) {                                      // range test of the scaled queries of this block
+          float mq = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) mq = fmaxf(mq, fmaxf(fabsf(qq[e]), fabsf(qq[e + 1])));
+          float sq = 1.0f, sq_inv = 1.0f;
+          if (wh_out_of_range(mq)) {
+            wh_wave_scale(mq, sq, sq_inv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qq[e] *= sq;
+          }
+          ss = sk * sq;                                         // the scores come out of the matrix cores times ss
+          ss_inv = sk_inv * sq_inv;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -199,10 +279,15 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
         const f32x4 acc = *reinterpret_cast<const f32x4*>(bias_lds + i * BS + jb * 16 + 4 * g);
         f32x4 sc = acc;
         if (TERMS == 3) {                                      // smallest terms first
+          if (ss != 1.0f) sc = acc * ss;                        // scalar: only windows that needed a range scale
           sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfm[jb], qf, sc, 0, 0, 0);
           sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qfm, sc, 0, 0, 0);
         }
         s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[jb], qf, sc, 0, 0, 0);
+      }
+      if (TERMS == 3 && ss != 1.0f) {                           // scalar
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) s[jb] *= ss_inv;
       }
       if (mask_w) {   // scalar: last row / column of windows only
         // unconditional loads at clamped indices + a select (see window_attn.hip: a load behind a lane condition made
@@ -249,7 +334,7 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;     // of query n (the same value in the four lane groups)
+      const float inv = (1.0f / sum) * sv_inv;     // of query n (the same value in the four lane groups); V's range scale undone
 
       // out[ib] (16 queries x 32 channels) = P[ib, :] @ V : two 16-channel halves
       f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};

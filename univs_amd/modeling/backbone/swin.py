@@ -48,6 +48,11 @@ class Mlp(nn.Module):
         """fc2(GELU(fc1(x))) (+ residual) (swin.py:35-58; the block's `shortcut + mlp(...)` of :291-293 rides in fc2's
         epilogue).  On the GPU both Linears take the three-product fp16 kernel with the GELU / the residual add fused into the
         store where the shape is covered (ops.linear_fused); the library GEMM + elementwise passes otherwise."""
+        if SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda:
+            # both Linears, the GELU and the shortcut add in one kernel (csrc/mlp_f16x3.hip): stages with C <= 256
+            y = ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual)
+            if y is not None:
+                return y
         h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 2) and x.is_cuda) else None
         if h is None:
             h = self.act(self.fc1(x))

@@ -156,7 +156,12 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                               ref_per_query=ref_per_query)
         src = layer_norm(self.norm1, src2, residual=src)
-        ffn = linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias)
+        ffn = None
+        if SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu:
+            # linear1 + ReLU + linear2 in one kernel, the [tokens, d_ffn] activations stay in registers (csrc/mlp_f16x3.hip)
+            ffn = ops.mlp_fused(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu")
+        if ffn is None:
+            ffn = linear(linear_act(src, self.linear1, self.activation), self.linear2.weight, self.linear2.bias)
         if want_next_query and pos is not None and src.is_cuda:
             return layer_norm(self.norm2, ffn, residual=src, post_add=pos)
         src = layer_norm(self.norm2, ffn, residual=src)

@@ -250,22 +250,39 @@ _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 from .switches import SWITCHES   # linear_kmax: widest K routed to the hand-written Linears
 
 
-_PRESPLIT = {}      # id(weight tensor) -> (weak reference to it, (version, data_ptr, device), wp, winv, event recorded behind the
-                    # split, ids of the streams already ordered behind it); dropped with the tensor
+_PRESPLIT = {}      # (id(weight tensor), mode) -> (weak reference to it, (version, data_ptr, device), wp, winv, event recorded behind
+                    # the split, ids of the streams already ordered behind it); dropped with the tensor
+PRESPLIT_MODES = {"linear": 0, "conv": 1, "mlp2": 2}    # include/univs_hip.h: univs_presplit_weights_f32 `conv`
 
 
-def presplit_weights(weight, conv=False):
+def invalidate_presplit(weight=None):
+    """Drop the cached splits of `weight` (all of them without an argument).  The cache notices in-place updates that bump the
+    tensor's version counter (load_state_dict, optimizer steps, `weight.copy_`) and new storages; writes through `weight.data`
+    (common in checkpoint / EMA code) bump a DIFFERENT counter and leave the address unchanged -- after those, call this."""
+    if weight is None:
+        _PRESPLIT.clear()
+        return
+    for mode in PRESPLIT_MODES.values():
+        _PRESPLIT.pop((id(weight), mode), None)
+
+
+def presplit_weights(weight, conv=False, mode=None):
     """The split of a weight tensor for the three-product fp16 GEMM kernels (include/univs_hip.h:
     univs_presplit_weights_f32): `weight` [N, K] (a Linear) or [N, Cin, 3, 3] with `conv=True` -> (wp [N * K] int32 = two fp16
-    parts per element in the kernels' LDS order, winv [N]).  Done once per tensor and cached on the tensor object; an
-    in-place update (load_state_dict, optimizer step), a move to another device or a new storage invalidates the entry."""
+    parts per element in the kernels' LDS order, winv [N]).  `mode="mlp2"`: the second Linear of `mlp_fused` (its k-order).
+    Done once per tensor and mode and cached; an in-place update (load_state_dict, optimizer step), a move to another device
+    or a new storage invalidates the entry (writes through `.data`: see `invalidate_presplit`)."""
+    mode = PRESPLIT_MODES["conv" if conv else (mode or "linear")]
     key = (weight._version, weight.data_ptr(), weight.device)
-    e = _PRESPLIT.get(id(weight))
+    e = _PRESPLIT.get((id(weight), mode))
     if e is not None and e[0]() is weight and e[1] == key:
         # made on another stream (the prompt sampler's side stream, a caller's own): order this stream behind the split, once
-        sid = torch.cuda.current_stream(weight.device).cuda_stream
+        cur = torch.cuda.current_stream(weight.device)
+        sid = cur.cuda_stream
         if sid not in e[5] and not torch.cuda.is_current_stream_capturing():   # (a capture follows eager warm-up calls: graphs.py)
-            torch.cuda.current_stream(weight.device).wait_event(e[4])
+            cur.wait_event(e[4])
+            e[2].record_stream(cur)
+            e[3].record_stream(cur)
             e[5].add(sid)
         return e[2], e[3]
     _require_gpu("presplit_weights", weight)
@@ -273,20 +290,61 @@ def presplit_weights(weight, conv=False):
         raise RuntimeError("presplit_weights: float32 only")
     N = weight.shape[0]
     K = weight.numel() // max(N, 1)
-    if conv and (weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3)):
+    if mode == 1 and (weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3)):
         raise RuntimeError("presplit_weights: conv=True takes a [N, Cin, 3, 3] weight")
     w = weight.detach().contiguous()
     wp = torch.empty(N * K, dtype=torch.int32, device=weight.device)
     winv = torch.empty(N, dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(_lib.load().univs_presplit_weights_f32(_ptr(w), N, K, int(bool(conv)), _ptr(wp), _ptr(winv), _stream_ptr(w)),
+        _lib.check(_lib.load().univs_presplit_weights_f32(_ptr(w), N, K, mode, _ptr(wp), _ptr(winv), _stream_ptr(w)),
                    "presplit_weights")
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(weight.device))
-    wid = id(weight)
+    wid = (id(weight), mode)
     _PRESPLIT[wid] = (weakref.ref(weight, lambda _r, _i=wid: _PRESPLIT.pop(_i, None)), key, wp, winv, done,
                       {torch.cuda.current_stream(weight.device).cuda_stream})
     return wp, winv
+
+
+MLP_WIDTHS = (96, 128, 192, 256)
+
+
+def mlp_fused(x, w1, b1, w2, b2, act, residual=None):
+    """act(x W1^T + b1) W2^T + b2 (+ residual) in ONE kernel (include/univs_hip.h: univs_mlp_presplit_f32; csrc/mlp_f16x3.hip):
+    the encoder FFN (msdeformattn.py:87-91) and the Swin Mlp + shortcut (swin.py:35-58, :291-293).  Both products use the
+    three-product fp16 arithmetic of `linear_fused`; the [M, Hd] hidden activations stay in registers.  `act`: 'relu' | 'gelu'.
+    Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256, Hd % 32, fewer than 2048 rows, autograd needed):
+    the caller keeps two `linear_fused` calls."""
+    C = x.shape[-1]
+    Hd = w1.shape[0]
+    M = x.numel() // max(C, 1)
+    if needs_grad(x, w1, b1, w2, b2, residual) or act not in ("relu", "gelu"):
+        return None
+    if (not x.is_cuda or x.dtype != torch.float32 or w1.dtype != torch.float32 or w2.dtype != torch.float32 or C not in MLP_WIDTHS
+            or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048 or M * C * 4 >= 2 ** 31 - 1
+            or (2 * Hd + 130 * C) * 4 > 160 * 1024):
+        return None
+    x2 = x.contiguous().view(M, C)
+    _require_gpu("mlp_fused", x2)
+    for b, n in ((b1, Hd), (b2, C)):
+        if b is not None and (b.dtype != torch.float32 or tuple(b.shape) != (n,) or not b.is_cuda or not b.is_contiguous()):
+            raise RuntimeError("mlp_fused: biases must be contiguous float32 [Hd] / [C] on the GPU")
+    r = None
+    if residual is not None:
+        if residual.dtype != torch.float32 or not residual.is_cuda or tuple(residual.shape) != tuple(x.shape):
+            raise RuntimeError(f"mlp_fused: residual must be float32 of x's shape on the GPU (got {tuple(residual.shape)})")
+        r = residual.contiguous()
+    y = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        w1p, w1inv = presplit_weights(w1)
+        w2p, w2inv = presplit_weights(w2, mode="mlp2")
+        rc = _lib.load().univs_mlp_presplit_f32(_ptr(x2), _ptr(w1p), _ptr(w1inv), _ptr(b1) if b1 is not None else None, _ptr(w2p),
+                                                _ptr(w2inv), _ptr(b2) if b2 is not None else None, _ptr(r) if r is not None else None,
+                                                M, C, Hd, _ACTS[act], _ptr(y), _stream_ptr(x2))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "mlp_fused")
+    return y.view(x.shape)
 
 
 def linear_fused(x, weight, bias=None, act=None, residual=None):

@@ -31,6 +31,9 @@ class Switches:
     # `swin_fused_parts`: diagnostic bit set, 1 qkv / proj, 2 fc1 + GELU, 4 fc2 + shortcut
     swin_fused_linear: bool = True
     swin_fused_parts: int = 7
+    # two-Linear MLPs (encoder FFN, Swin Mlp + shortcut at C <= 256) in ONE kernel, hidden activations in registers
+    # (csrc/mlp_f16x3.hip); False: two fused Linears
+    fused_mlp: bool = True
     # widest K routed to the hand-written Linears
     linear_kmax: int = 4096
     # Linears with K >= presplit_kmin and the 3 x 3 convolution run on the three-product fp16 kernel with weights split once
@@ -48,7 +51,7 @@ SWITCHES = Switches(
     split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
-    presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")))
+    presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
