@@ -259,20 +259,23 @@ int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv
                                float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * y[M, C] = act(x[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16
+ * y[M, C] = act(LN(x)[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16
  * arithmetic of univs_linear_fused_f32 in both products; the [M, Hd] hidden activations stay in registers (they are neither
- * written to nor read from memory).
+ * written to nor read from memory).  LN: with ln_weight != NULL the rows of x first go through nn.LayerNorm(C) (weight, bias or
+ * NULL, eps; two-pass statistics in registers) -- the pre-norm block `x + mlp(norm2(x))` of the Swin stages is then ONE launch
+ * with residual == x.
  *   w1p, w1inv   univs_presplit_weights_f32(W1 [Hd, C], Hd, C, 0, ...)
  *   w2p, w2inv   univs_presplit_weights_f32(W2 [C, Hd], C, Hd, 2, ...)     (mode 2: the MLP k-order)
  *   b1 [Hd], b2 [C], residual [M, C]: optional (NULL);  act: 1 ReLU, 2 GELU (erf form, as univs_linear_fused_f32)
- * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 130 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
+ * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 132 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
  * aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps two univs_linear_* calls).
  * Replaces: linear2(dropout(activation(linear1(src)))) of the MSDeformAttn encoder layer
  *   (mask2former/modeling/pixel_decoder/msdeformattn.py:87-91) and Mlp.forward + the block's shortcut add of the Swin stages
- *   with C <= 256 (mask2former/modeling/backbone/swin.py:35-58, :291-293).
+ *   with C <= 256 (mask2former/modeling/backbone/swin.py:35-58, :291-293; with LN also norm2 of :289-293).
  * ------------------------------------------------------------------------------------------- */
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                           const float* b2, const float* residual, long long M, int C, int Hd, int act, float* y, void* stream);
+                           const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
+                           long long M, int C, int Hd, int act, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.

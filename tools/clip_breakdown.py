@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--last", type=int, default=8, help="clips to average over")
     ap.add_argument("--skip", type=int, default=-1, help="clips to skip from the start (default: take the LAST clips of the trace)")
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--timeline", action="store_true", help="every launch of ONE clip in order: start (us from the clip's first "
+                    "launch), duration, gap to the previous kernel's end, name")
     ap.add_argument("--detail", default="", help="substring: list every launch of matching kernels in ONE clip with its neighbours")
     args = ap.parse_args()
     rows = []
@@ -50,6 +52,14 @@ def main():
     first = anchors[c0 * args.per_clip]
     end = anchors[(c0 + args.last) * args.per_clip]
     seg = rows[first:end]
+    if args.timeline:
+        one = rows[first:anchors[(c0 + 1) * args.per_clip]]
+        print(f"# clip {c0}: {len(one)} launches;   start_us   dur_us   gap_us  kernel")
+        t0, prev_end = one[0][0], one[0][0]
+        for s_, e_, n_ in one:
+            print(f"  {(s_ - t0) / 1e3:10.1f} {(e_ - s_) / 1e3:8.1f} {(s_ - prev_end) / 1e3:8.1f}  {short(n_)[:90]}")
+            prev_end = max(prev_end, e_)
+        return
     if args.detail:
         one = rows[first:anchors[(c0 + 1) * args.per_clip]]
         print(f"# launches matching {args.detail!r} in clip {c0} (us, previous kernel -> next kernel)")

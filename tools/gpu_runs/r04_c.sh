@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU call C: LayerNorm fused into the Swin MLP launch + shortcut in the proj epilogue, window-attention range scaling
+# (both directions); ATen glue by source line (torch.profiler), one clip's launch timeline, bench.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r04_c
+mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
+timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -s -p no:cacheprovider -k "mlp_fused or window_attention" > $O/ops.log 2>&1
+echo "pytest rc $?" >> $O/ops.log
+timeout 900 python -m pytest tests/test_modules_gpu.py -q -m gpu -p no:cacheprovider -k "swin or config2 or config4_teacher" > $O/parity.log 2>&1
+echo "pytest rc $?" >> $O/parity.log
+timeout 300 python tools/torch_prof.py 0 > $O/torch_prof.txt 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config5 --no-frame-sharded > $O/bench.json 2> $O/bench.err
+cd /tmp; export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-frame-sharded > $O/bench_rocprof.json 2> $O/trace.err
+CSV=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+python $R/tools/clip_breakdown.py $CSV --skip 4 --last 8 --top 80 > $O/clip_breakdown.txt 2>&1
+python $R/tools/clip_breakdown.py $CSV --skip 6 --last 1 --timeline > $O/clip_timeline.txt 2>&1
+rm -rf $O/trace
+echo done

@@ -59,8 +59,8 @@ int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStre
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
-int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*, float*,
-                  long long, int, int, int, hipStream_t);
+int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
+                  const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -196,7 +196,8 @@ int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp,
 }
 
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                           const float* b2, const float* residual, long long M, int C, int Hd, int act, float* y, void* stream) {
+                           const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
+                           long long M, int C, int Hd, int act, float* y, void* stream) {
   clear_sticky_error();
   if (M < 0 || C < 1 || Hd < 1 || (act != 1 && act != 2)) {
     set_error("univs_mlp_presplit_f32: bad arguments M=%lld C=%d Hd=%d act=%d (1 ReLU, 2 GELU)", M, C, Hd, act);
@@ -207,7 +208,8 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
     set_error("univs_mlp_presplit_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, y, M, C, Hd, act, static_cast<hipStream_t>(stream));
+  const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, y, M, C, Hd, act,
+                                      static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256, Hd %% 32 == 0, "
               "M >= 2048)", M, C, Hd);

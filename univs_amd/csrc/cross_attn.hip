@@ -1,0 +1,415 @@
+// Masked multi-head cross-attention core in one pass over the keys: softmax(Q K^T * scale, masked) V per (batch entry, head),
+// the [N h, L, S] scores never reach memory.
+//
+// Replaces, inside nn.MultiheadAttention as the UniVS decoder's CrossAttentionLayer uses it
+// (univs/modeling/transformer_decoder/transformer_layers.py:95-115, called at ...decoder_univs.py:400-405): the scaled score
+// GEMM, `masked_fill(attn_mask, -inf)`, the softmax over the S = H_l W_l keys and the product with V -- three launches and
+// five passes over a [T 8, Q', H_l W_l] fp32 tensor (235 MB at the 1/8 level of a 720p clip) per decoder layer.  The
+// in- and out-projections stay Linears.
+//
+// Arithmetic: the three-product fp16 form of the window attention (window_attn_f16.hip, TERMS = 3): q * scale * log2e, k, v
+// and the un-normalised probabilities are each two fp16 parts (h = fp16(x), m = fp16(x - h)), every product is
+// m h' + h m' + h h' on v_mfma_f32_16x16x32_f16 with fp32 accumulation (error <= 2^-21.7 per product); softmax in fp32 in the
+// exp2 domain.  Range: as there, a wave tests its operands and applies a wave-uniform power of two only when a magnitude
+// would leave fp16's range or the whole block is tiny.
+//
+// Organisation: one WAVE per workgroup handles one (batch entry n, head h) and one segment of the keys, all (<= 128) queries:
+//   * S^T = K (Q scale)^T per 16-key block and 16-query block, so that a lane holds S[query j][keys 4 g .. 4 g + 3]: the
+//     probabilities of TWO key blocks are, as they stand, the A operand of one 16x16x32 product P V over 32 keys with the
+//     k-order (4 g + e, 16 + 4 g + e);
+//   * V is staged per wave in LDS as fp16 parts, transposed ([plane][channel][32 keys]): the transpose is done in registers
+//     on the way in (a lane loads 4 keys x 4 channels and writes four 8-byte rows), the B operand is two 8-byte reads;
+//   * online softmax with a LAZY reference maximum per query: it is raised (and the accumulators rescaled: four cross-lane
+//     reads per query block) only when a block's maximum exceeds it by more than 8 -- un-normalised probabilities up to 2^8
+//     are harmless in fp32 accumulators and fp16 parts -- which after the first blocks is rare;
+//   * every wave writes (m, l, O[32]) per query for its segment; a second small kernel merges the segments
+//     (out = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M)) and stores [L, N, h d].
+#include "common.h"
+#include "config.h"
+#include "f16x3.h"
+
+#include <algorithm>
+
+namespace univs {
+
+typedef _Float16 xa_h4 __attribute__((ext_vector_type(4)));
+typedef unsigned xa_u2 __attribute__((ext_vector_type(2)));
+
+struct XaArgs {
+  const float* q;            // [L, N, H * 32]
+  const float* k;            // [S, N, H * 32]
+  const float* v;            // [S, N, H * 32]
+  const unsigned char* mask; // [N, L, S] (non-zero = masked out) or null
+  float* ws;                 // [N * H][nseg][16 NQB][34]: O[32], m, l
+  float* out;                // [L, N, H * 32]
+  int L, S, N, H, nseg;      // L: queries of this launch (<= 128)
+  int Lfull, l0;             // rows of the mask per batch entry, and the first query of this launch among them
+  float qscale;              // scale * log2(e)
+};
+
+constexpr int XA_PART = 34;
+constexpr int XA_VS = 40;    // halves per channel row of the transposed V (32 keys + 8 of padding: conflict-free 8-byte accesses)
+
+// largest magnitude of the wave -> (power of two that brings it into [2^14, 2^15), its inverse), wave-uniform
+__device__ __forceinline__ void xa_wave_scale(float mx, float& s, float& inv) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  int e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
+  e = max(-40, min(e, 128));
+  s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 + 14 - e) << 23));
+  inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 - 14 + e) << 23));
+}
+__device__ __forceinline__ bool xa_out_of_range(float mx, float lo) {
+  return __builtin_amdgcn_ballot_w64(!(mx < 32768.0f)) != 0 || __builtin_amdgcn_ballot_w64(mx >= lo) == 0;
+}
+__device__ __forceinline__ void xa_split8(const float (&x)[8], f16x8& h, f16x8& m) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 hh = (_Float16)x[e];
+    h[e] = hh;
+    m[e] = (_Float16)(x[e] - (float)hh);
+  }
+}
+// maximum / sum over the four lanes (lane >> 4) that share lane & 15
+__device__ __forceinline__ float xa_col_max(float v) {
+  const xa_u2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float r1 = fmaxf(__uint_as_float(s1.x), __uint_as_float(s1.y));
+  const xa_u2 s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+  return fmaxf(__uint_as_float(s2.x), __uint_as_float(s2.y));
+}
+__device__ __forceinline__ float xa_col_sum(float v) {
+  const xa_u2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float r1 = __uint_as_float(s1.x) + __uint_as_float(s1.y);
+  const xa_u2 s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+  return __uint_as_float(s2.x) + __uint_as_float(s2.y);
+}
+
+template <int NQB>
+__global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
+  constexpr int HD = 32;
+  __shared__ __attribute__((aligned(16))) _Float16 vt[2 * HD * XA_VS];   // [plane][channel][XA_VS]
+  const int lane = threadIdx.x;
+  const int j = lane & 15, g = lane >> 4;
+  const int seg = blockIdx.x, nh = blockIdx.y;
+  const int n = nh / a.H, h = nh - n * a.H;
+  const int L = a.L, S = a.S, N = a.N;
+  const int E = a.H * HD;
+  const long long row_stride = (long long)N * E;                 // floats between consecutive sequence positions
+  const float* qb_ = a.q + (long long)n * E + h * HD;
+  const float* kb_ = a.k + (long long)n * E + h * HD;
+  const float* vb_ = a.v + (long long)n * E + h * HD;
+
+  // this segment's range of 32-key iterations
+  const int nit = (S + 31) >> 5;
+  const int it0 = (int)((long long)nit * seg / a.nseg), it1 = (int)((long long)nit * (seg + 1) / a.nseg);
+
+  // ---- Q fragments: lane holds Q[16 qb + j][8 g .. 8 g + 7] * scale * log2e as two fp16 parts
+  f16x8 qh[NQB], qm[NQB];
+  float ss = 1.0f, ss_inv = 1.0f;                                // the scores come out of the matrix cores times ss (Q's and K's range scales)
+  float sq = 1.0f, sq_inv = 1.0f;
+  {
+    float qraw[NQB][8];
+    float mq = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      const int qi = 16 * qb + j;
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (qi < L) {
+        const float4* p = reinterpret_cast<const float4*>(qb_ + (long long)qi * row_stride + 8 * g);
+        x0 = p[0];
+        x1 = p[1];
+      }
+      const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = t[e] * a.qscale;
+        asm volatile("" : "+v"(v));                              // both fp16 parts from the ROUNDED product (window_attn_f16.hip)
+        qraw[qb][e] = v;
+        mq = fmaxf(mq, fabsf(v));
+      }
+    }
+    if (xa_out_of_range(mq, 0.015625f)) {
+      xa_wave_scale(mq, sq, sq_inv);
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qraw[qb][e] *= sq;
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) xa_split8(qraw[qb], qh[qb], qm[qb]);
+  }
+
+  float mref[NQB], lsum[NQB];                                    // of query 16 qb + j (lsum: this lane's keys only until the end)
+  f32x4 oacc[NQB][2];                                            // O[queries 16 qb + 4 g + r][channel 16 half + j]
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    mref[qb] = -1.0e30f;
+    lsum[qb] = 0.f;
+    oacc[qb][0] = oacc[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // V staging roles: lanes 0-31 key block A (keys s0 .. s0 + 15), lanes 32-63 block B; key group kgl (4 keys), channel group hg
+  const int half = lane >> 5, kgl = (lane >> 3) & 3, hg = lane & 7;
+
+#pragma unroll 1
+  for (int it = it0; it < it1; ++it) {
+    const int s0 = it << 5;
+    // ---- K: two blocks, lane holds K[s0 + 16 kb + j][8 g .. 8 g + 7]
+    f16x8 kh[2], km[2];
+    float sk = 1.0f, sk_inv = 1.0f;
+    {
+      float kraw[2][8];
+      float mk = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int s = s0 + 16 * kb + j;
+        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+        if (s < S) {
+          const float4* p = reinterpret_cast<const float4*>(kb_ + (long long)s * row_stride + 8 * g);
+          x0 = p[0];
+          x1 = p[1];
+        }
+        const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kraw[kb][e] = t[e];
+          mk = fmaxf(mk, fabsf(t[e]));
+        }
+      }
+      if (xa_out_of_range(mk, 0.0625f)) {
+        xa_wave_scale(mk, sk, sk_inv);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kraw[kb][e] *= sk;
+      }
+      xa_split8(kraw[0], kh[0], km[0]);
+      xa_split8(kraw[1], kh[1], km[1]);
+    }
+    ss = sq * sk;
+    ss_inv = sq_inv * sk_inv;
+
+    // ---- V: 4 keys x 4 channels per lane, transposed into LDS as two fp16 planes
+    float sv_inv = 1.0f;
+    {
+      float4 vr[4];
+      float mv = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = s0 + 16 * half + 4 * kgl + e;
+        vr[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S) vr[e] = *reinterpret_cast<const float4*>(vb_ + (long long)s * row_stride + 4 * hg);
+        mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vr[e].x), fabsf(vr[e].y))), fmaxf(fabsf(vr[e].z), fabsf(vr[e].w)));
+      }
+      if (xa_out_of_range(mv, 0.0625f)) {
+        float sv;
+        xa_wave_scale(mv, sv, sv_inv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vr[e].x *= sv;
+          vr[e].y *= sv;
+          vr[e].z *= sv;
+          vr[e].w *= sv;
+        }
+      }
+      const float vv[4][4] = {{vr[0].x, vr[1].x, vr[2].x, vr[3].x}, {vr[0].y, vr[1].y, vr[2].y, vr[3].y},
+                              {vr[0].z, vr[1].z, vr[2].z, vr[3].z}, {vr[0].w, vr[1].w, vr[2].w, vr[3].w}};
+      __builtin_amdgcn_wave_barrier();                           // the previous iteration's reads of vt are done (one wave: program order)
+      _Float16* dst = vt + (4 * hg) * XA_VS + 16 * half + 4 * kgl;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                              // channel 4 hg + c: four keys
+        xa_h4 ch, cm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ch[e] = (_Float16)vv[c][e];
+          cm[e] = (_Float16)(vv[c][e] - (float)ch[e]);
+        }
+        *reinterpret_cast<xa_h4*>(dst + c * XA_VS) = ch;
+        *reinterpret_cast<xa_h4*>(dst + HD * XA_VS + c * XA_VS) = cm;
+      }
+    }
+
+    // ---- V^T fragments of this iteration: B[channel 16 half + j][k-slots: keys 4 g + e, 16 + 4 g + e], two parts
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    __builtin_amdgcn_wave_barrier();
+    f16x8 vh[2], vm[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const _Float16* row = vt + (16 * hf + j) * XA_VS + 4 * g;
+      const xa_h4 a0 = *reinterpret_cast<const xa_h4*>(row), a1 = *reinterpret_cast<const xa_h4*>(row + 16);
+      const xa_h4 b0 = *reinterpret_cast<const xa_h4*>(row + HD * XA_VS), b1 = *reinterpret_cast<const xa_h4*>(row + HD * XA_VS + 16);
+      vh[hf] = (f16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      vm[hf] = (f16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+
+    // ---- per query block: scores of the two key blocks, mask, lazy maximum, probabilities, O += P V over the 32 keys
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      const int qi = min(a.l0 + 16 * qb + j, a.Lfull - 1);
+      f32x4 sc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(km[kb], qh[qb], c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qm[qb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qh[qb], c, 0, 0, 0);
+        if (ss != 1.0f) c *= ss_inv;                              // scalar: only blocks that needed a range scale
+        const int sb = s0 + 16 * kb + 4 * g;                     // my four keys
+        unsigned mw = 0u;
+        if (a.mask) {
+          // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
+          const int sbc = min(sb, S - 4);
+          mw = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * S + sbc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (((mw >> (8 * r)) & 0xffu) != 0u || sb + r >= S) c[r] = -INFINITY;
+        sc[kb] = c;
+      }
+      float bm = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+      bm = xa_col_max(bm);                                       // over the 32 keys, for query j
+      if (__builtin_amdgcn_ballot_w64(bm > mref[qb] + 8.0f) != 0) {   // rare after the first blocks: raise reference maxima
+        const float mnew = (bm > mref[qb] + 8.0f) ? bm : mref[qb];
+        const float alpha = __builtin_amdgcn_exp2f(mref[qb] - mnew);   // of query j (1 when unchanged; 0 at the very first block)
+        mref[qb] = mnew;
+        lsum[qb] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // O's rows are queries 4 g + r: their factors sit in lanes 4 g + r
+          const float ar = __shfl(alpha, 4 * g + r, 64);
+          oacc[qb][0][r] *= ar;
+          oacc[qb][1][r] *= ar;
+        }
+      }
+      float pv[8];
+      float part = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sc[kb][r] - mref[qb]);   // exp2(-inf) = 0 for masked keys
+          part += e;
+          pv[4 * kb + r] = e * sv_inv;                           // V's range scale undone on the probabilities (exact)
+        }
+      lsum[qb] += part;
+      f16x8 ph, pm;                                              // P[query 16 qb + j][k-slots: block A keys 4 g + e, block B keys 4 g + e]
+      xa_split8(pv, ph, pm);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        f32x4 o = oacc[qb][hf];
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pm, vh[hf], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vm[hf], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[hf], o, 0, 0, 0);
+        oacc[qb][hf] = o;
+      }
+    }
+  }
+
+  // ---- this segment's partial: O rows = queries 4 g + r, columns = channels 16 half + j; m and l from the lanes g == 0
+  float* wsb = a.ws + ((long long)nh * a.nseg + seg) * (16 * NQB) * XA_PART;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    const float ltot = xa_col_sum(lsum[qb]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* p = wsb + (long long)(16 * qb + 4 * g + r) * XA_PART;
+      p[j] = oacc[qb][0][r];
+      p[16 + j] = oacc[qb][1][r];
+    }
+    if (g == 0) {
+      float* p = wsb + (long long)(16 * qb + j) * XA_PART;
+      p[32] = mref[qb];
+      p[33] = ltot;
+    }
+  }
+}
+
+// out[q, n, h * 32 + c] = sum_p O_p[c] 2^(m_p - M) / sum_p l_p 2^(m_p - M); one thread per (n h, query, channel)
+__global__ __launch_bounds__(256) void xattn_merge(const float* __restrict__ ws, float* __restrict__ out, int L, int Lp, int N, int H, int nseg) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * H * L * 32;
+  if (idx >= total) return;
+  const int c = (int)(idx & 31);
+  const long long t = idx >> 5;
+  const int q = (int)(t % L);
+  const int nh = (int)(t / L);
+  const int n = nh / H, h = nh - n * H;
+  const float* base = ws + ((long long)nh * nseg * Lp + q) * XA_PART;
+  const long long pstride = (long long)Lp * XA_PART;
+  float M = -INFINITY;
+  for (int p = 0; p < nseg; ++p) M = fmaxf(M, base[p * pstride + 32]);
+  float acc = 0.f, l = 0.f;
+  for (int p = 0; p < nseg; ++p) {
+    const float f = __builtin_amdgcn_exp2f(base[p * pstride + 32] - M);
+    acc = fmaf(base[p * pstride + c], f, acc);
+    l = fmaf(base[p * pstride + 33], f, l);
+  }
+  out[((long long)q * N + n) * (H * 32) + h * 32 + c] = acc / l;
+}
+
+static int xa_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n_cu = v;
+  }
+  return n_cu;
+}
+
+// segments per (batch entry, head) so that ~10 waves per CU run, each with at least two 32-key iterations
+int cross_attention_segments(int S, int N, int H) {
+  const int nit = (S + 31) / 32;
+  const long long want = (10LL * xa_cus() + (long long)N * H - 1) / ((long long)N * H);
+  return (int)std::max<long long>(1, std::min<long long>(want, nit / 2 > 0 ? nit / 2 : 1));
+}
+
+size_t cross_attention_workspace_floats(int L, int S, int N, int H) {
+  const int nqb = (std::min(L, 128) + 15) / 16;
+  return (size_t)N * H * cross_attention_segments(S, N, H) * (16 * nqb) * XA_PART;
+}
+
+// returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.  Queries beyond 128 are handled in chunks.
+int cross_attention_f32(const float* q, const float* k, const float* v, const unsigned char* mask, int L, int S, int N, int H, int hd,
+                        float scale, float* ws, float* out, hipStream_t st) {
+  if (L <= 0 || N <= 0 || H <= 0) return UNIVS_OK;
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (hd != 32 || S < 32 || (mask && (S % 4 != 0 || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
+      mis(ws) || (long long)N * H > 65535)
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  const int nseg = cross_attention_segments(S, N, H);
+  const int E = H * 32;
+  for (int l0 = 0; l0 < L; l0 += 128) {
+    const int Lc = std::min(128, L - l0);
+    const int nqb = (Lc + 15) / 16;
+    XaArgs a{};
+    a.q = q + (long long)l0 * N * E;
+    a.k = k; a.v = v;
+    a.mask = mask;
+    a.ws = ws; a.out = out + (long long)l0 * N * E;
+    a.L = Lc; a.S = S; a.N = N; a.H = H; a.nseg = nseg;
+    a.Lfull = L; a.l0 = l0;
+    a.qscale = scale * 1.4426950408889634f;
+    dim3 grid((unsigned)nseg, (unsigned)(N * H));
+    switch (nqb) {
+      case 1: hipLaunchKernelGGL(xattn_partial<1>, grid, dim3(64), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(xattn_partial<2>, grid, dim3(64), 0, st, a); break;
+      case 3: hipLaunchKernelGGL(xattn_partial<3>, grid, dim3(64), 0, st, a); break;
+      case 4: hipLaunchKernelGGL(xattn_partial<4>, grid, dim3(64), 0, st, a); break;
+      case 5: hipLaunchKernelGGL(xattn_partial<5>, grid, dim3(64), 0, st, a); break;
+      case 6: hipLaunchKernelGGL(xattn_partial<6>, grid, dim3(64), 0, st, a); break;
+      case 7: hipLaunchKernelGGL(xattn_partial<7>, grid, dim3(64), 0, st, a); break;
+      default: hipLaunchKernelGGL(xattn_partial<8>, grid, dim3(64), 0, st, a); break;
+    }
+    int rc = check_launch("xattn_partial");
+    if (rc != UNIVS_OK) return rc;
+    const long long total = (long long)N * H * Lc * 32;
+    hipLaunchKernelGGL(xattn_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, a.out, Lc, 16 * nqb, N, H, nseg);
+    rc = check_launch("xattn_merge");
+    if (rc != UNIVS_OK) return rc;
+  }
+  return UNIVS_OK;
+}
+
+}  // namespace univs

@@ -45,8 +45,21 @@ struct MlpArgs {
   const float* b2;      // [C] or null
   const float* Res;     // [M, C] or null
   float* Y;             // [M, C]
+  const float* ln_g;    // [C] or null: x is first normalised over its C channels (nn.LayerNorm: weight, bias, eps)
+  const float* ln_b;    // [C]
+  float ln_eps;
   int M, Hd, nwg;
 };
+
+// sum over the four lanes (k-groups, lane >> 4) that hold one row.  (The two results are taken through a typed vector and
+// __uint_as_float: hipcc 7.2 evaluates `__builtin_bit_cast(float, s[1])` on the builtin's result as element 0.)
+typedef unsigned ml_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ml_row_sum(float v) {
+  const ml_u2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float r1 = __uint_as_float(s1.x) + __uint_as_float(s1.y);
+  const ml_u2 s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+  return __uint_as_float(s2.x) + __uint_as_float(s2.y);
+}
 
 template <int N>
 __device__ __forceinline__ void ml_wait_lgkm(u32x4 (&d)[2][2]) {   // the operands tie the MFMAs behind this wait
@@ -89,7 +102,7 @@ constexpr int ml_ring(int upt, int nbat) {          // most units in flight at o
 }
 
 // LDS (16-byte units): 2 x { W1 part [C/8 k-chunks][2 parts][32 hidden rows] | W2 part [4 k-groups][2 parts][C rows] } |
-//                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C]
+//                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C] | ln weight[C] | ln bias[C]
 template <int KS1, int CT, int ACT, int NW, int ABL>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
@@ -110,6 +123,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   float* w1inv_lds = b1_lds + Hd;
   float* b2_lds = w1inv_lds + Hd;
   float* w2inv_lds = b2_lds + C;
+  float* lng_lds = w2inv_lds + C;
+  float* lnb_lds = lng_lds + C;
+  const bool with_ln = a.ln_g != nullptr;                        // uniform
   const int ngroups = (M + RG - 1) / RG;
   if ((int)blockIdx.x >= ngroups) return;
 
@@ -120,7 +136,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   for (int r = tid; r < C; r += THREADS) {
     b2_lds[r] = a.b2 ? a.b2[r] : 0.f;
     w2inv_lds[r] = a.w2inv[r];
+    lng_lds[r] = with_ln ? a.ln_g[r] : 1.f;
+    lnb_lds[r] = (with_ln && a.ln_b) ? a.ln_b[r] : 0.f;
   }
+  if (with_ln) __syncthreads();                                  // (the first x tile is normalised before the chunk loop's barrier)
 
   // ---- weight stream: unit i = tid + THREADS v of the chunk image
   auto w_src = [&](int c, int v) __attribute__((always_inline)) -> const u32x4* {
@@ -177,6 +196,33 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
       for (int ks = 0; ks < KS1; ++ks) {
         raw[ks][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, ks * 128, 0));
         raw[ks][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 16u, ks * 128, 0));
+      }
+      if (with_ln) {
+        // nn.LayerNorm over the row's C channels, exact two-pass statistics in registers (as layer_norm.hip), then weight / bias
+        float sm = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm += raw[ks][0][e] + raw[ks][1][e];
+        const float mean = ml_row_sum(sm) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            raw[ks][h2] -= mean;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sq = fmaf(raw[ks][h2][e], raw[ks][h2][e], sq);
+          }
+        const float rstd = 1.0f / sqrtf(ml_row_sum(sq) * (1.0f / C) + a.ln_eps);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(lng_lds + 32 * ks + 8 * g + 4 * h2);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(lnb_lds + 32 * ks + 8 * g + 4 * h2);
+            raw[ks][h2] = (raw[ks][h2] * rstd) * gm + bt;
+          }
       }
       unsigned mx = 0u;
 #pragma unroll
@@ -395,7 +441,7 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
   constexpr int C = 32 * KS1;
   constexpr int RG = NW * 16 * CT;
   const int ngroups = (a.M + RG - 1) / RG;
-  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 2 * C) * 4;
+  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 4 * C) * 4;
   if (lds > 160 * 1024) return UNIVS_ERR_NOT_IMPLEMENTED;
   const int abl = config().linear_ablate;                         // 2 / 3 / 4: timing experiments (encoder FFN and Swin stage 1 only)
   if (abl >= 2 && abl <= 4 && ((KS1 == 8 && act == ML_ACT_RELU) || (KS1 == 3 && act == ML_ACT_GELU))) {
@@ -416,15 +462,17 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
 int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                  const float* b2, const float* residual, float* y, long long M, int C, int Hd, int act, hipStream_t st) {
+                  const float* b2, const float* residual, const float* ln_w, const float* ln_b, float ln_eps, float* y, long long M,
+                  int C, int Hd, int act, hipStream_t st) {
   if (M <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
-      mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2))
+      mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2) || (ln_b && !ln_w))
     return UNIVS_ERR_NOT_IMPLEMENTED;
   MlpArgs a{};
   a.X = x; a.W1p = reinterpret_cast<const u32x4*>(w1p); a.w1inv = w1inv; a.b1 = b1;
   a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = residual; a.Y = y;
+  a.ln_g = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
   a.M = (int)M; a.Hd = Hd;
   switch (C) {
     case 96: return ml_launch<3, 2, 4>(a, act, st);

@@ -40,20 +40,25 @@ constexpr int WH_WAVES = 8;
 // TERMS = 1: fp16 operands (UNIVS_MMA_F16).  TERMS = 3: every operand as TWO fp16 parts (h = fp16(x), m = fp16(x - h)) and three
 // of the four part products -- fp32-accurate (<= 2^-21.7 per product, see linear_f16x3.hip) at 3/16 of the exact-f32 MFMA time
 // (UNIVS_MMA_F16X3).  Range: a window whose k, v or scaled q holds a magnitude >= 2^15 would turn into Inf - Inf = NaN in the
-// split; every wave therefore tests its operands (one max per two elements and a ballot) and, in that rare case only, brings
+// split, and one whose largest magnitude is below 2^-4 (2^-6 for the scaled q) would lose the second part to fp16's subnormals;
+// every wave therefore tests its operands (one max per two elements and two ballots) and, in those rare cases only, brings
 // the operand into [2^14, 2^15) by a wave-uniform power of two -- exact, undone on the fp32 scores (bias scaled with them)
 // and on the 1/sum normaliser -- so the result stays what the exact-f32 kernel returns for any finite input.
 // rare path of the range test: the wave's largest magnitude -> (power of two that brings it into [2^14, 2^15), its inverse),
-// the same value in every lane and in scalar registers
+// the same value in every lane and in scalar registers.  Magnitudes below 2^-40 are scaled as if they were 2^-40 (the product
+// of two scales then stays finite; operands that small contribute < 2^-40 to a score or an output in any case).
 __device__ __forceinline__ void wh_wave_scale(float mx, float& s, float& inv) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  l3_scale(__builtin_bit_cast(unsigned, mx), 14, s, inv);
-  s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
-  inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv)));
+  int e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;   // 2^e <= max < 2^(e+1)
+  e = max(-40, min(e, 128));
+  s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 + 14 - e) << 23));
+  inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 - 14 + e) << 23));
 }
-__device__ __forceinline__ bool wh_out_of_range(float mx) {       // wave-uniform: some lane holds a magnitude >= 2^15 (or Inf)
-  return __builtin_amdgcn_ballot_w64(!(mx < 32768.0f)) != 0;
+// wave-uniform: some lane's largest magnitude is >= 2^15 (the split would overflow: Inf - Inf), or no lane reaches `lo` (the
+// second fp16 part of every element would be subnormal: the operand would carry fewer than ~20 bits)
+__device__ __forceinline__ bool wh_out_of_range(float mx, float lo) {
+  return __builtin_amdgcn_ballot_w64(!(mx < 32768.0f)) != 0 || __builtin_amdgcn_ballot_w64(mx >= lo) == 0;
 }
 
 template <int NB, bool MASK4, int TERMS>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vraw[r][e].x), fabsf(vraw[r][e].y))), fmaxf(fabsf(vraw[r][e].z), fabsf(vraw[r][e].w)));
-      if (wh_out_of_range(mv)) {
+      if (wh_out_of_range(mv, 0.0625f)) {
         float sv;
         wh_wave_scale(mv, sv, sv_inv);
 #pragma unroll
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
         for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
           for (int e = 0; e < 8; e += 2) mk = fmaxf(mk, fmaxf(fabsf(kraw[jb][e]), fabsf(kraw[jb][e + 1])));
-        if (wh_out_of_range(mk)) {
+        if (wh_out_of_range(mk, 0.0625f)) {
           wh_wave_scale(mk, sk, sk_inv);
 #pragma unroll
           for (int jb = 0; jb < NB; ++jb)
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float
 #pragma unroll
           for (int e = 0; e < 8; e += 2) mq = fmaxf(mq, fmaxf(fabsf(qq[e]), fabsf(qq[e + 1])));
           float sq = 1.0f, sq_inv = 1.0f;
-          if (wh_out_of_range(mq)) {
+          if (wh_out_of_range(mq, 0.015625f)) {
             wh_wave_scale(mq, sq, sq_inv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) qq[e] *= sq;

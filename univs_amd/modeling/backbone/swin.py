@@ -44,15 +44,21 @@ class Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = nn.Linear(hidden_features, out_features)
 
+    def fused(self, x, residual=None, norm=None):
+        """Both Linears, the GELU, the shortcut add and (with `norm`, an nn.LayerNorm applied to x first) the block's norm2 in
+        ONE kernel (csrc/mlp_f16x3.hip): stages with C <= 256.  None when the shape is not covered or the fusion is off."""
+        if not (SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda):
+            return None
+        ln = None if norm is None else (norm.weight, norm.bias, norm.eps)
+        return ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual, ln=ln)
+
     def forward(self, x, residual=None):
         """fc2(GELU(fc1(x))) (+ residual) (swin.py:35-58; the block's `shortcut + mlp(...)` of :291-293 rides in fc2's
         epilogue).  On the GPU both Linears take the three-product fp16 kernel with the GELU / the residual add fused into the
         store where the shape is covered (ops.linear_fused); the library GEMM + elementwise passes otherwise."""
-        if SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda:
-            # both Linears, the GELU and the shortcut add in one kernel (csrc/mlp_f16x3.hip): stages with C <= 256
-            y = ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual)
-            if y is not None:
-                return y
+        y = self.fused(x, residual)
+        if y is not None:
+            return y
         h = ops.linear_fused(x, self.fc1.weight, self.fc1.bias, act="gelu") if (SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 2) and x.is_cuda) else None
         if h is None:
             h = self.act(self.fc1(x))
@@ -117,16 +123,22 @@ class WindowAttention(nn.Module):
             self._bias_cache = (key, b.detach())
         return self._bias_cache[1]
 
-    def forward_image(self, x, H, W, shift, mask=None):
+    def forward_image(self, x, H, W, shift, mask=None, residual=None):
         """x: [B, H*W, C] tokens in image order.  Same result as pad -> roll -> window_partition -> forward ->
         window_reverse -> roll -> crop (the reference block, swin.py:252-284), with all of that data movement
         done by index arithmetic inside the attention kernel (the qkv / proj Linears are per token, so they
-        commute with the partition)."""
+        commute with the partition).  `residual` [B, H*W, C]: added to the result."""
         B, L, C = x.shape
         qkv = _linear(self.qkv, x).view(B, L, 3, self.num_heads, C // self.num_heads)
         out = ops.window_attention_image(qkv, self.qkv.bias, self._bias(), mask, H, W, self.window_size[0], shift,
                                          self.scale, mma=self.mma)
-        return _linear(self.proj, out)
+        if residual is None:
+            return _linear(self.proj, out)
+        # the block's `shortcut + attn branch` (swin.py:286) in the proj Linear's epilogue
+        y = None
+        if SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 1) and x.is_cuda:
+            y = ops.linear_fused(out, self.proj.weight, self.proj.bias, residual=residual)
+        return y if y is not None else residual + self.proj(out)
 
     def forward(self, x, mask=None):
         """x: [num_windows*B, N, C]; mask: [nW, N, N] (0 / -100) or None."""
@@ -157,6 +169,13 @@ class SwinTransformerBlock(nn.Module):
         assert L == H * W, "input feature has wrong size"
         ws = self.window_size
         shortcut = x
+        if x.is_cuda and SWITCHES.fused_mlp:
+            # x = shortcut + attn branch from the proj Linear's epilogue; then x + mlp(norm2(x)) in ONE launch where the fused
+            # MLP covers the width (its x tile sits in registers: the LayerNorm costs no pass over memory), else norm2 + Mlp
+            x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
+                                        mask_matrix if self.shift_size > 0 else None, residual=shortcut).reshape(B, H * W, C)
+            y = self.mlp.fused(x, residual=x, norm=self.norm2)
+            return y if y is not None else self.mlp(layer_norm(self.norm2, x), residual=x)
         x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
                                     mask_matrix if self.shift_size > 0 else None)
         # residual add and norm2 in one pass: x = shortcut + attn branch, h = norm2(x)

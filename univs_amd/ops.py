@@ -309,10 +309,12 @@ def presplit_weights(weight, conv=False, mode=None):
 MLP_WIDTHS = (96, 128, 192, 256)
 
 
-def mlp_fused(x, w1, b1, w2, b2, act, residual=None):
-    """act(x W1^T + b1) W2^T + b2 (+ residual) in ONE kernel (include/univs_hip.h: univs_mlp_presplit_f32; csrc/mlp_f16x3.hip):
+def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None):
+    """act(LN(x) W1^T + b1) W2^T + b2 (+ residual) in ONE kernel (include/univs_hip.h: univs_mlp_presplit_f32; csrc/mlp_f16x3.hip):
     the encoder FFN (msdeformattn.py:87-91) and the Swin Mlp + shortcut (swin.py:35-58, :291-293).  Both products use the
     three-product fp16 arithmetic of `linear_fused`; the [M, Hd] hidden activations stay in registers.  `act`: 'relu' | 'gelu'.
+    `ln` = (weight, bias, eps) of an nn.LayerNorm(C) applied to the rows of x inside the kernel first (the Swin block's
+    `x + mlp(norm2(x))`, swin.py:289-293, is then one launch with residual=x).
     Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256, Hd % 32, fewer than 2048 rows, autograd needed):
     the caller keeps two `linear_fused` calls."""
     C = x.shape[-1]
@@ -322,8 +324,17 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None):
         return None
     if (not x.is_cuda or x.dtype != torch.float32 or w1.dtype != torch.float32 or w2.dtype != torch.float32 or C not in MLP_WIDTHS
             or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048 or M * C * 4 >= 2 ** 31 - 1
-            or (2 * Hd + 130 * C) * 4 > 160 * 1024):
+            or (2 * Hd + 132 * C) * 4 > 160 * 1024):
         return None
+    lw = lb = None
+    leps = 0.0
+    if ln is not None:
+        lw, lb, leps = ln
+        for t_ in (lw, lb):
+            if t_ is not None and (t_.dtype != torch.float32 or tuple(t_.shape) != (C,) or not t_.is_cuda or not t_.is_contiguous()):
+                raise RuntimeError("mlp_fused: LayerNorm weight / bias must be contiguous float32 [C] on the GPU")
+        if lw is None:
+            raise RuntimeError("mlp_fused: ln needs a weight")
     x2 = x.contiguous().view(M, C)
     _require_gpu("mlp_fused", x2)
     for b, n in ((b1, Hd), (b2, C)):
@@ -340,6 +351,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None):
         w2p, w2inv = presplit_weights(w2, mode="mlp2")
         rc = _lib.load().univs_mlp_presplit_f32(_ptr(x2), _ptr(w1p), _ptr(w1inv), _ptr(b1) if b1 is not None else None, _ptr(w2p),
                                                 _ptr(w2inv), _ptr(b2) if b2 is not None else None, _ptr(r) if r is not None else None,
+                                                _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
                                                 M, C, Hd, _ACTS[act], _ptr(y), _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
