@@ -257,6 +257,13 @@ int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv,
                               long long M, int N, int K, int act, float* y, void* stream);
 int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
                                float* y, void* stream);
+/* univs_conv1x1_presplit_f32: y = conv2d(x, w [Cout, Cin, 1, 1], bias) (stride 1, no padding) on contiguous float32 NCHW tensors
+ *   through the same kernel (tap addressing with the centre tap alone); (wp, winv) = univs_presplit_weights_f32(w, Cout, Cin, 0),
+ *   bias [Cout] or NULL rides in the epilogue.  Covered: Cin % 96 == 0 or Cin % 128 == 0, Cout % 16 == 0, T*H*W >= 4096.
+ *   Replaces: the 1 x 1 convolutions of the pixel decoder -- lateral convolutions, `mask_features`, `input_proj`
+ *   (mask2former/modeling/pixel_decoder/msdeformattn.py:205-232, :262-283, :331-355). */
+int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, int T, int Cin, int Cout, int H,
+                               int W, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y[M, C] = act(LN(x)[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16
@@ -276,6 +283,26 @@ int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
                            long long M, int C, int Hd, int act, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked multi-head attention core in one pass over the keys (cross_attn.hip):
+ *   out[l, n, h, :] = softmax_s(scale * q[l, n, h, :] . k[s, n, h, :]  masked)  v[s, n, h, :]
+ * Replaces: inside nn.MultiheadAttention.forward as CrossAttentionLayer calls it
+ *           (univs/modeling/transformer_decoder/transformer_layers.py:95-115; ...decoder_univs.py:400-405), between the in- and
+ *           out-projections: the scaled score GEMM, masked_fill(attn_mask, -inf), softmax over the keys, and the product with
+ *           V -- the [N * H, L, S] scores are never written.
+ *   q [L, N, H * head_dim], k / v [S, N, H * head_dim]  sequence-first, contiguous fp32 (the Linears' outputs as they stand)
+ *   mask [N, L, S] uint8 / bool, non-zero = key masked out for that query, shared by the heads; or NULL
+ *        (rows in which every key is masked yield NaN, as nn.MultiheadAttention; the decoder resets such rows beforehand,
+ *        ...decoder_univs.py:390 -- univs_mask_decode_attn_f32 does)
+ *   workspace  univs_cross_attention_workspace(L, S, N, H) floats (per-segment partial results; no allocation inside)
+ * Arithmetic: both products as three products of two-part fp16 splits with fp32 accumulation (the class of
+ * univs_linear_fused_f32), softmax in fp32.  Covered: head_dim == 32, S >= 32, S % 4 == 0 with a mask, N * H <= 65535;
+ * otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps GEMM + univs_masked_softmax_f32 + GEMM).
+ * ------------------------------------------------------------------------------------------- */
+long long univs_cross_attention_workspace(int L, int S, int N, int H);
+int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
+                              float scale, float* workspace, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.

@@ -566,6 +566,96 @@ def test_window_attention_image_matches_reference_data_movement(cuda, mma, B, H,
     assert err < (4e-6 if mma == "f16x3" else 2e-5)
 
 
+def _xattn_reference(q, k, v, mask, H, scale):
+    """nn.MultiheadAttention's core in fp64: q [L, N, E], k / v [S, N, E], mask [N, L, S] bool (True = masked)."""
+    L, N, E = q.shape
+    S = k.shape[0]
+    d = E // H
+    qd = q.double().reshape(L, N, H, d).permute(1, 2, 0, 3)
+    kd = k.double().reshape(S, N, H, d).permute(1, 2, 0, 3)
+    vd = v.double().reshape(S, N, H, d).permute(1, 2, 0, 3)
+    sc = torch.matmul(qd * scale, kd.transpose(-1, -2))
+    if mask is not None:
+        sc = sc.masked_fill(mask.bool()[:, None], float("-inf"))
+    out = torch.matmul(torch.softmax(sc, -1), vd)
+    return out.permute(2, 0, 1, 3).reshape(L, N, E)
+
+
+@pytest.mark.parametrize("L,S,N,H,masked", [(100, 920, 5, 8, True), (100, 14720, 2, 8, True), (20, 3680, 3, 8, True), (100, 3680, 5, 8, False),
+                                             (7, 1000, 1, 2, True), (130, 1504, 2, 4, True), (112, 516, 1, 8, True)], ids=lambda v: str(v))
+def test_cross_attention_matches_torch(cuda, L, S, N, H, masked):
+    """ops.cross_attention (csrc/cross_attn.hip: scores, mask, softmax and P V in one pass over the keys, three-product fp16
+    arithmetic, per-segment partials merged by a second kernel) == nn.MultiheadAttention's core
+    (transformer_layers.py:95-115) in fp64 to fp32 rounding; masks with whole 32-key blocks and whole segments masked for
+    some queries, a query with one visible key, more than 128 queries (chunks), S not a multiple of 32."""
+    E = 32 * H
+    q = synth.normal(f"xa/q/{L}x{N}x{E}", (L, N, E))
+    k = synth.normal(f"xa/k/{S}x{N}x{E}", (S, N, E))
+    v = synth.normal(f"xa/v/{S}x{N}x{E}", (S, N, E))
+    mask = None
+    if masked:
+        g = torch.Generator().manual_seed(L * 7 + S)
+        mask = torch.rand(N, L, S, generator=g) < 0.6
+        mask[:, 1::5, : S // 2] = True                      # half of the keys (whole segments) masked for some queries
+        mask[:, 2::7, 64:640] = True                        # runs of whole 32-key blocks
+        mask[0, 3] = True
+        mask[0, 3, S - 5] = False                            # one visible key
+        mask[..., 0] = mask[..., 0] & ~mask.all(-1)          # no fully masked row: its first key becomes visible
+        assert not mask.all(-1).any()
+    scale = 32 ** -0.5
+    dev = [t.to(cuda) if t is not None else None for t in (q, k, v, mask)]
+    got = ops.cross_attention(dev[0], dev[1], dev[2], dev[3], H, scale)
+    assert got is not None and tuple(got.shape) == (L, N, E)
+    ref64 = _xattn_reference(dev[0], dev[1], dev[2], dev[3], H, scale)
+    sc32 = torch.matmul((dev[0] * scale).reshape(L, N, H, 32).permute(1, 2, 0, 3), dev[1].reshape(S, N, H, 32).permute(1, 2, 3, 0))
+    if mask is not None:
+        sc32 = sc32.masked_fill(dev[3][:, None], float("-inf"))
+    ref32 = torch.matmul(torch.softmax(sc32, -1), dev[2].reshape(S, N, H, 32).permute(1, 2, 0, 3)).permute(2, 0, 1, 3).reshape(L, N, E)
+    err = (got.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    print(f"cross attention {L, S, N, H, masked}: max-abs-err {err:.2e} (ATen fp32 path {err32:.2e})")
+    assert torch.isfinite(got).all()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+    if mask is not None:                                     # uint8 masks are taken as they are
+        assert torch.equal(ops.cross_attention(dev[0], dev[1], dev[2], dev[3].to(torch.uint8), H, scale), got)
+
+
+def test_cross_attention_ranges_and_module_path(cuda):
+    """Operands outside fp16's range (wave-uniform power-of-two scaling inside the kernel), large score spreads (the lazy
+    reference maximum is raised many times), and layers.MultiheadAttention taking the fused core == the unfused path."""
+    from univs_amd import layers
+    from univs_amd.switches import override
+    L, S, N, H = 100, 3680, 2, 8
+    E = 32 * H
+    q = synth.normal("xa2/q", (L, N, E))
+    k = synth.normal("xa2/k", (S, N, E))
+    v = synth.normal("xa2/v", (S, N, E))
+    scale = 32 ** -0.5
+    for name, sq, sk, sv, tol in (("large v", 1.0, 1.0, 1.0e6, 2e-5), ("large k, small q", 1.0e-5, 1.0e5, 1.0, 2e-5),
+                                  ("large q, small k", 3.0e5, 2.0e-6, 1.0, 2e-5), ("sharp scores", 6.0, 6.0, 1.0, 1e-4)):
+        a = [(q * sq).to(cuda), (k * sk).to(cuda), (v * sv).to(cuda)]
+        got = ops.cross_attention(a[0], a[1], a[2], None, H, scale)
+        ref = _xattn_reference(a[0], a[1], a[2], None, H, scale)
+        err = ((got.double() - ref).abs().max() / ref.abs().max()).item()
+        print(f"cross attention, {name}: relative max error {err:.2e}")
+        assert torch.isfinite(got).all() and err < tol, (name, err)
+    mha = layers.MultiheadAttention(E, H).to(cuda).eval()
+    with torch.no_grad():
+        for n_, p_ in mha.named_parameters():
+            p_.copy_(synth.normal(f"xa2/mha/{n_}", tuple(p_.shape), std=0.08).to(cuda))
+        tgt = synth.normal("xa2/tgt", (L, N, E)).to(cuda)
+        mem = synth.normal("xa2/mem", (S, N, E)).to(cuda)
+        key = mem + synth.normal("xa2/pos", (S, N, E)).to(cuda)
+        msk = (torch.rand(N, L, S, generator=torch.Generator().manual_seed(5)) < 0.5).to(cuda)
+        fused = mha(tgt, key, mem, attn_mask=msk)[0]
+        with override(fused_cross_attention=False):
+            plain = mha(tgt, key, mem, attn_mask=msk)[0]
+    assert (fused - plain).abs().max().item() < 2e-5
+    assert ops.cross_attention(torch.zeros(4, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda),
+                               None, 2, 1.0) is None                                            # fewer than 32 keys
+    assert ops.cross_attention(torch.zeros(4, 1, 64), torch.zeros(64, 1, 64), torch.zeros(64, 1, 64), None, 2, 1.0) is None   # CPU
+
+
 @pytest.mark.parametrize("B,H,W,ws,shift,nH", [(2, 14, 21, 7, 3, 3), (1, 20, 31, 9, 4, 2), (1, 23, 40, 7, 0, 2)], ids=lambda v: str(v))
 def test_window_attention_f16x3_out_of_range_operands(cuda, B, H, W, ws, shift, nH):
     """The three-product window attention (the Swin default) on operands OUTSIDE fp16's range: windows whose k, v or scaled q
@@ -903,6 +993,34 @@ def test_conv3x3_matches_torch(cuda, T, Cin, Cout, H, W):
     assert err < max(4.0 * err32, 5e-6), (err, err32)
     assert ops.conv3x3(torch.zeros(1, 96, 64, 64, device=cuda), torch.zeros(64, 96, 3, 3, device=cuda)) is None   # Cin % 128
     assert ops.conv3x3(torch.zeros(1, 128, 16, 16, device=cuda), torch.zeros(128, 128, 3, 3, device=cuda)) is None  # < 4096 pixels
+
+
+@pytest.mark.parametrize("T,Cin,Cout,H,W,bias", [(2, 256, 256, 92, 160, True), (3, 96, 256, 60, 77, False), (1, 192, 256, 46, 93, True),
+                                                  (2, 384, 256, 46, 80, True), (5, 768, 256, 23, 40, True), (1, 128, 64, 70, 70, False)],
+                         ids=lambda v: str(v))
+def test_conv1x1_matches_torch(cuda, T, Cin, Cout, H, W, bias):
+    """ops.conv1x1 (the streamed three-product GEMM with the centre tap alone, bias in the epilogue) == F.conv2d to fp32 rounding:
+    the lateral / mask-feature / input-projection convolutions of the pixel decoder (msdeformattn.py:205-232, :262-283)."""
+    F = torch.nn.functional
+    x = synth.normal(f"c1/x/{T}/{Cin}/{H}/{W}", (T, Cin, H, W)).to(cuda)
+    w = synth.normal(f"c1/w/{Cout}/{Cin}", (Cout, Cin, 1, 1), std=Cin ** -0.5).to(cuda)
+    b = synth.normal(f"c1/b/{Cout}", (Cout,)).to(cuda) if bias else None
+    y = ops.conv1x1(x, w, b)
+    assert y is not None and tuple(y.shape) == (T, Cout, H, W)
+    ref64 = F.conv2d(x.double(), w.double(), b.double() if bias else None)
+    ref32 = F.conv2d(x, w, b)
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    assert err < max(4.0 * err32, 5e-6), (err, err32)
+    assert ops.conv1x1(torch.zeros(1, 80, 64, 64, device=cuda), torch.zeros(64, 80, 1, 1, device=cuda)) is None      # Cin
+    assert ops.conv1x1(torch.zeros(1, 128, 16, 16, device=cuda), torch.zeros(128, 128, 1, 1, device=cuda)) is None   # < 4096 pixels
+    from univs_amd import layers
+    conv = layers.Conv2d(Cin, Cout, kernel_size=1, bias=bias).to(cuda)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        if bias:
+            conv.bias.copy_(b)
+        assert (conv(x) - ref32).abs().max().item() < max(8.0 * err32, 1e-5)
 
 
 def test_presplit_weights_cache_and_wide_linear(cuda):

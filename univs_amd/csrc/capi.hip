@@ -59,11 +59,15 @@ int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStre
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
+int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, int, int, int, int, int, float, float*, float*,
+                        hipStream_t);
+size_t cross_attention_workspace_floats(int, int, int, int);
 int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
                   const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
+int conv1x1_f16x3_f32(const float*, const void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int window_attention_image_f16mma(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                   int, float, int, float*, hipStream_t);
 int window_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float,
@@ -193,6 +197,49 @@ int univs_presplit_weights_f32(const float* w, int N, int K, int conv, void* wp,
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return univs::presplit_f16x3(w, N, K, conv == 1 ? K / 9 : 0, conv == 2 ? 1 : 0, wp, winv, static_cast<hipStream_t>(stream));
+}
+
+int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, int T, int Cin, int Cout, int H,
+                               int W, float* y, void* stream) {
+  clear_sticky_error();
+  if (T < 0 || Cin < 1 || Cout < 0 || H < 0 || W < 0) {
+    set_error("univs_conv1x1_presplit_f32: bad dimensions T=%d Cin=%d Cout=%d H=%d W=%d", T, Cin, Cout, H, W);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0 || Cout == 0 || H == 0 || W == 0) return UNIVS_OK;
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_conv1x1_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::conv1x1_f16x3_f32(x, wp, winv, bias, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_conv1x1_presplit_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 96 or %% 128, Cout %% 16, >= 4096 pixels)", T,
+              Cin, Cout, H, W);
+  return rc;
+}
+
+long long univs_cross_attention_workspace(int L, int S, int N, int H) {
+  if (L <= 0 || S <= 0 || N <= 0 || H <= 0) return 0;
+  return (long long)univs::cross_attention_workspace_floats(L, S, N, H);
+}
+
+int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
+                              float scale, float* workspace, float* out, void* stream) {
+  clear_sticky_error();
+  if (L < 0 || S < 1 || N < 0 || H < 1 || head_dim < 1) {
+    set_error("univs_cross_attention_f32: bad dimensions L=%d S=%d N=%d H=%d head_dim=%d", L, S, N, H, head_dim);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (L == 0 || N == 0) return UNIVS_OK;
+  if (!q || !k || !v || !workspace || !out) {
+    set_error("univs_cross_attention_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::cross_attention_f32(q, k, v, mask, L, S, N, H, head_dim, scale, workspace, out, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_cross_attention_f32: L=%d S=%d N=%d H=%d head_dim=%d not covered (head_dim == 32, S >= 32, with a mask S %% 4 == 0, "
+              "N * H <= 65535, 16-byte aligned pointers)", L, S, N, H, head_dim);
+  return rc;
 }
 
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,

@@ -75,6 +75,7 @@ struct GsArgs {
   float* Y;
   int M, N, K, rows_per_pass, epi;
   int Cin, Cout, H, Wd, HW;      // conv (XMODE 1): X [T, Cin, H, W], Y [T, Cout, H, W]
+  int tap0;                      // conv: first tap of the kernel (0: all nine taps of a 3 x 3; 4: the centre alone = a 1 x 1)
 };
 
 // LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp]
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
       }
     } else {
       // 8 input channels (a plane apart) of tap ks / kspt at my pixel; taps outside the image read 0 (offset out of range)
-      const int tap = ks / kspt, cb = (ks - tap * kspt) * 32;    // uniform
+      const int tap_ = ks / kspt, cb = (ks - tap_ * kspt) * 32;  // uniform
+      const int tap = tap_ + a.tap0;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -420,7 +422,28 @@ int conv3x3_f16x3_f32(const float* x, const void* wp, const float* winv, float* 
   a.X = x; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = nullptr; a.Res = nullptr; a.Y = y;
   a.M = (int)M; a.N = Cout; a.K = 9 * Cin; a.epi = GS_EPI_NONE;
   a.Cin = Cin; a.Cout = Cout; a.H = H; a.Wd = W; a.HW = H * W;
+  a.tap0 = 0;
   return gs_launch<1>(a, 4, st);
+}
+
+// y = conv2d(x, w [Cout, Cin, 1, 1], bias) on NCHW tensors: the same kernel with the centre tap alone (K = Cin; w pre-split as a
+// Linear's [Cout, Cin]).  The lateral / mask-feature / input-projection convolutions of the pixel decoder
+// (msdeformattn.py:214-232, :262-283): the library runs them as fp32 GEMMs at ~110 TF/s and adds the bias in a second pass.
+int conv1x1_f16x3_f32(const float* x, const void* wp, const float* winv, const float* bias, float* y, int T, int Cin, int Cout, int H,
+                      int W, hipStream_t st) {
+  if (T <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UNIVS_OK;
+  const long long M = (long long)T * H * W;
+  const int ring = Cin % 128 == 0 ? 4 : Cin % 96 == 0 ? 3 : 0;
+  if (ring == 0 || Cout % 16 != 0 || M < 4096 || M * std::max(Cin, Cout) * 4 >= 0x7FFFFFFFLL ||
+      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wp) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (reinterpret_cast<uintptr_t>(winv) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  GsArgs a{};
+  a.X = x; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = bias; a.Res = nullptr; a.Y = y;
+  a.M = (int)M; a.N = Cout; a.K = Cin; a.epi = GS_EPI_NONE;
+  a.Cin = Cin; a.Cout = Cout; a.H = H; a.Wd = W; a.HW = H * W;
+  a.tap0 = 4;
+  return gs_launch<1>(a, ring, st);
 }
 
 }  // namespace univs

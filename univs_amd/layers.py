@@ -61,6 +61,10 @@ class Conv2d(nn.Conv2d):
                 and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1):
             from . import ops
             y = ops.conv3x3(x, self.weight)       # None when not covered
+        elif (SWITCHES.split_conv and x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+              and self.dilation == (1, 1) and self.groups == 1):
+            from . import ops
+            y = ops.conv1x1(x, self.weight, self.bias)   # bias in the epilogue; None when not covered
         x = y if y is not None else F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if isinstance(self.norm, nn.GroupNorm) and x.dtype == torch.float32:
             # GroupNorm (+ ReLU) epilogue through the HIP operator; the module only holds the parameters
@@ -133,6 +137,15 @@ class MultiheadAttention(nn.Module):
             else:
                 k = lin(key, w[E:2 * E], b[E:2 * E])
                 v = lin(value, w[2 * E:], b[2 * E:])
+        if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 512 and L <= 512
+                and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8) and attn_mask.dim() == 3
+                                           and attn_mask.shape[0] == N))):
+            # long key sequences against few queries (the decoder's masked cross-attention over the H_l W_l pixels of a
+            # level): scores, mask, softmax and P V in one pass over the keys, the [N h, L, S] scores never exist
+            from . import ops
+            out = ops.cross_attention(q, k, v, attn_mask, h, 1.0 / math.sqrt(d))
+            if out is not None:
+                return self.out_proj(out), None
         # [L, N, h, d] -> [N, h, L, d]
         q = q.reshape(L, N, h, d).permute(1, 2, 0, 3)
         k = k.reshape(S, N, h, d).permute(1, 2, 0, 3)

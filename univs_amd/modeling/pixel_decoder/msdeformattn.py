@@ -317,11 +317,22 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 return g({k: features[k] for k in self.in_features})
             return self._forward_features(features)
 
+    def _input_proj(self, idx, x):
+        """input_proj[idx] = Sequential(Conv2d 1 x 1, GroupNorm(32)) (msdeformattn.py:205-212) through the HIP operators (the
+        modules only hold the parameters; plain nn.Conv2d / nn.GroupNorm would take MIOpen + ATen)."""
+        conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+        if x.is_cuda and x.dtype == torch.float32 and not ops.needs_grad(x, conv.weight):
+            y = ops.conv1x1(x, conv.weight, conv.bias) if SWITCHES.split_conv else None
+            if y is None:
+                y = conv(x)
+            return ops.group_norm(y, gn.num_groups, gn.weight, gn.bias, gn.eps)
+        return self.input_proj[idx](x)
+
     def _forward_features(self, features):
         srcs, pos = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f].float()
-            srcs.append(self.input_proj[idx](x))
+            srcs.append(self._input_proj(idx, x))
             pos.append(self._pos(x))
         y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
         bs = y.shape[0]

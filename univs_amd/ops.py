@@ -582,6 +582,33 @@ def conv3x3(x, weight):
     return y
 
 
+def conv1x1(x, weight, bias=None):
+    """F.conv2d(x, weight, bias) for a 1 x 1 kernel (stride 1, no padding), float32 NCHW on the GPU, through the three-product fp16
+    streamed GEMM (include/univs_hip.h: univs_conv1x1_presplit_f32) with the bias in the epilogue: the lateral, mask-feature and
+    input-projection convolutions of the pixel decoder (msdeformattn.py:205-232, :262-283).  None when not covered."""
+    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or x.dim() != 4 or weight.dim() != 4
+            or tuple(weight.shape[2:]) != (1, 1) or weight.shape[1] != x.shape[1] or needs_grad(x, weight, bias)
+            or SWITCHES.presplit_kmin <= 0):
+        return None
+    T, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if (Cin % 96 and Cin % 128) or Cout % 16 or T * H * W < 4096:
+        return None
+    if bias is not None and (bias.dtype != torch.float32 or tuple(bias.shape) != (Cout,) or not bias.is_cuda):
+        return None
+    x = x.contiguous()
+    b = bias.contiguous() if bias is not None else None
+    y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        wp, winv = presplit_weights(weight)
+        rc = _lib.load().univs_conv1x1_presplit_f32(_ptr(x), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None, T, Cin, Cout, H, W,
+                                                    _ptr(y), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "conv1x1")
+    return y
+
+
 def transpose_last2(x):
     """Contiguous copy of `x.transpose(-2, -1)` for a float32 tensor on the GPU (LDS tile transpose at HBM rate instead of
     ATen's strided copy): tokens [B, H*W, C] <-> channel-major [B, C, H*W] at the edges of the Swin backbone
@@ -693,6 +720,37 @@ def masked_softmax_(scores, mask=None):
         rc = _lib.load().univs_masked_softmax_f32(_ptr(scores), mptr, N, h, L, S, _stream_ptr(scores))
     _lib.check(rc, "masked_softmax_")
     return scores
+
+
+def cross_attention(q, k, v, mask, num_heads, scale):
+    """softmax(scale q k^T, masked) v per (batch entry, head) in one pass over the keys (include/univs_hip.h:
+    univs_cross_attention_f32; csrc/cross_attn.hip): the attention core of nn.MultiheadAttention as the decoder's
+    CrossAttentionLayer uses it (transformer_layers.py:95-115) between the in- and out-projections.
+    q [L, N, E], k / v [S, N, E] sequence-first contiguous float32 (E = num_heads * 32); mask bool / uint8 [N, L, S] (True =
+    masked out, shared by the heads) or None.  Returns [L, N, E], or None when the shape is not covered."""
+    _inference_only("cross_attention", q, k, v)
+    if not (q.is_cuda and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32):
+        return None
+    L, N, E = q.shape
+    S = k.shape[0]
+    H = int(num_heads)
+    if E != 32 * H or tuple(k.shape) != (S, N, E) or tuple(v.shape) != (S, N, E) or S < 32 or N * H > 65535 or L < 1:
+        return None
+    if mask is not None:
+        if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8) or S % 4 != 0 or not mask.is_cuda:
+            return None
+        mask = mask.contiguous()
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    lib = _lib.load()
+    ws = torch.empty(int(lib.univs_cross_attention_workspace(L, S, N, H)), dtype=torch.float32, device=q.device)
+    out = torch.empty((L, N, E), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.univs_cross_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask) if mask is not None else None, L, S, N, H, 32,
+                                           float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "cross_attention")
+    return out
 
 
 MMA_DTYPES = {"f32": 0, "f16": 1, "f16x3": 2}      # UNIVS_MMA_F32 / _F16 / _F16X3 (include/univs_hip.h)

@@ -34,6 +34,9 @@ class Switches:
     # two-Linear MLPs (encoder FFN, Swin Mlp + shortcut at C <= 256) in ONE kernel, hidden activations in registers
     # (csrc/mlp_f16x3.hip); False: two fused Linears
     fused_mlp: bool = True
+    # decoder cross-attention core (scores, mask, softmax, P V) as one pass over the keys (csrc/cross_attn.hip); False: two
+    # library GEMMs around the masked-softmax kernel
+    fused_cross_attention: bool = True
     # widest K routed to the hand-written Linears
     linear_kmax: int = 4096
     # Linears with K >= presplit_kmin and the 3 x 3 convolution run on the three-product fp16 kernel with weights split once
@@ -51,7 +54,8 @@ SWITCHES = Switches(
     split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
-    presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True))
+    presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
+    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
