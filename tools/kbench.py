@@ -212,6 +212,30 @@ def main():
                 for tag, abl in (("no_mfma_us", 2), ("no_lds_reads_us", 3), ("no_activation_split_us", 4)):
                     with ops.configured(linear_ablate=abl):
                         res[nm][tag] = timeit(lambda: ops.mlp_fused(xs, w1, b1, w2, b2, act, residual=rs)) * 1e6
+    if args.only and "smallm" in args.only:
+        # the Swin stage-3 / stage-4 Linears (few rows, wide): time by output features per pass and by workgroups along the rows
+        from univs_amd.switches import override as _ov
+        for nm, Mr, K_, N_, act, res_ in (("s3_qkv", T * 3680, 384, 1152, None, False), ("s3_proj", T * 3680, 384, 384, None, True),
+                                          ("s3_fc1", T * 3680, 384, 1536, "gelu", False), ("s3_fc2", T * 3680, 1536, 384, None, True),
+                                          ("s4_qkv", T * 920, 768, 2304, None, False), ("s4_fc1", T * 920, 768, 3072, "gelu", False),
+                                          ("s4_fc2", T * 920, 3072, 768, None, True)):
+            xs = synth.normal(f"kb/sm/x{K_}/{Mr}", (Mr, K_)).to(dev)
+            w_ = synth.normal(f"kb/sm/w{K_}x{N_}", (N_, K_), std=K_ ** -0.5).to(dev)
+            b_ = synth.normal(f"kb/sm/b{N_}", (N_,)).to(dev)
+            rs = synth.normal(f"kb/sm/r{N_}/{Mr}", (Mr, N_)).to(dev) if res_ else None
+            row = {}
+            for kind, kmin in (("resident", 0), ("stream", 96)):
+                if kind == "resident" and K_ > 768:
+                    continue
+                with _ov(presplit_kmin=kmin):
+                    for rpp in (0, 64, 32):
+                        for gx in (0, 16, 32, 64, 128):
+                            with ops.configured(linear_rows_per_pass=rpp, linear_grid_x=gx):
+                                if ops.linear_fused(xs, w_, b_, act=act, residual=rs) is None:
+                                    continue
+                                row[f"{kind}_r{rpp}_g{gx}"] = round(timeit(lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs), iters=10, warmup=3) * 1e6, 1)
+            best = min(row, key=row.get)
+            res[nm] = dict(best=best, best_us=row[best], default_resident=row.get("resident_r0_g0"), default_stream=row.get("stream_r0_g0"), all=row)
     if args.only and "conv" in args.only:
         from univs_amd.switches import override as _ov
         xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)

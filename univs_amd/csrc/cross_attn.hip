@@ -22,6 +22,9 @@
 //   * online softmax with a LAZY reference maximum per query: it is raised (and the accumulators rescaled: four cross-lane
 //     reads per query block) only when a block's maximum exceeds it by more than 8 -- un-normalised probabilities up to 2^8
 //     are harmless in fp32 accumulators and fp16 parts -- which after the first blocks is rare;
+//   * the Q fragments (two fp16 parts, 16 NQB x 32 x 4 bytes) live in LDS in B-operand order and are re-read per query block
+//     (two conflict-free 16-byte reads), which leaves the registers for a PREFETCH of the next iteration's K rows, V rows and
+//     mask words: a wave has one partner per SIMD at most, so nothing else hides the memory latency of these loads;
 //   * every wave writes (m, l, O[32]) per query for its segment; a second small kernel merges the segments
 //     (out = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M)) and stores [L, N, h d].
 #include "common.h"
@@ -88,6 +91,7 @@ template <int NQB>
 __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   constexpr int HD = 32;
   __shared__ __attribute__((aligned(16))) _Float16 vt[2 * HD * XA_VS];   // [plane][channel][XA_VS]
+  __shared__ __attribute__((aligned(16))) f16x8 qlds[2 * NQB * 64];      // [part][query block][lane]
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int seg = blockIdx.x, nh = blockIdx.y;
@@ -103,8 +107,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   const int nit = (S + 31) >> 5;
   const int it0 = (int)((long long)nit * seg / a.nseg), it1 = (int)((long long)nit * (seg + 1) / a.nseg);
 
-  // ---- Q fragments: lane holds Q[16 qb + j][8 g .. 8 g + 7] * scale * log2e as two fp16 parts
-  f16x8 qh[NQB], qm[NQB];
+  // ---- Q fragments: lane's Q[16 qb + j][8 g .. 8 g + 7] * scale * log2e as two fp16 parts -> LDS (B-operand order)
   float ss = 1.0f, ss_inv = 1.0f;                                // the scores come out of the matrix cores times ss (Q's and K's range scales)
   float sq = 1.0f, sq_inv = 1.0f;
   {
@@ -136,7 +139,12 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
         for (int e = 0; e < 8; ++e) qraw[qb][e] *= sq;
     }
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) xa_split8(qraw[qb], qh[qb], qm[qb]);
+    for (int qb = 0; qb < NQB; ++qb) {
+      f16x8 h8, m8;
+      xa_split8(qraw[qb], h8, m8);
+      qlds[qb * 64 + lane] = h8;
+      qlds[(NQB + qb) * 64 + lane] = m8;
+    }
   }
 
   float mref[NQB], lsum[NQB];                                    // of query 16 qb + j (lsum: this lane's keys only until the end)
@@ -150,31 +158,76 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   // V staging roles: lanes 0-31 key block A (keys s0 .. s0 + 15), lanes 32-63 block B; key group kgl (4 keys), channel group hg
   const int half = lane >> 5, kgl = (lane >> 3) & 3, hg = lane & 7;
 
+  // raw operands of one 32-key iteration: K rows (lane: key 16 kb + j, channels 8 g ..), V rows (lane: 4 keys x 4 channels), and
+  // the mask dword of (query 16 qb + j, keys 16 kb + 4 g ..) per query block; loaded one iteration ahead
+  float4 kn[2][2], vn[4];
+  unsigned mwn[NQB][2];
+  auto load_iter = [&](int it) __attribute__((always_inline)) {
+    const int s0 = it << 5;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int s = s0 + 16 * kb + j;
+      kn[kb][0] = kn[kb][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < S) {
+        const float4* p = reinterpret_cast<const float4*>(kb_ + (long long)s * row_stride + 8 * g);
+        kn[kb][0] = p[0];
+        kn[kb][1] = p[1];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s = s0 + 16 * half + 4 * kgl + e;
+      vn[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < S) vn[e] = *reinterpret_cast<const float4*>(vb_ + (long long)s * row_stride + 4 * hg);
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        mwn[qb][kb] = 0u;
+        if (a.mask) {
+          // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
+          const int qi = min(a.l0 + 16 * qb + j, a.Lfull - 1);
+          const int sbc = min(s0 + 16 * kb + 4 * g, S - 4);
+          mwn[qb][kb] = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * S + sbc);
+        }
+      }
+  };
+  if (it0 < it1) load_iter(it0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): the Q fragments are in LDS
+  __builtin_amdgcn_wave_barrier();
+
 #pragma unroll 1
   for (int it = it0; it < it1; ++it) {
     const int s0 = it << 5;
-    // ---- K: two blocks, lane holds K[s0 + 16 kb + j][8 g .. 8 g + 7]
+    // ---- this iteration's operands out of the prefetch registers; the next iteration's loads go out behind them
+    float kraw[2][8];
+    float4 vr[4];
+    unsigned mw[NQB][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const float t[8] = {kn[kb][0].x, kn[kb][0].y, kn[kb][0].z, kn[kb][0].w, kn[kb][1].x, kn[kb][1].y, kn[kb][1].z, kn[kb][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kraw[kb][e] = t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[e] = vn[e];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      mw[qb][0] = mwn[qb][0];
+      mw[qb][1] = mwn[qb][1];
+    }
+    if (it + 1 < it1) load_iter(it + 1);                         // scalar
+
+    // ---- K: two blocks, two fp16 parts
     f16x8 kh[2], km[2];
     float sk = 1.0f, sk_inv = 1.0f;
     {
-      float kraw[2][8];
       float mk = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int s = s0 + 16 * kb + j;
-        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-        if (s < S) {
-          const float4* p = reinterpret_cast<const float4*>(kb_ + (long long)s * row_stride + 8 * g);
-          x0 = p[0];
-          x1 = p[1];
-        }
-        const float t[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          kraw[kb][e] = t[e];
-          mk = fmaxf(mk, fabsf(t[e]));
-        }
-      }
+        for (int e = 0; e < 8; e += 2) mk = fmaxf(mk, fmaxf(fabsf(kraw[kb][e]), fabsf(kraw[kb][e + 1])));
       if (xa_out_of_range(mk, 0.0625f)) {
         xa_wave_scale(mk, sk, sk_inv);
 #pragma unroll
@@ -191,15 +244,10 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
     // ---- V: 4 keys x 4 channels per lane, transposed into LDS as two fp16 planes
     float sv_inv = 1.0f;
     {
-      float4 vr[4];
       float mv = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = s0 + 16 * half + 4 * kgl + e;
-        vr[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < S) vr[e] = *reinterpret_cast<const float4*>(vb_ + (long long)s * row_stride + 4 * hg);
+      for (int e = 0; e < 4; ++e)
         mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vr[e].x), fabsf(vr[e].y))), fmaxf(fabsf(vr[e].z), fabsf(vr[e].w)));
-      }
       if (xa_out_of_range(mv, 0.0625f)) {
         float sv;
         xa_wave_scale(mv, sv, sv_inv);
@@ -244,25 +292,19 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
     // ---- per query block: scores of the two key blocks, mask, lazy maximum, probabilities, O += P V over the 32 keys
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-      const int qi = min(a.l0 + 16 * qb + j, a.Lfull - 1);
+      const f16x8 qh = qlds[qb * 64 + lane], qm = qlds[(NQB + qb) * 64 + lane];
       f32x4 sc[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(km[kb], qh[qb], c, 0, 0, 0);   // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qm[qb], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qh[qb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(km[kb], qh, c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kb], qh, c, 0, 0, 0);
         if (ss != 1.0f) c *= ss_inv;                              // scalar: only blocks that needed a range scale
         const int sb = s0 + 16 * kb + 4 * g;                     // my four keys
-        unsigned mw = 0u;
-        if (a.mask) {
-          // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
-          const int sbc = min(sb, S - 4);
-          mw = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * S + sbc);
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (((mw >> (8 * r)) & 0xffu) != 0u || sb + r >= S) c[r] = -INFINITY;
+          if (((mw[qb][kb] >> (8 * r)) & 0xffu) != 0u || sb + r >= S) c[r] = -INFINITY;
         sc[kb] = c;
       }
       float bm = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
@@ -358,11 +400,12 @@ static int xa_cus() {
   return n_cu;
 }
 
-// segments per (batch entry, head) so that ~10 waves per CU run, each with at least two 32-key iterations
+// segments per (batch entry, head): one round of the 8 waves per CU the kernel's registers allow, each wave with at least three
+// 32-key iterations (the Q fragments cost about one)
 int cross_attention_segments(int S, int N, int H) {
   const int nit = (S + 31) / 32;
-  const long long want = (10LL * xa_cus() + (long long)N * H - 1) / ((long long)N * H);
-  return (int)std::max<long long>(1, std::min<long long>(want, nit / 2 > 0 ? nit / 2 : 1));
+  const long long want = std::max<long long>(1, (8LL * xa_cus()) / ((long long)N * H));
+  return (int)std::max<long long>(1, std::min<long long>(want, nit / 3 > 0 ? nit / 3 : 1));
 }
 
 size_t cross_attention_workspace_floats(int L, int S, int N, int H) {

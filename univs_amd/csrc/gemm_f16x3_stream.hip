@@ -355,7 +355,8 @@ static int gs_cus() {
 template <int XMODE>
 static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   GsArgs a = a0;
-  const int r_cap = 128;
+  const UnivsConfig cfg_ = config();
+  const int r_cap = cfg_.linear_rows_per_pass >= 16 ? std::min(128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16) : 128;
   const int passes = (a.N + r_cap - 1) / r_cap;
   int rows = (a.N + passes - 1) / passes;
   rows = (rows + 3) & ~3;
@@ -366,6 +367,7 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   long long gx = std::max<long long>(1, gs_cus() / passes);
   gx = std::min(gx, std::max<long long>(1, WT / 8));
   if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;     // the passes of a row range share an XCD (linear_f16x3.hip)
+  if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
   const size_t lds = (size_t)2 * ring * 8 * (16 * RB) * 16 + 8 * (size_t)(16 * RB);
   dim3 grid((unsigned)gx, (unsigned)passes), block(GS_THREADS);
 #define UNIVS_GS(rb, rg)                                                                                          \

@@ -304,6 +304,8 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
   const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + inverse scales + zero tail + row maxima
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 4 + 12), 16 * L3_MAX_RB);
   r_cap -= r_cap % 16;                                     // the LDS image holds whole 16-feature blocks
+  const UnivsConfig cfg_ = config();
+  if (cfg_.linear_rows_per_pass >= 16) r_cap = std::min(r_cap, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16);
   if (r_cap < 16) return 0;
   const int passes = (N + r_cap - 1) / r_cap;
   int rows = (N + passes - 1) / passes;
@@ -326,6 +328,7 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
   long long gx = std::max<long long>(1, n_cu / passes);
   gx = std::min(gx, std::max<long long>(1, WT / (2 * (L3_THREADS / 64))));
   if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;
+  if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
   const size_t lds = (size_t)K * (16 * RB) * 4 + 12 * (size_t)rows + 256 + 16;
   dim3 grid((unsigned)gx, (unsigned)passes), block(L3_THREADS);
 #define UNIVS_L3(rb, rg)                                                                                             \

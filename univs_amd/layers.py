@@ -131,12 +131,16 @@ class MultiheadAttention(nn.Module):
         if query is key and key is value:
             q, k, v = lin(query, w, b).chunk(3, dim=-1)
         else:
-            q = lin(query, w[:E], b[:E])
-            if key is value:
-                k, v = lin(key, w[E:], b[E:]).chunk(2, dim=-1)
-            else:
-                k = lin(key, w[E:2 * E], b[E:2 * E])
+            if query is key:      # self-attention with positional queries (q = k = tgt + pos, v = tgt): q and k in one projection
+                q, k = lin(query, w[:2 * E], b[:2 * E]).chunk(2, dim=-1)
                 v = lin(value, w[2 * E:], b[2 * E:])
+            else:
+                q = lin(query, w[:E], b[:E])
+                if key is value:
+                    k, v = lin(key, w[E:], b[E:]).chunk(2, dim=-1)
+                else:
+                    k = lin(key, w[E:2 * E], b[E:2 * E])
+                    v = lin(value, w[2 * E:], b[2 * E:])
         if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 512 and L <= 512
                 and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8) and attn_mask.dim() == 3
                                            and attn_mask.shape[0] == N))):
@@ -184,7 +188,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            # hidden layers: the ReLU rides in the GEMM epilogue on the GPU (linear_act: one launch instead of GEMM + bias + clamp)
+            x = linear_act(x, layer, F.relu) if i < self.num_layers - 1 else layer(x)
         return x
 
 

@@ -198,7 +198,7 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
         x = x.view(B, -1, 4 * C)
-        return self.reduction(layer_norm(self.norm, x))
+        return _linear(self.reduction, layer_norm(self.norm, x))   # 4C -> 2C, no bias: the three-product Linear where covered
 
 
 class BasicLayer(nn.Module):

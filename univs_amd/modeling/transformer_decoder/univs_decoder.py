@@ -368,7 +368,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 return x.view(bs, t, *x.shape[1:]).mean(1)
             return fs.all_reduce_sum(x.sum(0, keepdim=True)) / float(t_total)
 
-        decoder_output = self.decoder_norm(output).transpose(0, 1)  # [T, Q', C]
+        decoder_qt = self.decoder_norm(output)                      # [Q', T, C], contiguous: the per-token MLPs run on this
+        decoder_output = decoder_qt.transpose(0, 1)                 # [T, Q', C] (a view)
         # class logits of the intermediate layers are only ever returned as aux outputs (the attention mask of the next
         # layer depends on the mask embedding alone): the 8 launches of this head run where their result is used
         outputs_class = self.vis2text_projection(decoder_output) if need_class else None
@@ -385,7 +386,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             outputs_class = mean_over_frames(outputs_class)
             outputs_class = torch.einsum("bqc,bkc->bqk", outputs_class, clip_exp)
 
-        mask_embed = self.mask_embed(decoder_output)  # [T, Q', C]
+        mask_embed = self.mask_embed(decoder_qt).transpose(0, 1)    # [T, Q', C] (a view; made contiguous below)
         outputs_reid = [None] * bs
         if self.prompt_as_queries and task == "grounding":
             assert len(targets) == 1, "Only support bacth size is 1 now"
