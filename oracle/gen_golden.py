@@ -203,6 +203,23 @@ def g6_head_first_clip():
 
 
 @gen
+def g6c_head_t10_q200():
+    """the decoder at BASELINE config 5's length -- T = 10 frames, 200 learnable queries (2 000-token
+    spatio-temporal self-attention, class logits averaged over 10 frames) -- through the unmodified reference head on
+    reduced-resolution synthetic features (64 x 96: the decoder is agnostic to H x W; the reference's own 1080p run at T = 10
+    needs > 100 GB).  Stored: every 4th query of the mask logits / embeddings (all frames); every 16th class logit, the largest class
+    logit and its index per query; per-query magnitude and positive-pixel count of the mask logits."""
+    R = rh.ref()
+    case = cases.HEAD_CASE_T10
+    head = _ref_head(R, case)
+    out = head(cases.backbone_features(case), targets=cases.targets_first_clip(case))
+    save("g6c_head_t10_q200", pred_logits_k16=out["pred_logits"][:, :, ::16], pred_logits_max=out["pred_logits"].amax(-1),
+         pred_logits_argmax=out["pred_logits"].argmax(-1), pred_masks_q4=out["pred_masks"][:, ::4],
+         pred_embds_q4=out["pred_embds"][:, ::4], pred_masks_absmax=out["pred_masks"].abs().amax(dim=(0, 2, 3, 4)),
+         pred_masks_positive=(out["pred_masks"] > 0).sum(dim=(0, 2, 3, 4)))
+
+
+@gen
 def g4_g5_teacher_forced():
     """per-call fixtures from INSIDE the reference decoder (first clip of HEAD_CASE),
     captured with module hooks while the unmodified reference runs:

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from univs_amd import synth
-from univs_amd.workloads import (CFG2, CFG5, CFG5_GOLDEN_T, cfg5_frames, HEAD_CASE, PIXDEC, R50_SHAPES, SWIN_B, SWIN_L, SWIN_T, SWINL_SHAPES,  # noqa: F401
+from univs_amd.workloads import (CFG2, CFG5, CFG5_GOLDEN_T, cfg5_frames, HEAD_CASE, HEAD_CASE_T10, PIXDEC, R50_SHAPES, SWIN_B, SWIN_L, SWIN_T, SWINL_SHAPES,  # noqa: F401
                                  SWINT_SHAPES, backbone_features, cfg2_frames, clip_table, decoder_kwargs, preprocess, sampler_kwargs,
                                  targets_first_clip, targets_with_entities)
 

@@ -74,6 +74,22 @@ def test_pixel_decoder_matches_reference(golden_dir):
         assert err < 2e-4, (k, err)
 
 
+def test_head_t10_q200_matches_reference(golden_dir):
+    """Host logic at BASELINE config 5's decoder length (T = 10, 200 queries) against golden g6c (the reference head on
+    reduced-resolution features): the CPU path of the same module tree (oracle stand-ins for the HIP operators)."""
+    g = _g(golden_dir, "g6c_head_t10_q200")
+    case = cases.HEAD_CASE_T10
+    head = helpers.build_head(case, return_aux=False)
+    with cpu_ops(), torch.no_grad():
+        out = head(cases.backbone_features(case), targets=cases.targets_first_clip(case))
+    pm, ref = out["pred_masks"], torch.from_numpy(g["pred_masks_q4"])
+    assert (pm[:, ::4] - ref).abs().max().item() < 1e-3
+    assert (((pm[:, ::4] > 0) != (ref > 0)) & (ref.abs() > 1e-3)).sum().item() == 0
+    tol_log = 1e-3 * max(1.0, float(np.abs(g["pred_logits_k16"]).max()) / 10.0)
+    assert (out["pred_logits"][:, :, ::16] - torch.from_numpy(g["pred_logits_k16"])).abs().max().item() < tol_log
+    assert (out["pred_embds"][:, ::4] - torch.from_numpy(g["pred_embds_q4"])).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("name,dec_over,targets_fn,seed", helpers.HEAD_SCENARIOS, ids=[s[0] for s in helpers.HEAD_SCENARIOS])
 def test_head_matches_reference(golden_dir, name, dec_over, targets_fn, seed):
     g = _g(golden_dir, name)

@@ -74,6 +74,33 @@ def test_head_matches_reference(cuda, golden_dir, name, dec_over, targets_fn, se
         helpers.check_head_outputs(out3, g, "clip3_", tol=1e-3)
 
 
+def test_head_t10_q200_matches_reference(cuda, golden_dir):
+    """The decoder at BASELINE config 5's length (T = 10, 200 queries: 2 000-token spatio-temporal self-attention, class means
+    over 10 frames) against the reference head run on reduced-resolution synthetic features (golden g6c): mask logits within
+    1e-3, sign-identical; class logits, embeddings, per-query magnitudes and positive counts."""
+    g = _g(golden_dir, "g6c_head_t10_q200")
+    case = cases.HEAD_CASE_T10
+    head = helpers.build_head(case, cuda, return_aux=False)
+    with torch.no_grad():
+        out = head(_to(cases.backbone_features(case), cuda), targets=_targets_to(cases.targets_first_clip(case), cuda))
+    pm = out["pred_masks"].cpu()
+    ref = torch.from_numpy(g["pred_masks_q4"])
+    err = (pm[:, ::4] - ref).abs().max().item()
+    flips = (((pm[:, ::4] > 0) != (ref > 0)) & (ref.abs() > 1e-3)).sum().item()
+    e_log = (out["pred_logits"].cpu()[:, :, ::16] - torch.from_numpy(g["pred_logits_k16"])).abs().max().item()
+    e_max = (out["pred_logits"].cpu().amax(-1) - torch.from_numpy(g["pred_logits_max"])).abs().max().item()
+    e_emb = (out["pred_embds"].cpu()[:, ::4] - torch.from_numpy(g["pred_embds_q4"])).abs().max().item()
+    e_abs = (pm.abs().amax(dim=(0, 2, 3, 4)) - torch.from_numpy(g["pred_masks_absmax"])).abs().max().item()
+    d_pos = ((pm > 0).sum(dim=(0, 2, 3, 4)) - torch.from_numpy(g["pred_masks_positive"])).abs().max().item()
+    print(f"T=10 Q=200 head: mask logits {err:.2e} ({flips} flips), class logits {e_log:.2e} / max {e_max:.2e}, embeddings {e_emb:.2e}, "
+          f"per-query |logit| max {e_abs:.2e}, positive-pixel count difference {d_pos}")
+    assert err < 1e-3 and flips == 0
+    # class logits are not part of the north-star bound: relative to their magnitude, as helpers.check_head_outputs
+    tol_log = 1e-3 * max(1.0, float(np.abs(g["pred_logits_k16"]).max()) / 10.0)
+    assert e_log < tol_log and e_max < tol_log and e_emb < 1e-3 and e_abs < 1e-3
+    assert d_pos <= 2          # pixels whose reference logit is within 1e-3 of zero may land on either side
+
+
 def test_prompt_prefetch_on_a_side_stream_equals_the_inline_sampler(cuda, monkeypatch):
     """The head starts the annotation-only part of the visual-prompt sampler on a side stream before the pixel decoder
     (VisualPromptSampler.prefetch: candidate pixels, feature-resolution masks, the sizes of the reference's randperm

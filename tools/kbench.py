@@ -312,8 +312,12 @@ def main():
             res[f"resample_{h}x{w}"] = dict(ms=t * 1e3, GBps=byts / t / 1e9, frac_hbm=byts / t / HBM_PEAK)
             t = timeit(lambda: torch.nn.functional.interpolate(f, size=(h, w), mode="bilinear", align_corners=False))
             res[f"resample_{h}x{w}_aten"] = dict(ms=t * 1e3)
+    def fmt(vv):
+        if isinstance(vv, (int, float)) and not isinstance(vv, bool):
+            return round(vv, 4) if abs(vv) > 1e-3 or vv == 0 else float(f'{vv:.3e}')
+        return vv
     for k, v in res.items():
-        print(k, json.dumps({kk: (round(vv, 4) if abs(vv) > 1e-3 or vv == 0 else float(f'{vv:.3e}')) for kk, vv in v.items()}))
+        print(k, json.dumps({kk: fmt(vv) for kk, vv in v.items()}))
 
 
 if __name__ == "__main__":

@@ -356,7 +356,12 @@ template <int XMODE>
 static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   GsArgs a = a0;
   const UnivsConfig cfg_ = config();
-  const int r_cap = cfg_.linear_rows_per_pass >= 16 ? std::min(128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16) : 128;
+  // output features per pass: 128, or 64 for short tall-K problems with a narrow output (Swin stage-3 / stage-4 proj and fc2:
+  // few row tiles, N <= 768 <= K -- twice the passes fill the CUs; 172 -> 126 us at 18 400 x 1536 -> 384, 60 -> 43 us at
+  // 18 400 x 384 -> 384: profiles/r04_kbench_smallm_v1.txt)
+  const bool narrow = XMODE == 0 && a.N <= 768 && a.K >= a.N && a.M <= 32768;
+  const int r_cap = cfg_.linear_rows_per_pass >= 16 ? std::min(128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16)
+                                                    : (narrow ? 64 : 128);
   const int passes = (a.N + r_cap - 1) / r_cap;
   int rows = (a.N + passes - 1) / passes;
   rows = (rows + 3) & ~3;

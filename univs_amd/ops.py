@@ -12,12 +12,43 @@ import torch
 
 from . import _lib
 
+# Host cost of a wrapper call matters: a clip is ~250 calls into the library, and the decoder's kernels are shorter than a
+# Python call.  The three helpers below are the cheap forms of `torch.cuda.current_stream(dev).cuda_stream` (6 us),
+# `with torch.cuda.device(dev)` (5-8 us) and `ctypes.c_void_p(t.data_ptr())`: the raw stream of the tensor's device straight
+# from the C extension, a device switch only when the tensor does NOT live on the current device, and plain integers
+# (ctypes converts them for the declared c_void_p parameters; None stays NULL).
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 def _stream_ptr(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+class _on:
+    """`with _on(t):` -- the current CUDA device is t's device inside the block (what `torch.cuda.device(t.device)` does), at
+    the cost of one integer comparison when it already is."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _require_gpu(name, *tensors):
@@ -108,7 +139,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     lib = _lib.load()
     fn = lib.univs_msda_forward_f32 if value.dtype == torch.float32 else lib.univs_msda_forward_f64
-    with torch.cuda.device(value.device):
+    with _on(value):
         rc = fn(_ptr(value), sh, st, _ptr(sampling_loc), _ptr(attn_weight), N, S, M, D, L, Lq, P,
                 _ptr(out), _stream_ptr(value))
     _lib.check(rc, "ms_deform_attn_forward")
@@ -130,7 +161,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gv = torch.empty_like(value)
     gl = torch.empty_like(sampling_loc)
     ga = torch.empty_like(attn_weight)
-    with torch.cuda.device(value.device):
+    with _on(value):
         rc = _lib.load().univs_msda_backward_f32(_ptr(value), shapes, starts, _ptr(sampling_loc), _ptr(attn_weight),
                                                  _ptr(grad_output), N, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
                                                  _stream_ptr(value))
@@ -179,7 +210,7 @@ def msda_forward_strips(value_hm, proj_hm, ref_points, spatial_shapes, level_sta
         return None
     out = torch.empty((N, S, M * 32), dtype=torch.float32, device=value_hm.device)
     rbs = 0 if ref_points.shape[0] == 1 else S * 2
-    with torch.cuda.device(value_hm.device):
+    with _on(value_hm):
         rc = _lib.load().univs_msda_forward_strips_f32(_ptr(value_hm), sh, st, _ptr(proj_hm), _ptr(ref_points), rbs, N, S, M, 32,
                                                        L, S, P, _ptr(out), _stream_ptr(value_hm))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
@@ -296,7 +327,7 @@ def presplit_weights(weight, conv=False, mode=None):
     w = weight.detach().contiguous()
     wp = torch.empty(N * K, dtype=torch.int32, device=weight.device)
     winv = torch.empty(N, dtype=torch.float32, device=weight.device)
-    with torch.cuda.device(weight.device):
+    with _on(weight):
         _lib.check(_lib.load().univs_presplit_weights_f32(_ptr(w), N, K, mode, _ptr(wp), _ptr(winv), _stream_ptr(w)),
                    "presplit_weights")
         done = torch.cuda.Event()
@@ -347,7 +378,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None):
             raise RuntimeError(f"mlp_fused: residual must be float32 of x's shape on the GPU (got {tuple(residual.shape)})")
         r = residual.contiguous()
     y = torch.empty((M, C), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         w1p, w1inv = presplit_weights(w1)
         w2p, w2inv = presplit_weights(w2, mode="mlp2")
         rc = _lib.load().univs_mlp_presplit_f32(_ptr(x2), _ptr(w1p), _ptr(w1inv), _ptr(b1) if b1 is not None else None, _ptr(w2p),
@@ -392,9 +423,11 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
                                f"(got {tuple(residual.shape)}, output {tuple(x.shape[:-1]) + (N,)})")
         r = residual.contiguous()
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.ERR_NOT_IMPLEMENTED
-        if 0 < SWITCHES.presplit_kmin <= K:
+        # the streamed kernel (weights split once per tensor): wide K, and short square-ish problems (Swin stage-3 proj: 18 400
+        # rows, 384 -> 384), where re-splitting the W slab in every workgroup of the resident kernel costs more than the rows
+        if 0 < SWITCHES.presplit_kmin <= K or (SWITCHES.presplit_kmin > 0 and K >= 384 and N <= K and M <= 32768):
             wp, winv = presplit_weights(weight)
             rc = _lib.load().univs_linear_presplit_f32(_ptr(x2), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None,
                                                        _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
@@ -426,7 +459,7 @@ def linear_blocked(x, weight, bias, rows_per_batch, col_block):
         return None
     b = bias.contiguous() if bias is not None else None
     y = torch.empty((Mrows // rows, N // cb, rows, cb), dtype=torch.float32, device=x2.device)
-    with torch.cuda.device(x2.device):
+    with _on(x2):
         rc = _lib.load().univs_linear_blocked_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, Mrows, N, K, rows, cb,
                                                   _ptr(y), _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
@@ -461,7 +494,7 @@ def mask_decode(mask_embed, mask_features):
     if T2 != T or C2 != C:
         raise RuntimeError(f"mask_decode: shape mismatch {tuple(mask_embed.shape)} vs {tuple(mask_features.shape)}")
     out = torch.empty((Q, T, H, W), dtype=torch.float32, device=mask_embed.device)
-    with torch.cuda.device(mask_embed.device):
+    with _on(mask_embed):
         rc = _lib.load().univs_mask_decode_f32(_ptr(mask_embed), _ptr(mask_features), T, Q, C, H * W,
                                                _ptr(out), _stream_ptr(mask_embed))
     _lib.check(rc, "mask_decode")
@@ -482,7 +515,7 @@ def mask_decode_attn(mask_embed, feat_lowres):
         raise RuntimeError("mask_decode_attn: shape mismatch")
     mask = torch.empty((T, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
     ws = torch.empty((max(T * Q, 1),), dtype=torch.int32, device=mask_embed.device)
-    with torch.cuda.device(mask_embed.device):
+    with _on(mask_embed):
         rc = _lib.load().univs_mask_decode_attn_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w,
                                                     _ptr(mask), _ptr(ws), _stream_ptr(mask_embed))
     _lib.check(rc, "mask_decode_attn")
@@ -505,7 +538,7 @@ def window_attention(qkv, bias, shift_mask, num_windows, scale):
         if tuple(shift_mask.shape) != (num_windows, Ntok, Ntok) or B_ % num_windows != 0:
             raise RuntimeError("window_attention: bad shift_mask shape")
     out = torch.empty((B_, Ntok, nH * hd), dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with _on(qkv):
         rc = _lib.load().univs_window_attention_f32(
             _ptr(qkv), _ptr(bias), _ptr(shift_mask) if shift_mask is not None else None, B_,
             int(num_windows), Ntok, nH, hd, float(scale), _ptr(out), _stream_ptr(qkv))
@@ -527,7 +560,7 @@ def bilinear_pyramid3(x):
         return None
     planes = x.numel() // (H * W)
     outs = [torch.empty(tuple(x.shape[:-2]) + (H >> k, W >> k), dtype=torch.float32, device=x.device) for k in (1, 2, 3)]
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.load().univs_bilinear_pyramid3_f32(_ptr(x), planes, H, W, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
@@ -554,7 +587,7 @@ def bilinear_resample(x, size, addend=None):
         if tuple(addend.shape) != oshape or addend.dtype != torch.float32:
             raise RuntimeError("bilinear_resample: addend must be float32 of the output shape")
     out = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.load().univs_bilinear_resample_f32(_ptr(x), _ptr(addend) if addend is not None else None, _ptr(out),
                                                     planes, Hin, Win, Hout, Wout, _stream_ptr(x))
     _lib.check(rc, "bilinear_resample")
@@ -572,7 +605,7 @@ def conv3x3(x, weight):
     Cout = weight.shape[0]
     x = x.contiguous()
     y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.ERR_NOT_IMPLEMENTED
         if SWITCHES.presplit_kmin > 0:
             wp, winv = presplit_weights(weight, conv=True)
@@ -600,7 +633,7 @@ def conv1x1(x, weight, bias=None):
     x = x.contiguous()
     b = bias.contiguous() if bias is not None else None
     y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         wp, winv = presplit_weights(weight)
         rc = _lib.load().univs_conv1x1_presplit_f32(_ptr(x), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None, T, Cin, Cout, H, W,
                                                     _ptr(y), _stream_ptr(x))
@@ -620,7 +653,7 @@ def transpose_last2(x):
     R, C = x.shape[-2], x.shape[-1]
     B = x.numel() // max(R * C, 1)
     out = torch.empty(x.shape[:-2] + (C, R), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.load().univs_transpose_f32(_ptr(x), B, R, C, _ptr(out), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return x.transpose(-2, -1).contiguous()
@@ -667,12 +700,12 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, post_
         if not ok:
             raise RuntimeError("layer_norm: post_add must match x or broadcast over its leading dimensions")
         out2 = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x):
             rc = _lib.load().univs_layer_norm_add_f32(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(post_add), arows, rows,
                                                       C, float(eps), None, _ptr(out), _ptr(out2), _stream_ptr(x))
         _lib.check(rc, "layer_norm")
         return out, out2
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.load().univs_layer_norm_f32(_ptr(x), _ptr(residual) if residual is not None else None,
                                              _ptr(weight.contiguous()), _ptr(bias.contiguous()), rows, C, float(eps),
                                              _ptr(s) if s is not None else None, _ptr(out), _stream_ptr(x))
@@ -694,7 +727,7 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     HW = x.numel() // max(N * C, 1)
     out = torch.empty_like(x)
     ws = torch.empty(N * C * 2 * max(1, (HW + 8191) // 8192), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x):
         rc = _lib.load().univs_group_norm_f32(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), N, C, HW,
                                              int(num_groups), float(eps), 1 if relu else 0, _ptr(ws), ws.numel(),
                                              _ptr(out), _stream_ptr(x))
@@ -717,7 +750,7 @@ def masked_softmax_(scores, mask=None):
         if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8):
             raise RuntimeError("masked_softmax_: mask must be bool / uint8 [N, L, S]")
         mptr = _ptr(mask)
-    with torch.cuda.device(scores.device):
+    with _on(scores):
         rc = _lib.load().univs_masked_softmax_f32(_ptr(scores), mptr, N, h, L, S, _stream_ptr(scores))
     _lib.check(rc, "masked_softmax_")
     return scores
@@ -745,7 +778,7 @@ def cross_attention(q, k, v, mask, num_heads, scale):
     lib = _lib.load()
     ws = torch.empty(int(lib.univs_cross_attention_workspace(L, S, N, H)), dtype=torch.float32, device=q.device)
     out = torch.empty((L, N, E), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q):
         rc = lib.univs_cross_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask) if mask is not None else None, L, S, N, H, 32,
                                            float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
@@ -789,7 +822,7 @@ def window_attention_image(qkv, qkv_bias, bias, shift_mask, H, W, window_size, s
         if qkv_bias.numel() != 3 * nH * hd:
             raise RuntimeError("window_attention_image: bad qkv_bias shape")
     out = torch.empty((B, L, nH * hd), dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with _on(qkv):
         rc = _lib.load().univs_window_attention_image_mma(
             _ptr(qkv), _ptr(qkv_bias) if qkv_bias is not None else None, _ptr(bias),
             _ptr(shift_mask) if shift_mask is not None else None, B, int(H), int(W), ws, int(shift), nH, hd,
@@ -819,7 +852,7 @@ def msda_prepare(proj, n_off, reference_points, spatial_shapes, num_heads, num_l
     loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=proj.device)
     attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=proj.device)
     rbs = 0 if reference_points.shape[0] == 1 else Lq * L * 2
-    with torch.cuda.device(proj.device):
+    with _on(proj):
         rc = _lib.load().univs_msda_prepare_f32(_ptr(proj), C, int(n_off), _ptr(reference_points), rbs, sh, N, Lq, M, L, P,
                                                _ptr(loc), _ptr(attn), _stream_ptr(proj))
     _lib.check(rc, "msda_prepare")

@@ -31,6 +31,10 @@ SWINL_SHAPES = {"res2": (192, 4), "res3": (384, 8), "res4": (768, 16), "res5": (
 
 # a small head case: features of a 64x96 padded input with R50 channel counts
 HEAD_CASE = dict(name="head", T=2, H=64, W=96, Q=20, shapes=R50_SHAPES)
+# BASELINE config 5's decoder length (T = 10 frames, 200 queries: a 2 000-token spatio-temporal self-attention, class / re-id
+# means over 10 frames) on reduced-resolution features -- the decoder does not care about H x W, the reference's own 1080p run
+# at T = 10 needs > 100 GB on the CPU (golden g6c)
+HEAD_CASE_T10 = dict(name="head_t10", T=10, H=64, W=96, Q=200, shapes=R50_SHAPES)
 
 
 def backbone_features(case=HEAD_CASE):
