@@ -439,7 +439,7 @@ def run(args):
                 return head5(swin5(x5), targets=[dict(tg5)])
             c5res = {"workload": "BASELINE config 5: Swin-L (12 x 12 windows), T=10 @ 1080p (1088x1920 padded), 200 queries, "
                                  "first clip; 2 warm-up + 3 timed clips per variant", "frames_per_clip": c5["T"]}
-            for mma in ("f16", "f32"):
+            for mma in ("f16", "f16x3", "f32"):       # fp16 operands (what config 5 names) / fp32-accurate three-product (the default) / exact f32
                 swin5.set_attention_mma(mma)
                 for _ in range(2):
                     step5()

@@ -273,19 +273,23 @@ int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv
  * arithmetic of univs_linear_fused_f32 in both products; the [M, Hd] hidden activations stay in registers (they are neither
  * written to nor read from memory).  LN: with ln_weight != NULL the rows of x first go through nn.LayerNorm(C) (weight, bias or
  * NULL, eps; two-pass statistics in registers) -- the pre-norm block `x + mlp(norm2(x))` of the Swin stages is then ONE launch
- * with residual == x.
+ * with residual == x.  POST-norm: with post_ln_weight != NULL the finished rows (bias and residual added) go through a second
+ * nn.LayerNorm(C) before they are stored -- `norm2(src + ffn(src))` of the MSDeformAttn encoder layer; y2 (optional) additionally
+ * receives y + post_add[row % post_add_rows] (the next layer's `with_pos_embed(src, pos)`, post_add [post_add_rows, C]).
  *   w1p, w1inv   univs_presplit_weights_f32(W1 [Hd, C], Hd, C, 0, ...)
  *   w2p, w2inv   univs_presplit_weights_f32(W2 [C, Hd], C, Hd, 2, ...)     (mode 2: the MLP k-order)
  *   b1 [Hd], b2 [C], residual [M, C]: optional (NULL);  act: 1 ReLU, 2 GELU (erf form, as univs_linear_fused_f32)
- * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 132 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
+ * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 134 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
  * aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps two univs_linear_* calls).
  * Replaces: linear2(dropout(activation(linear1(src)))) of the MSDeformAttn encoder layer
  *   (mask2former/modeling/pixel_decoder/msdeformattn.py:87-91) and Mlp.forward + the block's shortcut add of the Swin stages
- *   with C <= 256 (mask2former/modeling/backbone/swin.py:35-58, :291-293; with LN also norm2 of :289-293).
+ *   with C <= 256 (mask2former/modeling/backbone/swin.py:35-58, :291-293; with LN also norm2 of :289-293); with the post-norm also
+ *   `src = norm2(src + ...)` and the next layer's `with_pos_embed` (msdeformattn.py:61-63, :91-95).
  * ------------------------------------------------------------------------------------------- */
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
-                           long long M, int C, int Hd, int act, float* y, void* stream);
+                           const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
+                           long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked multi-head attention core in one pass over the keys (cross_attn.hip):
@@ -294,7 +298,9 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
  *           (univs/modeling/transformer_decoder/transformer_layers.py:95-115; ...decoder_univs.py:400-405), between the in- and
  *           out-projections: the scaled score GEMM, masked_fill(attn_mask, -inf), softmax over the keys, and the product with
  *           V -- the [N * H, L, S] scores are never written.
- *   q [L, N, H * head_dim], k / v [S, N, H * head_dim]  sequence-first, contiguous fp32 (the Linears' outputs as they stand)
+ *   q [L, N, H * head_dim], k / v [S, N, H * head_dim]  sequence-first fp32 (the Linears' outputs as they stand); ldq / ldk / ldv:
+ *        floats between consecutive batch entries (0 = H * head_dim, dense) -- a tensor may be a column slice of a wider
+ *        projection (the K or V of several decoder layers that attend to the same level, computed by one Linear)
  *   mask [N, L, S] uint8 / bool, non-zero = key masked out for that query, shared by the heads; or NULL
  *        (rows in which every key is masked yield NaN, as nn.MultiheadAttention; the decoder resets such rows beforehand,
  *        ...decoder_univs.py:390 -- univs_mask_decode_attn_f32 does)
@@ -305,7 +311,7 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
  * ------------------------------------------------------------------------------------------- */
 long long univs_cross_attention_workspace(int L, int S, int N, int H);
 int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
-                              float scale, float* workspace, float* out, void* stream);
+                              int ldq, int ldk, int ldv, float scale, float* workspace, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.

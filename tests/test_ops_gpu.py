@@ -639,6 +639,13 @@ def test_cross_attention_ranges_and_module_path(cuda):
         err = ((got.double() - ref).abs().max() / ref.abs().max()).item()
         print(f"cross attention, {name}: relative max error {err:.2e}")
         assert torch.isfinite(got).all() and err < tol, (name, err)
+    # k / v as column slices of wider projections (one Linear for the keys of several layers): same result as dense copies
+    wide_k = torch.cat([synth.normal("xa2/wk0", (S, N, E)), k, synth.normal("xa2/wk2", (S, N, E))], -1).to(cuda)
+    wide_v = torch.cat([v, synth.normal("xa2/wv1", (S, N, 2 * E))], -1).to(cuda)
+    msk2 = (torch.rand(N, L, S, generator=torch.Generator().manual_seed(9)) < 0.7).to(cuda)
+    dense = ops.cross_attention(q.to(cuda), k.to(cuda), v.to(cuda), msk2, H, scale)
+    sliced = ops.cross_attention(q.to(cuda), wide_k[..., E:2 * E], wide_v[..., :E], msk2, H, scale)
+    assert torch.equal(dense, sliced)
     mha = layers.MultiheadAttention(E, H).to(cuda).eval()
     with torch.no_grad():
         for n_, p_ in mha.named_parameters():
@@ -650,7 +657,12 @@ def test_cross_attention_ranges_and_module_path(cuda):
         fused = mha(tgt, key, mem, attn_mask=msk)[0]
         with override(fused_cross_attention=False):
             plain = mha(tgt, key, mem, attn_mask=msk)[0]
+        # precomputed key / value projections (the decoder's per-level batching) == the module's own projections
+        kk = layers.linear(key, mha.in_proj_weight[E:2 * E], mha.in_proj_bias[E:2 * E])
+        vv = layers.linear(mem, mha.in_proj_weight[2 * E:], mha.in_proj_bias[2 * E:])
+        given = mha(tgt, None, None, attn_mask=msk, kv=(kk, vv))[0]
     assert (fused - plain).abs().max().item() < 2e-5
+    assert torch.equal(given, fused)
     assert ops.cross_attention(torch.zeros(4, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda),
                                None, 2, 1.0) is None                                            # fewer than 32 keys
     assert ops.cross_attention(torch.zeros(4, 1, 64), torch.zeros(64, 1, 64), torch.zeros(64, 1, 64), None, 2, 1.0) is None   # CPU
@@ -875,6 +887,39 @@ def test_mlp_fused_with_layer_norm(cuda, M, C, Hd):
     err2 = (two.double() - ref64).abs().max().item()
     print(f"mlp_fused + LN {M, C, Hd}: {err:.2e} (ATen fp32 {err32:.2e}, LN kernel + fused MLP {err2:.2e})")
     assert err < max(4.0 * err32, 2e-5), (err, err32)
+
+
+@pytest.mark.parametrize("N,S,C,Hd", [(2, 9660, 256, 1024), (3, 1111, 256, 512), (1, 4000, 192, 384)], ids=lambda v: str(v))
+def test_mlp_fused_post_norm(cuda, N, S, C, Hd):
+    """ops.mlp_fused(..., residual=x, post_ln=..., post_add=pos) == (y, y + pos) with y = LayerNorm(x + linear2(relu(linear1(x)))):
+    the tail of the MSDeformAttn encoder layer (msdeformattn.py:87-95) and the next layer's `with_pos_embed` as one launch; pos
+    [1, S, C] broadcast over the N frames; also without post_add."""
+    F = torch.nn.functional
+    x = synth.normal(f"mlppn/x/{N}x{S}x{C}", (N, S, C))
+    x[:, ::5] += 3.0
+    pos = synth.normal(f"mlppn/pos/{S}x{C}", (1, S, C))
+    g_ = 1.0 + 0.2 * synth.normal(f"mlppn/g/{C}", (C,))
+    b_ = 0.1 * synth.normal(f"mlppn/b/{C}", (C,))
+    w1 = synth.normal(f"mlppn/w1/{Hd}x{C}", (Hd, C), std=C ** -0.5)
+    b1 = synth.normal(f"mlppn/b1/{Hd}", (Hd,), std=0.5)
+    w2 = synth.normal(f"mlppn/w2/{C}x{Hd}", (C, Hd), std=Hd ** -0.5)
+    b2 = synth.normal(f"mlppn/b2/{C}", (C,), std=0.5)
+    xd, pd, gd, bd, w1d, b1d, w2d, b2d = (t.to(cuda) for t in (x, pos, g_, b_, w1, b1, w2, b2))
+    res = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", residual=xd, post_ln=(gd, bd, 1e-5), post_add=pd)
+    assert res is not None and len(res) == 2
+    y, y2 = res
+    ffn64 = F.linear(F.relu(F.linear(xd.double(), w1d.double(), b1d.double())), w2d.double(), b2d.double())
+    ref64 = F.layer_norm(xd.double() + ffn64, (C,), gd.double(), bd.double(), 1e-5)
+    ref32 = F.layer_norm(xd + F.linear(F.relu(F.linear(xd, w1d, b1d)), w2d, b2d), (C,), gd, bd, 1e-5)
+    err = (y.double() - ref64).abs().max().item()
+    err32 = (ref32.double() - ref64).abs().max().item()
+    print(f"mlp_fused post-norm {N, S, C, Hd}: {err:.2e} (ATen fp32 {err32:.2e})")
+    assert tuple(y.shape) == (N, S, C) and err < max(4.0 * err32, 5e-6), (err, err32)
+    assert torch.equal(y2, y + pd)
+    y_only = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", residual=xd, post_ln=(gd, bd, 1e-5))
+    assert torch.equal(y_only, y)
+    with pytest.raises(RuntimeError):
+        ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", post_add=pd)
 
 
 def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):

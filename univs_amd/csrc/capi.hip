@@ -59,11 +59,12 @@ int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStre
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
-int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, int, int, int, int, int, float, float*, float*,
-                        hipStream_t);
+int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, int, int, int, int, int, int, int, int, float,
+                        float*, float*, hipStream_t);
 size_t cross_attention_workspace_floats(int, int, int, int);
 int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
-                  const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
+                  const float*, const float*, float, const float*, const float*, float, const float*, long long, float*, float*, long long,
+                  int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -224,7 +225,7 @@ long long univs_cross_attention_workspace(int L, int S, int N, int H) {
 }
 
 int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
-                              float scale, float* workspace, float* out, void* stream) {
+                              int ldq, int ldk, int ldv, float scale, float* workspace, float* out, void* stream) {
   clear_sticky_error();
   if (L < 0 || S < 1 || N < 0 || H < 1 || head_dim < 1) {
     set_error("univs_cross_attention_f32: bad dimensions L=%d S=%d N=%d H=%d head_dim=%d", L, S, N, H, head_dim);
@@ -235,7 +236,8 @@ int univs_cross_attention_f32(const float* q, const float* k, const float* v, co
     set_error("univs_cross_attention_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::cross_attention_f32(q, k, v, mask, L, S, N, H, head_dim, scale, workspace, out, static_cast<hipStream_t>(stream));
+  const int rc = univs::cross_attention_f32(q, k, v, mask, L, S, N, H, head_dim, ldq, ldk, ldv, scale, workspace, out,
+                                            static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_cross_attention_f32: L=%d S=%d N=%d H=%d head_dim=%d not covered (head_dim == 32, S >= 32, with a mask S %% 4 == 0, "
               "N * H <= 65535, 16-byte aligned pointers)", L, S, N, H, head_dim);
@@ -244,7 +246,8 @@ int univs_cross_attention_f32(const float* q, const float* k, const float* v, co
 
 int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
-                           long long M, int C, int Hd, int act, float* y, void* stream) {
+                           const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
+                           long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream) {
   clear_sticky_error();
   if (M < 0 || C < 1 || Hd < 1 || (act != 1 && act != 2)) {
     set_error("univs_mlp_presplit_f32: bad arguments M=%lld C=%d Hd=%d act=%d (1 ReLU, 2 GELU)", M, C, Hd, act);
@@ -255,8 +258,8 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
     set_error("univs_mlp_presplit_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, y, M, C, Hd, act,
-                                      static_cast<hipStream_t>(stream));
+  const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, post_ln_weight, post_ln_bias,
+                                      post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256, Hd %% 32 == 0, "
               "M >= 2048)", M, C, Hd);

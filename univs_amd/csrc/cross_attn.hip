@@ -47,6 +47,7 @@ struct XaArgs {
   float* out;                // [L, N, H * 32]
   int L, S, N, H, nseg;      // L: queries of this launch (<= 128)
   int Lfull, l0;             // rows of the mask per batch entry, and the first query of this launch among them
+  int ldq, ldk, ldv;         // floats between consecutive batch entries of q / k / v (>= H * 32: slices of wider projections)
   float qscale;              // scale * log2(e)
 };
 
@@ -98,10 +99,11 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   const int n = nh / a.H, h = nh - n * a.H;
   const int L = a.L, S = a.S, N = a.N;
   const int E = a.H * HD;
-  const long long row_stride = (long long)N * E;                 // floats between consecutive sequence positions
-  const float* qb_ = a.q + (long long)n * E + h * HD;
-  const float* kb_ = a.k + (long long)n * E + h * HD;
-  const float* vb_ = a.v + (long long)n * E + h * HD;
+  const long long qrow = (long long)N * a.ldq, krow = (long long)N * a.ldk, vrow = (long long)N * a.ldv;   // floats between sequence positions
+  const float* qb_ = a.q + (long long)n * a.ldq + h * HD;
+  const float* kb_ = a.k + (long long)n * a.ldk + h * HD;
+  const float* vb_ = a.v + (long long)n * a.ldv + h * HD;
+  (void)E;
 
   // this segment's range of 32-key iterations
   const int nit = (S + 31) >> 5;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       const int qi = 16 * qb + j;
       float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
       if (qi < L) {
-        const float4* p = reinterpret_cast<const float4*>(qb_ + (long long)qi * row_stride + 8 * g);
+        const float4* p = reinterpret_cast<const float4*>(qb_ + (long long)qi * qrow + 8 * g);
         x0 = p[0];
         x1 = p[1];
       }
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       const int s = s0 + 16 * kb + j;
       kn[kb][0] = kn[kb][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (s < S) {
-        const float4* p = reinterpret_cast<const float4*>(kb_ + (long long)s * row_stride + 8 * g);
+        const float4* p = reinterpret_cast<const float4*>(kb_ + (long long)s * krow + 8 * g);
         kn[kb][0] = p[0];
         kn[kb][1] = p[1];
       }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int s = s0 + 16 * half + 4 * kgl + e;
       vn[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < S) vn[e] = *reinterpret_cast<const float4*>(vb_ + (long long)s * row_stride + 4 * hg);
+      if (s < S) vn[e] = *reinterpret_cast<const float4*>(vb_ + (long long)s * vrow + 4 * hg);
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -415,7 +417,7 @@ size_t cross_attention_workspace_floats(int L, int S, int N, int H) {
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.  Queries beyond 128 are handled in chunks.
 int cross_attention_f32(const float* q, const float* k, const float* v, const unsigned char* mask, int L, int S, int N, int H, int hd,
-                        float scale, float* ws, float* out, hipStream_t st) {
+                        int ldq, int ldk, int ldv, float scale, float* ws, float* out, hipStream_t st) {
   if (L <= 0 || N <= 0 || H <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (hd != 32 || S < 32 || (mask && (S % 4 != 0 || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
@@ -423,16 +425,19 @@ int cross_attention_f32(const float* q, const float* k, const float* v, const un
     return UNIVS_ERR_NOT_IMPLEMENTED;
   const int nseg = cross_attention_segments(S, N, H);
   const int E = H * 32;
+  ldq = ldq > 0 ? ldq : E; ldk = ldk > 0 ? ldk : E; ldv = ldv > 0 ? ldv : E;
+  if (ldq < E || ldk < E || ldv < E || ldq % 4 || ldk % 4 || ldv % 4) return UNIVS_ERR_NOT_IMPLEMENTED;
   for (int l0 = 0; l0 < L; l0 += 128) {
     const int Lc = std::min(128, L - l0);
     const int nqb = (Lc + 15) / 16;
     XaArgs a{};
-    a.q = q + (long long)l0 * N * E;
+    a.q = q + (long long)l0 * N * ldq;
     a.k = k; a.v = v;
     a.mask = mask;
     a.ws = ws; a.out = out + (long long)l0 * N * E;
     a.L = Lc; a.S = S; a.N = N; a.H = H; a.nseg = nseg;
     a.Lfull = L; a.l0 = l0;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.qscale = scale * 1.4426950408889634f;
     dim3 grid((unsigned)nseg, (unsigned)(N * H));
     switch (nqb) {

@@ -48,6 +48,12 @@ struct MlpArgs {
   const float* ln_g;    // [C] or null: x is first normalised over its C channels (nn.LayerNorm: weight, bias, eps)
   const float* ln_b;    // [C]
   float ln_eps;
+  const float* pln_g;   // [C] or null: nn.LayerNorm applied to the RESULT rows (after bias and residual): the post-norm layer
+  const float* pln_b;   // [C]       `norm(x + mlp(x))` (msdeformattn.py:91-95)
+  const float* padd;    // [padd_rows, C] or null: second output Y2 = Y + padd[row % padd_rows] (the next layer's `src + pos`)
+  float* Y2;            // [M, C]
+  float pln_eps;
+  int padd_rows;
   int M, Hd, nwg;
 };
 
@@ -102,7 +108,7 @@ constexpr int ml_ring(int upt, int nbat) {          // most units in flight at o
 }
 
 // LDS (16-byte units): 2 x { W1 part [C/8 k-chunks][2 parts][32 hidden rows] | W2 part [4 k-groups][2 parts][C rows] } |
-//                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C] | ln weight[C] | ln bias[C]
+//                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C] | ln weight[C] | ln bias[C] | post-ln weight[C] | post-ln bias[C]
 template <int KS1, int CT, int ACT, int NW, int ABL>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
@@ -125,7 +131,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   float* w2inv_lds = b2_lds + C;
   float* lng_lds = w2inv_lds + C;
   float* lnb_lds = lng_lds + C;
+  float* plng_lds = lnb_lds + C;
+  float* plnb_lds = plng_lds + C;
   const bool with_ln = a.ln_g != nullptr;                        // uniform
+  const bool with_pln = a.pln_g != nullptr;                      // uniform
   const int ngroups = (M + RG - 1) / RG;
   if ((int)blockIdx.x >= ngroups) return;
 
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
     w2inv_lds[r] = a.w2inv[r];
     lng_lds[r] = with_ln ? a.ln_g[r] : 1.f;
     lnb_lds[r] = (with_ln && a.ln_b) ? a.ln_b[r] : 0.f;
+    plng_lds[r] = with_pln ? a.pln_g[r] : 1.f;
+    plnb_lds[r] = (with_pln && a.pln_b) ? a.pln_b[r] : 0.f;
   }
   if (with_ln) __syncthreads();                                  // (the first x tile is normalised before the chunk loop's barrier)
 
@@ -159,6 +170,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.Y2 ? a.Y2 : a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.padd ? a.padd : a.X), 0, (int)((long long)(a.padd ? a.padd_rows : M) * C * 4), 0x00020000);
 
   u32x4 afr[3][2][2];                                            // [ring][block][part]
   if (ABL == 2) {
@@ -391,15 +405,57 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int m = row0 + 16 * ct + j;
+      const unsigned rowoff = m < M ? (unsigned)m * (unsigned)C * 4u : 0xFFFFFFF0u;   // out of range: loads give 0, stores are dropped
+      if (!with_pln) {
 #pragma unroll
-      for (int ob = 0; ob < NOB; ++ob) {
-        const int f = ob * 16 + 4 * g;
-        const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
-        f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
-        const unsigned offc = m < M ? ((unsigned)m * (unsigned)C + (unsigned)f) * 4u : 0xFFFFFFF0u;   // out of range: dropped
-        if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+        for (int ob = 0; ob < NOB; ++ob) {
+          const int f = ob * 16 + 4 * g;
+          const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
+          f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
+          const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+        }
+      } else {
+        // post-norm: LayerNorm over the finished row (bias and residual added), two-pass statistics over the row's C values -- 4 NOB
+        // in this lane, the rest in the three other lanes of the row --, then weight / bias; optionally a second output + padd
+        float sm = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+          const int f = ob * 16 + 4 * g;
+          const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
+          f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
+          const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          acc2[ob][ct] = v;
+          sm += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mean = ml_row_sum(sm) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+          acc2[ob][ct] -= mean;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq = fmaf(acc2[ob][ct][e], acc2[ob][ct][e], sq);
+        }
+        const float rstd = 1.0f / sqrtf(ml_row_sum(sq) * (1.0f / C) + a.pln_eps);
+        const unsigned prow = a.padd ? (unsigned)(min(m, M - 1) % a.padd_rows) * (unsigned)C * 4u : 0u;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+          const int f = ob * 16 + 4 * g;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(plng_lds + f);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(plnb_lds + f);
+          const f32x4 y = (acc2[ob][ct] * rstd) * gm + bt;
+          const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), yrs, offc, 0, 0);
+          if (a.Y2) {
+            f32x4 y2 = y;
+            if (a.padd) y2 += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pars, prow + (unsigned)f * 4u, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y2), y2rs, offc, 0, 0);
+          }
+        }
       }
     }
   }
@@ -441,7 +497,7 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
   constexpr int C = 32 * KS1;
   constexpr int RG = NW * 16 * CT;
   const int ngroups = (a.M + RG - 1) / RG;
-  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 4 * C) * 4;
+  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 6 * C) * 4;
   if (lds > 160 * 1024) return UNIVS_ERR_NOT_IMPLEMENTED;
   const int abl = config().linear_ablate;                         // 2 / 3 / 4: timing experiments (encoder FFN and Swin stage 1 only)
   if (abl >= 2 && abl <= 4 && ((KS1 == 8 && act == ML_ACT_RELU) || (KS1 == 3 && act == ML_ACT_GELU))) {
@@ -462,17 +518,21 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
 int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                  const float* b2, const float* residual, const float* ln_w, const float* ln_b, float ln_eps, float* y, long long M,
+                  const float* b2, const float* residual, const float* ln_w, const float* ln_b, float ln_eps, const float* pln_w,
+                  const float* pln_b, float pln_eps, const float* post_add, long long post_add_rows, float* y2, float* y, long long M,
                   int C, int Hd, int act, hipStream_t st) {
   if (M <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
-      mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2) || (ln_b && !ln_w))
+      mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2) || (ln_b && !ln_w) ||
+      mis(post_add) || mis(y2) || (pln_b && !pln_w) || ((post_add || y2) && !pln_w) || (post_add && (!y2 || post_add_rows < 1 ||
+      post_add_rows * (long long)C * 4 >= 0x7FFFFFFFLL)))
     return UNIVS_ERR_NOT_IMPLEMENTED;
   MlpArgs a{};
   a.X = x; a.W1p = reinterpret_cast<const u32x4*>(w1p); a.w1inv = w1inv; a.b1 = b1;
   a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = residual; a.Y = y;
   a.ln_g = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
+  a.pln_g = pln_w; a.pln_b = pln_b; a.pln_eps = pln_eps; a.padd = post_add; a.padd_rows = (int)post_add_rows; a.Y2 = y2;
   a.M = (int)M; a.Hd = Hd;
   switch (C) {
     case 96: return ml_launch<3, 2, 4>(a, act, st);

@@ -35,7 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WH_WAVES = 8;
+// waves per workgroup: 8; 4 for the three-product kernel on 12 x 12 windows, whose two fp16 planes of V leave room for four
+// waves beside the bias table (144 x 148 x 4 + 4 x 2 x 32 x 152 x 2 = 163 072 B of the CU's 163 840)
+constexpr int wh_waves(int nb, int terms) { return (terms == 3 && nb > 6) ? 4 : 8; }
 
 // TERMS = 1: fp16 operands (UNIVS_MMA_F16).  TERMS = 3: every operand as TWO fp16 parts (h = fp16(x), m = fp16(x - h)) and three
 // of the four part products -- fp32-accurate (<= 2^-21.7 per product, see linear_f16x3.hip) at 3/16 of the exact-f32 MFMA time
@@ -62,13 +64,13 @@ __device__ __forceinline__ bool wh_out_of_range(float mx, float lo) {
 }
 
 template <int NB, bool MASK4, int TERMS>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
-__global__ __launch_bounds__(64 * WH_WAVES) void window_attn_img_f16(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * wh_waves(NB, TERMS)) void window_attn_img_f16(const float* __restrict__ qkv,
                                                                       const float* __restrict__ qkv_bias,
                                                                       const float* __restrict__ bias,
                                                                       const float* __restrict__ shift_mask, int B_, int nW,
                                                                       int nH, float scale, float* __restrict__ out,
                                                                       WinImage wi, int magic) {
-  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + 8;
+  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + 8, WH_WAVES = wh_waves(NB, TERMS);
   constexpr int VR = (NB + 1) / 2;   // V staging rounds: lanes 0-31 take key block r, lanes 32-63 block r + VR
   constexpr float LOG2E = 1.4426950408889634f;
   const int Ntok = wi.ws * wi.ws;
@@ -378,6 +380,7 @@ template <int NB, bool MASK4, int TERMS>
 static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B_, int nW,
                       int nH, float scale, float* out, const WinImage& wi, int n_cu, hipStream_t st) {
   constexpr int NP = 16 * NB;
+  constexpr int WH_WAVES = wh_waves(NB, TERMS);
   const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * (TERMS == 3 ? 2 : 1) * 32 * (NP + 8) * sizeof(_Float16);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
   // workgroups = resident slots rounded DOWN to a multiple of the head count: one extra workgroup would double the tail
@@ -391,12 +394,12 @@ static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias
 }
 
 // qkv [B, H*W, 3, nH, hd] in token order; out [B, H*W, nH*hd]
-// terms = 1: fp16 operands; terms = 3: two fp16 parts per operand, three products (windows up to 9 x 9: returns
-// UNIVS_ERR_NOT_IMPLEMENTED beyond, the caller then runs the exact-f32 kernel)
+// terms = 1: fp16 operands; terms = 3: two fp16 parts per operand, three products (12 x 12 windows with four waves per
+// workgroup)
 int window_attention_image_f16mma(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B,
                                   int H, int W, int ws, int shift, int nH, int hd, float scale, int terms, float* out,
                                   hipStream_t st) {
-  if (terms == 3 && (ws > 9 || hd != 32)) return UNIVS_ERR_NOT_IMPLEMENTED;
+  if (terms == 3 && hd != 32) return UNIVS_ERR_NOT_IMPLEMENTED;
   if (hd != 32) {
     set_error("window_attention_image (fp16 operands): head_dim=%d (only 32, the Swin-T/B/L value)", hd);
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -427,7 +430,9 @@ int window_attention_image_f16mma(const float* qkv, const float* qkv_bias, const
   const int ntok = ws * ws;
   if (terms == 3) {
     if (ntok <= 64) return launch_f16<4, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
-    return launch_f16<6, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+    if (ntok <= 96) return launch_f16<6, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+    if (ntok % 4 == 0) return launch_f16<9, true, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+    return launch_f16<9, false, 3>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
   }
   if (ntok <= 64) return launch_f16<4, false, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
   if (ntok <= 96) return launch_f16<6, false, 1>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);

@@ -121,14 +121,19 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
 
     def forward(self, query, key, value, attn_mask: Optional[torch.Tensor] = None, need_weights=False,
-                average_attn_weights=True):
+                average_attn_weights=True, kv=None):
+        """`kv` = (k, v) [S, N, E]: the key / value projections when the caller already has them (the decoder computes the K and V
+        of all layers that attend to one feature level with ONE Linear each; `key` / `value` are then ignored)."""
         L, N, E = query.shape
-        S = key.shape[0]
+        S = key.shape[0] if kv is None else kv[0].shape[0]
         h, d = self.num_heads, self.head_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         lin = linear     # tall projections (cross-attention K / V of the 1/8-resolution memory: 73 600 rows) take the fp16
         #                  three-product kernel (62 vs 90 us in the tuned library GEMM); short ones stay on the library
-        if query is key and key is value:
+        if kv is not None:
+            q = lin(query, w[:E], b[:E])
+            k, v = kv
+        elif query is key and key is value:
             q, k, v = lin(query, w, b).chunk(3, dim=-1)
         else:
             if query is key:      # self-attention with positional queries (q = k = tgt + pos, v = tgt): q and k in one projection

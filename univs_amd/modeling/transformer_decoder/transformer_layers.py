@@ -55,15 +55,16 @@ class CrossAttentionLayer(nn.Module):
 
     def forward(self, tgt, memory, memory_mask: Optional[Tensor] = None,
                 memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
-                query_pos: Optional[Tensor] = None, key: Optional[Tensor] = None):
+                query_pos: Optional[Tensor] = None, key: Optional[Tensor] = None, kv=None):
         """`key`: optional precomputed `memory + pos` (it does not change across the decoder layers that
-        attend to the same feature level, so the caller builds it once per level)."""
+        attend to the same feature level, so the caller builds it once per level); `kv`: optional precomputed key / value
+        PROJECTIONS of this layer (layers.MultiheadAttention.forward)."""
         assert memory_key_padding_mask is None
         src = layer_norm(self.norm, tgt) if self.normalize_before else tgt
         # nn.MultiheadAttention's default averages the returned weights over heads; the reference
         # never passes `average_attn_weights` through, so neither do we (transformer_layers.py:101-105)
-        out, w = self.multihead_attn(_with_pos(src, query_pos), key if key is not None else _with_pos(memory, pos), memory,
-                                     attn_mask=memory_mask, need_weights=self.need_weights)
+        out, w = self.multihead_attn(_with_pos(src, query_pos), key if (key is not None or kv is not None) else _with_pos(memory, pos),
+                                     memory, attn_mask=memory_mask, need_weights=self.need_weights, kv=kv)
         tgt = tgt + out if self.normalize_before else layer_norm(self.norm, out, residual=tgt)
         return (tgt, w) if self.need_weights else tgt
 

@@ -276,6 +276,10 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         # cross-attention inputs per level, contiguous and built once (every third layer reuses them)
         mem = [s_.contiguous() for s_ in src]
         mem_key = [(s_ + p_).contiguous() for s_, p_ in zip(src, pos)]
+        # key / value projections of the cross-attention: the layers i, i + L, i + 2 L, ... attend to the same level with
+        # different weights -- ONE Linear per level for all their keys (N = 256 x layers), one for their values: the level's
+        # memory is read once instead of once per layer; a layer takes its 256-column slice in place
+        kv_proj = self._cross_kv(mem, mem_key) if (mem[0].is_cuda and not self.transformer_cross_attention_layers[0].need_weights) else None
         for i in range(self.num_layers):
             if self.prompt_as_queries and 0 < i < self.prompt_self_attn_layers:
                 output = self.forward_transformer_prompt_self_attention_layer(
@@ -283,7 +287,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             lvl = i % self.num_feature_levels
             # per-frame masked cross-attention; attn_mask [T, Q', HW_l] (rows already reset per :390)
             output = self.transformer_cross_attention_layers[i](
-                output, mem[lvl], memory_mask=attn_mask, pos=None, query_pos=query_embed, key=mem_key[lvl])
+                output, mem[lvl], memory_mask=attn_mask, pos=None, query_pos=query_embed, key=mem_key[lvl],
+                kv=None if kv_proj is None else kv_proj[i])
             # spatio-temporal self-attention over Q'*T tokens: 'Q (B T) C -> (Q T) B C'
             Qn = output.shape[0]
             if fs is None:
@@ -554,6 +559,36 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return out[1], out[0]
 
     @torch.no_grad()
+    def _cross_kv(self, mem, mem_key):
+        """(k, v) per decoder layer: [HW_l, T, 256] column slices of one [HW_l, T, 256 n_l] projection per level and kind."""
+        from ...layers import linear
+        nl = self.num_feature_levels
+        E = self.transformer_cross_attention_layers[0].multihead_attn.embed_dim
+        mods = [layer.multihead_attn for layer in self.transformer_cross_attention_layers]
+        key = tuple((m.in_proj_weight.data_ptr(), m.in_proj_weight._version, m.in_proj_bias._version) for m in mods) + (str(mem[0].device),)
+        c = self.__dict__.get("_cross_kv_cache")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                per_level = []
+                for lvl in range(nl):
+                    idx = list(range(lvl, self.num_layers, nl))
+                    wk = torch.cat([mods[i].in_proj_weight[E:2 * E] for i in idx]).contiguous()
+                    bk = torch.cat([mods[i].in_proj_bias[E:2 * E] for i in idx]).contiguous()
+                    wv = torch.cat([mods[i].in_proj_weight[2 * E:] for i in idx]).contiguous()
+                    bv = torch.cat([mods[i].in_proj_bias[2 * E:] for i in idx]).contiguous()
+                    per_level.append((idx, wk, bk, wv, bv))
+            c = (key, per_level)
+            self.__dict__["_cross_kv_cache"] = c
+        out = [None] * self.num_layers
+        for lvl, (idx, wk, bk, wv, bv) in enumerate(c[1]):
+            if not idx:
+                continue
+            k_all = linear(mem_key[lvl], wk, bk)
+            v_all = linear(mem[lvl], wv, bv)
+            for j, i in enumerate(idx):
+                out[i] = (k_all[..., j * E:(j + 1) * E], v_all[..., j * E:(j + 1) * E])
+        return out
+
     def _sa_mask_rows(self, mask, Qn, t_total, sl):
         """Rows of the [Q' T, Q' T] self-attention mask that belong to the frames `sl` (token order (q, t)): [Q' T_loc, Q' T]."""
         key = ("rows", id(mask), Qn, t_total, sl.start, sl.stop)

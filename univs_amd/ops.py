@@ -341,12 +341,15 @@ def presplit_weights(weight, conv=False, mode=None):
 MLP_WIDTHS = (96, 128, 192, 256)
 
 
-def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None):
+def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post_add=None):
     """act(LN(x) W1^T + b1) W2^T + b2 (+ residual) in ONE kernel (include/univs_hip.h: univs_mlp_presplit_f32; csrc/mlp_f16x3.hip):
     the encoder FFN (msdeformattn.py:87-91) and the Swin Mlp + shortcut (swin.py:35-58, :291-293).  Both products use the
     three-product fp16 arithmetic of `linear_fused`; the [M, Hd] hidden activations stay in registers.  `act`: 'relu' | 'gelu'.
     `ln` = (weight, bias, eps) of an nn.LayerNorm(C) applied to the rows of x inside the kernel first (the Swin block's
-    `x + mlp(norm2(x))`, swin.py:289-293, is then one launch with residual=x).
+    `x + mlp(norm2(x))`, swin.py:289-293, is then one launch with residual=x).  `post_ln` = (weight, bias, eps): the finished rows
+    (bias and residual added) go through that LayerNorm before they are stored -- the encoder layer's `norm2(src + ffn(src))`,
+    msdeformattn.py:91-95 -- and with `post_add` [rows, C] (rows dividing M: broadcast over the leading dimension) the call
+    returns the pair (y, y + post_add), the second being the next layer's `with_pos_embed(src, pos)`.
     Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256, Hd % 32, fewer than 2048 rows, autograd needed):
     the caller keeps two `linear_fused` calls."""
     C = x.shape[-1]
@@ -356,8 +359,24 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None):
         return None
     if (not x.is_cuda or x.dtype != torch.float32 or w1.dtype != torch.float32 or w2.dtype != torch.float32 or C not in MLP_WIDTHS
             or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048 or M * C * 4 >= 2 ** 31 - 1
-            or (2 * Hd + 132 * C) * 4 > 160 * 1024):
+            or (2 * Hd + 134 * C) * 4 > 160 * 1024):
         return None
+    pw = pb = pa = None
+    peps, parows = 0.0, 0
+    if post_ln is not None:
+        pw, pb, peps = post_ln
+        for t_ in (pw, pb):
+            if t_ is not None and (t_.dtype != torch.float32 or tuple(t_.shape) != (C,) or not t_.is_cuda or not t_.is_contiguous()):
+                raise RuntimeError("mlp_fused: LayerNorm weight / bias must be contiguous float32 [C] on the GPU")
+        if pw is None:
+            raise RuntimeError("mlp_fused: post_ln needs a weight")
+    if post_add is not None:
+        if post_ln is None:
+            raise RuntimeError("mlp_fused: post_add needs post_ln")
+        pa = post_add.contiguous()
+        parows = pa.numel() // C
+        if pa.dtype != torch.float32 or not pa.is_cuda or pa.shape[-1] != C or parows < 1 or M % parows != 0:
+            raise RuntimeError("mlp_fused: post_add must be float32 [rows, C] on the GPU with rows dividing the number of tokens")
     lw = lb = None
     leps = 0.0
     if ln is not None:
@@ -378,17 +397,20 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None):
             raise RuntimeError(f"mlp_fused: residual must be float32 of x's shape on the GPU (got {tuple(residual.shape)})")
         r = residual.contiguous()
     y = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((M, C), dtype=torch.float32, device=x.device) if pa is not None else None
     with _on(x):
         w1p, w1inv = presplit_weights(w1)
         w2p, w2inv = presplit_weights(w2, mode="mlp2")
         rc = _lib.load().univs_mlp_presplit_f32(_ptr(x2), _ptr(w1p), _ptr(w1inv), _ptr(b1) if b1 is not None else None, _ptr(w2p),
                                                 _ptr(w2inv), _ptr(b2) if b2 is not None else None, _ptr(r) if r is not None else None,
                                                 _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
+                                                _ptr(pw) if pw is not None else None, _ptr(pb) if pb is not None else None, float(peps),
+                                                _ptr(pa) if pa is not None else None, parows, _ptr(y2) if y2 is not None else None,
                                                 M, C, Hd, _ACTS[act], _ptr(y), _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "mlp_fused")
-    return y.view(x.shape)
+    return (y.view(x.shape), y2.view(x.shape)) if y2 is not None else y.view(x.shape)
 
 
 def linear_fused(x, weight, bias=None, act=None, residual=None):
@@ -756,12 +778,23 @@ def masked_softmax_(scores, mask=None):
     return scores
 
 
+def _seq_first_ld(t, N, E):
+    """Leading dimension (floats between batch entries) of a sequence-first [S, N, E] tensor that is dense or a column slice of a
+    wider dense [S, N, E'] tensor; None when the layout is anything else."""
+    if t.stride(-1) != 1 or t.dim() != 3:
+        return None
+    ld = t.stride(1) if N > 1 else (t.stride(0) if t.shape[0] > 1 else E)
+    if ld < E or ld % 4 or (t.shape[0] > 1 and t.stride(0) != N * ld) or (t.data_ptr() & 15):
+        return None
+    return ld
+
+
 def cross_attention(q, k, v, mask, num_heads, scale):
     """softmax(scale q k^T, masked) v per (batch entry, head) in one pass over the keys (include/univs_hip.h:
     univs_cross_attention_f32; csrc/cross_attn.hip): the attention core of nn.MultiheadAttention as the decoder's
     CrossAttentionLayer uses it (transformer_layers.py:95-115) between the in- and out-projections.
-    q [L, N, E], k / v [S, N, E] sequence-first contiguous float32 (E = num_heads * 32); mask bool / uint8 [N, L, S] (True =
-    masked out, shared by the heads) or None.  Returns [L, N, E], or None when the shape is not covered."""
+    q [L, N, E], k / v [S, N, E] sequence-first float32 (E = num_heads * 32), dense or column slices of wider projections; mask
+    bool / uint8 [N, L, S] (True = masked out, shared by the heads) or None.  Returns [L, N, E], or None when not covered."""
     _inference_only("cross_attention", q, k, v)
     if not (q.is_cuda and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32):
         return None
@@ -774,13 +807,20 @@ def cross_attention(q, k, v, mask, num_heads, scale):
         if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8) or S % 4 != 0 or not mask.is_cuda:
             return None
         mask = mask.contiguous()
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    lds_ = []
+    for t in (q, k, v):
+        ld = _seq_first_ld(t, N, E)
+        if ld is None:
+            t = t.contiguous()
+            ld = E
+        lds_.append((t, ld))
+    (q, ldq), (k, ldk), (v, ldv) = lds_
     lib = _lib.load()
     ws = torch.empty(int(lib.univs_cross_attention_workspace(L, S, N, H)), dtype=torch.float32, device=q.device)
     out = torch.empty((L, N, E), dtype=torch.float32, device=q.device)
     with _on(q):
         rc = lib.univs_cross_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask) if mask is not None else None, L, S, N, H, 32,
-                                           float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
+                                           ldq, ldk, ldv, float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "cross_attention")
