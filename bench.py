@@ -564,7 +564,7 @@ def run(args):
                                                          "achieved": (alg + prep) / sec / 1e9, "frac": (alg + prep) / sec / HBM_PEAK}
             # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
             # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
-            for fn in ("r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+            for fn in ("r04_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
                         tr = json.load(f)

@@ -82,16 +82,25 @@ class _Sine3DBase(nn.Module):
         self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
         self.scale = 2 * math.pi if scale is None else scale
 
-    def _compose(self, z, y, x, device):
-        """z [..t], y [h], x [w] already scaled -> [..t, 2F, h, w] = cat(sin/cos(y), sin/cos(x)) + sin/cos(z)."""
-        F_ = self.num_pos_feats
-        dim_t = _dim_t(F_, self.temperature, device)
-        dim_t_z = _dim_t(2 * F_, self.temperature, device)
-        pos_y = _interleaved_sincos(y, dim_t)     # [h, F]
-        pos_x = _interleaved_sincos(x, dim_t)     # [w, F]
+    def _yx(self, h, w, device):
+        """The spatial part [h, w, 2F] = cat(sin/cos(y), sin/cos(x)) and the frequency table of the temporal part: pure
+        functions of the shape (a dozen tiny launches per level otherwise), cached per (h, w, device)."""
+        if not hasattr(self, "_yx_cache"):
+            self._yx_cache = _ShapeCache(cap=16)
+
+        def make():
+            F_ = self.num_pos_feats
+            dim_t = _dim_t(F_, self.temperature, device)
+            pos_y = _interleaved_sincos(_axis(h, self.scale, device), dim_t)     # [h, F]
+            pos_x = _interleaved_sincos(_axis(w, self.scale, device), dim_t)     # [w, F]
+            yx = torch.cat((pos_y[:, None, :].expand(h, w, -1), pos_x[None, :, :].expand(h, w, -1)), dim=2).contiguous()
+            return yx, _dim_t(2 * F_, self.temperature, device)
+        return self._yx_cache.get((h, w, str(device)), make)
+
+    def _compose(self, z, h, w, device):
+        """z [..t] already scaled -> [..t, 2F, h, w] = cat(sin/cos(y), sin/cos(x)) + sin/cos(z)."""
+        yx, dim_t_z = self._yx(h, w, device)
         pos_z = _interleaved_sincos(z, dim_t_z)   # [..t, 2F]
-        h, w = y.shape[0], x.shape[0]
-        yx = torch.cat((pos_y[:, None, :].expand(h, w, -1), pos_x[None, :, :].expand(h, w, -1)), dim=2)  # [h,w,2F]
         pos = yx + pos_z[..., None, None, :]       # [..t, h, w, 2F]
         return pos.movedim(-1, -3)                 # [..t, 2F, h, w]
 
@@ -118,8 +127,7 @@ class PositionEmbeddingSine3D(_Sine3DBase):
         assert self.normalize
         if not hasattr(self, "_cache"):
             self._cache = _ShapeCache()
-        pos = self._cache.get((t, h, w, str(dev)), lambda: self._compose(
-            _axis(t, self.scale, dev), _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev))
+        pos = self._cache.get((t, h, w, str(dev)), lambda: self._compose(_axis(t, self.scale, dev), h, w, dev))
         return pos[None].expand(b, -1, -1, -1, -1)
 
     def forward_points_with_size(self, size, xy_embed_normalized):
@@ -144,7 +152,7 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
         if t_indices is None:
             t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
         z = t_indices.to(dev) / self.num_max_frames * self.scale  # [b, t]
-        return self._compose(z, _axis(h, self.scale, dev), _axis(w, self.scale, dev), dev)
+        return self._compose(z, h, w, dev)
 
     def forward_points_with_size(self, size, xy_embed_normalized, t_indices=None):
         dev = xy_embed_normalized.device
