@@ -279,7 +279,8 @@ int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv
  *   w1p, w1inv   univs_presplit_weights_f32(W1 [Hd, C], Hd, C, 0, ...)
  *   w2p, w2inv   univs_presplit_weights_f32(W2 [C, Hd], C, Hd, 2, ...)     (mode 2: the MLP k-order)
  *   b1 [Hd], b2 [C], residual [M, C]: optional (NULL);  act: 1 ReLU, 2 GELU (erf form, as univs_linear_fused_f32)
- * Covered: C in {96, 128, 192, 256}, Hd % 32 == 0 (2 Hd + 134 C floats of LDS <= 160 KB), M >= 2048, M * C * 4 < 2^31, 16-byte
+ * Covered: C in {96, 128, 192, 256, 384}, Hd % 32 == 0 (2 Hd + 134 C floats of LDS <= 160 KB; C = 384: 2 Hd + 70 C, one weight image
+ * instead of two), M >= 2048, M * C * 4 < 2^31, 16-byte
  * aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps two univs_linear_* calls).
  * Replaces: linear2(dropout(activation(linear1(src)))) of the MSDeformAttn encoder layer
  *   (mask2former/modeling/pixel_decoder/msdeformattn.py:87-91) and Mlp.forward + the block's shortcut add of the Swin stages

@@ -826,7 +826,8 @@ def test_linear_fused_matches_torch(cuda, linear_terms, terms, M, K, N, act, res
 
 @pytest.mark.parametrize("M,C,Hd,act,res", [(19320, 256, 1024, "relu", False), (58880, 96, 384, "gelu", True), (14720, 192, 768, "gelu", True),
                                              (5000, 128, 512, "gelu", True), (4099, 96, 384, "gelu", False), (2049, 256, 32, "relu", True),
-                                             (3000, 256, 2048, "gelu", False), (2048, 192, 96, "relu", False)], ids=lambda v: str(v))
+                                             (3000, 256, 2048, "gelu", False), (2048, 192, 96, "relu", False), (18400, 384, 1536, "gelu", True),
+                                             (2100, 384, 64, "relu", False)], ids=lambda v: str(v))
 def test_mlp_fused_matches_torch(cuda, M, C, Hd, act, res):
     """ops.mlp_fused (csrc/mlp_f16x3.hip: both Linears of an MLP in one kernel, hidden activations in registers, W2 pre-split
     in the k-order of the first product's accumulators) == linear -> activation -> linear (+ residual) to fp32 rounding:
@@ -861,7 +862,8 @@ def test_mlp_fused_matches_torch(cuda, M, C, Hd, act, res):
         assert torch.equal(ops.mlp_fused(4.0 * xd, w1d, None, w2d, None, act), 4.0 * y3.view(M, C))
 
 
-@pytest.mark.parametrize("M,C,Hd", [(58880, 96, 384), (14720, 192, 768), (4099, 256, 512), (3000, 128, 512)], ids=lambda v: str(v))
+@pytest.mark.parametrize("M,C,Hd", [(58880, 96, 384), (14720, 192, 768), (4099, 256, 512), (3000, 128, 512), (3680, 384, 1536)],
+                         ids=lambda v: str(v))
 def test_mlp_fused_with_layer_norm(cuda, M, C, Hd):
     """ops.mlp_fused(..., ln=...) == x + fc2(gelu(fc1(LayerNorm(x)))): the Swin block's norm2 + Mlp + shortcut (swin.py:289-293)
     as one launch, the LayerNorm evaluated on the x tile in registers.  Rows with offsets far from zero (mean >> std) included."""
@@ -957,8 +959,8 @@ def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):
         bad = torch.zeros(M, dtype=torch.bool, device=cuda)
         bad[100] = bad[200] = True
         assert torch.equal(y2[~bad], y[~bad]) and not torch.isfinite(y2[100]).any() and torch.isnan(y2[200]).all()
-    assert ops.mlp_fused(torch.zeros(4096, 384, device=cuda), torch.zeros(1536, 384, device=cuda), None,
-                         torch.zeros(384, 1536, device=cuda), None, "gelu") is None                              # C = 384
+    assert ops.mlp_fused(torch.zeros(4096, 768, device=cuda), torch.zeros(3072, 768, device=cuda), None,
+                         torch.zeros(768, 3072, device=cuda), None, "gelu") is None                              # C = 768
     assert ops.mlp_fused(xd[:100], w1d, b1d, w2d, b2d, "relu") is None                                           # few rows
     assert ops.mlp_fused(xd, w1d[:500], b1d[:500], w2d[:, :500].contiguous(), b2d, "relu") is None               # Hd % 32
     assert ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "tanh") is None

@@ -195,7 +195,7 @@ def main():
         # two-Linear MLPs in one kernel (csrc/mlp_f16x3.hip) against the two fused Linears they replace: the encoder FFN and the
         # Swin Mlp + shortcut of the stages with C <= 256, at 720p x T frames
         for nm, Mr, C, Hd, act, with_res in (("encoder_ffn", T * 19320, 256, 1024, "relu", False), ("swin_s1_mlp", T * 184 * 320, 96, 384, "gelu", True),
-                                           ("swin_s2_mlp", T * 92 * 160, 192, 768, "gelu", True)):
+                                           ("swin_s2_mlp", T * 92 * 160, 192, 768, "gelu", True), ("swin_s3_mlp", T * 46 * 80, 384, 1536, "gelu", True)):
             xs = synth.normal(f"kb/mlp/x{C}/{Mr}", (Mr, C)).to(dev)
             w1 = synth.normal(f"kb/mlp/w1/{C}", (Hd, C), std=C ** -0.5).to(dev)
             b1 = synth.normal(f"kb/mlp/b1/{C}", (Hd,), std=0.5).to(dev)

@@ -261,7 +261,7 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
   const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, post_ln_weight, post_ln_bias,
                                       post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
-    set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256, Hd %% 32 == 0, "
+    set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256 / 384, Hd %% 32 == 0, "
               "M >= 2048)", M, C, Hd);
   return rc;
 }

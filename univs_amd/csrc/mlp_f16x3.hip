@@ -109,8 +109,11 @@ constexpr int ml_ring(int upt, int nbat) {          // most units in flight at o
 
 // LDS (16-byte units): 2 x { W1 part [C/8 k-chunks][2 parts][32 hidden rows] | W2 part [4 k-groups][2 parts][C rows] } |
 //                      b1[Hd] | w1inv[Hd] | b2[C] | w2inv[C] | ln weight[C] | ln bias[C] | post-ln weight[C] | post-ln bias[C]
-template <int KS1, int CT, int ACT, int NW, int ABL>
-__global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
+// DB: the chunk images double-buffered (one barrier per chunk).  !DB (C = 384, where two 96-KB images do not fit): ONE image, its
+// W1 part refilled with the next chunk's rows during the second product and its W2 part with this chunk's k-step during the
+// first, a barrier between the two products as well; a workgroup is then 4 waves, one per SIMD (512 registers per lane).
+template <int KS1, int CT, int ACT, int NW, int ABL, bool DB>
+__global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
   constexpr int THREADS = 64 * NW;
   constexpr int C = 32 * KS1;
@@ -118,14 +121,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
   constexpr int NBAT = 2 * KS1;                                  // A-fragment batches per chunk: KS1 k-steps of GEMM 1, KS1 block pairs of GEMM 2
   constexpr int W1U = 8 * C, W2U = 8 * C, CHU = W1U + W2U;       // units per chunk
   constexpr int UPT = CHU / THREADS;                             // units per thread and chunk
-  constexpr int WR = ml_ring(UPT, NBAT), WD = ml_dist(NBAT);
+  constexpr int UPH = W1U / THREADS;                             // !DB: units per thread and phase (W1U == W2U)
+  constexpr int WR = DB ? ml_ring(UPT, NBAT) : ml_ring(UPH, KS1), WD = DB ? ml_dist(NBAT) : ml_dist(KS1);
+  constexpr int NBUF = DB ? 2 : 1;
+  static_assert(W1U % THREADS == 0, "phase geometry");
   static_assert(CHU % THREADS == 0 && NOB == 2 * KS1 && NBAT >= 4, "chunk geometry");
   constexpr int RG = NW * 16 * CT;                               // rows per workgroup round
   const int M = a.M, Hd = a.Hd, NCH = Hd >> 5, nwg = a.nwg;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  float* b1_lds = reinterpret_cast<float*>(Lds + 2 * CHU);
+  float* b1_lds = reinterpret_cast<float*>(Lds + NBUF * CHU);
   float* w1inv_lds = b1_lds + Hd;
   float* b2_lds = w1inv_lds + Hd;
   float* w2inv_lds = b2_lds + C;
@@ -158,11 +164,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
     return i < W1U ? a.W1p + ((size_t)(i >> 5) * Hd + 32 * c + (i & 31)) : a.W2p + ((size_t)c * W2U + (i - W1U));
   };
   {
-    u32x4 w0[UPT];                                               // chunk 0 -> buffer 0
+    constexpr int U0 = DB ? UPT : UPH;                           // chunk 0 -> buffer 0 (!DB: its W1 part; W2 follows in the loop)
+    u32x4 w0[U0];
 #pragma unroll
-    for (int v = 0; v < UPT; ++v) w0[v] = *w_src(0, v);
+    for (int v = 0; v < U0; ++v) w0[v] = *w_src(0, v);
 #pragma unroll
-    for (int v = 0; v < UPT; ++v) Lds[tid + THREADS * v] = w0[v];
+    for (int v = 0; v < U0; ++v) Lds[tid + THREADS * v] = w0[v];
   }
   u32x4 wreg[WR];
 
@@ -266,10 +273,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
     for (int c = 0; c < NCH; ++c, ++gq) {
       __syncthreads();                                           // chunk gq's image is complete; the other buffer is free
       const int cn = (c + 1 == NCH) ? 0 : c + 1;
-      const int bufc = gq & 1;
+      const int bufc = DB ? (gq & 1) : 0;
       const unsigned a1 = a1_lane + (unsigned)(bufc * CHU * 16);
       const unsigned a2 = a2_lane + (unsigned)(bufc * CHU * 16);
-      u32x4* const wdst = Lds + (bufc ^ 1) * CHU + tid;
+      u32x4* const wdst = Lds + (DB ? (bufc ^ 1) * CHU : 0) + tid;
       read_batch(afr[0], a1, 512u);
       read_batch(afr[1], a1 + 4096u, 512u);
 
@@ -283,19 +290,42 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
       // one batch slot: this slot's share of the weight stream, wait for batch T's fragments, request batch T + 2, six CT MFMAs
       auto slot = [&](auto tc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value;
-        ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
-          constexpr int V = decltype(vc)::value;
-          if constexpr (ml_fs(V, UPT, NBAT) + WD == T) wdst[THREADS * V] = wreg[V % WR];
-        });
-        ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
-          constexpr int V = decltype(vc)::value;
-          if constexpr (ml_fs(V, UPT, NBAT) == T) wreg[V % WR] = *w_src(cn, V);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 2) ml_wait_lgkm<(T + 1 < NBAT ? 4 : 0) + ml_commits_in(T, UPT, NBAT)>(afr[T % 3]);
-        if constexpr (T + 2 < NBAT) {
-          if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], a1 + (unsigned)((T + 2) * 4096), 512u);
-          else read_batch(afr[(T + 2) % 3], a2 + (unsigned)((T + 2 - KS1) * 512), (unsigned)(C * 16));
+        if constexpr (DB) {
+          ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value;
+            if constexpr (ml_fs(V, UPT, NBAT) + WD == T) wdst[THREADS * V] = wreg[V % WR];
+          });
+          ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value;
+            if constexpr (ml_fs(V, UPT, NBAT) == T) wreg[V % WR] = *w_src(cn, V);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          if (ABL != 2) ml_wait_lgkm<(T + 1 < NBAT ? 4 : 0) + ml_commits_in(T, UPT, NBAT)>(afr[T % 3]);
+          if constexpr (T + 2 < NBAT) {
+            if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], a1 + (unsigned)((T + 2) * 4096), 512u);
+            else read_batch(afr[(T + 2) % 3], a2 + (unsigned)((T + 2 - KS1) * 512), (unsigned)(C * 16));
+          }
+        } else {
+          // one image: during GEMM 1 (slots < KS1) the W2 part of THIS chunk is streamed in (units W1U + ...), during GEMM 2 the
+          // W1 part of the NEXT chunk (units 0 ...); fragment requests do not cross the barrier between the two products
+          constexpr int PT = T < KS1 ? T : T - KS1;                // slot within its phase
+          constexpr int UOFF = T < KS1 ? UPH : 0;                  // first unit (per thread) of the part this phase refills
+          ml_static_for<0, UPH>([&](auto vc) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value;
+            if constexpr (ml_fs(V, UPH, KS1) + WD == PT) wdst[THREADS * (UOFF + V)] = wreg[V % WR];
+          });
+          ml_static_for<0, UPH>([&](auto vc) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value;
+            if constexpr (ml_fs(V, UPH, KS1) == PT) wreg[V % WR] = *w_src(T < KS1 ? c : cn, UOFF + V);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr bool next_requested = T < KS1 ? (T + 1 < KS1) : (T + 1 < NBAT);
+          if (ABL != 2) ml_wait_lgkm<(next_requested ? 4 : 0) + ml_commits_in(PT, UPH, KS1)>(afr[T % 3]);
+          if constexpr (T < KS1) {
+            if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], a1 + (unsigned)((T + 2) * 4096), 512u);
+          } else if constexpr (T + 2 < NBAT) {
+            read_batch(afr[(T + 2) % 3], a2 + (unsigned)((T + 2 - KS1) * 512), (unsigned)(C * 16));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1) {
@@ -341,6 +371,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_f16x3(const MlpArgs a) {
       };
 
       ml_static_for<0, KS1>(slot);
+      if constexpr (!DB) {
+        __syncthreads();                                         // this chunk's W2 part is complete; everybody is done with the W1 part
+        read_batch(afr[KS1 % 3], a2, (unsigned)(C * 16));
+        read_batch(afr[(KS1 + 1) % 3], a2 + 512u, (unsigned)(C * 16));
+      }
 
       // ---- hidden activations of this chunk: bias, activation, running row scale, two fp16 parts = the B operand of GEMM 2
       if (ABL == 1) {
@@ -474,9 +509,9 @@ static int ml_cus() {
   return n_cu;
 }
 
-template <int KS1, int CT, int ACT, int NW, int ABL>
+template <int KS1, int CT, int ACT, int NW, int ABL, bool DB = true>
 static int ml_launch1(MlpArgs a, size_t lds, int ngroups, hipStream_t st) {
-  const void* fn = reinterpret_cast<const void*>(&mlp_f16x3<KS1, CT, ACT, NW, ABL>);
+  const void* fn = reinterpret_cast<const void*>(&mlp_f16x3<KS1, CT, ACT, NW, ABL, DB>);
   static int per_cu = 0;                                          // resident workgroups per CU (LDS and registers)
   if (per_cu == 0) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -488,16 +523,16 @@ static int ml_launch1(MlpArgs a, size_t lds, int ngroups, hipStream_t st) {
     per_cu = nb;
   }
   a.nwg = std::min(ml_cus() * per_cu, ngroups);
-  hipLaunchKernelGGL((mlp_f16x3<KS1, CT, ACT, NW, ABL>), dim3((unsigned)a.nwg), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((mlp_f16x3<KS1, CT, ACT, NW, ABL, DB>), dim3((unsigned)a.nwg), dim3(64 * NW), lds, st, a);
   return check_launch("mlp_f16x3");
 }
 
-template <int KS1, int CT, int NW>
+template <int KS1, int CT, int NW, bool DB = true>
 static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
   constexpr int C = 32 * KS1;
   constexpr int RG = NW * 16 * CT;
   const int ngroups = (a.M + RG - 1) / RG;
-  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 6 * C) * 4;
+  const size_t lds = (size_t)(DB ? 2 : 1) * 16 * C * 16 + (size_t)(2 * a.Hd + 6 * C) * 4;
   if (lds > 160 * 1024) return UNIVS_ERR_NOT_IMPLEMENTED;
   const int abl = config().linear_ablate;                         // 2 / 3 / 4: timing experiments (encoder FFN and Swin stage 1 only)
   if (abl >= 2 && abl <= 4 && ((KS1 == 8 && act == ML_ACT_RELU) || (KS1 == 3 && act == ML_ACT_GELU))) {
@@ -512,8 +547,8 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
       return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 3>(a, lds, ngroups, st);
     }
   }
-  if (act == ML_ACT_RELU) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 0>(a, lds, ngroups, st);
-  return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 0>(a, lds, ngroups, st);
+  if (act == ML_ACT_RELU) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 0, DB>(a, lds, ngroups, st);
+  return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 0, DB>(a, lds, ngroups, st);
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
@@ -539,6 +574,7 @@ int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const flo
     case 128: return ml_launch<4, 1, 8>(a, act, st);
     case 192: return ml_launch<6, 1, 8>(a, act, st);
     case 256: return ml_launch<8, 1, 8>(a, act, st);
+    case 384: return ml_launch<12, 1, 4, false>(a, act, st);
     default: return UNIVS_ERR_NOT_IMPLEMENTED;
   }
 }

@@ -47,7 +47,8 @@ class Mlp(nn.Module):
     def fused(self, x, residual=None, norm=None):
         """Both Linears, the GELU, the shortcut add and (with `norm`, an nn.LayerNorm applied to x first) the block's norm2 in
         ONE kernel (csrc/mlp_f16x3.hip): stages with C <= 256.  None when the shape is not covered or the fusion is off."""
-        if not (SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda):
+        if not (SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda
+                and x.shape[-1] <= SWITCHES.fused_mlp_max_c):
             return None
         ln = None if norm is None else (norm.weight, norm.bias, norm.eps)
         return ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual, ln=ln)

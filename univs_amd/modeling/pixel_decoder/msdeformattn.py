@@ -227,9 +227,23 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         for (h, w) in spatial_shapes:
             level_start_index.append(acc)
             acc += h * w
-        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
-                             for lvl, p in enumerate(pos_embeds)], 1)
+        if srcs[0].is_cuda and not torch.is_grad_enabled():
+            # NCHW -> tokens per level by the LDS tile transpose, then one concatenation of contiguous pieces (a concatenation of
+            # transposed views runs at 0.6 TB/s: 175 us for the 99 MB of a 720p clip)
+            src_flatten = torch.cat([ops.transpose_last2(s.flatten(2).contiguous()) for s in srcs], 1)
+        else:
+            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        # position embedding + level embedding: a function of the shapes and of one parameter (cached with its version)
+        le = self.level_embed
+        pkey = (tuple(spatial_shapes), tuple(int(p.shape[0]) for p in pos_embeds), str(src_flatten.device), le._version, le.data_ptr(),
+                tuple(p.data_ptr() for p in pos_embeds))
+        pc = self.__dict__.get("_lvl_pos_cache")
+        if pc is not None and pc[0] == pkey and not torch.is_grad_enabled():
+            lvl_pos = pc[1]
+        else:
+            lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + le[lvl].view(1, 1, -1) for lvl, p in enumerate(pos_embeds)], 1)
+            if not torch.is_grad_enabled():
+                self.__dict__["_lvl_pos_cache"] = (pkey, lvl_pos, list(pos_embeds))     # (the embeddings are kept alive with their addresses)
         key = (tuple(spatial_shapes), str(src_flatten.device))
         ref = self._ref_cache.get(key)
         if ref is None:

@@ -338,7 +338,7 @@ def presplit_weights(weight, conv=False, mode=None):
     return wp, winv
 
 
-MLP_WIDTHS = (96, 128, 192, 256)
+MLP_WIDTHS = (96, 128, 192, 256, 384)
 
 
 def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post_add=None):
@@ -350,7 +350,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
     (bias and residual added) go through that LayerNorm before they are stored -- the encoder layer's `norm2(src + ffn(src))`,
     msdeformattn.py:91-95 -- and with `post_add` [rows, C] (rows dividing M: broadcast over the leading dimension) the call
     returns the pair (y, y + post_add), the second being the next layer's `with_pos_embed(src, pos)`.
-    Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256, Hd % 32, fewer than 2048 rows, autograd needed):
+    Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256 / 384, Hd % 32, fewer than 2048 rows, autograd needed):
     the caller keeps two `linear_fused` calls."""
     C = x.shape[-1]
     Hd = w1.shape[0]
@@ -359,7 +359,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
         return None
     if (not x.is_cuda or x.dtype != torch.float32 or w1.dtype != torch.float32 or w2.dtype != torch.float32 or C not in MLP_WIDTHS
             or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048 or M * C * 4 >= 2 ** 31 - 1
-            or (2 * Hd + 134 * C) * 4 > 160 * 1024):
+            or ((1 if C == 384 else 2) * 64 * C + 2 * Hd + 6 * C) * 4 > 160 * 1024):
         return None
     pw = pb = pa = None
     peps, parows = 0.0, 0

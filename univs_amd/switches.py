@@ -34,6 +34,10 @@ class Switches:
     # two-Linear MLPs (encoder FFN, Swin Mlp + shortcut at C <= 256) in ONE kernel, hidden activations in registers
     # (csrc/mlp_f16x3.hip); False: two fused Linears
     fused_mlp: bool = True
+    # widest C the Swin blocks route to the fused MLP.  The kernel also covers C = 384 (one weight image, two barriers per chunk,
+    # 4-wave workgroups) but measured 321 us against 257 us for the two fused Linears at Swin stage 3 (18 400 rows: 288 row groups
+    # on 256 CUs, one wave per SIMD) -- profiles/r04_kbench_mlp_v2.txt
+    fused_mlp_max_c: int = 256
     # decoder cross-attention core (scores, mask, softmax, P V) as one pass over the keys (csrc/cross_attn.hip); False: two
     # library GEMMs around the masked-softmax kernel
     fused_cross_attention: bool = True
