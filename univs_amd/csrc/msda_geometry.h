@@ -1,6 +1,7 @@
 // Host-side tile geometry shared by the LDS-tiled MSDA kernels (msda_tiled.hip, msda_tiled2.hip).
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -36,7 +37,41 @@ struct GeoEntry {
   long long qmax;    // max queries of a tile
   long long win_px;  // max window pixels of a (tile, level)
   long long lvl_px[UNIVS_MAX_LEVELS];   // ... per level
+  hipEvent_t last_use = nullptr;        // recorded behind every launch that reads `table` (geo_mark_use)
 };
+
+// Lifetime of a cached geometry: callers hold a shared_ptr for the duration of their launch call (an eviction by another host
+// thread cannot free the entry under them), every launch records `last_use` on its stream, and an evicted entry's device table
+// is freed only once that event has completed -- no hipDeviceSynchronize, nothing of another device is touched.  While a
+// stream is being captured a cache MISS returns nullptr (hipMalloc / hipMemcpy are illegal there): warm the cache with one
+// eager call per geometry before capturing.
+template <class E>
+static inline void geo_mark_use(const std::shared_ptr<E>& e, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone) return;                 // (a replayed graph is ordered by its own stream; see graphs.py)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!e->last_use && hipEventCreateWithFlags(&e->last_use, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    e->last_use = nullptr;
+    return;
+  }
+  (void)hipEventRecord(e->last_use, st);
+}
+template <class E>
+static inline bool geo_idle(const std::shared_ptr<E>& e) {       // nobody holds it and the GPU is done with it
+  if (e.use_count() > 1) return false;
+  if (!e->last_use) return true;
+  const hipError_t q = hipEventQuery(e->last_use);
+  if (q != hipSuccess) (void)hipGetLastError();
+  return q == hipSuccess;
+}
+static inline bool geo_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+  return cs != hipStreamCaptureStatusNone;
+}
 
 // one axis of one level: query interval and window interval of tile t
 // ring = 1: the window may include the one-pixel zero ring around the level (pixels -1 and Nq: msda_tiled.hip /
@@ -57,17 +92,28 @@ static void axis_entry(int t, int ntile, int T, int Nq, int Nf, int R, int cap, 
   e.x = (int)lo; e.y = (int)(hi - lo); e.z = (int)w0; e.w = (int)wn;
 }
 
-static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, long long cap_px,
-                                int ring = 1) {
+static void geo_free(GeoEntry* e) {
+  if (!e) return;
+  if (e->table) (void)hipFree(e->table);
+  if (e->last_use) (void)hipEventDestroy(e->last_use);
+  delete e;
+}
+
+static std::shared_ptr<GeoEntry> geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, long long cap_px,
+                                          hipStream_t st, int ring = 1) {
   static std::mutex mu;
-  static std::vector<GeoEntry*> cache;
+  static std::vector<std::shared_ptr<GeoEntry>> cache, retired;
   GeoKey key{};
   if (hipGetDevice(&key.dev) != hipSuccess) return nullptr;
   key.L = L; key.TH = TH; key.TW = TW; key.R = R; key.ring = ring; key.cap_px = cap_px;
   for (int l = 0; l < L; ++l) { key.H[l] = lv.H[l]; key.W[l] = lv.W[l]; }
   std::lock_guard<std::mutex> lock(mu);
-  for (const GeoEntry* e : cache)
+  for (size_t i = 0; i < retired.size();)                       // evicted earlier: free what the GPU has finished with
+    if (geo_idle(retired[i])) retired.erase(retired.begin() + i);
+    else ++i;
+  for (const auto& e : cache)
     if (e->key == key) return e;
+  if (geo_capturing(st)) return nullptr;
 
   GeoEntry* ge = new GeoEntry();
   ge->key = key;
@@ -100,20 +146,24 @@ static const GeoEntry* geometry(const LevelTable& lv, int L, int fine, int TH, i
     }
     ge->qmax += (long long)mqx * mqy;
   }
+  ge->table = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&ge->table), tab.size() * sizeof(int4)) != hipSuccess ||
       hipMemcpy(ge->table, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipGetLastError();
-    delete ge;
+    geo_free(ge);
     return nullptr;
   }
-  if (cache.size() >= 32) {   // bounded (image datasets: many resolutions): drop the oldest entry; nobody may still be reading it
-    (void)hipDeviceSynchronize();
-    (void)hipFree(cache.front()->table);
-    delete cache.front();
-    cache.erase(cache.begin());
+  std::shared_ptr<GeoEntry> sp(ge, geo_free);
+  if (cache.size() >= 32) {   // bounded (image datasets: many resolutions): retire the oldest entry OF THIS DEVICE
+    for (size_t i = 0; i < cache.size(); ++i)
+      if (cache[i]->key.dev == key.dev) {
+        retired.push_back(cache[i]);
+        cache.erase(cache.begin() + i);
+        break;
+      }
   }
-  cache.push_back(ge);
-  return ge;
+  cache.push_back(sp);
+  return sp;
 }
 
 

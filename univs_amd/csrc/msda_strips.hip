@@ -31,6 +31,7 @@
 //     loads ahead of time and read with v_readlane; samples whose footprint leaves the window are added from global
 //     memory by the whole wave (as in generation 4).
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 
@@ -404,6 +405,7 @@ struct S5Geo {
   size_t lds = 0;
   bool ok = false;
   unsigned long long stamp = 0;
+  hipEvent_t last_use = nullptr;   // recorded behind every launch that reads the tables (msda_geometry.h: geo_mark_use)
 };
 
 static void s5_free(S5Geo* g) {
@@ -411,12 +413,15 @@ static void s5_free(S5Geo* g) {
   if (g->tiles) (void)hipFree(g->tiles);
   if (g->pieces) (void)hipFree(g->pieces);
   if (g->qtable) (void)hipFree(g->qtable);
+  if (g->last_use) (void)hipEventDestroy(g->last_use);
   delete g;
 }
 
-static const S5Geo* s5_geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R) {
+// Shared ownership + event-deferred frees: see msda_geometry.h (an evicted entry is freed once nobody holds it and the last
+// launch that read its tables has completed; a cache miss during stream capture returns nullptr).
+static std::shared_ptr<S5Geo> s5_geometry(const LevelTable& lv, int L, int fine, int TH, int TW, int R, hipStream_t st) {
   static std::mutex mu;
-  static std::vector<S5Geo*> cache;
+  static std::vector<std::shared_ptr<S5Geo>> cache, retired;
   static unsigned long long clock_ = 0;
   constexpr size_t CACHE_MAX = 24;
   S5Key key{};
@@ -424,8 +429,12 @@ static const S5Geo* s5_geometry(const LevelTable& lv, int L, int fine, int TH, i
   key.L = L; key.TH = TH; key.TW = TW; key.R = R;
   for (int l = 0; l < L; ++l) { key.H[l] = lv.H[l]; key.W[l] = lv.W[l]; }
   std::lock_guard<std::mutex> lock(mu);
-  for (S5Geo* e : cache)
+  for (size_t i = 0; i < retired.size();)
+    if (geo_idle(retired[i])) retired.erase(retired.begin() + i);
+    else ++i;
+  for (const auto& e : cache)
     if (e->key == key) { e->stamp = ++clock_; return e; }
+  if (geo_capturing(st)) return nullptr;
   S5Host h;
   s5_build_host(lv, L, fine, TH, TW, R, h);
   S5Geo* g = new S5Geo();
@@ -442,20 +451,22 @@ static const S5Geo* s5_geometry(const LevelTable& lv, int L, int fine, int TH, i
       return nullptr;
     }
   }
-  if (cache.size() >= CACHE_MAX) {   // evict the least recently used geometry (image datasets: many resolutions)
-    size_t lru = 0;
-    for (size_t i = 1; i < cache.size(); ++i)
-      if (cache[i]->stamp < cache[lru]->stamp) lru = i;
-    (void)hipDeviceSynchronize();    // nobody may still be reading the tables
-    s5_free(cache[lru]);
-    cache.erase(cache.begin() + lru);
+  std::shared_ptr<S5Geo> sp(g, s5_free);
+  if (cache.size() >= CACHE_MAX) {   // retire the least recently used geometry of THIS device (image datasets: many resolutions)
+    size_t lru = cache.size();
+    for (size_t i = 0; i < cache.size(); ++i)
+      if (cache[i]->key.dev == key.dev && (lru == cache.size() || cache[i]->stamp < cache[lru]->stamp)) lru = i;
+    if (lru < cache.size()) {
+      retired.push_back(cache[lru]);
+      cache.erase(cache.begin() + lru);
+    }
   }
-  cache.push_back(g);
-  return g;
+  cache.push_back(sp);
+  return sp;
 }
 
 template <int L>
-static void launch_strips(unsigned grid, unsigned nitems, hipStream_t st, const S5Geo* g, const S5Args& a) {
+static void launch_strips(unsigned grid, unsigned nitems, hipStream_t st, const std::shared_ptr<S5Geo>& g, const S5Args& a) {
   auto kfn = msda_fwd_strips<L>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * S5_NW), g->lds, st, a, g->lv, g->tiles, g->pieces, g->qtable, g->ntiles, nitems);
@@ -482,12 +493,12 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
   const int TW = cfg.msda_strip_w > 0 ? cfg.msda_strip_w : 12, R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
   int TH = cfg.msda_strip_h > 0 ? cfg.msda_strip_h : 8;
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
-  const S5Geo* g = nullptr;
+  std::shared_ptr<S5Geo> g;
   for (; TH >= 2; TH -= 2) {   // the windows of two workgroups must fit one CU's LDS
-    g = s5_geometry(lv, L, fine, TH, TW, R);
+    g = s5_geometry(lv, L, fine, TH, TW, R, st);
     if (!g) return 0;
     if (g->ok && g->lds <= (size_t)S5_LDS_MAX) break;
-    g = nullptr;
+    g.reset();
   }
   if (!g) return 0;
 
@@ -511,6 +522,7 @@ int msda_forward_strips_f32(const float* vhm, const LevelTable& lv, const float*
     default: launch_strips<4>(grid, (unsigned)nb, st, g, a); break;
   }
   int rc = check_launch("msda_fwd_strips");
+  geo_mark_use(g, st);
   return rc == UNIVS_OK ? 1 : rc;
 }
 

@@ -417,7 +417,7 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
   const int R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
   if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
   const long long cap_px = std::min<long long>(T2_WIN_PX, (long long)T2_WR * T2_OCTETS);
-  const GeoEntry* ge = geometry(lv, L, fine, TH, TW, R, cap_px);
+  const std::shared_ptr<GeoEntry> ge = geometry(lv, L, fine, TH, TW, R, cap_px, st);
   if (!ge || ge->qmax > T2_QCAP) return 0;
 
   // region plan: step parity picks the region; an odd level count makes odd items start in B, so they
@@ -464,6 +464,7 @@ int msda_forward_tiled2_f32(const float* value, const LevelTable& lv, const floa
     default: launch_tiled2<4>(grid, (unsigned)nb, lds, st, value, lv, tg, ge->table, loc, attn, N, S, M, out); break;
   }
   int rc = check_launch("msda_fwd_tiled2");
+  geo_mark_use(ge, st);
   return rc == UNIVS_OK ? 1 : rc;
 }
 

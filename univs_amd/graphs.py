@@ -54,10 +54,26 @@ def _spec_key(spec):
 class GraphedCallable:
     """`fn(*args)` with tensors / nested containers of tensors in and out, replayed as a hipGraph per input signature."""
 
-    def __init__(self, fn, max_graphs=4, warmup=2):
+    def __init__(self, fn, max_graphs=4, warmup=2, module=None):
+        """`module`: the nn.Module whose parameters `fn` reads.  A captured graph bakes in pointers to tensors DERIVED from the
+        parameters (pre-split weights, permuted / merged projection weights, bias tables): the fingerprint of the module's
+        parameters and buffers (address + version of each) is part of the graph key, so `load_state_dict`, an optimizer step or
+        `.to()` re-captures instead of replaying against stale or freed memory.  Writes through `.data` bump no version
+        counter: call `reset()` after those (as `ops.invalidate_presplit`)."""
         self.fn, self.max_graphs, self.warmup = fn, max_graphs, warmup
+        self.module = module if module is not None else getattr(fn, "__self__", None)
         self.entries = collections.OrderedDict()
         self.replays = 0
+
+    def reset(self):
+        """Drop every captured graph (the next call captures again)."""
+        self.entries.clear()
+
+    def _fingerprint(self):
+        m = self.module
+        if not isinstance(m, torch.nn.Module):
+            return ()
+        return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     def eligible(self, flat):
         return (bool(flat) and all(t.is_cuda for t in flat) and not torch.is_grad_enabled()
@@ -68,7 +84,7 @@ class GraphedCallable:
         spec = _flatten(args, flat)
         if not self.eligible(flat):
             return self.fn(*args)
-        key = (_spec_key(spec), tuple((tuple(t.shape), t.dtype, str(t.device)) for t in flat))
+        key = (_spec_key(spec), tuple((tuple(t.shape), t.dtype, str(t.device)) for t in flat), self._fingerprint())
         e = self.entries.get(key)
         if e is None:
             e = self._capture(flat, spec)

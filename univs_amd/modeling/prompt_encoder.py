@@ -709,11 +709,25 @@ class VisualPromptSampler:
         with torch.cuda.stream(side):
             jobs = self._annotation_jobs(tv, num_frames, device)
             ev = side.record_event()
-        tv["_prompt_prefetch"] = {"jobs": jobs, "event": ev, "key": (tv["first_frame_idx"], num_frames, id(tv["masks"]))}
+        tv["_prompt_prefetch"] = {"jobs": jobs, "event": ev, "key": self._prefetch_key(tv, num_frames)}
+
+    @staticmethod
+    def _prefetch_key(tv, num_frames):
+        """What the prefetched jobs were computed from: the clip position and the identity AND version of every annotation tensor
+        they read -- an in-place update of masks / boxes / first-appearance indices between `prefetch` and the forward makes
+        the key differ and the work is redone inline."""
+        def ident(k):
+            t = tv.get(k)
+            return (id(t), t._version) if isinstance(t, torch.Tensor) else None
+        return (tv["first_frame_idx"], num_frames, ident("masks"), ident("boxes"), ident("first_appear_frame_idxs"), ident("ids"))
 
     def _take_jobs(self, tv, num_frames, device, prompt_type):
         pf = tv.pop("_prompt_prefetch", None)
-        if pf is not None and pf["key"] == (tv["first_frame_idx"], num_frames, id(tv["masks"])) and prompt_type == "masks":
+        if pf is not None and not (pf["key"] == self._prefetch_key(tv, num_frames) and prompt_type == "masks"):
+            # stale or unused: the side stream's work is abandoned, but its tensors must not be freed under it
+            torch.cuda.current_stream(device).wait_event(pf["event"])
+            pf = None
+        if pf is not None:
             main = torch.cuda.current_stream(device)
             main.wait_event(pf["event"])
             for j in (pf["jobs"]["prev"], pf["jobs"]["clip"]):
