@@ -293,6 +293,28 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
                            long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Swin PatchEmbed in one pass (transpose.hip): out[t, (y/4) * (W/4) + x/4, :] = LayerNorm(conv4x4_stride4(x)[t, :, y/4, x/4] + bias)
+ * Replaces: PatchEmbed.forward (mask2former/modeling/backbone/swin.py:307-339: `self.proj(x)`, `x.flatten(2).transpose(1, 2)`,
+ *           `self.norm(x)`) for in_chans = 3, patch_size = 4 -- tokens come out in the layout the blocks consume.
+ *   x [T, 3, H, W] (H, W multiples of 4: the caller pads as PatchEmbed does), weight [E, 3, 4, 4], bias [E] or NULL,
+ *   ln_weight / ln_bias [E] or NULL (no norm), out [T, H/4 * W/4, E].  E in {96, 128, 192}.  Plain fp32 FMAs.
+ * ------------------------------------------------------------------------------------------- */
+int univs_patch_embed4_f32(const float* x, const float* weight, const float* bias, const float* ln_weight, const float* ln_bias, float ln_eps,
+                           int T, int H, int W, int E, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The decoder's cross-attention memory of one feature level from the NCHW feature map, one pass (transpose.hip):
+ *   memory[hw][t][c] = x[t][c][hw] + level_embed[c]
+ *   key[hw][t][c]    = memory[hw][t][c] + (pos_yx[hw][c] + pos_t[t][c])
+ * Replaces: `src = input_proj(x).flatten(2) + level_embed[..., None]` permuted to [hw, bt, C] and `with_pos_embed(memory, pos)`
+ *           with the 3-D sine embedding pos = yx + t (univs/modeling/transformer_decoder/...decoder_univs.py:350-355, :400-405;
+ *           position_encoding.py:100-160) -- a broadcast add, two permuted copies and a strided add in ATen.
+ *   x [T, C, HW]; level_embed [C]; pos_yx [HW, C]; pos_t [T, C]; memory / key [HW, T, C].  C % 4 == 0, HW % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int univs_decoder_memory_f32(const float* x, const float* level_embed, const float* pos_yx, const float* pos_t, int T, int C, int HW,
+                             float* memory, float* key, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Masked multi-head attention core in one pass over the keys (cross_attn.hip):
  *   out[l, n, h, :] = softmax_s(scale * q[l, n, h, :] . k[s, n, h, :]  masked)  v[s, n, h, :]
  * Replaces: inside nn.MultiheadAttention.forward as CrossAttentionLayer calls it

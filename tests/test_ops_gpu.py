@@ -1015,6 +1015,62 @@ def test_linear_split_uncovered_shapes_return_none(cuda):
     assert tuple(y.shape) == (4096, 96)
 
 
+@pytest.mark.parametrize("T,H,W,E,norm", [(2, 736, 1280, 96, True), (1, 64, 96, 96, True), (3, 36, 52, 128, True), (1, 72, 40, 192, False),
+                                          (2, 20, 44, 96, False)], ids=lambda v: str(v))
+def test_patch_embed4_matches_torch(cuda, T, H, W, E, norm):
+    """ops.patch_embed4 == LayerNorm(conv2d(x, w, b, stride 4).flatten(2).transpose(1, 2)) (swin.py:307-339) to fp32 rounding
+    (plain fp32 FMAs, another summation order than the library's convolution)."""
+    F = torch.nn.functional
+    x = (synth.normal(f"pe4/x/{T}/{H}/{W}", (T, 3, H, W)) * 2.0).to(cuda)
+    w = synth.normal(f"pe4/w/{E}", (E, 3, 4, 4), std=48 ** -0.5).to(cuda)
+    b = synth.normal(f"pe4/b/{E}", (E,), std=0.3).to(cuda)
+    g_ = (1.0 + 0.2 * synth.normal(f"pe4/g/{E}", (E,))).to(cuda)
+    be = (0.1 * synth.normal(f"pe4/be/{E}", (E,))).to(cuda)
+    got = ops.patch_embed4(x, w, b, (g_, be, 1e-5) if norm else None)
+    assert got is not None and tuple(got.shape) == (T, (H // 4) * (W // 4), E)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=4).flatten(2).transpose(1, 2)
+    if norm:
+        ref = F.layer_norm(ref, (E,), g_.double(), be.double(), 1e-5)
+    err = (got.double() - ref).abs().max().item()
+    assert err < 2e-5, err
+    assert ops.patch_embed4(x[:, :, : H - 1], w, b) is None                                   # H % 4
+    from univs_amd.modeling.backbone.swin import PatchEmbed
+    pe = PatchEmbed(4, 3, E, patch_norm=norm).to(cuda).eval()
+    with torch.no_grad():
+        pe.proj.weight.copy_(w)
+        pe.proj.bias.copy_(b)
+        if norm:
+            pe.norm.weight.copy_(g_)
+            pe.norm.bias.copy_(be)
+        tok, Wh, Ww = pe.tokens(x[:, :, : H - 2, : W - 1])                                     # ragged image: padded as the module does
+        nchw = pe(x[:, :, : H - 2, : W - 1])
+    assert (Wh, Ww) == (nchw.size(2), nchw.size(3)) and (tok - nchw.flatten(2).transpose(1, 2)).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("T,C,H,W", [(5, 256, 92, 160), (2, 256, 23, 40), (3, 64, 7, 12), (1, 256, 46, 80)], ids=lambda v: str(v))
+def test_decoder_memory_is_exact(cuda, T, C, H, W):
+    """ops.decoder_memory == the reference's expressions bit for bit: memory = (x.flatten(2) + level_embed[:, None]) permuted to
+    [hw, t, C]; key = memory + pos with the 3-D sine embedding pos = yx + pos_t (...decoder_univs.py:350-355, :400-405); and the
+    separable pieces of the embedding add up to the module's own forward."""
+    from univs_amd.modeling.position_encoding import PositionEmbeddingSine3DArbitraryT
+    x = synth.normal(f"dm/x/{T}/{C}/{H}/{W}", (T, C, H, W)).to(cuda)
+    le = synth.normal(f"dm/le/{C}", (C,)).to(cuda)
+    pe = PositionEmbeddingSine3DArbitraryT(C // 2, normalize=True)
+    fi = torch.arange(3, 3 + T, device=cuda)[None]
+    xi = x.view(1, T, C, H, W)
+    yx, pz = pe.forward_separable(xi, fi)
+    pos = pe(xi, fi)                                            # [1, T, C, H, W]
+    assert torch.equal((yx.view(H, W, C)[None] + pz[0][:, None, None, :]).permute(0, 3, 1, 2), pos[0])
+    got = ops.decoder_memory(x, le, yx, pz[0])
+    assert got is not None
+    mem, key = got
+    s = x.flatten(2) + le[None, :, None]
+    want_mem = s.permute(2, 0, 1).contiguous()
+    want_key = (s.permute(2, 0, 1) + pos.flatten(3).flatten(0, 1).permute(2, 0, 1)).contiguous()
+    assert torch.equal(mem, want_mem) and torch.equal(key, want_key)
+    assert ops.decoder_memory(x[:, :, :, :W - 1].contiguous(), le, yx[:H * (W - 1)], pz[0]) is None or (W - 1) * H % 4 == 0
+
+
 @pytest.mark.parametrize("shape", [(5, 58880, 96), (2, 920, 768), (3, 7, 96, 100), (1, 64, 64), (2, 10, 6), (1, 68, 132)], ids=str)
 def test_transpose_last2_is_exact(cuda, shape):
     """ops.transpose_last2 == x.transpose(-2, -1).contiguous() bit for bit: LDS-tiled where both extents are multiples of

@@ -51,6 +51,8 @@ SIGNATURES = {
     "univs_linear_presplit_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_conv3x3_presplit_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univs_conv1x1_presplit_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_patch_embed4_f32": (_I, [_P, _P, _P, _P, _P, _c.c_float, _I, _I, _I, _I, _P, _P]),
+    "univs_decoder_memory_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "univs_cross_attention_workspace": (_c.c_longlong, [_I, _I, _I, _I]),
     "univs_cross_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_float, _P, _P, _P]),
     "univs_mlp_presplit_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _c.c_float, _P, _c.c_longlong, _P,

@@ -59,6 +59,8 @@ int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStre
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
+int decoder_memory_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
+int patch_embed4_f32(const float*, const float*, const float*, const float*, const float*, float, float*, int, int, int, int, hipStream_t);
 int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, int, int, int, int, int, int, int, int, float,
                         float*, float*, hipStream_t);
 size_t cross_attention_workspace_floats(int, int, int, int);
@@ -300,6 +302,41 @@ int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv
   const int rc = univs::conv3x3_f16x3_f32(x, wp, winv, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_conv3x3_presplit_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout %% 16, >= 4096 pixels)", T, Cin, Cout, H, W);
+  return rc;
+}
+
+int univs_patch_embed4_f32(const float* x, const float* weight, const float* bias, const float* ln_weight, const float* ln_bias, float ln_eps,
+                           int T, int H, int W, int E, float* out, void* stream) {
+  clear_sticky_error();
+  if (T < 0 || H < 0 || W < 0 || E < 1) {
+    set_error("univs_patch_embed4_f32: bad dimensions T=%d H=%d W=%d E=%d", T, H, W, E);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0 || H == 0 || W == 0) return UNIVS_OK;
+  if (!x || !weight || !out) {
+    set_error("univs_patch_embed4_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::patch_embed4_f32(x, weight, bias, ln_weight, ln_bias, ln_eps, out, T, H, W, E, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_patch_embed4_f32: T=%d H=%d W=%d E=%d not covered (E in 96 / 128 / 192, H %% 4, W %% 4, 16-byte alignment)", T, H, W, E);
+  return rc;
+}
+
+int univs_decoder_memory_f32(const float* x, const float* level_embed, const float* pos_yx, const float* pos_t, int T, int C, int HW,
+                             float* memory, float* key, void* stream) {
+  clear_sticky_error();
+  if (T < 0 || C < 0 || HW < 0) {
+    set_error("univs_decoder_memory_f32: bad dimensions T=%d C=%d HW=%d", T, C, HW);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0 || C == 0 || HW == 0) return UNIVS_OK;
+  if (!x || !level_embed || !pos_yx || !pos_t || !memory || !key) {
+    set_error("univs_decoder_memory_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::decoder_memory_f32(x, level_embed, pos_yx, pos_t, memory, key, T, C, HW, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_decoder_memory_f32: T=%d C=%d HW=%d not covered (C %% 4, HW %% 4, 16-byte alignment)", T, C, HW);
   return rc;
 }
 

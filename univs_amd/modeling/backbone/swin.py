@@ -270,6 +270,23 @@ class PatchEmbed(nn.Module):
             x = x.transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
         return x
 
+    def tokens(self, x):
+        """(tokens [B, Wh*Ww, E], Wh, Ww): the same as `forward(x).flatten(2).transpose(1, 2)`; on the GPU, for 3-channel images and
+        4 x 4 patches, convolution + bias + token layout + patch norm are ONE kernel (ops.patch_embed4)."""
+        if x.is_cuda and self.patch_size == (4, 4) and self.in_chans == 3:
+            _, _, H, W = x.size()
+            xp = x
+            if W % 4 != 0:
+                xp = F.pad(xp, (0, 4 - W % 4))
+            if H % 4 != 0:
+                xp = F.pad(xp, (0, 0, 0, 4 - H % 4))
+            ln = None if self.norm is None else (self.norm.weight, self.norm.bias, self.norm.eps)
+            t = ops.patch_embed4(xp, self.proj.weight, self.proj.bias, ln)
+            if t is not None:
+                return t, xp.shape[2] // 4, xp.shape[3] // 4
+        y = self.forward(x)
+        return y.flatten(2).transpose(1, 2), y.size(2), y.size(3)
+
 
 class SwinTransformer(nn.Module):
     def __init__(self, pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=(2, 2, 6, 2),
@@ -317,13 +334,13 @@ class SwinTransformer(nn.Module):
         return self
 
     def _forward(self, x):
-        x = self.patch_embed(x)
-        Wh, Ww = x.size(2), x.size(3)
         if self.ape:
+            x = self.patch_embed(x)
+            Wh, Ww = x.size(2), x.size(3)
             ape = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
             x = (x + ape).flatten(2).transpose(1, 2)
         else:
-            x = x.flatten(2).transpose(1, 2)
+            x, Wh, Ww = self.patch_embed.tokens(x)
         outs = {}
         for i in range(self.num_layers):
             x_out, H, W, x, Wh, Ww = self.layers[i](x, Wh, Ww)

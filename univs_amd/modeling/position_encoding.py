@@ -97,6 +97,12 @@ class _Sine3DBase(nn.Module):
             return yx, _dim_t(2 * F_, self.temperature, device)
         return self._yx_cache.get((h, w, str(device)), make)
 
+    def separable(self, z, h, w, device):
+        """(yx [h*w, 2F], pos_z [t, 2F]) with pos[t, :, y, x] = yx[y*w + x] + pos_z[t]: what `_compose` adds up -- for consumers
+        that add the embedding to something else anyway (ops.decoder_memory)."""
+        yx, dim_t_z = self._yx(h, w, device)
+        return yx.view(h * w, -1), _interleaved_sincos(z, dim_t_z)
+
     def _compose(self, z, h, w, device):
         """z [..t] already scaled -> [..t, 2F, h, w] = cat(sin/cos(y), sin/cos(x)) + sin/cos(z)."""
         yx, dim_t_z = self._yx(h, w, device)
@@ -130,6 +136,12 @@ class PositionEmbeddingSine3D(_Sine3DBase):
         pos = self._cache.get((t, h, w, str(dev)), lambda: self._compose(_axis(t, self.scale, dev), h, w, dev))
         return pos[None].expand(b, -1, -1, -1, -1)
 
+    def forward_separable(self, x):
+        """(yx [h*w, 2F], pos_t [1, t, 2F]) whose broadcast sum is `forward(x)` (channels last)."""
+        _, t, _, h, w = x.shape
+        yx, pz = self.separable(_axis(t, self.scale, x.device), h, w, x.device)
+        return yx, pz[None]
+
     def forward_points_with_size(self, size, xy_embed_normalized):
         t, h, w = size
         assert self.normalize
@@ -145,14 +157,21 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
         assert normalize, "Must enable normalization!"
         self.num_max_frames = num_max_frames
 
+    def _z(self, b, t, dev, t_indices):
+        if t_indices is None:
+            t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
+        return t_indices.to(dev) / self.num_max_frames * self.scale  # [b, t]
+
     def forward(self, x, t_indices=None, mask=None):
         assert x.dim() == 5 and mask is None
         b, t, _, h, w = x.shape
         dev = x.device
-        if t_indices is None:
-            t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
-        z = t_indices.to(dev) / self.num_max_frames * self.scale  # [b, t]
-        return self._compose(z, h, w, dev)
+        return self._compose(self._z(b, t, dev, t_indices), h, w, dev)
+
+    def forward_separable(self, x, t_indices=None):
+        """(yx [h*w, 2F], pos_t [b, t, 2F]) whose broadcast sum is `forward(x, t_indices)` (channels last)."""
+        b, t, _, h, w = x.shape
+        return self.separable(self._z(b, t, x.device, t_indices), h, w, x.device)
 
     def forward_points_with_size(self, size, xy_embed_normalized, t_indices=None):
         dev = xy_embed_normalized.device

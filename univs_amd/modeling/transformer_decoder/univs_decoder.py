@@ -42,6 +42,30 @@ combined_datasets_category_info = {
 }
 
 
+class _LazyList:
+    """A list whose None entries are produced on first access (`makers[i]()`): the per-level position embeddings, which only
+    the prompt encoder reads once the cross-attention keys come out of ops.decoder_memory."""
+
+    def __init__(self, items, makers):
+        self._items, self._makers = list(items), dict(makers)
+
+    def _get(self, i):
+        if self._items[i] is None:
+            self._items[i] = self._makers[i]()
+        return self._items[i]
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(len(self._items)))]
+        return self._get(i if i >= 0 else len(self._items) + i)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self._items)))
+
+
 @TRANSFORMER_DECODER_REGISTRY.register()
 class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
     _version = 2
@@ -217,17 +241,32 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             assert frame_indices.shape[1] == t_total, "targets['frame_indices'] must list the frames of ALL ranks"
             self._frame_indices_all = frame_indices
             frame_indices = frame_indices[:, fs.local_slice(t)]
+        mem_fused = [None] * self.num_feature_levels     # (memory, key) of a level from ONE kernel (ops.decoder_memory), where covered
         for i in range(self.num_feature_levels):
             size_list.append(tuple(int(s) for s in x[i].shape[-2:]))
             xi = x[i].view(bs, t, -1, size_list[-1][0], size_list[-1][1])
-            if self.position_embedding_sin3d_type == "FixedT":
-                p = self.pe_layer(xi)
+            fixed_t = self.position_embedding_sin3d_type == "FixedT"
+
+            def make_pos(xi=xi, fixed_t=fixed_t):          # [b,t,C,h,w] -> [hw, bt, C]
+                p = self.pe_layer(xi) if fixed_t else self.pe_layer(xi, frame_indices)
+                return p.flatten(3).flatten(0, 1).permute(2, 0, 1)
+            xin = self.input_proj[i](x[i])
+            if xin.is_cuda and bs == 1 and not torch.is_grad_enabled():
+                # NCHW -> [hw, t, C] + level embedding, and the same + position embedding, in one pass over the features; the
+                # position embedding itself is only materialised if the prompt encoder asks for it
+                yx, pz = self.pe_layer.forward_separable(xi) if fixed_t else self.pe_layer.forward_separable(xi, frame_indices)
+                mem_fused[i] = ops.decoder_memory(xin, self.level_embed.weight[i], yx, pz[0])
+            if mem_fused[i] is not None:
+                src.append(mem_fused[i][0])
+                pos.append(None)
+                pos_makers = self.__dict__.setdefault("_pos_makers", {})
+                pos_makers[i] = make_pos
             else:
-                p = self.pe_layer(xi, frame_indices)
-            # [b,t,C,h,w] -> [hw, bt, C]
-            pos.append(p.flatten(3).flatten(0, 1).permute(2, 0, 1))
-            s = self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]
-            src.append(s.permute(2, 0, 1))
+                pos.append(make_pos())
+                s = xin.flatten(2) + self.level_embed.weight[i][None, :, None]
+                src.append(s.permute(2, 0, 1))
+        if any(m is not None for m in mem_fused):
+            pos = _LazyList(pos, self.__dict__.get("_pos_makers", {}))
 
         query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bt, 1)
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bt, 1)
@@ -274,8 +313,9 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         self_attn_mask = self.generate_self_attn_mask(bs, t_total, num_queries_lp, dev, targets[0]["dataset_name"], task)
         query_embed_all = query_embed if fs is None else fs.all_gather_frames(query_embed, dim=1)
         # cross-attention inputs per level, contiguous and built once (every third layer reuses them)
-        mem = [s_.contiguous() for s_ in src]
-        mem_key = [(s_ + p_).contiguous() for s_, p_ in zip(src, pos)]
+        mem = [m[0] if m is not None else s_.contiguous() for m, s_ in zip(mem_fused, src)]
+        mem_key = [m[1] if m is not None else (src[i_] + pos[i_]).contiguous() for i_, m in enumerate(mem_fused)]
+        self.__dict__.pop("_pos_makers", None)
         # key / value projections of the cross-attention: the layers i, i + L, i + 2 L, ... attend to the same level with
         # different weights -- ONE Linear per level for all their keys (N = 256 x layers), one for their values: the level's
         # memory is read once instead of once per layer; a layer takes its 256-column slice in place

@@ -665,6 +665,54 @@ def conv1x1(x, weight, bias=None):
     return y
 
 
+def patch_embed4(x, weight, bias=None, ln=None):
+    """Swin PatchEmbed in one pass (include/univs_hip.h: univs_patch_embed4_f32): the 4 x 4 / stride-4 convolution of a 3-channel
+    image + bias, tokens in [T, H/4 * W/4, E] order, optionally LayerNorm `ln` = (weight, bias, eps) on each token
+    (swin.py:307-339).  x [T, 3, H, W] with H, W multiples of 4.  None when not covered."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or needs_grad(x, weight, bias):
+        return None
+    T, Cin, H, W = x.shape
+    E = weight.shape[0]
+    if Cin != 3 or tuple(weight.shape[1:]) != (3, 4, 4) or H % 4 or W % 4 or E not in (96, 128, 192):
+        return None
+    lw = lb = None
+    leps = 0.0
+    if ln is not None:
+        lw, lb, leps = ln
+    x, weight = x.contiguous(), weight.contiguous()
+    out = torch.empty((T, (H // 4) * (W // 4), E), dtype=torch.float32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_patch_embed4_f32(_ptr(x), _ptr(weight), _ptr(bias) if bias is not None else None,
+                                                _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
+                                                T, H, W, E, _ptr(out), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "patch_embed4")
+    return out
+
+
+def decoder_memory(x, level_embed, pos_yx, pos_t):
+    """(memory, key) [HW, T, C] of one feature level for the decoder's cross-attention, from the NCHW features in one pass
+    (include/univs_hip.h: univs_decoder_memory_f32): memory = x transposed + level_embed, key = memory + (pos_yx + pos_t).
+    x [T, C, H, W] (or [T, C, HW]); level_embed [C]; pos_yx [HW, C]; pos_t [T, C].  None when not covered."""
+    if not (x.is_cuda and x.dtype == torch.float32) or needs_grad(x, level_embed):
+        return None
+    T, C = x.shape[:2]
+    HW = x.numel() // max(T * C, 1)
+    if C % 4 or HW % 4 or tuple(level_embed.shape) != (C,) or tuple(pos_yx.shape) != (HW, C) or tuple(pos_t.shape) != (T, C):
+        return None
+    x, level_embed, pos_yx, pos_t = x.contiguous(), level_embed.contiguous(), pos_yx.contiguous(), pos_t.contiguous()
+    mem = torch.empty((HW, T, C), dtype=torch.float32, device=x.device)
+    key = torch.empty((HW, T, C), dtype=torch.float32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_decoder_memory_f32(_ptr(x), _ptr(level_embed), _ptr(pos_yx), _ptr(pos_t), T, C, HW, _ptr(mem), _ptr(key),
+                                                  _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "decoder_memory")
+    return mem, key
+
+
 def transpose_last2(x):
     """Contiguous copy of `x.transpose(-2, -1)` for a float32 tensor on the GPU (LDS tile transpose at HBM rate instead of
     ATen's strided copy): tokens [B, H*W, C] <-> channel-major [B, C, H*W] at the edges of the Swin backbone
