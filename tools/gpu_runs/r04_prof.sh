@@ -11,6 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o 
 find $O/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 CSV=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 python $R/tools/clip_breakdown.py $CSV --skip 4 --last 8 --top 60 > $O/clip_breakdown.txt 2>&1
+python $R/tools/clip_breakdown.py $CSV --skip 6 --last 1 --timeline > $O/clip_timeline.txt 2>&1
 rm -rf $O/trace
 cd $R
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
