@@ -556,6 +556,52 @@ def g19_cfg5_swinl_1080p():
 
 
 @gen
+def g19b_cfg5_reference_autocast():
+    """A yardstick for BASELINE config 5's fp16 variant: how far does the REFERENCE sit from its own fp32 run when it is evaluated
+    the way train_net.py:334 evaluates it (`with autocast(): inference_on_dataset(...)`: fp16 Linears / matmuls in the backbone
+    and the decoder, the pixel decoder pinned to fp32 by `@autocast(enabled=False)`, msdeformattn.py:316)?  Emulated on the CPU:
+    torch.autocast("cpu", dtype=float16) around backbone + head, the pixel decoder's forward_features taken out of the region as
+    the reference's decorator does on CUDA.  The CPU and CUDA autocast op lists differ slightly (both lower Linear / conv / matmul /
+    bmm and keep softmax / layer_norm in fp32), so this is an emulation, stated as such in the test.  Same input, weights and
+    strided samples as g19; stores the autocast run's samples and its deviations from the fp32 run of this process."""
+    R = rh.ref()
+    case = dict(cases.CFG5, T=cases.CFG5_GOLDEN_T)
+    swin = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_L)
+    swin.eval()
+    synth.load_synthetic(swin, prefix="backbone.")
+    head = _ref_head(R, case)
+    x = cases.preprocess(cases.cfg5_frames(case["T"]))
+    pd_forward = head.pixel_decoder.forward_features
+
+    def fp32_pixel_decoder(features, *a, **k):
+        with torch.autocast("cpu", enabled=False):
+            return pd_forward({n: f.float() for n, f in features.items()}, *a, **k)
+    head.pixel_decoder.forward_features = fp32_pixel_decoder
+
+    def run():
+        feats = swin(x)
+        out = head(feats, targets=cases.targets_first_clip(case))
+        return ({k: v.float()[:, ::16, ::4, ::4] for k, v in feats.items()}, out["pred_masks"].float(), out["pred_logits"].float())
+    f32, pm32, pl32 = run()
+    with torch.autocast("cpu", dtype=torch.float16):
+        f16, pm16, pl16 = run()
+    d = {"emulation": "torch.autocast('cpu', dtype=float16) around backbone + head; pixel decoder outside the region"}
+    for k in f32:
+        d["feat_" + k + "_s"] = f16[k]
+        d["feat_" + k + "_err"] = (f16[k] - f32[k]).abs().max()
+    d["pred_masks_s"] = pm16[0, :, :, ::16, ::16]
+    d["pred_masks_err_s"] = (pm16 - pm32)[0, :, :, ::16, ::16].abs().max()
+    d["pred_masks_err_full"] = (pm16 - pm32).abs().max()
+    d["pred_masks_abs_max"] = pm32.abs().max()
+    d["pred_masks_sign_flips"] = ((pm16 > 0) != (pm32 > 0)).sum()
+    d["pred_masks_sign_flips_beyond_5e-3"] = (((pm16 > 0) != (pm32 > 0)) & (pm32.abs() > 5e-3)).sum()
+    d["pred_logits_err"] = (pl16 - pl32).abs().max()
+    print("   reference under emulated autocast vs its fp32 run:", {k: (float(v) if getattr(v, "ndim", 1) == 0 else None)
+                                                                  for k, v in d.items() if k != "emulation"})
+    save("g19b_cfg5_reference_autocast", **d)
+
+
+@gen
 def g11b_clip_loop_scripted():
     """scripted scene (tests/cases.py ScriptedHead): several entities, NMS, a newcomer, a leaver"""
     case = cases.SCRIPT_CASE

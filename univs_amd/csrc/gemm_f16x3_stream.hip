@@ -189,7 +189,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
   f32x4 acc[RB][2];
   int eset[2];
   float sx[2], sx_inv[2];
-  constexpr int NB = RB > 6 ? 4 : 2;
+  constexpr int NB = RB > 12 ? 8 : RB > 6 ? 4 : 2;
   constexpr int BSZ = (RB + NB - 1) / NB;
   u32x4 afr[2][BSZ][2];
   const unsigned a_lane = (unsigned)((g * 2 * Rp + j) * 16);
@@ -353,20 +353,27 @@ static int gs_cus() {
 }
 
 template <int XMODE>
-static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
+static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {   // ring: 4 or 3 k-steps per slab (2 is chosen here)
   GsArgs a = a0;
   const UnivsConfig cfg_ = config();
   // output features per pass: 128, or 64 for short tall-K problems with a narrow output (Swin stage-3 / stage-4 proj and fc2:
   // few row tiles, N <= 768 <= K -- twice the passes fill the CUs; 172 -> 126 us at 18 400 x 1536 -> 384, 60 -> 43 us at
   // 18 400 x 384 -> 384: profiles/r04_kbench_smallm_v1.txt)
   const bool narrow = XMODE == 0 && a.N <= 768 && a.K >= a.N && a.M <= 32768;
-  const int r_cap = cfg_.linear_rows_per_pass >= 16 ? std::min(128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16)
-                                                    : (narrow ? 64 : 128);
+  // wide passes (192 / 256 features, RING = 2): every pass re-reads x (the convolution: once per tap on top), so fewer passes cut
+  // the traffic between L2 and the CUs; needs an even number of k-steps
+  const bool can_wide = (a.K >> 5) % 2 == 0;
+  int r_cap = narrow ? 64 : 128;
+  if (cfg_.linear_rows_per_pass >= 16) r_cap = std::min(can_wide ? 256 : 128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16);
   const int passes = (a.N + r_cap - 1) / r_cap;
   int rows = (a.N + passes - 1) / passes;
   rows = (rows + 3) & ~3;
   if (XMODE == 1) rows = (rows + 15) & ~15;
-  const int RB = (rows + 15) / 16;
+  int RB = (rows + 15) / 16;
+  if (RB > 8) {
+    RB = RB > 12 ? 16 : 12;
+    ring = 2;
+  }
   a.rows_per_pass = rows;
   const long long WT = ((long long)a.M + GS_TILE_M - 1) / GS_TILE_M;
   long long gx = std::max<long long>(1, gs_cus() / passes);
@@ -394,7 +401,9 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
     UNIVS_GS_RB(5);
     UNIVS_GS_RB(6);
     UNIVS_GS_RB(7);
-    default: UNIVS_GS_RB(8);
+    UNIVS_GS_RB(8);
+    case 12: UNIVS_GS(12, 2); break;
+    default: UNIVS_GS(16, 2); break;
   }
 #undef UNIVS_GS_RB
 #undef UNIVS_GS
