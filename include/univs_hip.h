@@ -145,7 +145,8 @@ typedef struct UnivsConfig {
   int linear_rows_per_pass; /* kernel benchmarks: output features per pass of the three-product Linears (a multiple of 16; the streamed kernel
                              takes up to 256 when K / 32 is even; 0 = by shape) */
   int linear_grid_x;      /* kernel benchmarks: workgroups along the rows of the three-product Linears (0 = by shape) */
-  int reserved[4];
+  int linear_batches;     /* kernel benchmarks: A-fragment batches per k-step of the streamed kernel (0 = by shape) */
+  int reserved[3];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);

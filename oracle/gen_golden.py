@@ -563,7 +563,7 @@ def g19b_cfg5_reference_autocast():
     torch.autocast("cpu", dtype=float16) around backbone + head, the pixel decoder's forward_features taken out of the region as
     the reference's decorator does on CUDA.  The CPU and CUDA autocast op lists differ slightly (both lower Linear / conv / matmul /
     bmm and keep softmax / layer_norm in fp32), so this is an emulation, stated as such in the test.  Same input, weights and
-    strided samples as g19; stores the autocast run's samples and its deviations from the fp32 run of this process."""
+    strided samples as g19; stores the autocast run's deviations from the fp32 run of this process (scalars only)."""
     R = rh.ref()
     case = dict(cases.CFG5, T=cases.CFG5_GOLDEN_T)
     swin = R.SwinTransformer(drop_path_rate=0.3, **cases.SWIN_L)
@@ -587,17 +587,14 @@ def g19b_cfg5_reference_autocast():
         f16, pm16, pl16 = run()
     d = {"emulation": "torch.autocast('cpu', dtype=float16) around backbone + head; pixel decoder outside the region"}
     for k in f32:
-        d["feat_" + k + "_s"] = f16[k]
         d["feat_" + k + "_err"] = (f16[k] - f32[k]).abs().max()
-    d["pred_masks_s"] = pm16[0, :, :, ::16, ::16]
     d["pred_masks_err_s"] = (pm16 - pm32)[0, :, :, ::16, ::16].abs().max()
     d["pred_masks_err_full"] = (pm16 - pm32).abs().max()
     d["pred_masks_abs_max"] = pm32.abs().max()
     d["pred_masks_sign_flips"] = ((pm16 > 0) != (pm32 > 0)).sum()
     d["pred_masks_sign_flips_beyond_5e-3"] = (((pm16 > 0) != (pm32 > 0)) & (pm32.abs() > 5e-3)).sum()
     d["pred_logits_err"] = (pl16 - pl32).abs().max()
-    print("   reference under emulated autocast vs its fp32 run:", {k: (float(v) if getattr(v, "ndim", 1) == 0 else None)
-                                                                  for k, v in d.items() if k != "emulation"})
+    print("   reference under emulated autocast vs its fp32 run:", {k: float(v) for k, v in d.items() if k != "emulation"})
     save("g19b_cfg5_reference_autocast", **d)
 
 

@@ -286,6 +286,39 @@ def main():
                             if err > 2e-5 * float(ref.abs().max()):
                                 row[f"stream_r{rpp}_g{gx}_ERR"] = err
             res["wide_" + nm] = row
+    if args.only and "batches" in args.only:
+        # A-fragment batches per k-step of the streamed kernel (settings: linear_batches): 128 features per pass with 4 (default) or 2
+        # batches, 64 per pass with 2 (default) or 1
+        from univs_amd.switches import override as _ov
+        xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)
+        wc = synth.normal("kb/conv/w", (256, 256, 3, 3), std=1 / 48).to(dev)
+        w1 = synth.normal("kb/conv/w1", (256, 256, 1, 1), std=1 / 16).to(dev)
+        b1 = synth.normal("kb/conv/b1", (256,)).to(dev)
+        cases_ = [("conv3x3", lambda: ops.conv3x3(xc, wc)), ("conv1x1_256", lambda: ops.conv1x1(xc, w1, b1))]
+        keep = []
+        for nm, Mr, K_, N_, act, res_ in (("s3_qkv", T * 3680, 384, 1152, None, False), ("s3_proj", T * 3680, 384, 384, None, True),
+                                          ("s3_fc1", T * 3680, 384, 1536, "gelu", False), ("s3_fc2", T * 3680, 1536, 384, None, True),
+                                          ("s4_qkv", T * 920, 768, 2304, None, False), ("s4_proj", T * 920, 768, 768, None, True),
+                                          ("s4_fc1", T * 920, 768, 3072, "gelu", False), ("s4_fc2", T * 920, 3072, 768, None, True),
+                                          ("s2_fc2", T * 14720, 768, 192, None, True)):
+            xs = synth.normal(f"kb/sm/x{K_}/{Mr}", (Mr, K_)).to(dev)
+            w_ = synth.normal(f"kb/sm/w{K_}x{N_}", (N_, K_), std=K_ ** -0.5).to(dev)
+            b_ = synth.normal(f"kb/sm/b{N_}", (N_,)).to(dev)
+            rs = synth.normal(f"kb/sm/r{N_}/{Mr}", (Mr, N_)).to(dev) if res_ else None
+            keep.append((xs, w_, b_, rs))
+            cases_.append((nm, (lambda xs=xs, w_=w_, b_=b_, act=act, rs=rs: ops.linear_fused(xs, w_, b_, act=act, residual=rs))))
+        with _ov(presplit_kmin=96):
+            for nm, fn in cases_:
+                ref = fn()
+                row = {}
+                for rpp, nb in ((128, 0), (128, 2), (64, 0), (64, 1)):
+                    with ops.configured(linear_rows_per_pass=rpp, linear_batches=nb):
+                        y = fn()
+                        err = float((y - ref).abs().max())
+                        row[f"r{rpp}_b{nb}"] = round(timeit(fn, iters=10, warmup=3) * 1e6, 1)
+                        if err > 2e-5 * float(ref.abs().max()):
+                            row[f"r{rpp}_b{nb}_ERR"] = err
+                res["batches_" + nm] = row
     if args.only and "conv" in args.only:
         from univs_amd.switches import override as _ov
         xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)
