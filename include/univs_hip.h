@@ -142,11 +142,10 @@ typedef struct UnivsConfig {
                              C == 256 request every row of their columns at once, skinny_gemm_f32_oneshot) */
   int mask_decode_wave_tiles; /* split-bf16 mask decode: column tiles a wave should get before a workgroup is added (default 1;
                              the split of A is per workgroup, larger values trade balance for fewer splits) */
-  int linear_rows_per_pass; /* kernel benchmarks: output features per pass of the three-product Linears (a multiple of 16; the streamed kernel
-                             takes up to 256 when K / 32 is even; 0 = by shape) */
+  int linear_rows_per_pass; /* kernel benchmarks: output features per pass of the three-product Linears (a multiple of 16, <= 128;
+                             0 = as many as fit: 128 for the streamed kernel, the LDS capacity for the W-resident one) */
   int linear_grid_x;      /* kernel benchmarks: workgroups along the rows of the three-product Linears (0 = by shape) */
-  int linear_batches;     /* kernel benchmarks: A-fragment batches per k-step of the streamed kernel (0 = by shape) */
-  int reserved[3];
+  int reserved[4];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);

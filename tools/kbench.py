@@ -236,89 +236,6 @@ def main():
                                 row[f"{kind}_r{rpp}_g{gx}"] = round(timeit(lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs), iters=10, warmup=3) * 1e6, 1)
             best = min(row, key=row.get)
             res[nm] = dict(best=best, best_us=row[best], default_resident=row.get("resident_r0_g0"), default_stream=row.get("stream_r0_g0"), all=row)
-    if args.only and "wide" in args.only:
-        # output features per pass of the streamed kernel (64 ... 256): the 3 x 3 / 1 x 1 convolutions and the Swin stage-3 / stage-4
-        # Linears; every variant is checked against the default's output
-        from univs_amd.switches import override as _ov
-        xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)
-        wc = synth.normal("kb/conv/w", (256, 256, 3, 3), std=1 / 48).to(dev)
-        w1 = synth.normal("kb/conv/w1", (256, 256, 1, 1), std=1 / 16).to(dev)
-        b1 = synth.normal("kb/conv/b1", (256,)).to(dev)
-        x1 = synth.normal("kb/conv/x192", (T, 192, 92, 160)).to(dev)
-        w192 = synth.normal("kb/conv/w192", (256, 192, 1, 1), std=1 / 14).to(dev)
-        for nm, fn in (("conv3x3", lambda: ops.conv3x3(xc, wc)), ("conv1x1_256", lambda: ops.conv1x1(xc, w1, b1)),
-                       ("conv1x1_192", lambda: ops.conv1x1(x1, w192, b1))):
-            ref = fn()
-            row = {}
-            for rpp in (0, 64, 128, 192, 256):
-                for gx in (0, 128, 256):
-                    with ops.configured(linear_rows_per_pass=rpp, linear_grid_x=gx):
-                        y = fn()
-                        err = float((y - ref).abs().max())
-                        row[f"r{rpp}_g{gx}"] = round(timeit(fn, iters=10, warmup=3) * 1e6, 1)
-                        if err > 1e-5 * float(ref.abs().max()):
-                            row[f"r{rpp}_g{gx}_ERR"] = err
-            res["wide_" + nm] = row
-        for nm, Mr, K_, N_, act, res_ in (("s3_qkv", T * 3680, 384, 1152, None, False), ("s3_proj", T * 3680, 384, 384, None, True),
-                                          ("s3_fc1", T * 3680, 384, 1536, "gelu", False), ("s3_fc2", T * 3680, 1536, 384, None, True),
-                                          ("s4_qkv", T * 920, 768, 2304, None, False), ("s4_proj", T * 920, 768, 768, None, True),
-                                          ("s4_fc1", T * 920, 768, 3072, "gelu", False), ("s4_fc2", T * 920, 3072, 768, None, True),
-                                          ("s2_fc2", T * 14720, 768, 192, None, True), ("enc_v", T * 19320, 256, 256, None, False),
-                                          ("enc_q", T * 19320, 256, 288, None, False),
-                                          ("enc_o", T * 19320, 256, 256, None, True), ("s2_qkv", T * 14720, 192, 576, None, False),
-                                          ("s2_proj", T * 14720, 192, 192, None, True), ("dec_kv", T * 14720, 256, 768, None, False)):
-            xs = synth.normal(f"kb/sm/x{K_}/{Mr}", (Mr, K_)).to(dev)
-            w_ = synth.normal(f"kb/sm/w{K_}x{N_}", (N_, K_), std=K_ ** -0.5).to(dev)
-            b_ = synth.normal(f"kb/sm/b{N_}", (N_,)).to(dev)
-            rs = synth.normal(f"kb/sm/r{N_}/{Mr}", (Mr, N_)).to(dev) if res_ else None
-            fn = lambda: ops.linear_fused(xs, w_, b_, act=act, residual=rs)
-            ref = fn()
-            row = {"default": round(timeit(fn, iters=10, warmup=3) * 1e6, 1)}
-            with _ov(presplit_kmin=96):
-                for rpp in (0, 64, 128, 192, 256):
-                    for gx in (0, 64, 128, 256):
-                        with ops.configured(linear_rows_per_pass=rpp, linear_grid_x=gx):
-                            y = fn()
-                            if y is None:
-                                continue
-                            err = float((y - ref).abs().max())
-                            row[f"stream_r{rpp}_g{gx}"] = round(timeit(fn, iters=10, warmup=3) * 1e6, 1)
-                            if err > 2e-5 * float(ref.abs().max()):
-                                row[f"stream_r{rpp}_g{gx}_ERR"] = err
-            res["wide_" + nm] = row
-    if args.only and "batches" in args.only:
-        # A-fragment batches per k-step of the streamed kernel (settings: linear_batches): 128 features per pass with 4 (default) or 2
-        # batches, 64 per pass with 2 (default) or 1
-        from univs_amd.switches import override as _ov
-        xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)
-        wc = synth.normal("kb/conv/w", (256, 256, 3, 3), std=1 / 48).to(dev)
-        w1 = synth.normal("kb/conv/w1", (256, 256, 1, 1), std=1 / 16).to(dev)
-        b1 = synth.normal("kb/conv/b1", (256,)).to(dev)
-        cases_ = [("conv3x3", lambda: ops.conv3x3(xc, wc)), ("conv1x1_256", lambda: ops.conv1x1(xc, w1, b1))]
-        keep = []
-        for nm, Mr, K_, N_, act, res_ in (("s3_qkv", T * 3680, 384, 1152, None, False), ("s3_proj", T * 3680, 384, 384, None, True),
-                                          ("s3_fc1", T * 3680, 384, 1536, "gelu", False), ("s3_fc2", T * 3680, 1536, 384, None, True),
-                                          ("s4_qkv", T * 920, 768, 2304, None, False), ("s4_proj", T * 920, 768, 768, None, True),
-                                          ("s4_fc1", T * 920, 768, 3072, "gelu", False), ("s4_fc2", T * 920, 3072, 768, None, True),
-                                          ("s2_fc2", T * 14720, 768, 192, None, True)):
-            xs = synth.normal(f"kb/sm/x{K_}/{Mr}", (Mr, K_)).to(dev)
-            w_ = synth.normal(f"kb/sm/w{K_}x{N_}", (N_, K_), std=K_ ** -0.5).to(dev)
-            b_ = synth.normal(f"kb/sm/b{N_}", (N_,)).to(dev)
-            rs = synth.normal(f"kb/sm/r{N_}/{Mr}", (Mr, N_)).to(dev) if res_ else None
-            keep.append((xs, w_, b_, rs))
-            cases_.append((nm, (lambda xs=xs, w_=w_, b_=b_, act=act, rs=rs: ops.linear_fused(xs, w_, b_, act=act, residual=rs))))
-        with _ov(presplit_kmin=96):
-            for nm, fn in cases_:
-                ref = fn()
-                row = {}
-                for rpp, nb in ((128, 0), (128, 2), (64, 0), (64, 1)):
-                    with ops.configured(linear_rows_per_pass=rpp, linear_batches=nb):
-                        y = fn()
-                        err = float((y - ref).abs().max())
-                        row[f"r{rpp}_b{nb}"] = round(timeit(fn, iters=10, warmup=3) * 1e6, 1)
-                        if err > 2e-5 * float(ref.abs().max()):
-                            row[f"r{rpp}_b{nb}_ERR"] = err
-                res["batches_" + nm] = row
     if args.only and "conv" in args.only:
         from univs_amd.switches import override as _ov
         xc = synth.normal("kb/conv/x", (T, 256, 184, 320)).to(dev)

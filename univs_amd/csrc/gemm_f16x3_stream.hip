@@ -79,9 +79,7 @@ struct GsArgs {
 };
 
 // LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp]
-// NBX: A-fragment batches per k-step (0: by RB).  A batch is requested while the batch before it is multiplied: fewer, larger batches
-// give the reads more cover (BSZ * 6 MFMAs) at the price of fragment registers.
-template <int RB, int RING, int XMODE, int NBX = 0>
+template <int RB, int RING, int XMODE>
 __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];
   constexpr int Rp = 16 * RB;
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
   f32x4 acc[RB][2];
   int eset[2];
   float sx[2], sx_inv[2];
-  constexpr int NB = NBX > 0 ? NBX : RB > 12 ? 8 : RB > 6 ? 4 : 2;
+  constexpr int NB = RB > 6 ? 4 : 2;
   constexpr int BSZ = (RB + NB - 1) / NB;
   u32x4 afr[2][BSZ][2];
   const unsigned a_lane = (unsigned)((g * 2 * Rp + j) * 16);
@@ -210,15 +208,9 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]) : : "memory");
     else if constexpr (BSZ == 2)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]) : : "memory");
-    else if constexpr (BSZ == 3)
+    else
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
-    else {
-      static_assert(BSZ == 4, "batch sizes 1 ... 4");
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[3][0]), "+v"(d[3][1])
-                   : : "memory");
-    }
   };
 
   TileRows t_cur, t_next;
@@ -361,27 +353,20 @@ static int gs_cus() {
 }
 
 template <int XMODE>
-static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {   // ring: 4 or 3 k-steps per slab (2 is chosen here)
+static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   GsArgs a = a0;
   const UnivsConfig cfg_ = config();
   // output features per pass: 128, or 64 for short tall-K problems with a narrow output (Swin stage-3 / stage-4 proj and fc2:
   // few row tiles, N <= 768 <= K -- twice the passes fill the CUs; 172 -> 126 us at 18 400 x 1536 -> 384, 60 -> 43 us at
   // 18 400 x 384 -> 384: profiles/r04_kbench_smallm_v1.txt)
   const bool narrow = XMODE == 0 && a.N <= 768 && a.K >= a.N && a.M <= 32768;
-  // wide passes (192 / 256 features, RING = 2): every pass re-reads x (the convolution: once per tap on top), so fewer passes cut
-  // the traffic between L2 and the CUs; needs an even number of k-steps
-  const bool can_wide = (a.K >> 5) % 2 == 0;
-  int r_cap = narrow ? 64 : 128;
-  if (cfg_.linear_rows_per_pass >= 16) r_cap = std::min(can_wide ? 256 : 128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16);
+  const int r_cap = cfg_.linear_rows_per_pass >= 16 ? std::min(128, cfg_.linear_rows_per_pass - cfg_.linear_rows_per_pass % 16)
+                                                    : (narrow ? 64 : 128);
   const int passes = (a.N + r_cap - 1) / r_cap;
   int rows = (a.N + passes - 1) / passes;
   rows = (rows + 3) & ~3;
   if (XMODE == 1) rows = (rows + 15) & ~15;
-  int RB = (rows + 15) / 16;
-  if (RB > 8) {
-    RB = RB > 12 ? 16 : 12;
-    ring = 2;
-  }
+  const int RB = (rows + 15) / 16;
   a.rows_per_pass = rows;
   const long long WT = ((long long)a.M + GS_TILE_M - 1) / GS_TILE_M;
   long long gx = std::max<long long>(1, gs_cus() / passes);
@@ -390,40 +375,29 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {   // ring: 4 
   if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
   const size_t lds = (size_t)2 * ring * 8 * (16 * RB) * 16 + 8 * (size_t)(16 * RB);
   dim3 grid((unsigned)gx, (unsigned)passes), block(GS_THREADS);
-#define UNIVS_GS_NB(rb, rg, nb)                                                                                   \
+#define UNIVS_GS(rb, rg)                                                                                          \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_stream<rb, rg, XMODE, nb>),               \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_stream<rb, rg, XMODE>),                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-    hipLaunchKernelGGL((gemm_f16x3_stream<rb, rg, XMODE, nb>), grid, block, lds, st, a);                          \
+    hipLaunchKernelGGL((gemm_f16x3_stream<rb, rg, XMODE>), grid, block, lds, st, a);                              \
   } while (0)
-#define UNIVS_GS(rb, rg) UNIVS_GS_NB(rb, rg, 0)
 #define UNIVS_GS_RB(rb)                    \
   case rb:                                 \
     if (ring == 4) { UNIVS_GS(rb, 4); }    \
     else { UNIVS_GS(rb, 3); }              \
     break
-  const int nbx = cfg_.linear_batches;                           // kernel benchmarks: 0 = by shape
   switch (RB) {
     UNIVS_GS_RB(1);
     UNIVS_GS_RB(2);
     UNIVS_GS_RB(3);
-    case 4:
-      if (ring == 4) { if (nbx == 1) UNIVS_GS_NB(4, 4, 1); else UNIVS_GS(4, 4); }
-      else { if (nbx == 1) UNIVS_GS_NB(4, 3, 1); else UNIVS_GS(4, 3); }
-      break;
+    UNIVS_GS_RB(4);
     UNIVS_GS_RB(5);
     UNIVS_GS_RB(6);
     UNIVS_GS_RB(7);
-    case 8:
-      if (ring == 4) { if (nbx == 2) UNIVS_GS_NB(8, 4, 2); else UNIVS_GS(8, 4); }
-      else { if (nbx == 2) UNIVS_GS_NB(8, 3, 2); else UNIVS_GS(8, 3); }
-      break;
-    case 12: UNIVS_GS(12, 2); break;
-    default: UNIVS_GS(16, 2); break;
+    default: UNIVS_GS_RB(8);
   }
 #undef UNIVS_GS_RB
 #undef UNIVS_GS
-#undef UNIVS_GS_NB
   return check_launch("gemm_f16x3_stream");
 }
 
