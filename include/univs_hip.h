@@ -292,32 +292,6 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
                            const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
                            long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream);
 
-/* ---------------------------------------------------------------------------------------------
- * The Linear in front of such an MLP, the LayerNorm between them and the MLP in ONE kernel (mlp_f16x3.hip, PRE):
- *   y0 = x0 W0^T + b0 (+ res0)                       W0 [C, C]
- *   norm_first = 1:  y = y0 + mlp(LN(y0))            the tail of a Swin block: x = shortcut + proj(attn); x = x + mlp(norm2(x))
- *                                                    (mask2former/modeling/backbone/swin.py:286-293; x0 = the window attention's
- *                                                    output before `proj`, res0 = shortcut)
- *   norm_first = 0:  x = LN(y0); y = postLN(x + mlp(x)); y2 = y + post_add[row % post_add_rows]
- *                                                    the tail of an MSDeformAttn encoder layer: src = norm1(src + output_proj(sampled));
- *                                                    src = norm2(src + ffn(src)) and the next layer's with_pos_embed
- *                                                    (mask2former/modeling/pixel_decoder/msdeformattn.py:124-133, :61-63; x0 = the
- *                                                    sampled values before `output_proj`, res0 = src)
- * y0 and LN(y0) never reach memory as tensors (the MLP's residual rows are parked in y and read back by the lane that wrote them:
- * y must not alias x0 / res0).  mlp = act(. W1^T + b1) W2^T + b2 as in univs_mlp_presplit_f32.
- *   w0p, w0inv   univs_presplit_weights_f32(W0 [C, C], C, C, 0, ...)
- *   w1p, w1inv   univs_presplit_weights_f32(W1 [Hd, C], Hd, C, 2, ...)   -- mode 2 here: the normalised rows enter the first product
- *                in the k-order in which the matrix cores deliver y0
- *   w2p, w2inv   univs_presplit_weights_f32(W2 [C, Hd], C, Hd, 2, ...)
- *   ln_weight (required), ln_bias | NULL, ln_eps; post_ln_* | NULL; post_add | NULL, y2 | NULL (norm_first = 0 only)
- *   act 1 ReLU (C = 256), 2 GELU (C in 96 / 128 / 192 / 256); Hd % 32 == 0; M >= 2048; 16-byte aligned pointers.
- * Returns UNIVS_ERR_NOT_IMPLEMENTED for other shapes (the caller keeps univs_linear_* + univs_mlp_presplit_f32).
- * ------------------------------------------------------------------------------------------- */
-int univs_proj_mlp_presplit_f32(const float* x0, const void* w0p, const float* w0inv, const float* b0, const float* res0, int norm_first,
-                                const float* ln_weight, const float* ln_bias, float ln_eps, const void* w1p, const float* w1inv,
-                                const float* b1, const void* w2p, const float* w2inv, const float* b2, const float* post_ln_weight,
-                                const float* post_ln_bias, float post_ln_eps, const float* post_add, long long post_add_rows, float* y2,
-                                long long M, int C, int Hd, int act, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin PatchEmbed in one pass (transpose.hip): out[t, (y/4) * (W/4) + x/4, :] = LayerNorm(conv4x4_stride4(x)[t, :, y/4, x/4] + bias)
@@ -328,6 +302,17 @@ int univs_proj_mlp_presplit_f32(const float* x0, const void* w0p, const float* w
  * ------------------------------------------------------------------------------------------- */
 int univs_patch_embed4_f32(const float* x, const float* weight, const float* bias, const float* ln_weight, const float* ln_bias, float ln_eps,
                            int T, int H, int W, int E, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin PatchMerging's gather + LayerNorm in one pass (layer_norm.hip):
+ *   out[b, y2 * W2 + x2, :] = LayerNorm_{4C}( concat( x[b, 2 y2, 2 x2], x[b, 2 y2 + 1, 2 x2], x[b, 2 y2, 2 x2 + 1], x[b, 2 y2 + 1, 2 x2 + 1] ) )
+ * with H2 = ceil(H / 2), W2 = ceil(W / 2) and pixels beyond H / W read as zeros (the reference pads to even sizes first).
+ * Replaces: PatchMerging.forward up to `self.reduction` (mask2former/modeling/backbone/swin.py:341-386: F.pad, the four strided slices,
+ *           torch.cat(..., -1), self.norm).
+ *   x [B, H, W, C] (tokens of a stage in image order), gamma / beta [4 C], out [B, H2 * W2, 4 C].  C % 4 == 0, C <= 768.
+ * ------------------------------------------------------------------------------------------- */
+int univs_patch_merge_norm_f32(const float* x, const float* gamma, const float* beta, int B, int H, int W, int C, float eps, float* out,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The decoder's cross-attention memory of one feature level from the NCHW feature map, one pass (transpose.hip):

@@ -924,67 +924,28 @@ def test_mlp_fused_post_norm(cuda, N, S, C, Hd):
         ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", post_add=pd)
 
 
-@pytest.mark.parametrize("N,S,C,Hd,act,norm_first", [(2, 9660, 256, 1024, "relu", False), (3, 1111, 256, 512, "relu", False),
-                                                      (1, 58880, 96, 384, "gelu", True), (1, 14721, 192, 768, "gelu", True),
-                                                      (2, 1500, 128, 512, "gelu", True), (1, 4099, 256, 1024, "gelu", True),
-                                                      (1, 4000, 192, 384, "gelu", False)], ids=lambda v: str(v))
-def test_proj_mlp_fused(cuda, N, S, C, Hd, act, norm_first):
-    """ops.proj_mlp_fused (univs_proj_mlp_presplit_f32: mlp_f16x3.hip with the leading Linear): y0 = x0 W0^T + b0 + res0 and then
-    norm_first: y0 + mlp(LN(y0)) (the tail of a Swin block, swin.py:286-293) / else: x = LN(y0), postLN(x + mlp(x)) and + pos (the
-    tail of an MSDeformAttn encoder layer + the next layer's with_pos_embed, msdeformattn.py:124-133, :61-63) against fp64; the
-    separate launches it replaces (linear_fused + mlp_fused) compute the same thing to rounding."""
+@pytest.mark.parametrize("B,H,W,C", [(5, 184, 320, 96), (2, 92, 160, 192), (2, 46, 80, 384), (1, 23, 41, 128), (3, 7, 9, 768), (1, 1, 1, 4)],
+                         ids=lambda v: str(v))
+def test_patch_merge_norm(cuda, B, H, W, C):
+    """ops.patch_merge_norm == PatchMerging.forward up to its Linear (swin.py:341-386): zero padding to even sizes, the four strided
+    slices concatenated in the reference's order, LayerNorm over 4 C -- bit-identical to the LayerNorm kernel on the concatenated
+    tensor (same lanes, same summation order), and to ATen's layer_norm within fp32 rounding."""
     F = torch.nn.functional
-    tag = f"pmlp/{N}x{S}x{C}x{Hd}"
-    x0 = synth.normal(tag + "/x0", (N, S, C))
-    res0 = synth.normal(tag + "/r0", (N, S, C))
-    res0[:, ::5] += 3.0
-    pos = synth.normal(tag + "/pos", (1, S, C))
-    w0 = synth.normal(tag + "/w0", (C, C), std=C ** -0.5)
-    b0 = synth.normal(tag + "/b0", (C,), std=0.5)
-    g1 = 1.0 + 0.2 * synth.normal(tag + "/g1", (C,))
-    be1 = 0.1 * synth.normal(tag + "/be1", (C,))
-    g2 = 1.0 + 0.2 * synth.normal(tag + "/g2", (C,))
-    be2 = 0.1 * synth.normal(tag + "/be2", (C,))
-    w1 = synth.normal(tag + "/w1", (Hd, C), std=C ** -0.5)
-    b1 = synth.normal(tag + "/b1", (Hd,), std=0.5)
-    w2 = synth.normal(tag + "/w2", (C, Hd), std=Hd ** -0.5)
-    b2 = synth.normal(tag + "/b2", (C,), std=0.5)
-    x0d, r0d, pd, w0d, b0d, g1d, be1d, g2d, be2d, w1d, b1d, w2d, b2d = (t.to(cuda) for t in (x0, res0, pos, w0, b0, g1, be1, g2, be2, w1, b1, w2, b2))
-    fn = F.relu if act == "relu" else F.gelu
-
-    def ref(dt):
-        c = lambda t: t.to(dt)
-        y0 = F.linear(c(x0d), c(w0d), c(b0d)) + c(r0d)
-        h = F.layer_norm(y0, (C,), c(g1d), c(be1d), 1e-5)
-        m = F.linear(fn(F.linear(h, c(w1d), c(b1d))), c(w2d), c(b2d))
-        return y0 + m if norm_first else F.layer_norm(h + m, (C,), c(g2d), c(be2d), 1e-5)
-    ref64, ref32 = ref(torch.float64), ref(torch.float32)
-    if norm_first:
-        y = ops.proj_mlp_fused(x0d, w0d, b0d, r0d, (g1d, be1d, 1e-5), w1d, b1d, w2d, b2d, act, True)
-        assert y is not None
-        y1 = ops.linear_fused(x0d, w0d, b0d, residual=r0d)
-        two = ops.mlp_fused(y1, w1d, b1d, w2d, b2d, act, residual=y1, ln=(g1d, be1d, 1e-5))
-    else:
-        out = ops.proj_mlp_fused(x0d, w0d, b0d, r0d, (g1d, be1d, 1e-5), w1d, b1d, w2d, b2d, act, False, post_ln=(g2d, be2d, 1e-5), post_add=pd)
-        assert out is not None and len(out) == 2
-        y, y2 = out
-        assert torch.equal(y2, y + pd)
-        y_only = ops.proj_mlp_fused(x0d, w0d, b0d, r0d, (g1d, be1d, 1e-5), w1d, b1d, w2d, b2d, act, False, post_ln=(g2d, be2d, 1e-5))
-        assert torch.equal(y_only, y)
-        x1 = ops.layer_norm(ops.linear_fused(x0d, w0d, b0d, residual=r0d), g1d, be1d, 1e-5)
-        two = ops.mlp_fused(x1, w1d, b1d, w2d, b2d, act, residual=x1, post_ln=(g2d, be2d, 1e-5))
-    err = (y.double() - ref64).abs().max().item()
-    err32 = (ref32.double() - ref64).abs().max().item()
-    err2 = (two.double() - ref64).abs().max().item() if two is not None else float("nan")
-    print(f"proj_mlp_fused {N, S, C, Hd, act, norm_first}: {err:.2e} (ATen fp32 {err32:.2e}, separate launches {err2:.2e})")
-    assert tuple(y.shape) == (N, S, C) and err < max(4.0 * err32, 2e-5), (err, err32)
-    # no bias / no residual; inputs are not modified; shapes that are not covered
-    y3 = ops.proj_mlp_fused(x0d, w0d, None, None, (g1d, None, 1e-5), w1d, None, w2d, None, act, norm_first,
-                            post_ln=None if norm_first else (g2d, None, 1e-5))
-    assert y3 is not None and torch.isfinite(y3).all()
-    assert torch.equal(x0d.cpu(), x0) and torch.equal(r0d.cpu(), res0)
-    assert ops.proj_mlp_fused(x0d[:, :100], w0d, b0d, r0d[:, :100], (g1d, be1d, 1e-5), w1d, b1d, w2d, b2d, act, norm_first,
-                              post_ln=None if norm_first else (g2d, be2d, 1e-5)) is None
+    x = synth.normal(f"pm/x/{B}x{H}x{W}x{C}", (B, H, W, C))
+    x[:, ::3] += 2.0
+    g_ = 1.0 + 0.2 * synth.normal(f"pm/g/{C}", (4 * C,))
+    b_ = 0.1 * synth.normal(f"pm/b/{C}", (4 * C,))
+    xd, gd, bd = x.to(cuda), g_.to(cuda), b_.to(cuda)
+    y = ops.patch_merge_norm(xd, gd, bd, 1e-5)
+    xp = F.pad(xd, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xp[:, 0::2, 0::2, :], xp[:, 1::2, 0::2, :], xp[:, 0::2, 1::2, :], xp[:, 1::2, 1::2, :]], -1).reshape(B, -1, 4 * C)
+    assert y is not None and tuple(y.shape) == tuple(cat.shape)
+    ref64 = F.layer_norm(cat.double(), (4 * C,), gd.double(), bd.double(), 1e-5)
+    ref32 = F.layer_norm(cat, (4 * C,), gd, bd, 1e-5)
+    err, err32 = (y.double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+    assert err < max(2.0 * err32, 2e-6), (err, err32)
+    assert torch.equal(y, ops.layer_norm(cat.contiguous(), gd, bd, 1e-5))
+    assert ops.patch_merge_norm(torch.zeros(1, 4, 4, 6, device=cuda), torch.ones(24, device=cuda), torch.zeros(24, device=cuda)) is None
 
 
 def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):

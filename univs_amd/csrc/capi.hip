@@ -53,6 +53,7 @@ int bilinear_resample_f32(const float*, const float*, float*, long long, int, in
 int bilinear_pyramid3_f32(const float*, float*, float*, float*, long long, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
                    long long, hipStream_t);
+int patch_merge_norm_f32(const float*, const float*, const float*, int, int, int, int, float, float*, hipStream_t);
 int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
                    float*, hipStream_t);
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
@@ -67,9 +68,6 @@ size_t cross_attention_workspace_floats(int, int, int, int);
 int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
                   const float*, const float*, float, const float*, const float*, float, const float*, long long, float*, float*, long long,
                   int, int, int, hipStream_t);
-int proj_mlp_f16x3_f32(const float*, const void*, const float*, const float*, const float*, int, const float*, const float*, float,
-                       const void*, const float*, const float*, const void*, const float*, const float*, const float*, const float*, float,
-                       const float*, long long, float*, float*, long long, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -268,34 +266,6 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256 / 384, Hd %% 32 == 0, "
               "M >= 2048)", M, C, Hd);
-  return rc;
-}
-
-int univs_proj_mlp_presplit_f32(const float* x0, const void* w0p, const float* w0inv, const float* b0, const float* res0, int norm_first,
-                                const float* ln_weight, const float* ln_bias, float ln_eps, const void* w1p, const float* w1inv,
-                                const float* b1, const void* w2p, const float* w2inv, const float* b2, const float* post_ln_weight,
-                                const float* post_ln_bias, float post_ln_eps, const float* post_add, long long post_add_rows, float* y2,
-                                long long M, int C, int Hd, int act, float* y, void* stream) {
-  clear_sticky_error();
-  if (M < 0 || C < 1 || Hd < 1 || (act != 1 && act != 2)) {
-    set_error("univs_proj_mlp_presplit_f32: bad arguments M=%lld C=%d Hd=%d act=%d (1 ReLU, 2 GELU)", M, C, Hd, act);
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  if (M == 0) return UNIVS_OK;
-  if (!x0 || !w0p || !w0inv || !ln_weight || !w1p || !w1inv || !w2p || !w2inv || !y) {
-    set_error("univs_proj_mlp_presplit_f32: NULL data pointer (the LayerNorm between the Linear and the MLP is not optional)");
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  if (x0 == y || res0 == y) {
-    set_error("univs_proj_mlp_presplit_f32: y must not alias x0 / res0 (the MLP's residual rows are parked in y)");
-    return UNIVS_ERR_INVALID_ARGUMENT;
-  }
-  const int rc = univs::proj_mlp_f16x3_f32(x0, w0p, w0inv, b0, res0, norm_first, ln_weight, ln_bias, ln_eps, w1p, w1inv, b1, w2p, w2inv, b2,
-                                           post_ln_weight, post_ln_bias, post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act,
-                                           static_cast<hipStream_t>(stream));
-  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
-    set_error("univs_proj_mlp_presplit_f32: shape M=%lld C=%d Hd=%d act=%d (or alignment) is not covered (GELU: C in 96 / 128 / 192 / 256; "
-              "ReLU: C = 256; Hd %% 32 == 0, M >= 2048)", M, C, Hd, act);
   return rc;
 }
 
@@ -587,6 +557,24 @@ int univs_layer_norm_add_f32(const float* x, const float* residual, const float*
 int univs_layer_norm_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                          long long rows, int C, float eps, float* sum_out, float* out, void* stream) {
   return univs_layer_norm_add_f32(x, residual, gamma, beta, nullptr, 1, rows, C, eps, sum_out, out, nullptr, stream);
+}
+
+int univs_patch_merge_norm_f32(const float* x, const float* gamma, const float* beta, int B, int H, int W, int C, float eps, float* out,
+                               void* stream) {
+  clear_sticky_error();
+  if (B < 0 || H < 0 || W < 0 || C < 1) {
+    set_error("univs_patch_merge_norm_f32: bad dimensions B=%d H=%d W=%d C=%d", B, H, W, C);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)B * H * W == 0) return UNIVS_OK;
+  if (!x || !gamma || !beta || !out || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                                        reinterpret_cast<uintptr_t>(out)) & 15)) {
+    set_error("univs_patch_merge_norm_f32: NULL or misaligned data pointer (16 bytes)");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = patch_merge_norm_f32(x, gamma, beta, B, H, W, C, eps, out, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_patch_merge_norm_f32: C=%d not supported (C %% 4 == 0, C <= 768)", C);
+  return rc;
 }
 
 int univs_group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW,

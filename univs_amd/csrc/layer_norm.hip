@@ -113,4 +113,80 @@ int layer_norm_f32(const float* x, const float* res, const float* gamma, const f
   return check_launch("layer_norm_f32");
 }
 
+// ---- Swin PatchMerging's gather + LayerNorm in one pass (mask2former/modeling/backbone/swin.py:341-386: pad H, W to even, concatenate
+// the four pixels of every 2 x 2 patch along the channels in the order (0,0), (1,0), (0,1), (1,1) [dy, dx], `norm` over the 4 C
+// channels).  ATen runs the concatenation as a strided copy of its own (82 us for Swin-T stage 1 at 720p x 5) in front of the
+// LayerNorm; here the row is gathered straight into the registers that are normalised.  x [B, H, W, C], out [B, H2 * W2, 4 C].
+template <int G, int NV>
+__global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int B, int H, int W, int C, float eps,
+                                                               float* __restrict__ out) {
+  constexpr int RPB = 256 / G;
+  const int sub = threadIdx.x / G, lane = threadIdx.x % G;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const int cq = C / 4, nchunk = C;                              // 16-byte chunks per source pixel / per output row
+  const long long rows = (long long)B * H2 * W2;
+  const float inv_c = 1.f / (float)(4 * C);
+  for (long long row = (long long)blockIdx.x * RPB + sub; row < rows; row += (long long)gridDim.x * RPB) {
+    const int b = (int)(row / ((long long)H2 * W2));
+    const int rem = (int)(row - (long long)b * H2 * W2);
+    const int y2 = rem / W2, x2 = rem - y2 * W2;
+    v4f v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + j * G;
+      v[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+      if (c < nchunk) {
+        const int seg = c / cq, w = c - seg * cq;
+        const int yy = 2 * y2 + (seg & 1), xx = 2 * x2 + (seg >> 1);
+        if (yy < H && xx < W) v[j] = reinterpret_cast<const v4f*>(x + (((long long)b * H + yy) * W + xx) * C)[w];   // (else: the zero padding)
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      }
+    }
+    const float mean = group_sum<G>(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (lane + j * G < nchunk) {
+        const v4f d = v[j] - mean;
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      }
+    }
+    const float rstd = 1.f / sqrtf(group_sum<G>(q) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + j * G;
+      if (c < nchunk) {
+        const v4f g = reinterpret_cast<const v4f*>(gamma)[c], bt = reinterpret_cast<const v4f*>(beta)[c];
+        reinterpret_cast<v4f*>(out + row * 4 * C)[c] = (v[j] - mean) * rstd * g + bt;
+      }
+    }
+  }
+}
+
+template <int NV>
+static void launch_pm(const float* x, const float* gamma, const float* beta, int B, int H, int W, int C, float eps, float* out,
+                      hipStream_t st) {
+  const long long rows = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const long long want = (rows + 3) / 4;
+  const unsigned grid = (unsigned)(want < 256LL * 32 ? want : 256LL * 32);
+  hipLaunchKernelGGL((patch_merge_norm_kernel<64, NV>), dim3(grid), dim3(256), 0, st, x, gamma, beta, B, H, W, C, eps, out);
+}
+
+// returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED (C % 4 != 0 or C > 768)
+int patch_merge_norm_f32(const float* x, const float* gamma, const float* beta, int B, int H, int W, int C, float eps, float* out,
+                         hipStream_t st) {
+  if (C % 4 != 0 || C > 768 || C < 4) return UNIVS_ERR_NOT_IMPLEMENTED;
+  if ((long long)B * H * W <= 0) return UNIVS_OK;
+  if (C <= 64) launch_pm<1>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else if (C <= 128) launch_pm<2>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else if (C <= 192) launch_pm<3>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else if (C <= 256) launch_pm<4>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else if (C <= 384) launch_pm<6>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else if (C <= 512) launch_pm<8>(x, gamma, beta, B, H, W, C, eps, out, st);
+  else launch_pm<12>(x, gamma, beta, B, H, W, C, eps, out, st);
+  return check_launch("patch_merge_norm_f32");
+}
+
 }  // namespace univs

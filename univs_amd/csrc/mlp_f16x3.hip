@@ -21,16 +21,6 @@
 // ahead into a ring of three; the wait before a batch is `s_waitcnt lgkmcnt(n)` with n = the LDS operations issued after
 // that batch's reads (the next batch's four reads + this slot's commits): LDS operations complete in order and the loop
 // holds no scalar memory operation (checked in the ISA), so the count is exact.
-//
-// PRE (round 4): the Linear in FRONT of the MLP in the same kernel -- y0 = x0 W0^T + b0 + res0 with W0 [C, C] -- and the LayerNorm
-// between them:
-//   * the encoder layer's tail (msdeformattn.py:124-133: src = norm1(src + output_proj(sampled)); src = norm2(src + ffn(src))):
-//     x = LN(y0) is the MLP's input AND its residual (`res_normed`);
-//   * the Swin block's tail (swin.py:286-293: x = shortcut + proj(attn); x = x + mlp(norm2(x))): LN(y0) is the input, y0 the residual.
-// y0 comes out of the matrix cores as D[feature][token]; its blocks 2 ks and 2 ks + 1 ARE the k-step ks of the next product's B
-// operand in the permuted k-order, so W1 is pre-split with the permutation as well (presplit mode 2) and the normalised rows go
-// from accumulators to operands in registers.  The residual rows are parked in Y (each lane reads back what it wrote) instead of
-// 16 CT C / 64 more registers.  W0 streams through the chunk buffer that is idle between two row groups, 32 output features at a time.
 #include "common.h"
 #include "config.h"
 #include "f16x3.h"
@@ -65,12 +55,6 @@ struct MlpArgs {
   float pln_eps;
   int padd_rows;
   int M, Hd, nwg;
-  // PRE
-  const u32x4* W0p;     // W0 [C, C] pre-split, standard k order: unit (kc * 2 + part) * C + r
-  const float* w0inv;   // [C]
-  const float* b0;      // [C] or null
-  const float* Res0;    // [M, C] or null
-  int res_normed;       // the MLP's residual is LN(y0) (1) or y0 (0)
 };
 
 // sum over the four lanes (k-groups, lane >> 4) that hold one row.  (The two results are taken through a typed vector and
@@ -128,9 +112,8 @@ constexpr int ml_ring(int upt, int nbat) {          // most units in flight at o
 // DB: the chunk images double-buffered (one barrier per chunk).  !DB (C = 384, where two 96-KB images do not fit): ONE image, its
 // W1 part refilled with the next chunk's rows during the second product and its W2 part with this chunk's k-step during the
 // first, a barrier between the two products as well; a workgroup is then 4 waves, one per SIMD (512 registers per lane).
-template <int KS1, int CT, int ACT, int NW, int ABL, bool DB, bool PRE = false>
+template <int KS1, int CT, int ACT, int NW, int ABL, bool DB>
 __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a) {
-  static_assert(!PRE || (DB && ABL == 0), "the leading Linear: double-buffered variants only");
   extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
   constexpr int THREADS = 64 * NW;
   constexpr int C = 32 * KS1;
@@ -192,11 +175,8 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(PRE ? a.Y : a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r0rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Res0 ? a.Res0 : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
-  const bool with_res = PRE || a.Res != nullptr;                 // uniform
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.Y2 ? a.Y2 : a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.padd ? a.padd : a.X), 0, (int)((long long)(a.padd ? a.padd_rows : M) * C * 4), 0x00020000);
@@ -238,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
         raw[ks][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, ks * 128, 0));
         raw[ks][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 16u, ks * 128, 0));
       }
-      if (!PRE && with_ln) {
+      if (with_ln) {
         // nn.LayerNorm over the row's C channels, exact two-pass statistics in registers (as layer_norm.hip), then weight / bias
         float sm = 0.f;
 #pragma unroll
@@ -274,120 +254,6 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
       sx_inv[ct] = inv;
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) l3_split8(raw[ks][0], raw[ks][1], s, xh[ct][ks], xm[ct][ks]);
-    }
-
-    if constexpr (PRE) {
-      // ---- y0 = x0 W0^T + b0 + res0 for this wave's rows: W0 in KS1 chunks of 32 output features through the two halves of the
-      // chunk buffer that is idle between row groups (the other one already holds the MLP's chunk 0)
-      constexpr int U0 = W1U / THREADS;                          // units per thread and W0 chunk
-      __syncthreads();                                           // everybody has left the previous group's last chunk
-      u32x4* const stage = Lds + ((gq & 1) ^ 1) * CHU;
-      const unsigned st_lane = a1_lane + (unsigned)(((gq & 1) ^ 1) * CHU * 16);
-      auto w0_src = [&](int cc, int v) __attribute__((always_inline)) -> const u32x4* {
-        const int i = tid + THREADS * v;
-        return a.W0p + ((size_t)(i >> 5) * C + 32 * cc + (i & 31));
-      };
-      u32x4 w0r[U0];
-#pragma unroll
-      for (int v = 0; v < U0; ++v) w0r[v] = *w0_src(0, v);
-#pragma unroll
-      for (int v = 0; v < U0; ++v) stage[tid + THREADS * v] = w0r[v];
-      if constexpr (KS1 > 1) {
-#pragma unroll
-        for (int v = 0; v < U0; ++v) w0r[v] = *w0_src(1, v);
-      }
-      f32x4 acc0[NOB][CT];
-      ml_static_for<0, KS1>([&](auto ccc) __attribute__((always_inline)) {
-        constexpr int CC = decltype(ccc)::value;
-        __syncthreads();                                         // chunk CC is in half CC & 1; nobody reads the other half any more
-        if constexpr (CC + 1 < KS1) {
-#pragma unroll
-          for (int v = 0; v < U0; ++v) stage[((CC + 1) & 1) * W1U + tid + THREADS * v] = w0r[v];
-        }
-        if constexpr (CC + 2 < KS1) {
-#pragma unroll
-          for (int v = 0; v < U0; ++v) w0r[v] = *w0_src(CC + 2, v);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned ab = st_lane + (unsigned)((CC & 1) * W1U * 16);
-        read_batch(afr[0], ab, 512u);
-        if constexpr (KS1 > 1) read_batch(afr[1], ab + 4096u, 512u);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc0[2 * CC][ct] = acc0[2 * CC + 1][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        ml_static_for<0, KS1>([&](auto tc) __attribute__((always_inline)) {
-          constexpr int T = decltype(tc)::value;
-          ml_wait_lgkm<(T + 1 < KS1 ? 4 : 0)>(afr[T % 3]);
-          if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], ab + (unsigned)((T + 2) * 4096), 512u);
-          __builtin_amdgcn_sched_barrier(0);
-          const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[T % 3][0][0]), am0 = __builtin_bit_cast(f16x8, afr[T % 3][0][1]);
-          const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[T % 3][1][0]), am1 = __builtin_bit_cast(f16x8, afr[T % 3][1][1]);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            acc0[2 * CC][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, xh[ct][T], acc0[2 * CC][ct], 0, 0, 0);
-            acc0[2 * CC + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, xh[ct][T], acc0[2 * CC + 1][ct], 0, 0, 0);
-          }
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            acc0[2 * CC][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xm[ct][T], acc0[2 * CC][ct], 0, 0, 0);
-            acc0[2 * CC + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xm[ct][T], acc0[2 * CC + 1][ct], 0, 0, 0);
-          }
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            acc0[2 * CC][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh[ct][T], acc0[2 * CC][ct], 0, 0, 0);
-            acc0[2 * CC + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh[ct][T], acc0[2 * CC + 1][ct], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      });
-      // ---- bias, residual, LayerNorm (two-pass statistics: 4 NOB values of the row in this lane, the rest in its three other lanes),
-      // the MLP's residual rows parked in Y, the normalised rows split into the B operand (blocks 2 ks, 2 ks + 1 = k-step ks)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int m = row0 + 16 * ct + j;
-        const unsigned rowoff = m < M ? (unsigned)m * (unsigned)C * 4u : 0xFFFFFFF0u;
-        float sm = 0.f;
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-          const int f = ob * 16 + 4 * g;
-          const f32x4 wi = *reinterpret_cast<const f32x4*>(a.w0inv + f);
-          f32x4 v = (acc0[ob][ct] * sx_inv[ct]) * wi;
-          if (a.b0) v += *reinterpret_cast<const f32x4*>(a.b0 + f);
-          const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (a.Res0) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0rs, offc, 0, 0));
-          if (!a.res_normed) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
-          acc0[ob][ct] = v;
-          sm += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        const float mean = ml_row_sum(sm) * (1.0f / C);
-        float sq = 0.f;
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-          acc0[ob][ct] -= mean;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sq = fmaf(acc0[ob][ct][e], acc0[ob][ct][e], sq);
-        }
-        const float rstd = 1.0f / sqrtf(ml_row_sum(sq) * (1.0f / C) + a.ln_eps);
-        unsigned mx = 0u;
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-          const int f = ob * 16 + 4 * g;
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(lng_lds + f);
-          const f32x4 bt = *reinterpret_cast<const f32x4*>(lnb_lds + f);
-          acc0[ob][ct] = (acc0[ob][ct] * rstd) * gm + bt;
-          if (a.res_normed) {
-            const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0[ob][ct]), yrs, offc, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) mx = max(mx, l3_absmax8(acc0[2 * ks][ct], acc0[2 * ks + 1][ct]));
-        mx = l3_row_max(mx);
-        float s, inv;
-        l3_scale(mx, 14, s, inv);
-        sx_inv[ct] = inv;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) l3_split8(acc0[2 * ks][ct], acc0[2 * ks + 1][ct], s, xh[ct][ks], xm[ct][ks]);
-      }
     }
 
     f32x4 acc2[NOB][CT];
@@ -583,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (with_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, PRE ? 1 : 0));   // PRE: parked in Y by this lane; glc: from L2
+          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
         }
       } else {
@@ -597,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (with_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, PRE ? 1 : 0));   // PRE: parked in Y by this lane; glc: from L2
+          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           acc2[ob][ct] = v;
           sm += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -643,9 +509,9 @@ static int ml_cus() {
   return n_cu;
 }
 
-template <int KS1, int CT, int ACT, int NW, int ABL, bool DB = true, bool PRE = false>
+template <int KS1, int CT, int ACT, int NW, int ABL, bool DB = true>
 static int ml_launch1(MlpArgs a, size_t lds, int ngroups, hipStream_t st) {
-  const void* fn = reinterpret_cast<const void*>(&mlp_f16x3<KS1, CT, ACT, NW, ABL, DB, PRE>);
+  const void* fn = reinterpret_cast<const void*>(&mlp_f16x3<KS1, CT, ACT, NW, ABL, DB>);
   static int per_cu = 0;                                          // resident workgroups per CU (LDS and registers)
   if (per_cu == 0) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -657,7 +523,7 @@ static int ml_launch1(MlpArgs a, size_t lds, int ngroups, hipStream_t st) {
     per_cu = nb;
   }
   a.nwg = std::min(ml_cus() * per_cu, ngroups);
-  hipLaunchKernelGGL((mlp_f16x3<KS1, CT, ACT, NW, ABL, DB, PRE>), dim3((unsigned)a.nwg), dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((mlp_f16x3<KS1, CT, ACT, NW, ABL, DB>), dim3((unsigned)a.nwg), dim3(64 * NW), lds, st, a);
   return check_launch("mlp_f16x3");
 }
 
@@ -683,47 +549,6 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
   }
   if (act == ML_ACT_RELU) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 0, DB>(a, lds, ngroups, st);
   return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 0, DB>(a, lds, ngroups, st);
-}
-
-template <int KS1, int CT, int NW, int ACT>
-static int ml_launch_pre(const MlpArgs& a, hipStream_t st) {
-  constexpr int C = 32 * KS1;
-  constexpr int RG = NW * 16 * CT;
-  const int ngroups = (a.M + RG - 1) / RG;
-  const size_t lds = (size_t)2 * 16 * C * 16 + (size_t)(2 * a.Hd + 6 * C) * 4;
-  if (lds > 160 * 1024) return UNIVS_ERR_NOT_IMPLEMENTED;
-  return ml_launch1<KS1, CT, ACT, NW, 0, true, true>(a, lds, ngroups, st);
-}
-
-// y0 = x0 W0^T + b0 + res0;  norm_first (Swin): y = y0 + mlp(LN(y0));  else (encoder): x = LN(y0), y = postLN(x + mlp(x)) (+ y2).
-// W1 pre-split with the k-permutation (mode 2), as W2.  Returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.
-int proj_mlp_f16x3_f32(const float* x0, const void* w0p, const float* w0inv, const float* b0, const float* res0, int norm_first,
-                       const float* ln_w, const float* ln_b, float ln_eps, const void* w1p, const float* w1inv, const float* b1,
-                       const void* w2p, const float* w2inv, const float* b2, const float* pln_w, const float* pln_b, float pln_eps,
-                       const float* post_add, long long post_add_rows, float* y2, float* y, long long M, int C, int Hd, int act,
-                       hipStream_t st) {
-  if (M <= 0) return UNIVS_OK;
-  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
-      !ln_w || mis(x0) || mis(w0p) || mis(w0inv) || mis(b0) || mis(res0) || mis(w1p) || mis(w2p) || mis(y) || mis(w1inv) || mis(w2inv) ||
-      mis(b1) || mis(b2) || mis(post_add) || mis(y2) || (pln_b && !pln_w) || ((post_add || y2) && !pln_w) || x0 == y || res0 == y ||
-      (post_add && (!y2 || post_add_rows < 1 || post_add_rows * (long long)C * 4 >= 0x7FFFFFFFLL)))
-    return UNIVS_ERR_NOT_IMPLEMENTED;
-  MlpArgs a{};
-  a.X = x0; a.W0p = reinterpret_cast<const u32x4*>(w0p); a.w0inv = w0inv; a.b0 = b0; a.Res0 = res0; a.res_normed = norm_first ? 0 : 1;
-  a.W1p = reinterpret_cast<const u32x4*>(w1p); a.w1inv = w1inv; a.b1 = b1;
-  a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = nullptr; a.Y = y;
-  a.ln_g = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
-  a.pln_g = pln_w; a.pln_b = pln_b; a.pln_eps = pln_eps; a.padd = post_add; a.padd_rows = (int)post_add_rows; a.Y2 = y2;
-  a.M = (int)M; a.Hd = Hd;
-  if (act == ML_ACT_RELU) return C == 256 ? ml_launch_pre<8, 1, 8, ML_ACT_RELU>(a, st) : UNIVS_ERR_NOT_IMPLEMENTED;
-  switch (C) {
-    case 96: return ml_launch_pre<3, 2, 4, ML_ACT_GELU>(a, st);
-    case 128: return ml_launch_pre<4, 1, 8, ML_ACT_GELU>(a, st);
-    case 192: return ml_launch_pre<6, 1, 8, ML_ACT_GELU>(a, st);
-    case 256: return ml_launch_pre<8, 1, 8, ML_ACT_GELU>(a, st);
-    default: return UNIVS_ERR_NOT_IMPLEMENTED;
-  }
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered

@@ -124,22 +124,15 @@ class WindowAttention(nn.Module):
             self._bias_cache = (key, b.detach())
         return self._bias_cache[1]
 
-    def forward_image(self, x, H, W, shift, mask=None, residual=None, project=True):
+    def forward_image(self, x, H, W, shift, mask=None, residual=None):
         """x: [B, H*W, C] tokens in image order.  Same result as pad -> roll -> window_partition -> forward ->
         window_reverse -> roll -> crop (the reference block, swin.py:252-284), with all of that data movement
         done by index arithmetic inside the attention kernel (the qkv / proj Linears are per token, so they
-        commute with the partition).  `residual` [B, H*W, C]: added to the result.  `project=False`: the attention output
-        BEFORE `proj` (the block fuses that Linear into its MLP kernel)."""
+        commute with the partition).  `residual` [B, H*W, C]: added to the result."""
         B, L, C = x.shape
         qkv = _linear(self.qkv, x).view(B, L, 3, self.num_heads, C // self.num_heads)
         out = ops.window_attention_image(qkv, self.qkv.bias, self._bias(), mask, H, W, self.window_size[0], shift,
                                          self.scale, mma=self.mma)
-        if not project:
-            return out
-        return self.project(out, residual)
-
-    def project(self, out, residual=None):
-        """proj (+ the block's shortcut in its epilogue) of an attention output"""
         if residual is None:
             return _linear(self.proj, out)
         # the block's `shortcut + attn branch` (swin.py:286) in the proj Linear's epilogue
@@ -180,22 +173,8 @@ class SwinTransformerBlock(nn.Module):
         if x.is_cuda and SWITCHES.fused_mlp:
             # x = shortcut + attn branch from the proj Linear's epilogue; then x + mlp(norm2(x)) in ONE launch where the fused
             # MLP covers the width (its x tile sits in registers: the LayerNorm costs no pass over memory), else norm2 + Mlp
-            mlp = self.mlp
-            tail = (SWITCHES.fused_proj_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 7) == 7
-                    and C <= SWITCHES.fused_mlp_max_c and not torch.is_grad_enabled())
             x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
-                                        mask_matrix if self.shift_size > 0 else None, residual=shortcut, project=not tail)
-            if tail:
-                # proj + shortcut + norm2 + fc1 + GELU + fc2 + shortcut in ONE launch (csrc/mlp_f16x3.hip, PRE): `shortcut + proj(...)`
-                # only exists as the rows parked for the second shortcut
-                out = x.reshape(B, H * W, C)
-                y = ops.proj_mlp_fused(out, self.attn.proj.weight, self.attn.proj.bias, shortcut,
-                                       (self.norm2.weight, self.norm2.bias, self.norm2.eps), mlp.fc1.weight, mlp.fc1.bias,
-                                       mlp.fc2.weight, mlp.fc2.bias, "gelu", True)
-                if y is not None:
-                    return y
-                x = self.attn.project(out, shortcut)
-            x = x.reshape(B, H * W, C)
+                                        mask_matrix if self.shift_size > 0 else None, residual=shortcut).reshape(B, H * W, C)
             y = self.mlp.fused(x, residual=x, norm=self.norm2)
             return y if y is not None else self.mlp(layer_norm(self.norm2, x), residual=x)
         x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
@@ -216,6 +195,11 @@ class PatchMerging(nn.Module):
         B, L, C = x.shape
         assert L == H * W
         x = x.view(B, H, W, C)
+        if x.is_cuda and not torch.is_grad_enabled():
+            # pad + the four strided slices + concatenation + norm in one pass (csrc/layer_norm.hip: patch_merge_norm_kernel)
+            h = ops.patch_merge_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            if h is not None:
+                return _linear(self.reduction, h)
         if (H % 2 == 1) or (W % 2 == 1):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)

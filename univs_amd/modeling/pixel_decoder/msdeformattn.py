@@ -85,12 +85,11 @@ class MSDeformAttn(nn.Module):
         return c[1], c[2]
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, ref_per_query=None, project=True):
+                input_level_start_index, input_padding_mask=None, ref_per_query=None):
         """query [N,Lq,C]; reference_points [N|1,Lq,L,2]; input_flatten [N,S,C];
         input_spatial_shapes / input_level_start_index: python lists (or tensors).
         `ref_per_query` [N|1, Lq, 2] (optional): the caller's promise that every level shares one reference point per query
-        (the encoder's pixel centres, msdeformattn.py:143-158 with valid_ratio == 1) -- enables the head-major kernel.
-        `project=False`: the sampled values BEFORE `output_proj` (the encoder layer fuses that Linear into its tail kernel)."""
+        (the encoder's pixel centres, msdeformattn.py:143-158 with valid_ratio == 1) -- enables the head-major kernel."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -105,7 +104,7 @@ class MSDeformAttn(nn.Module):
                 if qp_hm is not None:
                     output = ops.msda_forward_strips(value_hm, qp_hm, ref_per_query, shapes, input_level_start_index, M, P)
                     if output is not None:
-                        return linear(output, self.output_proj.weight, self.output_proj.bias) if project else output
+                        return linear(output, self.output_proj.weight, self.output_proj.bias)
         value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
@@ -134,7 +133,7 @@ class MSDeformAttn(nn.Module):
         output = ops.ms_deform_attn_forward(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights.contiguous(),
                                             self.im2col_step)
-        return linear(output, self.output_proj.weight, self.output_proj.bias) if project else output
+        return linear(output, self.output_proj.weight, self.output_proj.bias)
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -154,30 +153,15 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         MSDeformAttn.forward."""
         if query is None:
             query = src if pos is None else src + pos
-        fused = SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu
-        n2 = (self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        with_next = want_next_query and pos is not None
-        tail = fused and SWITCHES.fused_proj_mlp and not torch.is_grad_enabled()
         src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                              ref_per_query=ref_per_query, project=not tail)
-        if tail:
-            # output_proj + residual + norm1 + linear1 + ReLU + linear2 + residual + norm2 (+ the next layer's `src + pos`) in ONE
-            # kernel (csrc/mlp_f16x3.hip, PRE): neither `src + output_proj(...)`, its normalised form nor the [tokens, d_ffn]
-            # activations reach memory
-            op = self.self_attn.output_proj
-            res = ops.proj_mlp_fused(src2, op.weight, op.bias, src, (self.norm1.weight, self.norm1.bias, self.norm1.eps),
-                                     self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu", False,
-                                     post_ln=n2, post_add=pos if with_next else None)
-            if res is not None:
-                if with_next:
-                    return res
-                return (res, None) if want_next_query else res
-            src2 = linear(src2, op.weight, op.bias)
+                              ref_per_query=ref_per_query)
         src = layer_norm(self.norm1, src2, residual=src)
         ffn = None
-        if fused:
+        if SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu:
             # linear1 + ReLU + linear2 + residual + norm2 (+ the next layer's `src + pos`) in ONE kernel: the [tokens, d_ffn]
             # activations stay in registers and the finished row is normalised before it is stored (csrc/mlp_f16x3.hip)
+            n2 = (self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            with_next = want_next_query and pos is not None
             res = ops.mlp_fused(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
                                 residual=src, post_ln=n2, post_add=pos if with_next else None)
             if res is not None:

@@ -413,71 +413,6 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
     return (y.view(x.shape), y2.view(x.shape)) if y2 is not None else y.view(x.shape)
 
 
-def proj_mlp_fused(x0, w0, b0, res0, ln, w1, b1, w2, b2, act, norm_first, post_ln=None, post_add=None):
-    """The Linear in front of an MLP, the LayerNorm between them and the MLP in ONE kernel (include/univs_hip.h:
-    univs_proj_mlp_presplit_f32; csrc/mlp_f16x3.hip, PRE):  y0 = x0 W0^T + b0 + res0, then
-      norm_first=True   y = y0 + mlp(LN(y0))                  -- the tail of a Swin block (swin.py:286-293: x0 = the window attention's
-                                                                 output before `proj`, res0 = the shortcut);
-      norm_first=False  x = LN(y0); y = post_ln(x + mlp(x))    -- the tail of an MSDeformAttn encoder layer (msdeformattn.py:124-133:
-                                                                 x0 = the sampled values before `output_proj`, res0 = src), with
-                                                                 `post_add` the pair (y, y + post_add) as `mlp_fused`.
-    `ln` / `post_ln` = (weight, bias, eps).  Returns None when the shape is not covered (GELU: C in 96 / 128 / 192 / 256, ReLU: C = 256;
-    Hd % 32; fewer than 2048 rows; autograd needed): the caller keeps `linear_fused` + `mlp_fused`."""
-    C = x0.shape[-1]
-    Hd = w1.shape[0]
-    M = x0.numel() // max(C, 1)
-    if needs_grad(x0, w0, b0, res0, w1, b1, w2, b2) or act not in ("relu", "gelu") or ln is None or ln[0] is None:
-        return None
-    if (not x0.is_cuda or any(t.dtype != torch.float32 for t in (x0, w0, w1, w2)) or C not in ((256,) if act == "relu" else (96, 128, 192, 256))
-            or tuple(w0.shape) != (C, C) or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048
-            or M * C * 4 >= 2 ** 31 - 1 or (2 * 64 * C + 2 * Hd + 6 * C) * 4 > 160 * 1024):
-        return None
-    if not norm_first and post_ln is None:
-        return None
-    if norm_first and (post_ln is not None or post_add is not None):
-        raise RuntimeError("proj_mlp_fused: post_ln / post_add belong to the post-norm form (norm_first=False)")
-
-    def vec(t_, n, what):
-        if t_ is not None and (t_.dtype != torch.float32 or tuple(t_.shape) != (n,) or not t_.is_cuda or not t_.is_contiguous()):
-            raise RuntimeError(f"proj_mlp_fused: {what} must be contiguous float32 [{n}] on the GPU")
-        return _ptr(t_) if t_ is not None else None
-    lw, lb, leps = ln
-    pw = pb = pa = None
-    peps, parows = 0.0, 0
-    if post_ln is not None:
-        pw, pb, peps = post_ln
-        if pw is None:
-            raise RuntimeError("proj_mlp_fused: post_ln needs a weight")
-    if post_add is not None:
-        pa = post_add.contiguous()
-        parows = pa.numel() // C
-        if pa.dtype != torch.float32 or not pa.is_cuda or pa.shape[-1] != C or parows < 1 or M % parows != 0:
-            raise RuntimeError("proj_mlp_fused: post_add must be float32 [rows, C] on the GPU with rows dividing the number of tokens")
-    x2 = x0.contiguous().view(M, C)
-    _require_gpu("proj_mlp_fused", x2)
-    r = None
-    if res0 is not None:
-        if res0.dtype != torch.float32 or not res0.is_cuda or tuple(res0.shape) != tuple(x0.shape):
-            raise RuntimeError(f"proj_mlp_fused: res0 must be float32 of x0's shape on the GPU (got {tuple(res0.shape)})")
-        r = res0.contiguous()
-    y = torch.empty((M, C), dtype=torch.float32, device=x0.device)
-    y2 = torch.empty((M, C), dtype=torch.float32, device=x0.device) if pa is not None else None
-    with _on(x0):
-        w0p, w0inv = presplit_weights(w0)
-        w1p, w1inv = presplit_weights(w1, mode="mlp2")           # the normalised rows arrive in the matrix cores' output order
-        w2p, w2inv = presplit_weights(w2, mode="mlp2")
-        rc = _lib.load().univs_proj_mlp_presplit_f32(
-            _ptr(x2), _ptr(w0p), _ptr(w0inv), vec(b0, C, "b0"), _ptr(r) if r is not None else None, 1 if norm_first else 0,
-            vec(lw, C, "LayerNorm weight"), vec(lb, C, "LayerNorm bias"), float(leps), _ptr(w1p), _ptr(w1inv), vec(b1, Hd, "b1"),
-            _ptr(w2p), _ptr(w2inv), vec(b2, C, "b2"), vec(pw, C, "post-LayerNorm weight"), vec(pb, C, "post-LayerNorm bias"), float(peps),
-            _ptr(pa) if pa is not None else None, parows, _ptr(y2) if y2 is not None else None, M, C, Hd, _ACTS[act], _ptr(y),
-            _stream_ptr(x2))
-    if rc == _lib.ERR_NOT_IMPLEMENTED:
-        return None
-    _lib.check(rc, "proj_mlp_fused")
-    return (y.view(x0.shape), y2.view(x0.shape)) if y2 is not None else y.view(x0.shape)
-
-
 def linear_fused(x, weight, bias=None, act=None, residual=None):
     """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [the erf form; erf to 4.7e-7 absolute]) or `residual`
     (a tensor of the output's shape that is added) -- for float32 on the GPU through the three-product fp16 kernels (fp32-accurate:
@@ -793,6 +728,26 @@ def transpose_last2(x):
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return x.transpose(-2, -1).contiguous()
     _lib.check(rc, "transpose_last2")
+    return out
+
+
+def patch_merge_norm(x, weight, bias, eps=1e-5):
+    """Swin PatchMerging up to its Linear in one pass (include/univs_hip.h: univs_patch_merge_norm_f32): x [B, H, W, C] float32 on the GPU
+    -> LayerNorm over the 4 C channels of the 2 x 2 patches [B, ceil(H/2) * ceil(W/2), 4 C], channel order and zero padding of odd sizes as
+    PatchMerging.forward (swin.py:341-386).  None when the width is not covered (C % 4, C > 768) or autograd is needed."""
+    if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or needs_grad(x, weight, bias) or x.shape[-1] % 4 != 0
+            or x.shape[-1] > 768):
+        return None
+    B, H, W, C = x.shape
+    x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+    if tuple(weight.shape) != (4 * C,) or tuple(bias.shape) != (4 * C,):
+        raise RuntimeError("patch_merge_norm: weight / bias must be [4 C]")
+    out = torch.empty((B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=torch.float32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_patch_merge_norm_f32(_ptr(x), _ptr(weight), _ptr(bias), B, H, W, C, float(eps), _ptr(out), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "patch_merge_norm")
     return out
 
 

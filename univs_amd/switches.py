@@ -38,11 +38,6 @@ class Switches:
     # 4-wave workgroups) but measured 321 us against 257 us for the two fused Linears at Swin stage 3 (18 400 rows: 288 row groups
     # on 256 CUs, one wave per SIMD) -- profiles/r04_kbench_mlp_v2.txt
     fused_mlp_max_c: int = 256
-    # the Linear in front of such an MLP (the encoder layer's output_proj + norm1, the Swin block's proj + shortcut + norm2) in the
-    # same kernel (csrc/mlp_f16x3.hip, PRE); False: its own fused Linear (+ LayerNorm launch).  Correct (tests) but NOT faster as it
-    # stands: 295-298 vs 301 frames/s on the same box (gpurun_out/r04_p) -- the leading Linear's eight barrier-separated W0 chunks
-    # run at half the main loop's efficiency
-    fused_proj_mlp: bool = False
     # decoder cross-attention core (scores, mask, softmax, P V) as one pass over the keys (csrc/cross_attn.hip); False: two
     # library GEMMs around the masked-softmax kernel
     fused_cross_attention: bool = True
@@ -64,7 +59,7 @@ SWITCHES = Switches(
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
-    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_proj_mlp=_flag("UNIVS_FUSED_PROJ_MLP", False))
+    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
