@@ -397,6 +397,29 @@ int univs_window_attention_image_mma(const float* qkv, const float* qkv_bias, co
                                      int nH, int hd, float scale, int mma, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The FPN top-down step for an exact 2x up-sampling (resample.hip):
+ *   out = (addend [* scale_p + bias_p]) + F.interpolate(in, scale 2, mode="bilinear", align_corners=False)
+ * Replaces: `y = cur_fpn + F.interpolate(y, size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)`
+ *           (mask2former/modeling/pixel_decoder/msdeformattn.py:350-351) and, with addend_affine, the GroupNorm of the lateral
+ *           convolution in front of it (`cur_fpn = lateral_conv(x)`, a Conv2d with norm = GroupNorm(32), :214-226, :349): addend is
+ *           then the raw convolution output and addend_affine [planes][2] the (scale, bias) pairs of univs_group_norm_affine_f32 --
+ *           the normalised lateral tensor is never written.  Same taps, weights and expression order as
+ *           univs_bilinear_resample_f32 (bit-identical results).
+ *   in [planes, Hin, Win], addend / out [planes, 2 Hin, 2 Win]; Win even; in 8-byte, addend / out 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int univs_upsample2x_add_f32(const float* in, const float* addend, const float* addend_affine, float* out, long long planes, int Hin,
+                             int Win, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm statistics in affine form (group_norm.hip): affine[(n * C + c) * 2 + {0, 1}] = (gamma_c / sqrt(var + eps),
+ * beta_c - mean * gamma_c / sqrt(var + eps)) of x [N, C, HW] with `groups` groups -- F.group_norm(x) == x * scale + bias, the values
+ * and the expression univs_group_norm_f32 applies.  For consumers that normalise while they read (univs_upsample2x_add_f32).
+ *   ws: N * C * 2 * ceil(HW / 8192) floats of scratch (as univs_group_norm_f32).
+ * ------------------------------------------------------------------------------------------- */
+int univs_group_norm_affine_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups, float eps,
+                                float* ws, long long ws_floats, float* affine, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bilinear resampling of image planes, align_corners = false (PyTorch semantics).
  * Replaces: F.interpolate(x, size=(Hout, Wout), mode="bilinear", align_corners=False) on the path of the
  *           attention-mask heads (univs/modeling/transformer_decoder/

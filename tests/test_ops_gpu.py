@@ -431,6 +431,35 @@ def test_bilinear_resample_matches_torch(cuda, shape, size):
         ops.bilinear_resample(x, size)          # CPU tensors are refused (no fallback)
 
 
+@pytest.mark.parametrize("shape", [(5, 256, 92, 160), (2, 32, 23, 40), (1, 64, 7, 130), (3, 32, 1, 2), (1, 32, 40, 66)], ids=lambda v: str(v))
+def test_upsample2x_add_with_group_norm(cuda, shape):
+    """ops.upsample2x_add == bilinear_resample(x, 2x, addend) bit for bit (same taps, weights and expression; the data movement
+    differs: 8-byte loads + lane exchanges), incl. the clamped border columns / rows and widths where column groups of different
+    rows share a wave; with `affine` = group_norm_affine(addend) == group_norm(addend) + upsample bit for bit, and within fp32
+    rounding of F.group_norm + F.interpolate (the FPN top-down step of msdeformattn.py:349-351)."""
+    F = torch.nn.functional
+    N, C, H, W = shape
+    x = synth.normal("up2/x/" + "x".join(map(str, shape)), shape)
+    add = synth.normal("up2/a/" + "x".join(map(str, shape)), (N, C, 2 * H, 2 * W)) * 2.0 + 0.3
+    g_ = 1.0 + 0.2 * synth.normal(f"up2/g/{C}", (C,))
+    b_ = 0.1 * synth.normal(f"up2/b/{C}", (C,))
+    xd, ad, gd, bd = x.to(cuda), add.to(cuda), g_.to(cuda), b_.to(cuda)
+    y = ops.upsample2x_add(xd, ad)
+    assert y is not None and torch.equal(y, ops.bilinear_resample(xd, (2 * H, 2 * W), addend=ad))
+    ref = add + F.interpolate(x, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    assert (y.cpu() - ref).abs().max().item() < 4e-6 * max(1.0, ref.abs().max().item())
+    aff = ops.group_norm_affine(ad, 32, gd, bd, 1e-5)
+    assert tuple(aff.shape) == (N * C, 2)
+    y2 = ops.upsample2x_add(xd, ad, aff)
+    two = ops.bilinear_resample(xd, (2 * H, 2 * W), addend=ops.group_norm(ad, 32, gd, bd, 1e-5))
+    assert torch.equal(y2, two)
+    ref2 = F.group_norm(add.double(), 32, g_.double(), b_.double(), 1e-5) + F.interpolate(x.double(), size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    ref2_32 = F.group_norm(add, 32, g_, b_, 1e-5) + F.interpolate(x, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    err, err32 = (y2.cpu().double() - ref2).abs().max().item(), (ref2_32.double() - ref2).abs().max().item()
+    assert err < max(4.0 * err32, 4e-6), (err, err32)
+    assert ops.upsample2x_add(xd, ad[..., :-1]) is None and ops.upsample2x_add(xd[..., :-1], ad[..., :-2]) is None   # not 2x / odd width
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 96), (513, 192), (300, 256), (257, 384), (129, 768), (65, 1536), (33, 3072), (7, 8), (0, 96), (77, 640), (50, 64)],
                          ids=lambda v: str(v))
 def test_layer_norm_matches_torch(cuda, rows, C):

@@ -58,6 +58,8 @@ SIGNATURES = {
     "univs_mlp_presplit_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _c.c_float, _P, _c.c_longlong, _P,
                                     _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_window_attention_image_mma": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _c.c_float, _I, _P, _P]),
+    "univs_upsample2x_add_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _I, _P]),
+    "univs_group_norm_affine_f32": (_I, [_P, _P, _P, _I, _I, _c.c_longlong, _I, _c.c_float, _P, _c.c_longlong, _P, _P]),
     "univs_bilinear_pyramid3_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P, _P, _P]),
     "univs_bilinear_resample_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P]),
     "univs_patch_merge_norm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _c.c_float, _P, _P]),

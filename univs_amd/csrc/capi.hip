@@ -50,6 +50,8 @@ int msda_backward_f32(const float*, const LevelTable&, const float*, const float
 int msda_prepare_f32(const float*, int, int, const float*, long long, const LevelTable&, int, int, int, int, int,
                      float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
+int upsample2x_add_f32(const float*, const float*, const float*, float*, long long, int, int, hipStream_t);
+int group_norm_affine_f32(const float*, const float*, const float*, int, int, long long, int, float, float*, long long, float*, hipStream_t);
 int bilinear_pyramid3_f32(const float*, float*, float*, float*, long long, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
                    long long, hipStream_t);
@@ -514,6 +516,39 @@ int univs_bilinear_resample_f32(const float* in, const float* addend, float* out
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return bilinear_resample_f32(in, addend, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
+}
+
+int univs_upsample2x_add_f32(const float* in, const float* addend, const float* addend_affine, float* out, long long planes, int Hin,
+                             int Win, void* stream) {
+  clear_sticky_error();
+  if (planes < 0 || Hin < 1 || Win < 1) {
+    set_error("univs_upsample2x_add_f32: bad dimensions planes=%lld in=%dx%d", planes, Hin, Win);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (planes == 0) return UNIVS_OK;
+  if (!in || !addend || !out) {
+    set_error("univs_upsample2x_add_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = upsample2x_add_f32(in, addend, addend_affine, out, planes, Hin, Win, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_upsample2x_add_f32: %dx%d not covered (Win even; in 8-byte, addend / out 16-byte aligned)", Hin, Win);
+  return rc;
+}
+
+int univs_group_norm_affine_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups, float eps,
+                                float* ws, long long ws_floats, float* affine, void* stream) {
+  clear_sticky_error();
+  if (N < 0 || C < 1 || HW < 0 || groups < 1 || C % groups != 0 || (long long)N * C > 0x7fffffffLL) {
+    set_error("univs_group_norm_affine_f32: bad dimensions N=%d C=%d HW=%lld groups=%d", N, C, HW, groups);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * HW == 0) return UNIVS_OK;
+  if (!x || !gamma || !beta || !ws || !affine) {
+    set_error("univs_group_norm_affine_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return group_norm_affine_f32(x, gamma, beta, N, C, HW, groups, eps, ws, ws_floats, affine, static_cast<hipStream_t>(stream));
 }
 
 int univs_bilinear_pyramid3_f32(const float* in, long long planes, int H, int W, float* out2, float* out4, float* out8,

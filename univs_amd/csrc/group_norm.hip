@@ -99,9 +99,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// the per-plane affine form of the normalisation -- scale = gamma / sqrt(var + eps), bias = beta - mean * scale, the very values
+// gn_apply_kernel uses (same sums in the same order) -- for a consumer that applies it while reading x (resample.hip:
+// upsample2x_add_kernel).  One workgroup per plane.
+__global__ __launch_bounds__(256) void gn_affine_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int C, int Cg, long long HW, int chunks,
+                                                        float eps, const float* __restrict__ partials, float* __restrict__ affine) {
+  __shared__ float red[4];
+  const long long plane = blockIdx.x;
+  const long long n = plane / C, c = plane % C, g = c / Cg;
+  const long long g0 = n * C + g * Cg;
+  const float shift = x[g0 * HW];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < Cg * chunks; i += 256) {
+    s1 += partials[(g0 * chunks + i) * 2];
+    s2 += partials[(g0 * chunks + i) * 2 + 1];
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  const float inv_n = 1.f / ((float)Cg * (float)HW);
+  const float m1 = s1 * inv_n;
+  const float var = fmaxf(s2 * inv_n - m1 * m1, 0.f);
+  const float mean = shift + m1;
+  const float scale = gamma[c] / sqrtf(var + eps);
+  const float bias = beta[c] - mean * scale;
+  if (threadIdx.x == 0) {
+    affine[2 * plane] = scale;
+    affine[2 * plane + 1] = bias;
+  }
+}
+
 // workspace: N * C * chunks * 2 floats; chunks is chosen here and returned through *chunks_out when ws == NULL
-int group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups,
-                   float eps, int relu, float* ws, long long ws_floats, float* out, hipStream_t st) {
+static int gn_chunks(int C, int groups, long long HW) {
   const int Cg = C / groups;
   // enough workgroups to fill the chip, chunks of >= 4 K elements, partial count per group <= 1024
   int chunks = (int)((HW + 8191) / 8192);
@@ -114,6 +143,13 @@ int group_norm_f32(const float* x, const float* gamma, const float* beta, int N,
       chunks = (int)((HW + per4 - 1) / per4);
     }
   }
+  return chunks;
+}
+
+int group_norm_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups,
+                   float eps, int relu, float* ws, long long ws_floats, float* out, hipStream_t st) {
+  const int Cg = C / groups;
+  const int chunks = gn_chunks(C, groups, HW);
   if ((long long)N * C * chunks * 2 > ws_floats) {
     set_error("group_norm_f32: workspace too small (%lld floats, need %lld)", ws_floats, (long long)N * C * chunks * 2);
     return UNIVS_ERR_INVALID_ARGUMENT;
@@ -122,6 +158,20 @@ int group_norm_f32(const float* x, const float* gamma, const float* beta, int N,
   hipLaunchKernelGGL(gn_partials_kernel, grid, dim3(256), 0, st, x, C, Cg, HW, chunks, ws);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, x, gamma, beta, C, Cg, HW, chunks, eps, relu, ws, out);
   return check_launch("group_norm_f32");
+}
+
+// statistics only: affine [N * C][2] = (scale, bias) per plane, y = x * scale + bias being the normalised value
+int group_norm_affine_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups, float eps,
+                          float* ws, long long ws_floats, float* affine, hipStream_t st) {
+  const int Cg = C / groups;
+  const int chunks = gn_chunks(C, groups, HW);
+  if ((long long)N * C * chunks * 2 > ws_floats) {
+    set_error("group_norm_affine_f32: workspace too small (%lld floats, need %lld)", ws_floats, (long long)N * C * chunks * 2);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL(gn_partials_kernel, dim3((unsigned)chunks, (unsigned)(N * C)), dim3(256), 0, st, x, C, Cg, HW, chunks, ws);
+  hipLaunchKernelGGL(gn_affine_kernel, dim3((unsigned)(N * C)), dim3(256), 0, st, x, gamma, beta, C, Cg, HW, chunks, eps, ws, affine);
+  return check_launch("group_norm_affine_f32");
 }
 
 }  // namespace univs

@@ -77,6 +77,61 @@ __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float*
   }
 }
 
+// ---- the FPN top-down step for an exact 2x up-sampling: out = (addend [* scale_p + bias_p]) + interpolate(in) with Hout = 2 Hin,
+// Wout = 2 Win (msdeformattn.py:350-351: `y = cur_fpn + F.interpolate(y, size=cur_fpn.shape[-2:], mode="bilinear")`).  Same taps,
+// weights and expression as the kernel above (bit-identical), different data movement: the four outputs of a thread read input
+// columns 2 X - 1 ... 2 X + 2 of two rows -- the thread loads (2 X, 2 X + 1) with ONE 8-byte load per row and takes the outer two
+// from its neighbour lanes (they hold the adjacent column groups of the same row), the addend with one 16-byte load: 4 memory
+// instructions per 16 output bytes instead of 21.  `affine` [planes][2] (optional): the addend is a convolution output whose
+// GroupNorm is applied on the way in (group_norm.hip: gn_affine_kernel wrote scale = gamma / sqrt(var + eps), bias = beta - mean *
+// scale per plane; `x * scale + bias` is gn_apply_kernel's expression) -- the normalised tensor is never written.
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __restrict__ in, const float* __restrict__ addend,
+                                                             const float* __restrict__ affine, float* __restrict__ out, int Hin,
+                                                             int Win, long long planes) {
+  const int Wout = 2 * Win, Hout = 2 * Hin, wq = Wout / 4;
+  const int total = Hout * wq;
+  const int q0 = blockIdx.x * 256 + threadIdx.x;
+  const bool active = q0 < total;
+  const int q = active ? q0 : total - 1;                       // idle threads follow along (the lane exchanges are wave-wide)
+  const int oy = q / wq, X = q - oy * wq, ox = 4 * X;
+  const Tap ty = make_tap(0.5f, oy, Hin);
+  Tap tx[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) tx[v] = make_tap(0.5f, ox + v, Win);
+  const int lane = threadIdx.x & 63;
+  const bool left_ok = lane > 0 && X > 0;                        // lane - 1 holds (oy, X - 1)
+  const bool right_ok = lane < 63 && X + 1 < wq && q0 + 1 < total;   // lane + 1 holds (oy, X + 1)
+  const int cl = max(2 * X - 1, 0), cr = min(2 * X + 2, Win - 1);
+  auto pick = [&](float a0, float a1, float a2, float a3, int col) __attribute__((always_inline)) {
+    const int rel = col - (2 * X - 1);
+    return rel == 0 ? a0 : rel == 1 ? a1 : rel == 2 ? a2 : a3;
+  };
+  for (long long p = blockIdx.y; p < planes; p += gridDim.y) {
+    const float* r0 = in + (p * Hin + ty.i0) * (long long)Win;
+    const float* r1 = r0 + (long long)ty.di * Win;
+    const float2 m0 = *reinterpret_cast<const float2*>(r0 + 2 * X), m1 = *reinterpret_cast<const float2*>(r1 + 2 * X);
+    float e0 = __shfl_up(m0.y, 1, 64), e1 = __shfl_up(m1.y, 1, 64);
+    float f0 = __shfl_down(m0.x, 1, 64), f1 = __shfl_down(m1.x, 1, 64);
+    if (!left_ok) { e0 = r0[cl]; e1 = r1[cl]; }
+    if (!right_ok) { f0 = r0[cr]; f1 = r1[cr]; }
+    float o[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float a = pick(e0, m0.x, m0.y, f0, tx[v].i0), b = pick(e0, m0.x, m0.y, f0, tx[v].i0 + tx[v].di);
+      const float c = pick(e1, m1.x, m1.y, f1, tx[v].i0), d = pick(e1, m1.x, m1.y, f1, tx[v].i0 + tx[v].di);
+      o[v] = ty.l0 * (tx[v].l0 * a + tx[v].l1 * b) + ty.l1 * (tx[v].l0 * c + tx[v].l1 * d);
+    }
+    const long long off = (p * Hout + oy) * (long long)Wout + ox;
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ ad = *reinterpret_cast<const v4f_*>(addend + off);
+    if (affine) {
+      const float scale = affine[2 * p], bias = affine[2 * p + 1];
+      ad = ad * scale + bias;
+    }
+    if (active) *reinterpret_cast<v4f_*>(out + off) = (v4f_){ad.x + o[0], ad.y + o[1], ad.z + o[2], ad.w + o[3]};
+  }
+}
+
 // ---- the three attention-mask resolutions of the decoder (1/2, 1/4, 1/8 of the mask-feature resolution) in ONE pass.
 // For an exact 2x / 4x / 8x reduction the taps of make_tap() are fixed: source index s * (dst + 0.5) - 0.5 = s * dst + s / 2 -
 // 0.5, i.e. rows / columns (2 d, 2 d + 1), (4 d + 1, 4 d + 2), (8 d + 3, 8 d + 4) with weights (0.5, 0.5) -- every output is the
@@ -128,6 +183,18 @@ int bilinear_pyramid3_f32(const float* in, float* out2, float* out4, float* out8
   const unsigned gx = (unsigned)(((long long)(H >> 3) * (W >> 3) + 255) / 256);
   hipLaunchKernelGGL(bilinear_pyramid3_f32_kernel, dim3(gx, gy), dim3(256), 0, st, in, out2, out4, out8, H, W, planes);
   return check_launch("bilinear_pyramid3_f32");
+}
+
+// returns UNIVS_ERR_NOT_IMPLEMENTED unless Win is even and the pointers are aligned (in: 8 bytes; addend, out: 16; affine: 4)
+int upsample2x_add_f32(const float* in, const float* addend, const float* affine, float* out, long long planes, int Hin, int Win,
+                       hipStream_t st) {
+  if (Win % 2 != 0 || Win < 2 || Hin < 1 || (reinterpret_cast<uintptr_t>(in) & 7) || (reinterpret_cast<uintptr_t>(addend) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || (long long)Hin * Win >= (1LL << 28))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
+  const unsigned gx = (unsigned)(((long long)(2 * Hin) * (Win / 2) + 255) / 256);
+  hipLaunchKernelGGL(upsample2x_add_kernel, dim3(gx, gy), dim3(256), 0, st, in, addend, affine, out, Hin, Win, planes);
+  return check_launch("upsample2x_add_f32");
 }
 
 int bilinear_resample_f32(const float* in, const float* addend, float* out, long long planes, int Hin, int Win,

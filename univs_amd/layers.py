@@ -55,6 +55,15 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
         self.activation = activation
 
+    def convolve(self, x):
+        """the convolution alone (no norm, no activation): for callers that fuse the norm into their next step"""
+        y = None
+        if (SWITCHES.split_conv and x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.dilation == (1, 1) and self.groups == 1):
+            from . import ops
+            y = ops.conv1x1(x, self.weight, self.bias)
+        return y if y is not None else F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
     def forward(self, x):
         y = None
         if (SWITCHES.split_conv and x.is_cuda and self.bias is None and self.kernel_size == (3, 3) and self.stride == (1, 1)

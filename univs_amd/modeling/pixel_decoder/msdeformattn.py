@@ -368,8 +368,21 @@ class MSDeformAttnPixelDecoder(nn.Module):
             out = [z.transpose(1, 2).reshape(bs, -1, spatial_shapes[i][0], spatial_shapes[i][1]) for i, z in enumerate(y)]
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             x = features[f].float()
-            cur_fpn = self.lateral_convs[idx](x)
-            y_ = ops.bilinear_resample(out[-1], cur_fpn.shape[-2:], addend=cur_fpn)
+            lat = self.lateral_convs[idx]
+            y_ = None
+            if (x.is_cuda and isinstance(lat.norm, nn.GroupNorm) and lat.activation is None and not torch.is_grad_enabled()
+                    and x.shape[-2] == 2 * out[-1].shape[-2] and x.shape[-1] == 2 * out[-1].shape[-1]):
+                # lateral 1 x 1 convolution, GroupNorm statistics, then `GroupNorm(lateral) + upsample(coarser)` in one pass that
+                # normalises the convolution output while reading it (csrc/resample.hip: upsample2x_add_kernel)
+                raw = lat.convolve(x)
+                y_ = ops.upsample2x_add(out[-1], raw, ops.group_norm_affine(raw, lat.norm.num_groups, lat.norm.weight, lat.norm.bias,
+                                                                          lat.norm.eps))
+                if y_ is None:
+                    cur_fpn = ops.group_norm(raw, lat.norm.num_groups, lat.norm.weight, lat.norm.bias, lat.norm.eps)
+                    y_ = ops.bilinear_resample(out[-1], cur_fpn.shape[-2:], addend=cur_fpn)
+            if y_ is None:
+                cur_fpn = lat(x)
+                y_ = ops.bilinear_resample(out[-1], cur_fpn.shape[-2:], addend=cur_fpn)
             out.append(self.output_convs[idx](y_))
         multi_scale_features = out[:self.maskformer_num_feature_levels]
         return self.mask_features(out[-1]), out[-1], out[0], multi_scale_features

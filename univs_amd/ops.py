@@ -616,6 +616,52 @@ def bilinear_resample(x, size, addend=None):
     return out
 
 
+def group_norm_affine(x, num_groups, weight, bias, eps=1e-5):
+    """GroupNorm statistics of contiguous float32 NCHW `x` on the GPU as per-plane (scale, bias) pairs [N * C, 2] with
+    F.group_norm(x) == x * scale + bias (include/univs_hip.h: univs_group_norm_affine_f32) -- for `upsample2x_add`, which applies
+    them while it reads x."""
+    x = x.contiguous()
+    _inference_only("group_norm_affine", x, weight, bias)
+    _require_gpu("group_norm_affine", x, weight, bias)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise RuntimeError("group_norm_affine: float32 [N, C, ...] only")
+    N, C = x.shape[:2]
+    if C % int(num_groups) != 0 or tuple(weight.shape) != (C,) or tuple(bias.shape) != (C,):
+        raise RuntimeError("group_norm_affine: bad channel / group / parameter shapes")
+    HW = x.numel() // max(N * C, 1)
+    affine = torch.empty((N * C, 2), dtype=torch.float32, device=x.device)
+    ws = torch.empty(N * C * 2 * max(1, (HW + 8191) // 8192), dtype=torch.float32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_group_norm_affine_f32(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), N, C, HW,
+                                                    int(num_groups), float(eps), _ptr(ws), ws.numel(), _ptr(affine), _stream_ptr(x))
+    _lib.check(rc, "group_norm_affine")
+    return affine
+
+
+def upsample2x_add(x, addend, affine=None):
+    """addend + F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) for float32 [..., H, W] / [..., 2 H, 2 W] on
+    the GPU: the FPN top-down step (msdeformattn.py:350-351), bit-identical to `bilinear_resample(x, size, addend)`; with `affine`
+    [planes, 2] (`group_norm_affine` of the addend) the addend is normalised on the way in.  None when the shape is not covered
+    (odd W, a size that is not exactly twice the input's)."""
+    if (not x.is_cuda or x.dtype != torch.float32 or addend.dtype != torch.float32 or x.dim() < 2 or needs_grad(x, addend)
+            or tuple(addend.shape[:-2]) != tuple(x.shape[:-2]) or addend.shape[-2] != 2 * x.shape[-2]
+            or addend.shape[-1] != 2 * x.shape[-1] or x.shape[-1] % 2 != 0):
+        return None
+    x, addend = x.contiguous(), addend.contiguous()
+    Hin, Win = x.shape[-2:]
+    planes = x.numel() // max(Hin * Win, 1)
+    if affine is not None and (affine.dtype != torch.float32 or tuple(affine.shape) != (planes, 2) or not affine.is_contiguous()):
+        raise RuntimeError("upsample2x_add: affine must be contiguous float32 [planes, 2]")
+    out = torch.empty_like(addend)
+    with _on(x):
+        rc = _lib.load().univs_upsample2x_add_f32(_ptr(x), _ptr(addend), _ptr(affine) if affine is not None else None, _ptr(out),
+                                                 planes, Hin, Win, _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "upsample2x_add")
+    return out
+
+
 def conv3x3(x, weight):
     """F.conv2d(x, weight, None, stride=1, padding=1) for a 3 x 3 kernel, float32 NCHW on the GPU, through the three-product fp16
     streamed GEMM with tap addressing on weights split once per tensor (the FPN output convolution, msdeformattn.py:227-232).  Returns None when the
