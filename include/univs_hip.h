@@ -195,6 +195,10 @@ int univs_linear_blocked_f32(const float* x, const float* weight, const float* b
  * Covered: R % 4 == 0, C % 4 == 0, B <= 65535, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller
  * keeps its own permuted copy). */
 int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, void* stream);
+/* the same with `in_batch_stride` floats (a multiple of 4, >= R * C; 0 = dense) between consecutive input matrices: a row range
+ * x[:, r0:r0 + R, :] of a wider [B, S, C] tensor without a copy of its own -- the per-level split of the pixel decoder's encoder output
+ * (mask2former/modeling/pixel_decoder/msdeformattn.py:336-344: `torch.split(y, ...)`, `z.transpose(1, 2).view(bs, -1, H_l, W_l)`). */
+int univs_transpose_strided_f32(const float* x, long long B, int R, int C, long long in_batch_stride, float* out, void* stream);
 
 /* Shorthand for UnivsConfig.mask_decode_impl (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel

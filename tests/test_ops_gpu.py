@@ -1131,6 +1131,12 @@ def test_transpose_last2_is_exact(cuda, shape):
     x = synth.normal(f"tr/{shape}", shape).to(cuda)
     got = ops.transpose_last2(x)
     assert got.is_contiguous() and torch.equal(got, x.transpose(-2, -1).contiguous())
+    if x.dim() == 3 and x.shape[1] >= 12:
+        # row ranges of the batch tensor (the per-level split of the pixel decoder's encoder output): read in place, no copy first
+        for r0, r1 in ((0, 8), (4, x.shape[1]), (x.shape[1] - 4, x.shape[1])):
+            z = x[:, r0:r1]
+            assert not z.is_contiguous() or x.shape[0] == 1
+            assert torch.equal(ops.transpose_last2(z), z.transpose(-2, -1).contiguous())
 
 
 @pytest.mark.parametrize("T,Cin,Cout,H,W", [(2, 256, 256, 48, 44), (1, 128, 128, 70, 64), (3, 256, 256, 17, 83), (1, 384, 256, 64, 64)], ids=str)

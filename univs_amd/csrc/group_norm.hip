@@ -87,13 +87,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const v4f* p4 = reinterpret_cast<const v4f*>(p);
     v4f* q4 = reinterpret_cast<v4f*>(q);
     for (long long i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-      v4f y = p4[i] * scale + bias;
+      v4f y = __builtin_elementwise_fma(p4[i], (v4f){scale, scale, scale, scale}, (v4f){bias, bias, bias, bias});
       if (relu) y = __builtin_elementwise_max(y, (v4f){0.f, 0.f, 0.f, 0.f});
       q4[i] = y;
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-      const float y = p[i] * scale + bias;
+      const float y = fmaf(p[i], scale, bias);
       q[i] = relu ? fmaxf(y, 0.f) : y;
     }
   }

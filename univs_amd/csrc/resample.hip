@@ -33,6 +33,14 @@ __device__ __forceinline__ Tap make_tap(float scale, int dst, int in_size) {
   return t;
 }
 
+// l0y (l0x a + l1x b) + l1y (l0x c + l1x d) with the roundings spelled out (three products, three fused multiply-adds): left to the
+// compiler's contraction the two kernels below rounded the same expression differently
+__device__ __forceinline__ float bilerp(const Tap& ty, const Tap& tx, float a, float b, float c, float d) {
+  const float top = fmaf(tx.l1, b, tx.l0 * a);
+  const float bot = fmaf(tx.l1, d, tx.l0 * c);
+  return fmaf(ty.l1, bot, ty.l0 * top);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ addend,
@@ -60,8 +68,7 @@ __global__ __launch_bounds__(256) void bilinear_resample_f32_kernel(const float*
     }
     float o[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v)
-      o[v] = ty.l0 * (tx[v].l0 * a[v] + tx[v].l1 * b[v]) + ty.l1 * (tx[v].l0 * c[v] + tx[v].l1 * d[v]);
+    for (int v = 0; v < VEC; ++v) o[v] = bilerp(ty, tx[v], a[v], b[v], c[v], d[v]);
     const long long off = (p * Hout + oy) * (long long)Wout + ox;
     if (addend) {   // FPN top-down path: lateral + upsampled coarser level in one pass
 #pragma unroll
@@ -119,14 +126,14 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __rest
     for (int v = 0; v < 4; ++v) {
       const float a = pick(e0, m0.x, m0.y, f0, tx[v].i0), b = pick(e0, m0.x, m0.y, f0, tx[v].i0 + tx[v].di);
       const float c = pick(e1, m1.x, m1.y, f1, tx[v].i0), d = pick(e1, m1.x, m1.y, f1, tx[v].i0 + tx[v].di);
-      o[v] = ty.l0 * (tx[v].l0 * a + tx[v].l1 * b) + ty.l1 * (tx[v].l0 * c + tx[v].l1 * d);
+      o[v] = bilerp(ty, tx[v], a, b, c, d);
     }
     const long long off = (p * Hout + oy) * (long long)Wout + ox;
     typedef float v4f_ __attribute__((ext_vector_type(4)));
     v4f_ ad = *reinterpret_cast<const v4f_*>(addend + off);
     if (affine) {
       const float scale = affine[2 * p], bias = affine[2 * p + 1];
-      ad = ad * scale + bias;
+      ad = __builtin_elementwise_fma(ad, (v4f_){scale, scale, scale, scale}, (v4f_){bias, bias, bias, bias});   // as gn_apply_kernel
     }
     if (active) *reinterpret_cast<v4f_*>(out + off) = (v4f_){ad.x + o[0], ad.y + o[1], ad.z + o[2], ad.w + o[3]};
   }

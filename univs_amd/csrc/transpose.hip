@@ -11,16 +11,18 @@ namespace univs {
 
 constexpr int TR_TILE = 64;
 
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+// in_bstride: floats between consecutive matrices of the input (R * C when dense; larger: row ranges of a wider batch tensor)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
+                                                            long long in_bstride) {
   __shared__ float tile[TR_TILE][TR_TILE + 1];
-  const long long base = (long long)blockIdx.z * R * C;
+  const long long base = (long long)blockIdx.z * R * C, ibase = (long long)blockIdx.z * in_bstride;
   const int r0 = blockIdx.y * TR_TILE, c0 = blockIdx.x * TR_TILE;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 4 floats each along the fast axis
 #pragma unroll
   for (int p = 0; p < TR_TILE; p += 16) {
     const int r = r0 + p + ty, c = c0 + 4 * tx;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + base + (long long)r * C + c);   // C % 4 == 0 (host-checked)
+    if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + ibase + (long long)r * C + c);   // C % 4 == 0 (host-checked)
     tile[p + ty][4 * tx + 0] = v.x;
     tile[p + ty][4 * tx + 1] = v.y;
     tile[p + ty][4 * tx + 2] = v.z;
@@ -94,13 +96,14 @@ int decoder_memory_f32(const float* x, const float* level_embed, const float* yx
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when R or C is not a multiple of 4 / the pointers are not 16-byte aligned
-int transpose_f32(const float* in, float* out, long long B, int R, int C, hipStream_t st) {
+int transpose_f32(const float* in, float* out, long long B, int R, int C, long long in_bstride, hipStream_t st) {
   if (B <= 0 || R <= 0 || C <= 0) return UNIVS_OK;
-  if (R % 4 != 0 || C % 4 != 0 || B > 65535 || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+  if (in_bstride == 0) in_bstride = (long long)R * C;
+  if (R % 4 != 0 || C % 4 != 0 || B > 65535 || in_bstride % 4 != 0 || in_bstride < (long long)R * C || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
     return UNIVS_ERR_NOT_IMPLEMENTED;
   dim3 grid((unsigned)((C + TR_TILE - 1) / TR_TILE), (unsigned)((R + TR_TILE - 1) / TR_TILE), (unsigned)B);
   if (grid.y > 65535) return UNIVS_ERR_NOT_IMPLEMENTED;
-  hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, st, in, out, R, C);
+  hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, st, in, out, R, C, in_bstride);
   return check_launch("transpose_f32");
 }
 

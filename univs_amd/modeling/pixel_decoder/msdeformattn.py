@@ -363,7 +363,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         # tokens [T, S_l, C] -> NCHW, contiguous: an LDS tile transpose per level on the GPU (a strided view would be copied
         # by ATen's generic kernel at the first consumer: 110 us for the 1/8 level instead of 22)
         if y[0].is_cuda:
-            out = [ops.transpose_last2(z.contiguous()).view(bs, -1, spatial_shapes[i][0], spatial_shapes[i][1]) for i, z in enumerate(y)]
+            out = [ops.transpose_last2(z).view(bs, -1, spatial_shapes[i][0], spatial_shapes[i][1]) for i, z in enumerate(y)]   # (a row range: no copy)
         else:
             out = [z.transpose(1, 2).reshape(bs, -1, spatial_shapes[i][0], spatial_shapes[i][1]) for i, z in enumerate(y)]
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):

@@ -762,15 +762,23 @@ def decoder_memory(x, level_embed, pos_yx, pos_t):
 def transpose_last2(x):
     """Contiguous copy of `x.transpose(-2, -1)` for a float32 tensor on the GPU (LDS tile transpose at HBM rate instead of
     ATen's strided copy): tokens [B, H*W, C] <-> channel-major [B, C, H*W] at the edges of the Swin backbone
-    (swin.py:331-336, :676-683).  Any leading dimensions; falls back to ATen for shapes the kernel does not cover."""
-    if (not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2 or not x.is_contiguous()
-            or (torch.is_grad_enabled() and x.requires_grad)):
+    (swin.py:331-336, :676-683).  Any leading dimensions; a 3-D input may be a row range x[:, r0:r1, :] of a wider contiguous
+    tensor (the per-level split of the encoder output): only its batch stride is then not dense, and no copy is made first.
+    Falls back to ATen for shapes the kernel does not cover."""
+    if (not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2 or (torch.is_grad_enabled() and x.requires_grad)):
         return x.transpose(-2, -1).contiguous()
     R, C = x.shape[-2], x.shape[-1]
+    bstride = 0
+    if not x.is_contiguous():
+        if (x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == C and x.stride(0) >= R * C and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0):
+            bstride = x.stride(0)
+        else:
+            x = x.contiguous()
     B = x.numel() // max(R * C, 1)
     out = torch.empty(x.shape[:-2] + (C, R), dtype=torch.float32, device=x.device)
     with _on(x):
-        rc = _lib.load().univs_transpose_f32(_ptr(x), B, R, C, _ptr(out), _stream_ptr(x))
+        rc = _lib.load().univs_transpose_strided_f32(_ptr(x), B, R, C, bstride, _ptr(out), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return x.transpose(-2, -1).contiguous()
     _lib.check(rc, "transpose_last2")
