@@ -240,6 +240,16 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
                                int C, int hw, uint8_t* attn_mask, uint32_t* row_any_ws,
                                void* stream);
 
+/* The same contraction with the all-masked-row rule DEFERRED to the consumer (no flag memset, no second pass over the mask): row r of
+ * attn_mask is to be read as "every key visible" wherever row_flags[r] != generation.  `generation`: any non-zero value the caller has
+ * not used on this row_flags buffer before (a counter); row_flags [T * Q] keeps older generations' values and needs no initialisation
+ * beyond not containing the first generation used.  univs_cross_attention_flagged_f32 consumes (attn_mask, row_flags, generation);
+ * univs_attn_mask_rows_reset turns attn_mask into the tensor univs_mask_decode_attn_f32 would have written. */
+int univs_mask_decode_attn_deferred_f32(const float* mask_embed, const float* feat_lowres, int T, int Q, int C, int hw, uint8_t* attn_mask,
+                                        uint32_t* row_flags, uint32_t generation, void* stream);
+int univs_attn_mask_rows_reset(uint8_t* attn_mask, const uint32_t* row_flags, uint32_t generation, long long rows, long long hw,
+                               void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pre-split weights for the three-product fp16 GEMM kernels whose W streams through LDS (gemm_f16x3_stream.hip): wide-K
  * Linears (K >= 768) and the 3 x 3 convolution.  The split of W -- row maxima, power-of-two row scales, two fp16 parts in
@@ -351,6 +361,11 @@ int univs_decoder_memory_f32(const float* x, const float* level_embed, const flo
 long long univs_cross_attention_workspace(int L, int S, int N, int H);
 int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
                               int ldq, int ldk, int ldv, float scale, float* workspace, float* out, void* stream);
+/* with the deferred all-masked-row rule of univs_mask_decode_attn_deferred_f32: mask row (n, l) counts only where
+ * mask_row_flags[n * L + l] == mask_generation (mask_row_flags NULL: every row counts, = univs_cross_attention_f32) */
+int univs_cross_attention_flagged_f32(const float* q, const float* k, const float* v, const uint8_t* mask, const uint32_t* mask_row_flags,
+                                      uint32_t mask_generation, int L, int S, int N, int H, int head_dim, int ldq, int ldk, int ldv,
+                                      float scale, float* workspace, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Swin window attention core.

@@ -34,7 +34,8 @@ def mask_decode(mask_embed, mask_features):
     return torch.einsum("tqc,tchw->qthw", mask_embed, mask_features).contiguous()
 
 
-def mask_decode_attn(mask_embed, feat_lowres):
+def mask_decode_attn(mask_embed, feat_lowres, deferred=False):
+    # (`deferred`: the HIP operator may hand the all-masked-row rule to its consumer; the stand-in always applies it here)
     logits = torch.einsum("tqc,tchw->tqhw", mask_embed, feat_lowres).flatten(2)
     m = logits.sigmoid() < 0.5
     m[torch.where(m.sum(-1) == m.shape[-1])] = False

@@ -456,7 +456,7 @@ def test_upsample2x_add_with_group_norm(cuda, shape):
     ref2 = F.group_norm(add.double(), 32, g_.double(), b_.double(), 1e-5) + F.interpolate(x.double(), size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
     ref2_32 = F.group_norm(add, 32, g_, b_, 1e-5) + F.interpolate(x, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
     err, err32 = (y2.cpu().double() - ref2).abs().max().item(), (ref2_32.double() - ref2).abs().max().item()
-    assert err < max(4.0 * err32, 4e-6), (err, err32)
+    assert err < max(4.0 * err32, 2e-5), (err, err32)          # (GroupNorm's own bound: test_group_norm_matches_torch)
     assert ops.upsample2x_add(xd, ad[..., :-1]) is None and ops.upsample2x_add(xd[..., :-1], ad[..., :-2]) is None   # not 2x / odd width
 
 
@@ -975,6 +975,39 @@ def test_patch_merge_norm(cuda, B, H, W, C):
     assert err < max(2.0 * err32, 2e-6), (err, err32)
     assert torch.equal(y, ops.layer_norm(cat.contiguous(), gd, bd, 1e-5))
     assert ops.patch_merge_norm(torch.zeros(1, 4, 4, 6, device=cuda), torch.ones(24, device=cuda), torch.zeros(24, device=cuda)) is None
+
+
+@pytest.mark.parametrize("T,Q,h,w", [(5, 100, 46, 80), (2, 130, 23, 40), (3, 17, 92, 160)], ids=lambda v: str(v))
+def test_deferred_attention_mask(cuda, T, Q, h, w):
+    """mask_decode_attn(deferred=True): the contraction without the flag memset and the row-reset pass; `materialize()` == the eager
+    mask bit for bit; cross_attention on the DeferredMask == cross_attention on the eager mask bit for bit -- with rows whose
+    every key is masked (the ...decoder_univs.py:390 rule: such a row attends to all keys), on a flags buffer that is reused by
+    consecutive calls (stale generations must not leak)."""
+    C, H = 256, 8
+    feat = synth.normal(f"dm/f/{T}x{h}x{w}", (T, C, h, w))
+    feat[:, 0] = feat[:, 0].abs() + 1.0                          # a strictly positive channel
+    feat = feat.to(cuda)
+    S = h * w
+    k = synth.normal(f"dm/k/{T}x{S}", (S, T, 256)).to(cuda)
+    v = synth.normal(f"dm/v/{T}x{S}", (S, T, 256)).to(cuda)
+    q = synth.normal(f"dm/q/{T}x{Q}", (Q, T, 256)).to(cuda)
+    for rnd in range(3):
+        me = synth.normal(f"dm/me/{T}x{Q}/{rnd}", (T, Q, C))
+        # rows that end up fully masked: logits negative everywhere (different rows every round)
+        for r in range(rnd, Q, 7):
+            me[:, r] = 0.0
+            me[:, r, 0] = -100.0
+        med = me.to(cuda)
+        eager = ops.mask_decode_attn(med, feat)
+        dm = ops.mask_decode_attn(med, feat, deferred=True)
+        assert isinstance(dm, ops.DeferredMask) and tuple(dm.shape) == (T, Q, S)
+        raw_full = (dm.mask.view(T * Q, S) != 0).all(dim=1)
+        assert int(raw_full.sum()) >= T * len(range(rnd, Q, 7)) and not eager.view(T * Q, S)[raw_full].any()
+        if S >= 512:
+            a = ops.cross_attention(q, k, v, dm, H, 32 ** -0.5)
+            b = ops.cross_attention(q, k, v, eager, H, 32 ** -0.5)
+            assert a is not None and torch.equal(a, b)
+        assert torch.equal(dm.materialize(), eager)
 
 
 def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):

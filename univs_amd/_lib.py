@@ -55,6 +55,9 @@ SIGNATURES = {
     "univs_patch_embed4_f32": (_I, [_P, _P, _P, _P, _P, _c.c_float, _I, _I, _I, _I, _P, _P]),
     "univs_decoder_memory_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "univs_cross_attention_workspace": (_c.c_longlong, [_I, _I, _I, _I]),
+    "univs_cross_attention_flagged_f32": (_I, [_P, _P, _P, _P, _P, _c.c_uint32, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_float, _P, _P, _P]),
+    "univs_mask_decode_attn_deferred_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _c.c_uint32, _P]),
+    "univs_attn_mask_rows_reset": (_I, [_P, _P, _c.c_uint32, _c.c_longlong, _c.c_longlong, _P]),
     "univs_cross_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_float, _P, _P, _P]),
     "univs_mlp_presplit_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _c.c_float, _P, _c.c_longlong, _P,
                                     _c.c_longlong, _I, _I, _I, _P, _P]),

@@ -42,8 +42,9 @@ int linear_split_f32(const float*, const float*, const float*, const float*, flo
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
 int mask_decode_last_impl();
-int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*,
+int mask_decode_attn_f32(const float*, const float*, int, int, int, long long, uint8_t*, unsigned*, unsigned,
                          hipStream_t);
+int attn_mask_rows_reset(uint8_t*, const unsigned*, unsigned, long long, long long, hipStream_t);
 
 int msda_backward_f32(const float*, const LevelTable&, const float*, const float*, const float*, int, int, int, int,
                       int, int, int, float*, float*, float*, hipStream_t);
@@ -64,8 +65,8 @@ int window_attention_image_f32(const float*, const float*, const float*, const f
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
 int decoder_memory_f32(const float*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
 int patch_embed4_f32(const float*, const float*, const float*, const float*, const float*, float, float*, int, int, int, int, hipStream_t);
-int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, int, int, int, int, int, int, int, int, float,
-                        float*, float*, hipStream_t);
+int cross_attention_f32(const float*, const float*, const float*, const unsigned char*, const unsigned*, unsigned, int, int, int, int, int,
+                        int, int, int, float, float*, float*, hipStream_t);
 size_t cross_attention_workspace_floats(int, int, int, int);
 int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
                   const float*, const float*, float, const float*, const float*, float, const float*, long long, float*, float*, long long,
@@ -231,18 +232,24 @@ long long univs_cross_attention_workspace(int L, int S, int N, int H) {
 
 int univs_cross_attention_f32(const float* q, const float* k, const float* v, const uint8_t* mask, int L, int S, int N, int H, int head_dim,
                               int ldq, int ldk, int ldv, float scale, float* workspace, float* out, void* stream) {
+  return univs_cross_attention_flagged_f32(q, k, v, mask, nullptr, 0u, L, S, N, H, head_dim, ldq, ldk, ldv, scale, workspace, out, stream);
+}
+
+int univs_cross_attention_flagged_f32(const float* q, const float* k, const float* v, const uint8_t* mask, const uint32_t* mask_row_flags,
+                                      uint32_t mask_generation, int L, int S, int N, int H, int head_dim, int ldq, int ldk, int ldv,
+                                      float scale, float* workspace, float* out, void* stream) {
   clear_sticky_error();
   if (L < 0 || S < 1 || N < 0 || H < 1 || head_dim < 1) {
     set_error("univs_cross_attention_f32: bad dimensions L=%d S=%d N=%d H=%d head_dim=%d", L, S, N, H, head_dim);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (L == 0 || N == 0) return UNIVS_OK;
-  if (!q || !k || !v || !workspace || !out) {
-    set_error("univs_cross_attention_f32: NULL data pointer");
+  if (!q || !k || !v || !workspace || !out || (mask_row_flags && !mask)) {
+    set_error("univs_cross_attention_f32: NULL data pointer (row flags come with a mask)");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::cross_attention_f32(q, k, v, mask, L, S, N, H, head_dim, ldq, ldk, ldv, scale, workspace, out,
-                                            static_cast<hipStream_t>(stream));
+  const int rc = univs::cross_attention_f32(q, k, v, mask, mask_row_flags, mask_generation, L, S, N, H, head_dim, ldq, ldk, ldv, scale,
+                                            workspace, out, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_cross_attention_f32: L=%d S=%d N=%d H=%d head_dim=%d not covered (head_dim == 32, S >= 32, with a mask S %% 4 == 0, "
               "N * H <= 65535, 16-byte aligned pointers)", L, S, N, H, head_dim);
@@ -485,8 +492,38 @@ int univs_mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres
     set_error("univs_mask_decode_attn_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  return mask_decode_attn_f32(mask_embed, feat_lowres, T, Q, C, hw, attn_mask, row_any_ws,
+  return mask_decode_attn_f32(mask_embed, feat_lowres, T, Q, C, hw, attn_mask, row_any_ws, 0u,
                               (hipStream_t)stream);
+}
+
+int univs_mask_decode_attn_deferred_f32(const float* mask_embed, const float* feat_lowres, int T, int Q, int C, int hw, uint8_t* attn_mask,
+                                        uint32_t* row_flags, uint32_t generation, void* stream) {
+  if (T < 0 || Q < 0 || C <= 0 || hw < 0 || generation == 0) {
+    set_error("univs_mask_decode_attn_deferred_f32: bad arguments T=%d Q=%d C=%d hw=%d generation=%u (non-zero)", T, Q, C, hw, generation);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)T * Q * hw == 0) return UNIVS_OK;
+  clear_sticky_error();
+  if (!mask_embed || !feat_lowres || !attn_mask || !row_flags) {
+    set_error("univs_mask_decode_attn_deferred_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return mask_decode_attn_f32(mask_embed, feat_lowres, T, Q, C, hw, attn_mask, row_flags, generation, (hipStream_t)stream);
+}
+
+int univs_attn_mask_rows_reset(uint8_t* attn_mask, const uint32_t* row_flags, uint32_t generation, long long rows, long long hw,
+                               void* stream) {
+  clear_sticky_error();
+  if (rows < 0 || hw < 0 || rows > 0x7fffffffLL) {
+    set_error("univs_attn_mask_rows_reset: bad dimensions rows=%lld hw=%lld", rows, hw);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (rows * hw == 0) return UNIVS_OK;
+  if (!attn_mask || !row_flags) {
+    set_error("univs_attn_mask_rows_reset: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return attn_mask_rows_reset(attn_mask, row_flags, generation, rows, hw, (hipStream_t)stream);
 }
 
 int univs_window_attention_f32(const float* qkv, const float* bias, const float* shift_mask,

@@ -43,6 +43,8 @@ struct XaArgs {
   const float* k;            // [S, N, H * 32]
   const float* v;            // [S, N, H * 32]
   const unsigned char* mask; // [N, L, S] (non-zero = masked out) or null
+  const unsigned* flags;     // [N, Lfull] or null: row (n, l) of the mask counts only where flags == gen; elsewhere every key is visible
+  unsigned gen;              //   (the all-masked-row rule of ...decoder_univs.py:390, deferred: mask_decode.hip)
   float* ws;                 // [N * H][nseg][16 NQB][34]: O[32], m, l
   float* out;                // [L, N, H * 32]
   int L, S, N, H, nseg;      // L: queries of this launch (<= 128)
@@ -164,6 +166,10 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   // the mask dword of (query 16 qb + j, keys 16 kb + 4 g ..) per query block; loaded one iteration ahead
   float4 kn[2][2], vn[4];
   unsigned mwn[NQB][2];
+  bool mrow[NQB];                                                // my query's mask row counts (see XaArgs.flags)
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb)
+    mrow[qb] = a.mask != nullptr && (a.flags == nullptr || a.flags[(long long)n * a.Lfull + min(a.l0 + 16 * qb + j, a.Lfull - 1)] == a.gen);
   auto load_iter = [&](int it) __attribute__((always_inline)) {
     const int s0 = it << 5;
 #pragma unroll
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         mwn[qb][kb] = 0u;
-        if (a.mask) {
+        if (mrow[qb]) {
           // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
           const int qi = min(a.l0 + 16 * qb + j, a.Lfull - 1);
           const int sbc = min(s0 + 16 * kb + 4 * g, S - 4);
@@ -416,8 +422,9 @@ size_t cross_attention_workspace_floats(int L, int S, int N, int H) {
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.  Queries beyond 128 are handled in chunks.
-int cross_attention_f32(const float* q, const float* k, const float* v, const unsigned char* mask, int L, int S, int N, int H, int hd,
-                        int ldq, int ldk, int ldv, float scale, float* ws, float* out, hipStream_t st) {
+int cross_attention_f32(const float* q, const float* k, const float* v, const unsigned char* mask, const unsigned* row_flags,
+                        unsigned generation, int L, int S, int N, int H, int hd, int ldq, int ldk, int ldv, float scale, float* ws,
+                        float* out, hipStream_t st) {
   if (L <= 0 || N <= 0 || H <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (hd != 32 || S < 32 || (mask && (S % 4 != 0 || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
@@ -434,6 +441,8 @@ int cross_attention_f32(const float* q, const float* k, const float* v, const un
     a.q = q + (long long)l0 * N * ldq;
     a.k = k; a.v = v;
     a.mask = mask;
+    a.flags = mask ? row_flags : nullptr;
+    a.gen = generation;
     a.ws = ws; a.out = out + (long long)l0 * N * E;
     a.L = Lc; a.S = S; a.N = N; a.H = H; a.nseg = nseg;
     a.Lfull = L; a.l0 = l0;

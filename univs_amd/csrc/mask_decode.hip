@@ -53,18 +53,19 @@ struct StoreLogits {
 // "has a visible key" flag used by the all-masked-row reset.
 struct StoreAttnMask {
   uint8_t* mask;       // [T, Q, N]
-  unsigned* row_any;   // [T, Q]  (zeroed before the launch)
+  unsigned* row_any;   // [T, Q]: `gen` is stored for a row with a visible key (the eager form zeroes the flags first and uses 1)
   int Q;
+  unsigned gen;
   __device__ __forceinline__ void operator()(int t, int q, long long n, long long N, float v) const {
     const bool masked = v < 0.f;
     mask[((long long)t * Q + q) * N + n] = masked ? 1 : 0;
-    if (!masked) row_any[t * Q + q] = 1u;  // benign race: every writer stores the same value
+    if (!masked) row_any[t * Q + q] = gen;  // benign race: every writer stores the same value
   }
   __device__ __forceinline__ void store4(int t, int q, long long n, long long N, f32x4 v) const {
     const unsigned m = (v.x < 0.f ? 1u : 0u) | (v.y < 0.f ? 0x100u : 0u) | (v.z < 0.f ? 0x10000u : 0u) |
                        (v.w < 0.f ? 0x1000000u : 0u);
     *reinterpret_cast<unsigned*>(mask + ((long long)t * Q + q) * N + n) = m;
-    if (m != 0x01010101u) row_any[t * Q + q] = 1u;
+    if (m != 0x01010101u) row_any[t * Q + q] = gen;
   }
 };
 
@@ -418,6 +419,7 @@ struct Store2AttnMask {
   unsigned* row_any;
   int Q;
   unsigned mask_bytes, flag_bytes;
+  unsigned gen;
   struct Res { __amdgpu_buffer_rsrc_t m, f; };
   __device__ __forceinline__ Res resources() const {
     return {__builtin_amdgcn_make_buffer_rsrc(mask, 0, (int)mask_bytes, 0x00020000),
@@ -427,7 +429,7 @@ struct Store2AttnMask {
     const unsigned short m = (unsigned short)((a < 0.f ? 1u : 0u) | (b < 0.f ? 0x100u : 0u));
     const unsigned row = (unsigned)t * (unsigned)Q + (unsigned)q;
     __builtin_amdgcn_raw_buffer_store_b16((short)m, r.m, valid ? row * (unsigned)N + (unsigned)n : 0xFFFFFFF0u, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(1u, r.f, (valid && real && m != 0x0101u) ? row * 4u : 0xFFFFFFF0u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(gen, r.f, (valid && real && m != 0x0101u) ? row * 4u : 0xFFFFFFF0u, 0, 0);
   }
 };
 
@@ -788,10 +790,10 @@ static int launch_skinny(const float* A, const float* B, int T, int Q, int K, lo
 
 // rows with no visible key -> all keys visible (":390": attn_mask[all-True rows] = False)
 __global__ __launch_bounds__(256) void attn_mask_row_reset(uint8_t* __restrict__ mask,
-                                                            const unsigned* __restrict__ row_any,
+                                                            const unsigned* __restrict__ row_any, unsigned gen,
                                                             long long N) {
   const long long row = blockIdx.x;
-  if (row_any[row] != 0u) return;
+  if (row_any[row] == gen) return;
   uint8_t* m = mask + row * N;
   for (long long i = threadIdx.x; i < N; i += blockDim.x) m[i] = 0;
 }
@@ -809,29 +811,41 @@ int mask_decode_f32(const float* mask_embed, const float* mask_features, int T, 
                        "mask_decode_f32");
 }
 
+// generation == 0: the eager form -- flags zeroed, the contraction, the reset of the rows that stayed fully masked: attn_mask is the
+// reference's tensor.  generation != 0 (the DEFERRED form): the contraction alone; row r of attn_mask is to be read as all-visible
+// by the consumer wherever row_flags[r] != generation (univs_cross_attention_f32 takes the flags), or made explicit later by
+// attn_mask_rows_reset.  The flags keep whatever older generations left in them: no memset, no second pass over the mask.
 int mask_decode_attn_f32(const float* mask_embed, const float* feat_lowres, int T, int Q, int C,
-                         long long hw, uint8_t* attn_mask, unsigned* row_any_ws, hipStream_t st) {
+                         long long hw, uint8_t* attn_mask, unsigned* row_any_ws, unsigned generation, hipStream_t st) {
   if (T == 0 || Q == 0 || hw == 0) return UNIVS_OK;
-  hipError_t e = hipMemsetAsync(row_any_ws, 0, sizeof(unsigned) * (size_t)T * Q, st);
-  if (e != hipSuccess) {
-    set_error("mask_decode_attn_f32: memset failed: %s", hipGetErrorString(e));
-    return UNIVS_ERR_LAUNCH;
+  const unsigned gen = generation ? generation : 1u;
+  if (generation == 0) {
+    hipError_t e = hipMemsetAsync(row_any_ws, 0, sizeof(unsigned) * (size_t)T * Q, st);
+    if (e != hipSuccess) {
+      set_error("mask_decode_attn_f32: memset failed: %s", hipGetErrorString(e));
+      return UNIVS_ERR_LAUNCH;
+    }
   }
   int rc;
   g_maskdec_last = 1;
   if (bf16x6_eligible(mask_embed, feat_lowres, attn_mask, T, Q, C, hw, 4) && (g_maskdec_last = 2))
     rc = maskdec_ct(C, (long long)T * Q * hw) == 2
              ? launch_bf16x6<2>(mask_embed, feat_lowres, T, Q, C, hw,
-                                Store2AttnMask{attn_mask, row_any_ws, Q, (unsigned)((long long)T * Q * hw), (unsigned)((long long)T * Q * 4)},
+                                Store2AttnMask{attn_mask, row_any_ws, Q, (unsigned)((long long)T * Q * hw), (unsigned)((long long)T * Q * 4), gen},
                                 st, "mask_decode_attn_bf16x6_n32")
-             : launch_bf16x6<4>(mask_embed, feat_lowres, T, Q, C, hw, StoreAttnMask{attn_mask, row_any_ws, Q}, st,
+             : launch_bf16x6<4>(mask_embed, feat_lowres, T, Q, C, hw, StoreAttnMask{attn_mask, row_any_ws, Q, gen}, st,
                                 "mask_decode_attn_bf16x6");
   else
-    rc = launch_skinny(mask_embed, feat_lowres, T, Q, C, hw, StoreAttnMask{attn_mask, row_any_ws, Q},
+    rc = launch_skinny(mask_embed, feat_lowres, T, Q, C, hw, StoreAttnMask{attn_mask, row_any_ws, Q, gen},
                        st, "mask_decode_attn_f32");
-  if (rc != UNIVS_OK) return rc;
-  hipLaunchKernelGGL(attn_mask_row_reset, dim3((unsigned)(T * Q)), dim3(256), 0, st, attn_mask,
-                     row_any_ws, hw);
+  if (rc != UNIVS_OK || generation != 0) return rc;
+  hipLaunchKernelGGL(attn_mask_row_reset, dim3((unsigned)(T * Q)), dim3(256), 0, st, attn_mask, row_any_ws, gen, hw);
+  return check_launch("attn_mask_row_reset");
+}
+
+int attn_mask_rows_reset(uint8_t* attn_mask, const unsigned* row_flags, unsigned generation, long long rows, long long hw, hipStream_t st) {
+  if (rows <= 0 || hw <= 0) return UNIVS_OK;
+  hipLaunchKernelGGL(attn_mask_row_reset, dim3((unsigned)rows), dim3(256), 0, st, attn_mask, row_flags, generation, hw);
   return check_launch("attn_mask_row_reset");
 }
 

@@ -164,6 +164,8 @@ class MultiheadAttention(nn.Module):
             out = ops.cross_attention(q, k, v, attn_mask, h, 1.0 / math.sqrt(d))
             if out is not None:
                 return self.out_proj(out), None
+        if attn_mask is not None and not isinstance(attn_mask, torch.Tensor):
+            attn_mask = attn_mask.materialize()                  # ops.DeferredMask: the paths below read the reference's tensor
         # [L, N, h, d] -> [N, h, L, d]
         q = q.reshape(L, N, h, d).permute(1, 2, 0, 3)
         k = k.reshape(S, N, h, d).permute(1, 2, 0, 3)

@@ -27,6 +27,7 @@ from torch import nn
 from ... import ops
 from ...layers import Conv2d, fp32_region
 from ...registry import TRANSFORMER_DECODER_REGISTRY, configurable
+from ...switches import SWITCHES
 from ..position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
 from ..prompt_encoder import VisualPromptSampler
 from .transformer_layers import MLP, CrossAttentionLayer, FFNLayer, SelfAttentionLayer
@@ -301,7 +302,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         def heads(out_tokens, target_size, last):
             cls_, msk_, attn_, reid_ = self.forward_prediction_heads(
                 out_tokens, mf, feat_lowres[target_size], task, targets, t, need_masks=(last or want_full),
-                t_total=t_total, need_class=(last or want_full))
+                t_total=t_total, need_class=(last or want_full), deferred_mask=SWITCHES.fused_cross_attention and not last)
             predictions_class.append(cls_)
             predictions_mask.append(msk_)
             predictions_embds.append(out_tokens.view(out_tokens.shape[0], bs, t, -1).permute(1, 0, 2, 3))
@@ -401,7 +402,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         return c
 
     def forward_prediction_heads(self, output, mask_features, feat_lowres, task, targets, t, need_masks,
-                                 t_total=None, need_class=True):
+                                 t_total=None, need_class=True, deferred_mask=False):
         """:498-567.  output [Q', T, C] (batch 1); mask_features [T, C, H, W]; feat_lowres [T, C, h, w].
         Returns (class logits [1,Q',K], mask logits [1,Q',T,H,W] or None, attn mask bool [T,Q',hw], reid)."""
         bs = 1
@@ -447,7 +448,9 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         outputs_mask = None
         if need_masks:
             outputs_mask = ops.mask_decode(mask_embed, mask_features).unsqueeze(0)  # [1, Q', T, H, W]
-        attn_mask = ops.mask_decode_attn(mask_embed, feat_lowres)                   # [T, Q', hw] bool
+        # [T, Q', hw] bool; `deferred_mask` (the layer loop): an ops.DeferredMask -- the fully-masked-row rule is applied by the
+        # cross-attention kernel that reads the mask, not by a pass of its own
+        attn_mask = ops.mask_decode_attn(mask_embed, feat_lowres, deferred=deferred_mask)
         return outputs_class, outputs_mask, attn_mask, outputs_reid
 
     # ---------------------------------------------------------------------------------------------

@@ -523,10 +523,46 @@ def mask_decode(mask_embed, mask_features):
     return out
 
 
-def mask_decode_attn(mask_embed, feat_lowres):
+class DeferredMask:
+    """An attention mask [T, Q, hw] (uint8, 1 = key masked out) whose all-masked-row rule (...decoder_univs.py:390) has NOT been applied
+    to the bytes: row r counts only where flags[r] == gen, elsewhere every key is visible (include/univs_hip.h:
+    univs_mask_decode_attn_deferred_f32).  `cross_attention` consumes it as it is; `materialize()` gives the reference's bool tensor."""
+    __slots__ = ("mask", "flags", "gen", "_bool")
+    dtype = torch.bool
+
+    def __init__(self, mask, flags, gen):
+        self.mask, self.flags, self.gen, self._bool = mask, flags, gen, None
+
+    @property
+    def shape(self):
+        return self.mask.shape
+
+    @property
+    def is_cuda(self):
+        return True
+
+    def dim(self):
+        return self.mask.dim()
+
+    def materialize(self):
+        if self._bool is None:
+            T, Q, hw = self.mask.shape
+            with _on(self.mask):
+                _lib.check(_lib.load().univs_attn_mask_rows_reset(_ptr(self.mask), _ptr(self.flags), self.gen, T * Q, hw,
+                                                                  _stream_ptr(self.mask)), "attn_mask_rows_reset")
+            self._bool = self.mask.view(torch.bool)
+        return self._bool
+
+
+_MASK_FLAGS = {}          # (device, stream, rows) -> [flags int32 zero-initialised, last generation]
+
+
+def mask_decode_attn(mask_embed, feat_lowres, deferred=False):
     """Fused attention-mask generation: mask_embed [T,Q,C], feat_lowres [T,C,h,w] (mask features
     resampled to the next level's size) -> bool [T,Q,h*w], True = key masked out; rows that would be
-    fully masked come back all-False (...decoder_univs.py:555-566 + :390)."""
+    fully masked come back all-False (...decoder_univs.py:555-566 + :390).
+    `deferred=True`: a `DeferredMask` instead -- the contraction alone (no flag memset, no second pass over the mask); the rule for
+    fully masked rows is applied by the consumer (`cross_attention`) from per-row generation flags."""
     _inference_only("mask_decode_attn", mask_embed, feat_lowres)
     _require_gpu("mask_decode_attn", mask_embed, feat_lowres)
     if mask_embed.dtype != torch.float32 or feat_lowres.dtype != torch.float32:
@@ -536,6 +572,19 @@ def mask_decode_attn(mask_embed, feat_lowres):
     if T2 != T or C2 != C:
         raise RuntimeError("mask_decode_attn: shape mismatch")
     mask = torch.empty((T, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
+    if deferred and T * Q > 0 and not torch.cuda.is_current_stream_capturing():
+        key = (mask_embed.device, _raw_stream(mask_embed.device.index), T * Q)
+        e = _MASK_FLAGS.get(key)
+        if e is None or e[1] >= 0x7FFFFFF0:
+            if len(_MASK_FLAGS) > 64:
+                _MASK_FLAGS.clear()
+            e = _MASK_FLAGS[key] = [torch.zeros((T * Q,), dtype=torch.int32, device=mask_embed.device), 0]
+        e[1] += 1
+        with _on(mask_embed):
+            rc = _lib.load().univs_mask_decode_attn_deferred_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w, _ptr(mask),
+                                                                 _ptr(e[0]), e[1], _stream_ptr(mask_embed))
+        _lib.check(rc, "mask_decode_attn")
+        return DeferredMask(mask, e[0], e[1])
     ws = torch.empty((max(T * Q, 1),), dtype=torch.int32, device=mask_embed.device)
     with _on(mask_embed):
         rc = _lib.load().univs_mask_decode_attn_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w,
@@ -916,7 +965,8 @@ def cross_attention(q, k, v, mask, num_heads, scale):
     univs_cross_attention_f32; csrc/cross_attn.hip): the attention core of nn.MultiheadAttention as the decoder's
     CrossAttentionLayer uses it (transformer_layers.py:95-115) between the in- and out-projections.
     q [L, N, E], k / v [S, N, E] sequence-first float32 (E = num_heads * 32), dense or column slices of wider projections; mask
-    bool / uint8 [N, L, S] (True = masked out, shared by the heads) or None.  Returns [L, N, E], or None when not covered."""
+    bool / uint8 [N, L, S] (True = masked out, shared by the heads), a `DeferredMask` of that shape, or None.
+    Returns [L, N, E], or None when not covered."""
     _inference_only("cross_attention", q, k, v)
     if not (q.is_cuda and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32):
         return None
@@ -925,7 +975,12 @@ def cross_attention(q, k, v, mask, num_heads, scale):
     H = int(num_heads)
     if E != 32 * H or tuple(k.shape) != (S, N, E) or tuple(v.shape) != (S, N, E) or S < 32 or N * H > 65535 or L < 1:
         return None
-    if mask is not None:
+    flags, gen = None, 0
+    if isinstance(mask, DeferredMask):
+        if tuple(mask.shape) != (N, L, S) or S % 4 != 0:
+            return None
+        mask, flags, gen = mask.mask, mask.flags, mask.gen
+    elif mask is not None:
         if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8) or S % 4 != 0 or not mask.is_cuda:
             return None
         mask = mask.contiguous()
@@ -941,8 +996,9 @@ def cross_attention(q, k, v, mask, num_heads, scale):
     ws = torch.empty(int(lib.univs_cross_attention_workspace(L, S, N, H)), dtype=torch.float32, device=q.device)
     out = torch.empty((L, N, E), dtype=torch.float32, device=q.device)
     with _on(q):
-        rc = lib.univs_cross_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask) if mask is not None else None, L, S, N, H, 32,
-                                           ldq, ldk, ldv, float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
+        rc = lib.univs_cross_attention_flagged_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask) if mask is not None else None,
+                                                   _ptr(flags) if flags is not None else None, gen, L, S, N, H, 32,
+                                                   ldq, ldk, ldv, float(scale), _ptr(ws), _ptr(out), _stream_ptr(q))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "cross_attention")
