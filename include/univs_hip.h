@@ -305,6 +305,14 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
                            const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
                            long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream);
+/* the same with `residual_is_normed_x` (residual NULL, ln_weight given, y distinct from x): the residual is LN(x) itself -- the
+ * post-norm chain `x1 = norm1(x); y = norm2(x1 + ffn(x1))` of an MSDeformAttn encoder layer (msdeformattn.py:124-133) with x = src +
+ * output_proj(...) as the producing Linear's epilogue left it: norm1 costs no launch and no pass over memory of its own. */
+int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
+                              const float* b2, const float* residual, int residual_is_normed_x, const float* ln_weight,
+                              const float* ln_bias, float ln_eps, const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps,
+                              const float* post_add, long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y,
+                              void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -297,8 +297,8 @@ def _cfg4_run(cuda, attn_hook=None):
     orig = ops.mask_decode_attn
     calls = {"n": 0}
 
-    def hooked(e, f):
-        m = orig(e, f)
+    def hooked(e, f, deferred=False):
+        m = orig(e, f)                  # (the eager form: the masks are compared with / replaced by the reference's tensors)
         k = calls["n"]
         calls["n"] += 1
         return m if attn_hook is None else attn_hook(k, m)

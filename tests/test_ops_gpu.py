@@ -951,6 +951,25 @@ def test_mlp_fused_post_norm(cuda, N, S, C, Hd):
     assert torch.equal(y_only, y)
     with pytest.raises(RuntimeError):
         ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", post_add=pd)
+    # the whole tail of the encoder layer behind `src + output_proj(...)`: x1 = norm1(x), y = norm2(x1 + ffn(x1)) -- norm1 on the x tile
+    # in registers, its result also the residual (parked in y, read back for the epilogue); == the LayerNorm launch + the call above
+    g1 = (1.0 + 0.2 * synth.normal(f"mlppn/g1/{C}", (C,))).to(cuda)
+    b1n = (0.1 * synth.normal(f"mlppn/b1n/{C}", (C,))).to(cuda)
+    res2 = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", ln=(g1, b1n, 1e-5), residual_normed=True, post_ln=(gd, bd, 1e-5), post_add=pd)
+    assert res2 is not None and len(res2) == 2
+    x1 = ops.layer_norm(xd, g1, b1n, 1e-5)
+    sep = ops.mlp_fused(x1, w1d, b1d, w2d, b2d, "relu", residual=x1, post_ln=(gd, bd, 1e-5))
+    x1_64 = F.layer_norm(xd.double(), (C,), g1.double(), b1n.double(), 1e-5)
+    ref2 = F.layer_norm(x1_64 + F.linear(F.relu(F.linear(x1_64, w1d.double(), b1d.double())), w2d.double(), b2d.double()), (C,), gd.double(),
+                        bd.double(), 1e-5)
+    x1_32 = F.layer_norm(xd, (C,), g1, b1n, 1e-5)
+    ref2_32 = F.layer_norm(x1_32 + F.linear(F.relu(F.linear(x1_32, w1d, b1d)), w2d, b2d), (C,), gd, bd, 1e-5)
+    e2, e2_32, e2_sep = ((t.double() - ref2).abs().max().item() for t in (res2[0], ref2_32, sep))
+    print(f"mlp_fused norm1 + ffn + norm2 {N, S, C, Hd}: {e2:.2e} (ATen fp32 {e2_32:.2e}, LayerNorm launch + fused MLP {e2_sep:.2e})")
+    assert e2 < max(4.0 * e2_32, 5e-6), (e2, e2_32)
+    assert torch.equal(res2[1], res2[0] + pd) and torch.equal(xd.cpu(), x)
+    with pytest.raises(RuntimeError):
+        ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "relu", residual=xd, ln=(g1, b1n, 1e-5), residual_normed=True)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(5, 184, 320, 96), (2, 92, 160, 192), (2, 46, 80, 384), (1, 23, 41, 128), (3, 7, 9, 768), (1, 1, 1, 4)],

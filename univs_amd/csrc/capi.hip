@@ -70,7 +70,7 @@ int cross_attention_f32(const float*, const float*, const float*, const unsigned
 size_t cross_attention_workspace_floats(int, int, int, int);
 int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const void*, const float*, const float*, const float*,
                   const float*, const float*, float, const float*, const float*, float, const float*, long long, float*, float*, long long,
-                  int, int, int, hipStream_t);
+                  int, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -260,6 +260,15 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
                            const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
                            long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream) {
+  return univs_mlp_presplit_v2_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, 0, ln_weight, ln_bias, ln_eps, post_ln_weight, post_ln_bias,
+                                   post_ln_eps, post_add, post_add_rows, y2, M, C, Hd, act, y, stream);
+}
+
+int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
+                              const float* b2, const float* residual, int residual_is_normed_x, const float* ln_weight,
+                              const float* ln_bias, float ln_eps, const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps,
+                              const float* post_add, long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y,
+                              void* stream) {
   clear_sticky_error();
   if (M < 0 || C < 1 || Hd < 1 || (act != 1 && act != 2)) {
     set_error("univs_mlp_presplit_f32: bad arguments M=%lld C=%d Hd=%d act=%d (1 ReLU, 2 GELU)", M, C, Hd, act);
@@ -270,8 +279,14 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
     set_error("univs_mlp_presplit_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
+  if (residual_is_normed_x && (residual || !ln_weight || x == y)) {
+    set_error("univs_mlp_presplit_f32: residual_is_normed_x needs ln_weight, no residual pointer and y distinct from x (the normalised "
+              "rows are parked in y)");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
   const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, post_ln_weight, post_ln_bias,
-                                      post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, static_cast<hipStream_t>(stream));
+                                      post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, residual_is_normed_x,
+                                      static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256 / 384, Hd %% 32 == 0, "
               "M >= 2048)", M, C, Hd);

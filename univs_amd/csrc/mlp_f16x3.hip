@@ -55,6 +55,9 @@ struct MlpArgs {
   float pln_eps;
   int padd_rows;
   int M, Hd, nwg;
+  int res_normed;       // with ln_g, Res == null: the residual is LN(x) -- the post-norm chain x1 = norm1(.), y = norm2(x1 + mlp(x1)) of the
+                        // encoder layer (msdeformattn.py:124-133).  The normalised rows are parked in Y when the x tile is made and
+                        // read back for the epilogue (same wave, through L2) instead of living in 16 CT C / 64 more registers.
 };
 
 // sum over the four lanes (k-groups, lane >> 4) that hold one row.  (The two results are taken through a typed vector and
@@ -175,8 +178,10 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+  const bool res_normed = a.res_normed != 0;                      // uniform
+  const bool with_res = a.Res != nullptr || res_normed;
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(res_normed ? a.Y : a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.Y2 ? a.Y2 : a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.padd ? a.padd : a.X), 0, (int)((long long)(a.padd ? a.padd_rows : M) * C * 4), 0x00020000);
@@ -243,6 +248,9 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
             const f32x4 gm = *reinterpret_cast<const f32x4*>(lng_lds + 32 * ks + 8 * g + 4 * h2);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(lnb_lds + 32 * ks + 8 * g + 4 * h2);
             raw[ks][h2] = (raw[ks][h2] * rstd) * gm + bt;
+            if (res_normed)                                      // park the residual row (rows past the end: dropped)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, raw[ks][h2]), yrs,
+                                                     row0 + 16 * ct + j < M ? vo + (unsigned)(16 * h2) : 0xFFFFFFF0u, ks * 128, 0);
           }
       }
       unsigned mx = 0u;
@@ -449,7 +457,9 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          if (with_res)                                           // (parked rows: written by other lanes of this wave -> glc, from L2)
+            v += res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
+                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
         }
       } else {
@@ -463,7 +473,9 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (a.Res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          if (with_res)                                           // (parked rows: written by other lanes of this wave -> glc, from L2)
+            v += res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
+                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           acc2[ob][ct] = v;
           sm += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -555,12 +567,13 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
 int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
                   const float* b2, const float* residual, const float* ln_w, const float* ln_b, float ln_eps, const float* pln_w,
                   const float* pln_b, float pln_eps, const float* post_add, long long post_add_rows, float* y2, float* y, long long M,
-                  int C, int Hd, int act, hipStream_t st) {
+                  int C, int Hd, int act, int residual_is_normed_x, hipStream_t st) {
   if (M <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
       mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2) || (ln_b && !ln_w) ||
-      mis(post_add) || mis(y2) || (pln_b && !pln_w) || ((post_add || y2) && !pln_w) || (post_add && (!y2 || post_add_rows < 1 ||
+      mis(post_add) || mis(y2) || (pln_b && !pln_w) || ((post_add || y2) && !pln_w) || (residual_is_normed_x && (residual || !ln_w || x == y)) ||
+      (post_add && (!y2 || post_add_rows < 1 ||
       post_add_rows * (long long)C * 4 >= 0x7FFFFFFFLL)))
     return UNIVS_ERR_NOT_IMPLEMENTED;
   MlpArgs a{};
@@ -568,7 +581,7 @@ int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const flo
   a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = residual; a.Y = y;
   a.ln_g = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
   a.pln_g = pln_w; a.pln_b = pln_b; a.pln_eps = pln_eps; a.padd = post_add; a.padd_rows = (int)post_add_rows; a.Y2 = y2;
-  a.M = (int)M; a.Hd = Hd;
+  a.M = (int)M; a.Hd = Hd; a.res_normed = residual_is_normed_x ? 1 : 0;
   switch (C) {
     case 96: return ml_launch<3, 2, 4>(a, act, st);
     case 128: return ml_launch<4, 1, 8>(a, act, st);

@@ -85,11 +85,12 @@ class MSDeformAttn(nn.Module):
         return c[1], c[2]
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, ref_per_query=None):
+                input_level_start_index, input_padding_mask=None, ref_per_query=None, residual=None):
         """query [N,Lq,C]; reference_points [N|1,Lq,L,2]; input_flatten [N,S,C];
         input_spatial_shapes / input_level_start_index: python lists (or tensors).
         `ref_per_query` [N|1, Lq, 2] (optional): the caller's promise that every level shares one reference point per query
-        (the encoder's pixel centres, msdeformattn.py:143-158 with valid_ratio == 1) -- enables the head-major kernel."""
+        (the encoder's pixel centres, msdeformattn.py:143-158 with valid_ratio == 1) -- enables the head-major kernel.
+        `residual` [N, Lq, C] (optional): added to the result in `output_proj`'s epilogue (the layer's `src + self_attn(...)`)."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -104,7 +105,7 @@ class MSDeformAttn(nn.Module):
                 if qp_hm is not None:
                     output = ops.msda_forward_strips(value_hm, qp_hm, ref_per_query, shapes, input_level_start_index, M, P)
                     if output is not None:
-                        return linear(output, self.output_proj.weight, self.output_proj.bias)
+                        return self._project(output, residual)
         value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
@@ -133,7 +134,14 @@ class MSDeformAttn(nn.Module):
         output = ops.ms_deform_attn_forward(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights.contiguous(),
                                             self.im2col_step)
-        return linear(output, self.output_proj.weight, self.output_proj.bias)
+        return self._project(output, residual)
+
+    def _project(self, output, residual):
+        w, b = self.output_proj.weight, self.output_proj.bias
+        if residual is None:
+            return linear(output, w, b)
+        y = ops.linear_fused(output, w, b, residual=residual) if (SWITCHES.split_linear and output.is_cuda) else None
+        return y if y is not None else residual + linear(output, w, b)
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -153,11 +161,28 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         MSDeformAttn.forward."""
         if query is None:
             query = src if pos is None else src + pos
-        src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                              ref_per_query=ref_per_query)
-        src = layer_norm(self.norm1, src2, residual=src)
+        fused = SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu
+        if fused and not torch.is_grad_enabled() and src.dtype == torch.float32:
+            # `src + self_attn(...)` from output_proj's epilogue, then norm1 + linear1 + ReLU + linear2 + residual + norm2 (+ the next
+            # layer's `src + pos`) in ONE kernel: norm1 is evaluated on the x tile in registers and is also the FFN's residual
+            # (csrc/mlp_f16x3.hip: res_normed)
+            sum1 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                  ref_per_query=ref_per_query, residual=src)
+            n1, n2 = (self.norm1.weight, self.norm1.bias, self.norm1.eps), (self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            with_next = want_next_query and pos is not None
+            res = ops.mlp_fused(sum1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, "relu",
+                                ln=n1, residual_normed=True, post_ln=n2, post_add=pos if with_next else None)
+            if res is not None:
+                if with_next:
+                    return res
+                return (res, None) if want_next_query else res
+            src = layer_norm(self.norm1, sum1)
+        else:
+            src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                  ref_per_query=ref_per_query)
+            src = layer_norm(self.norm1, src2, residual=src)
         ffn = None
-        if SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu:
+        if fused:
             # linear1 + ReLU + linear2 + residual + norm2 (+ the next layer's `src + pos`) in ONE kernel: the [tokens, d_ffn]
             # activations stay in registers and the finished row is normalised before it is stored (csrc/mlp_f16x3.hip)
             n2 = (self.norm2.weight, self.norm2.bias, self.norm2.eps)
