@@ -611,7 +611,8 @@ def _xattn_reference(q, k, v, mask, H, scale):
 
 
 @pytest.mark.parametrize("L,S,N,H,masked", [(100, 920, 5, 8, True), (100, 14720, 2, 8, True), (20, 3680, 3, 8, True), (100, 3680, 5, 8, False),
-                                             (7, 1000, 1, 2, True), (130, 1504, 2, 4, True), (112, 516, 1, 8, True)], ids=lambda v: str(v))
+                                             (7, 1000, 1, 2, True), (130, 1504, 2, 4, True), (112, 516, 1, 8, True),
+                                             (500, 500, 1, 8, True), (2000, 2000, 1, 8, True), (300, 260, 2, 4, False)], ids=lambda v: str(v))
 def test_cross_attention_matches_torch(cuda, L, S, N, H, masked):
     """ops.cross_attention (csrc/cross_attn.hip: scores, mask, softmax and P V in one pass over the keys, three-product fp16
     arithmetic, per-segment partials merged by a second kernel) == nn.MultiheadAttention's core
@@ -692,6 +693,19 @@ def test_cross_attention_ranges_and_module_path(cuda):
         given = mha(tgt, None, None, attn_mask=msk, kv=(kk, vv))[0]
     assert (fused - plain).abs().max().item() < 2e-5
     assert torch.equal(given, fused)
+    # the decoder's spatio-temporal self-attention (...decoder_univs.py:408-414): one batch entry, Q' T tokens, a [L, S] mask,
+    # q and k from ONE projection of tgt + pos, v from tgt
+    Ls = 500
+    with torch.no_grad():
+        t1 = synth.normal("xa2/sa/tgt", (Ls, 1, E)).to(cuda)
+        qk = t1 + synth.normal("xa2/sa/pos", (Ls, 1, E)).to(cuda)
+        m2 = (torch.rand(Ls, Ls, generator=torch.Generator().manual_seed(6)) < 0.4).to(cuda)
+        m2[torch.arange(Ls), torch.arange(Ls)] = False
+        for mm in (m2, None):
+            sa_fused = mha(qk, qk, t1, attn_mask=mm)[0]
+            with override(fused_cross_attention=False):
+                sa_plain = mha(qk, qk, t1, attn_mask=mm)[0]
+            assert (sa_fused - sa_plain).abs().max().item() < 2e-5
     assert ops.cross_attention(torch.zeros(4, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda),
                                None, 2, 1.0) is None                                            # fewer than 32 keys
     assert ops.cross_attention(torch.zeros(4, 1, 64), torch.zeros(64, 1, 64), torch.zeros(64, 1, 64), None, 2, 1.0) is None   # CPU

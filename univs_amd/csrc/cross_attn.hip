@@ -47,8 +47,8 @@ struct XaArgs {
   unsigned gen;              //   (the all-masked-row rule of ...decoder_univs.py:390, deferred: mask_decode.hip)
   float* ws;                 // [N * H][nseg][16 NQB][34]: O[32], m, l
   float* out;                // [L, N, H * 32]
-  int L, S, N, H, nseg;      // L: queries of this launch (<= 128)
-  int Lfull, l0;             // rows of the mask per batch entry, and the first query of this launch among them
+  int L, S, N, H, nseg;      // L: queries; a workgroup (blockIdx.z = chunk) handles queries [128 chunk, 128 chunk + 128)
+  int Lfull, l0;             // rows of the mask per batch entry (= L), 0
   int ldq, ldk, ldv;         // floats between consecutive batch entries of q / k / v (>= H * 32: slices of wider projections)
   float qscale;              // scale * log2(e)
 };
@@ -97,12 +97,13 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   __shared__ __attribute__((aligned(16))) f16x8 qlds[2 * NQB * 64];      // [part][query block][lane]
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
-  const int seg = blockIdx.x, nh = blockIdx.y;
+  const int seg = blockIdx.x, nh = blockIdx.y, chunk = blockIdx.z;
   const int n = nh / a.H, h = nh - n * a.H;
-  const int L = a.L, S = a.S, N = a.N;
+  const int l0 = 128 * chunk;                                    // first query of this chunk
+  const int L = min(128, a.L - l0), S = a.S, N = a.N;            // queries of this chunk
   const int E = a.H * HD;
   const long long qrow = (long long)N * a.ldq, krow = (long long)N * a.ldk, vrow = (long long)N * a.ldv;   // floats between sequence positions
-  const float* qb_ = a.q + (long long)n * a.ldq + h * HD;
+  const float* qb_ = a.q + (long long)l0 * qrow + (long long)n * a.ldq + h * HD;
   const float* kb_ = a.k + (long long)n * a.ldk + h * HD;
   const float* vb_ = a.v + (long long)n * a.ldv + h * HD;
   (void)E;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   bool mrow[NQB];                                                // my query's mask row counts (see XaArgs.flags)
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb)
-    mrow[qb] = a.mask != nullptr && (a.flags == nullptr || a.flags[(long long)n * a.Lfull + min(a.l0 + 16 * qb + j, a.Lfull - 1)] == a.gen);
+    mrow[qb] = a.mask != nullptr && (a.flags == nullptr || a.flags[(long long)n * a.Lfull + min(l0 + 16 * qb + j, a.Lfull - 1)] == a.gen);
   auto load_iter = [&](int it) __attribute__((always_inline)) {
     const int s0 = it << 5;
 #pragma unroll
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
         mwn[qb][kb] = 0u;
         if (mrow[qb]) {
           // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
-          const int qi = min(a.l0 + 16 * qb + j, a.Lfull - 1);
+          const int qi = min(l0 + 16 * qb + j, a.Lfull - 1);
           const int sbc = min(s0 + 16 * kb + 4 * g, S - 4);
           mwn[qb][kb] = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * S + sbc);
         }
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
   }
 
   // ---- this segment's partial: O rows = queries 4 g + r, columns = channels 16 half + j; m and l from the lanes g == 0
-  float* wsb = a.ws + ((long long)nh * a.nseg + seg) * (16 * NQB) * XA_PART;
+  float* wsb = a.ws + (((long long)chunk * gridDim.y + nh) * a.nseg + seg) * (16 * NQB) * XA_PART;
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
     const float ltot = xa_col_sum(lsum[qb]);
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(256) void xattn_merge(const float* __restrict__ ws,
   const int q = (int)(t % L);
   const int nh = (int)(t / L);
   const int n = nh / H, h = nh - n * H;
-  const float* base = ws + ((long long)nh * nseg * Lp + q) * XA_PART;
+  const int chunk = q >> 7, ql = q & 127;                        // (one chunk: Lp = 16 * query blocks; several: Lp = 128)
+  const float* base = ws + ((((long long)chunk * N * H + nh) * nseg) * Lp + ql) * XA_PART;
   const long long pstride = (long long)Lp * XA_PART;
   float M = -INFINITY;
   for (int p = 0; p < nseg; ++p) M = fmaxf(M, base[p * pstride + 32]);
@@ -408,17 +410,18 @@ static int xa_cus() {
   return n_cu;
 }
 
-// segments per (batch entry, head): one round of the 8 waves per CU the kernel's registers allow, each wave with at least three
-// 32-key iterations (the Q fragments cost about one)
-int cross_attention_segments(int S, int N, int H) {
-  const int nit = (S + 31) / 32;
-  const long long want = std::max<long long>(1, (8LL * xa_cus()) / ((long long)N * H));
+// segments per (batch entry, head, chunk of 128 queries): one round of the 8 waves per CU the kernel's registers allow, each wave
+// with at least three 32-key iterations (the Q fragments cost about one)
+static int xa_segments(int L, int S, int N, int H) {
+  const int nit = (S + 31) / 32, nchunks = (L + 127) / 128;
+  const long long want = std::max<long long>(1, (8LL * xa_cus()) / ((long long)N * H * nchunks));
   return (int)std::max<long long>(1, std::min<long long>(want, nit / 3 > 0 ? nit / 3 : 1));
 }
+int cross_attention_segments(int S, int N, int H) { return xa_segments(1, S, N, H); }
 
 size_t cross_attention_workspace_floats(int L, int S, int N, int H) {
-  const int nqb = (std::min(L, 128) + 15) / 16;
-  return (size_t)N * H * cross_attention_segments(S, N, H) * (16 * nqb) * XA_PART;
+  const int nqb = (std::min(L, 128) + 15) / 16, nchunks = (L + 127) / 128;
+  return (size_t)nchunks * N * H * xa_segments(L, S, N, H) * (16 * nqb) * XA_PART;
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.  Queries beyond 128 are handled in chunks.
@@ -430,43 +433,39 @@ int cross_attention_f32(const float* q, const float* k, const float* v, const un
   if (hd != 32 || S < 32 || (mask && (S % 4 != 0 || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
       mis(ws) || (long long)N * H > 65535)
     return UNIVS_ERR_NOT_IMPLEMENTED;
-  const int nseg = cross_attention_segments(S, N, H);
+  const int nseg = xa_segments(L, S, N, H);
   const int E = H * 32;
   ldq = ldq > 0 ? ldq : E; ldk = ldk > 0 ? ldk : E; ldv = ldv > 0 ? ldv : E;
   if (ldq < E || ldk < E || ldv < E || ldq % 4 || ldk % 4 || ldv % 4) return UNIVS_ERR_NOT_IMPLEMENTED;
-  for (int l0 = 0; l0 < L; l0 += 128) {
-    const int Lc = std::min(128, L - l0);
-    const int nqb = (Lc + 15) / 16;
-    XaArgs a{};
-    a.q = q + (long long)l0 * N * ldq;
-    a.k = k; a.v = v;
-    a.mask = mask;
-    a.flags = mask ? row_flags : nullptr;
-    a.gen = generation;
-    a.ws = ws; a.out = out + (long long)l0 * N * E;
-    a.L = Lc; a.S = S; a.N = N; a.H = H; a.nseg = nseg;
-    a.Lfull = L; a.l0 = l0;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-    a.qscale = scale * 1.4426950408889634f;
-    dim3 grid((unsigned)nseg, (unsigned)(N * H));
-    switch (nqb) {
-      case 1: hipLaunchKernelGGL(xattn_partial<1>, grid, dim3(64), 0, st, a); break;
-      case 2: hipLaunchKernelGGL(xattn_partial<2>, grid, dim3(64), 0, st, a); break;
-      case 3: hipLaunchKernelGGL(xattn_partial<3>, grid, dim3(64), 0, st, a); break;
-      case 4: hipLaunchKernelGGL(xattn_partial<4>, grid, dim3(64), 0, st, a); break;
-      case 5: hipLaunchKernelGGL(xattn_partial<5>, grid, dim3(64), 0, st, a); break;
-      case 6: hipLaunchKernelGGL(xattn_partial<6>, grid, dim3(64), 0, st, a); break;
-      case 7: hipLaunchKernelGGL(xattn_partial<7>, grid, dim3(64), 0, st, a); break;
-      default: hipLaunchKernelGGL(xattn_partial<8>, grid, dim3(64), 0, st, a); break;
-    }
-    int rc = check_launch("xattn_partial");
-    if (rc != UNIVS_OK) return rc;
-    const long long total = (long long)N * H * Lc * 32;
-    hipLaunchKernelGGL(xattn_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, a.out, Lc, 16 * nqb, N, H, nseg);
-    rc = check_launch("xattn_merge");
-    if (rc != UNIVS_OK) return rc;
+  const int nchunks = (L + 127) / 128;                           // a workgroup handles up to 128 queries
+  const int nqb = (std::min(L, 128) + 15) / 16;
+  if (nchunks > 65535) return UNIVS_ERR_NOT_IMPLEMENTED;
+  XaArgs a{};
+  a.q = q; a.k = k; a.v = v;
+  a.mask = mask;
+  a.flags = mask ? row_flags : nullptr;
+  a.gen = generation;
+  a.ws = ws; a.out = out;
+  a.L = L; a.S = S; a.N = N; a.H = H; a.nseg = nseg;
+  a.Lfull = L; a.l0 = 0;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.qscale = scale * 1.4426950408889634f;
+  dim3 grid((unsigned)nseg, (unsigned)(N * H), (unsigned)nchunks);
+  switch (nqb) {
+    case 1: hipLaunchKernelGGL(xattn_partial<1>, grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(xattn_partial<2>, grid, dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(xattn_partial<3>, grid, dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(xattn_partial<4>, grid, dim3(64), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(xattn_partial<5>, grid, dim3(64), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(xattn_partial<6>, grid, dim3(64), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(xattn_partial<7>, grid, dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(xattn_partial<8>, grid, dim3(64), 0, st, a); break;
   }
-  return UNIVS_OK;
+  int rc = check_launch("xattn_partial");
+  if (rc != UNIVS_OK) return rc;
+  const long long total = (long long)N * H * L * 32;
+  hipLaunchKernelGGL(xattn_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, out, L, 16 * nqb, N, H, nseg);
+  return check_launch("xattn_merge");
 }
 
 }  // namespace univs

@@ -155,13 +155,15 @@ class MultiheadAttention(nn.Module):
                 else:
                     k = lin(key, w[E:2 * E], b[E:2 * E])
                     v = lin(value, w[2 * E:], b[2 * E:])
-        if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 512 and L <= 512
-                and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8) and attn_mask.dim() == 3
-                                           and attn_mask.shape[0] == N))):
-            # long key sequences against few queries (the decoder's masked cross-attention over the H_l W_l pixels of a
-            # level): scores, mask, softmax and P V in one pass over the keys, the [N h, L, S] scores never exist
+        if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 256 and L <= 2048
+                and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8)
+                                           and ((attn_mask.dim() == 3 and attn_mask.shape[0] == N) or (attn_mask.dim() == 2 and N == 1))))):
+            # scores, mask, softmax and P V in one pass over the keys, the [N h, L, S] scores never exist: the decoder's masked
+            # cross-attention over the H_l W_l pixels of a level, and its spatio-temporal self-attention over the Q' T query tokens
+            # (one batch entry, a [L, S] mask)
             from . import ops
-            out = ops.cross_attention(q, k, v, attn_mask, h, 1.0 / math.sqrt(d))
+            m3 = attn_mask.view(1, L, S) if (attn_mask is not None and attn_mask.dim() == 2) else attn_mask
+            out = ops.cross_attention(q, k, v, m3, h, 1.0 / math.sqrt(d))
             if out is not None:
                 return self.out_proj(out), None
         if attn_mask is not None and not isinstance(attn_mask, torch.Tensor):

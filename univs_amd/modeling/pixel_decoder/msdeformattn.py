@@ -162,7 +162,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         if query is None:
             query = src if pos is None else src + pos
         fused = SWITCHES.fused_mlp and SWITCHES.split_linear and src.is_cuda and self.activation is F.relu
-        if fused and not torch.is_grad_enabled() and src.dtype == torch.float32:
+        if fused and SWITCHES.fused_norm1 and not torch.is_grad_enabled() and src.dtype == torch.float32:
             # `src + self_attn(...)` from output_proj's epilogue, then norm1 + linear1 + ReLU + linear2 + residual + norm2 (+ the next
             # layer's `src + pos`) in ONE kernel: norm1 is evaluated on the x tile in registers and is also the FFN's residual
             # (csrc/mlp_f16x3.hip: res_normed)

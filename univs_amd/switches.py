@@ -38,6 +38,9 @@ class Switches:
     # 4-wave workgroups) but measured 321 us against 257 us for the two fused Linears at Swin stage 3 (18 400 rows: 288 row groups
     # on 256 CUs, one wave per SIMD) -- profiles/r04_kbench_mlp_v2.txt
     fused_mlp_max_c: int = 256
+    # encoder layer: norm1 evaluated inside the fused FFN kernel (on the x tile; its result is also the FFN's residual) instead of a
+    # LayerNorm launch of its own
+    fused_norm1: bool = True
     # decoder cross-attention core (scores, mask, softmax, P V) as one pass over the keys (csrc/cross_attn.hip); False: two
     # library GEMMs around the masked-softmax kernel
     fused_cross_attention: bool = True
@@ -59,7 +62,7 @@ SWITCHES = Switches(
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
-    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True))
+    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
