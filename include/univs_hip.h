@@ -199,6 +199,13 @@ int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, v
  * x[:, r0:r0 + R, :] of a wider [B, S, C] tensor without a copy of its own -- the per-level split of the pixel decoder's encoder output
  * (mask2former/modeling/pixel_decoder/msdeformattn.py:336-344: `torch.split(y, ...)`, `z.transpose(1, 2).view(bs, -1, H_l, W_l)`). */
 int univs_transpose_strided_f32(const float* x, long long B, int R, int C, long long in_batch_stride, float* out, void* stream);
+/* the full form.  out_batch_stride (0 = dense): out may be a row range of a wider [B, S, R] tensor -- the levels of the pixel decoder's
+ * encoder input written straight into `src_flatten` (msdeformattn.py:168-188: `torch.cat(src_flatten, 1)`).  row_affine [B * R][2] | NULL:
+ * input row (b, r) is read as x * scale + bias -- `input_proj`'s GroupNorm (univs_group_norm_affine_f32 on the raw convolution output)
+ * applied on the way through (:205-212).  addend [C][R] + out2 | NULL: a second output out2 = out + addend in out's layout -- the first
+ * encoder layer's `with_pos_embed(src, pos)` (:61-63) with addend = the level's rows of lvl_pos_embed_flatten. */
+int univs_transpose_ex_f32(const float* x, long long B, int R, int C, long long in_batch_stride, const float* row_affine, float* out,
+                           long long out_batch_stride, const float* addend, float* out2, void* stream);
 
 /* Shorthand for UnivsConfig.mask_decode_impl (univs_mask_decode_f32 / univs_mask_decode_attn_f32):
  * 0 = by size (default: large feature maps take the split-bf16 kernel), 1 = exact-f32 MFMA kernel

@@ -1043,6 +1043,30 @@ def test_deferred_attention_mask(cuda, T, Q, h, w):
         assert torch.equal(dm.materialize(), eager)
 
 
+def test_tokens_from_nchw(cuda):
+    """ops.tokens_from_nchw: the levels' NCHW maps -> the encoder input [T, S, C] in one launch per level, GroupNorm applied on the way
+    (== group_norm + transpose + concatenation bit for bit), `src + pos` as a second output (== the add bit for bit); levels without a
+    GroupNorm; shapes that are not covered (msdeformattn.py:168-188, :205-212, :61-63)."""
+    T, C = 3, 256
+    shapes = [(6, 10), (12, 20), (23, 40)]
+    xs = [synth.normal(f"tok/x/{h}x{w}", (T, C, h, w)).to(cuda) * 3.0 + 0.5 for h, w in shapes]
+    S = sum(h * w for h, w in shapes)
+    pos = synth.normal("tok/pos", (1, S, C)).to(cuda)
+    g_ = (1.0 + 0.2 * synth.normal("tok/g", (C,))).to(cuda)
+    b_ = (0.1 * synth.normal("tok/b", (C,))).to(cuda)
+    affs = [ops.group_norm_affine(x, 32, g_, b_, 1e-5) for x in xs]
+    out = ops.tokens_from_nchw(xs, affs, pos)
+    assert out is not None
+    src, q0 = out
+    ref = torch.cat([ops.transpose_last2(ops.group_norm(x, 32, g_, b_, 1e-5).flatten(2)) for x in xs], 1)
+    assert tuple(src.shape) == (T, S, C) and torch.equal(src, ref) and torch.equal(q0, ref + pos)
+    src2, none = ops.tokens_from_nchw(xs, [None, affs[1], None], None)
+    assert none is None
+    ref2 = torch.cat([ops.transpose_last2((x if i != 1 else ops.group_norm(x, 32, g_, b_, 1e-5)).flatten(2)) for i, x in enumerate(xs)], 1)
+    assert torch.equal(src2, ref2)
+    assert ops.tokens_from_nchw([xs[0][..., :9]], [None], None) is None          # H * W % 4 != 0
+
+
 def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):
     """Rows of x over 80 binades, zero rows, hidden rows whose magnitude jumps between chunks (the running scale of the hidden
     activations is lowered with an exact rescaling of the output accumulators), Inf / NaN confined to their row; shapes the

@@ -40,6 +40,7 @@ SIGNATURES = {
     "univs_msda_last_tiled_generation": (_I, []),
     "univs_transpose_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P]),
     "univs_transpose_strided_f32": (_I, [_P, _c.c_longlong, _I, _I, _c.c_longlong, _P, _P]),
+    "univs_transpose_ex_f32": (_I, [_P, _c.c_longlong, _I, _I, _c.c_longlong, _P, _P, _c.c_longlong, _P, _P, _P]),
     "univs_linear_fused_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_mask_decode_set_impl": (_I, [_I]),
     "univs_mask_decode_last_impl": (_I, []),

@@ -37,7 +37,7 @@ int msda_forward_generic_f64(const double*, const LevelTable&, const double*, co
 int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const float*, int, int, int, int, int, int,
                             int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
-int transpose_f32(const float*, float*, long long, int, int, long long, hipStream_t);
+int transpose_f32(const float*, float*, long long, int, int, long long, long long, const float*, const float*, float*, hipStream_t);
 int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0);
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
@@ -370,18 +370,27 @@ int univs_transpose_f32(const float* x, long long B, int R, int C, float* out, v
 }
 
 int univs_transpose_strided_f32(const float* x, long long B, int R, int C, long long in_batch_stride, float* out, void* stream) {
+  return univs_transpose_ex_f32(x, B, R, C, in_batch_stride, nullptr, out, 0, nullptr, nullptr, stream);
+}
+
+int univs_transpose_ex_f32(const float* x, long long B, int R, int C, long long in_batch_stride, const float* row_affine, float* out,
+                           long long out_batch_stride, const float* addend, float* out2, void* stream) {
   clear_sticky_error();
-  if (B < 0 || R < 0 || C < 0 || in_batch_stride < 0 || (in_batch_stride != 0 && in_batch_stride < (long long)R * C)) {
-    set_error("univs_transpose_f32: bad dimensions B=%lld R=%d C=%d in_batch_stride=%lld", B, R, C, in_batch_stride);
+  if (B < 0 || R < 0 || C < 0 || in_batch_stride < 0 || (in_batch_stride != 0 && in_batch_stride < (long long)R * C) ||
+      out_batch_stride < 0 || (out_batch_stride != 0 && out_batch_stride < (long long)R * C)) {
+    set_error("univs_transpose_f32: bad dimensions B=%lld R=%d C=%d in_batch_stride=%lld out_batch_stride=%lld", B, R, C, in_batch_stride,
+              out_batch_stride);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   if (B == 0 || R == 0 || C == 0) return UNIVS_OK;
-  if (!x || !out) {
-    set_error("univs_transpose_f32: NULL data pointer");
+  if (!x || !out || (addend != nullptr) != (out2 != nullptr)) {
+    set_error("univs_transpose_f32: NULL data pointer (addend and out2 come together)");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::transpose_f32(x, out, B, R, C, in_batch_stride, static_cast<hipStream_t>(stream));
-  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_transpose_f32: R=%d C=%d B=%lld not covered (R %% 4, C %% 4, stride %% 4, B <= 65535, 16-byte alignment)", R, C, B);
+  const int rc = univs::transpose_f32(x, out, B, R, C, in_batch_stride, out_batch_stride, row_affine, addend, out2,
+                                      static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_transpose_f32: R=%d C=%d B=%lld not covered (R %% 4, C %% 4, strides %% 4, B <= 65535, 16-byte alignment)", R, C, B);
   return rc;
 }
 

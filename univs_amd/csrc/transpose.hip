@@ -11,18 +11,29 @@ namespace univs {
 
 constexpr int TR_TILE = 64;
 
-// in_bstride: floats between consecutive matrices of the input (R * C when dense; larger: row ranges of a wider batch tensor)
+// in_bstride / out_bstride: floats between consecutive matrices of the input / output (R * C when dense; larger: row ranges of a
+// wider batch tensor).  row_affine [B * R][2] (optional): input row (b, r) is read as x * scale + bias -- the GroupNorm of an NCHW
+// tensor (group_norm.hip: gn_affine_kernel, the expression of gn_apply_kernel) applied on the way through.  addend [C][R] + out2
+// (optional, both or neither): a second output out2 = out + addend, same layout as out -- the encoder's `src + pos`.
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
-                                                            long long in_bstride) {
+                                                            long long in_bstride, long long out_bstride,
+                                                            const float* __restrict__ row_affine, const float* __restrict__ addend,
+                                                            float* __restrict__ out2) {
   __shared__ float tile[TR_TILE][TR_TILE + 1];
-  const long long base = (long long)blockIdx.z * R * C, ibase = (long long)blockIdx.z * in_bstride;
+  const long long base = (long long)blockIdx.z * out_bstride, ibase = (long long)blockIdx.z * in_bstride;
   const int r0 = blockIdx.y * TR_TILE, c0 = blockIdx.x * TR_TILE;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 4 floats each along the fast axis
 #pragma unroll
   for (int p = 0; p < TR_TILE; p += 16) {
     const int r = r0 + p + ty, c = c0 + 4 * tx;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + ibase + (long long)r * C + c);   // C % 4 == 0 (host-checked)
+    if (r < R && c < C) {
+      v = *reinterpret_cast<const float4*>(in + ibase + (long long)r * C + c);   // C % 4 == 0 (host-checked)
+      if (row_affine) {
+        const float sc = row_affine[((long long)blockIdx.z * R + r) * 2], bi = row_affine[((long long)blockIdx.z * R + r) * 2 + 1];
+        v = make_float4(fmaf(v.x, sc, bi), fmaf(v.y, sc, bi), fmaf(v.z, sc, bi), fmaf(v.w, sc, bi));
+      }
+    }
     tile[p + ty][4 * tx + 0] = v.x;
     tile[p + ty][4 * tx + 1] = v.y;
     tile[p + ty][4 * tx + 2] = v.z;
@@ -36,6 +47,10 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
       const float4 v = make_float4(tile[4 * tx + 0][p + ty], tile[4 * tx + 1][p + ty], tile[4 * tx + 2][p + ty],
                                    tile[4 * tx + 3][p + ty]);
       *reinterpret_cast<float4*>(out + base + (long long)c * R + r) = v;
+      if (addend) {
+        const float4 ad = *reinterpret_cast<const float4*>(addend + (long long)c * R + r);
+        *reinterpret_cast<float4*>(out2 + base + (long long)c * R + r) = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
+      }
     }
   }
 }
@@ -96,14 +111,18 @@ int decoder_memory_f32(const float* x, const float* level_embed, const float* yx
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when R or C is not a multiple of 4 / the pointers are not 16-byte aligned
-int transpose_f32(const float* in, float* out, long long B, int R, int C, long long in_bstride, hipStream_t st) {
+int transpose_f32(const float* in, float* out, long long B, int R, int C, long long in_bstride, long long out_bstride,
+                  const float* row_affine, const float* addend, float* out2, hipStream_t st) {
   if (B <= 0 || R <= 0 || C <= 0) return UNIVS_OK;
   if (in_bstride == 0) in_bstride = (long long)R * C;
-  if (R % 4 != 0 || C % 4 != 0 || B > 65535 || in_bstride % 4 != 0 || in_bstride < (long long)R * C || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+  if (out_bstride == 0) out_bstride = (long long)R * C;
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (R % 4 != 0 || C % 4 != 0 || B > 65535 || in_bstride % 4 != 0 || in_bstride < (long long)R * C || out_bstride % 4 != 0 ||
+      out_bstride < (long long)R * C || (addend != nullptr) != (out2 != nullptr) || mis(in) || mis(out) || mis(addend) || mis(out2))
     return UNIVS_ERR_NOT_IMPLEMENTED;
   dim3 grid((unsigned)((C + TR_TILE - 1) / TR_TILE), (unsigned)((R + TR_TILE - 1) / TR_TILE), (unsigned)B);
   if (grid.y > 65535) return UNIVS_ERR_NOT_IMPLEMENTED;
-  hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, st, in, out, R, C, in_bstride);
+  hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, st, in, out, R, C, in_bstride, out_bstride, row_affine, addend, out2);
   return check_launch("transpose_f32");
 }
 

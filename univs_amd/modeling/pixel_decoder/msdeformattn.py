@@ -223,8 +223,9 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         reference_points = torch.cat(refs, 1)
         return reference_points[:, :, None].expand(-1, -1, len(spatial_shapes), -1).contiguous()
 
-    def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None, ref_per_query=None):
-        output, query = src, None
+    def forward(self, src, spatial_shapes, level_start_index, reference_points, pos=None, ref_per_query=None, query=None):
+        """`query`: `src + pos` for the first layer when the caller already has it"""
+        output = src
         for i, layer in enumerate(self.layers):
             if i + 1 < self.num_layers:
                 output, query = layer(output, pos, reference_points, spatial_shapes, level_start_index, None, query=query,
@@ -246,21 +247,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         nn.init.normal_(self.level_embed)
         self._ref_cache = {}
 
-    def forward(self, srcs, pos_embeds):
+    def forward(self, srcs, pos_embeds, affines=None):
+        """`affines` (optional, GPU inference): srcs are the RAW input-projection convolutions and affines[l] the per-plane (scale, bias)
+        of their GroupNorm (ops.group_norm_affine) -- applied while the level is written into the encoder input."""
         spatial_shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         level_start_index, acc = [], 0
         for (h, w) in spatial_shapes:
             level_start_index.append(acc)
             acc += h * w
-        if srcs[0].is_cuda and not torch.is_grad_enabled():
-            # NCHW -> tokens per level by the LDS tile transpose, then one concatenation of contiguous pieces (a concatenation of
-            # transposed views runs at 0.6 TB/s: 175 us for the 99 MB of a 720p clip)
-            src_flatten = torch.cat([ops.transpose_last2(s.flatten(2).contiguous()) for s in srcs], 1)
-        else:
-            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         # position embedding + level embedding: a function of the shapes and of one parameter (cached with its version)
         le = self.level_embed
-        pkey = (tuple(spatial_shapes), tuple(int(p.shape[0]) for p in pos_embeds), str(src_flatten.device), le._version, le.data_ptr(),
+        pkey = (tuple(spatial_shapes), tuple(int(p.shape[0]) for p in pos_embeds), str(srcs[0].device), le._version, le.data_ptr(),
                 tuple(p.data_ptr() for p in pos_embeds))
         pc = self.__dict__.get("_lvl_pos_cache")
         if pc is not None and pc[0] == pkey and not torch.is_grad_enabled():
@@ -269,6 +266,23 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + le[lvl].view(1, 1, -1) for lvl, p in enumerate(pos_embeds)], 1)
             if not torch.is_grad_enabled():
                 self.__dict__["_lvl_pos_cache"] = (pkey, lvl_pos, list(pos_embeds))     # (the embeddings are kept alive with their addresses)
+        query0 = None
+        fast = None
+        if srcs[0].is_cuda and not torch.is_grad_enabled() and lvl_pos.shape[0] == 1:
+            # NCHW -> tokens per level by the LDS tile transpose, written straight into the concatenated tensor, GroupNorm applied on
+            # the way in, `src + pos` for the first layer as a second output: one launch per level (a concatenation of transposed views
+            # runs at 0.6 TB/s: 175 us for the 99 MB of a 720p clip)
+            fast = ops.tokens_from_nchw(srcs, affines if affines is not None else [None] * len(srcs), lvl_pos.contiguous())
+        if fast is not None:
+            src_flatten, query0 = fast
+        else:
+            if affines is not None:
+                srcs = [s if a is None else s * a[:, 0].view(s.shape[0], s.shape[1], 1, 1) + a[:, 1].view(s.shape[0], s.shape[1], 1, 1)
+                        for s, a in zip(srcs, affines)]
+            if srcs[0].is_cuda and not torch.is_grad_enabled():
+                src_flatten = torch.cat([ops.transpose_last2(s.flatten(2).contiguous()) for s in srcs], 1)
+            else:
+                src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         key = (tuple(spatial_shapes), str(src_flatten.device))
         ref = self._ref_cache.get(key)
         if ref is None:
@@ -278,7 +292,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             # get_reference_points expands ONE point per query over the levels (valid_ratio == 1): keep that point too
             ref = (r, r[:, :, 0].contiguous())
             self._ref_cache[key] = ref
-        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, ref[0], lvl_pos, ref_per_query=ref[1])
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, ref[0], lvl_pos, ref_per_query=ref[1], query=query0)
         return memory, spatial_shapes, level_start_index
 
 
@@ -376,12 +390,25 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return self.input_proj[idx](x)
 
     def _forward_features(self, features):
-        srcs, pos = [], []
+        srcs, pos, affines = [], [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f].float()
-            srcs.append(self._input_proj(idx, x))
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            if x.is_cuda and not torch.is_grad_enabled() and not ops.needs_grad(x, conv.weight):
+                # the convolution alone + its GroupNorm in affine form: the normalisation is applied where the level is written into
+                # the encoder input (ops.tokens_from_nchw), not by a pass of its own
+                raw = ops.conv1x1(x, conv.weight, conv.bias) if SWITCHES.split_conv else None
+                raw = conv(x) if raw is None else raw
+                srcs.append(raw)
+                affines.append(ops.group_norm_affine(raw, gn.num_groups, gn.weight, gn.bias, gn.eps))
+            else:
+                srcs.append(self._input_proj(idx, x))
+                affines.append(None)
             pos.append(self._pos(x))
-        y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
+        if all(a is None for a in affines):
+            y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
+        else:
+            y, spatial_shapes, level_start_index = self.transformer(srcs, pos, affines)
         bs = y.shape[0]
         sizes = [h * w for (h, w) in spatial_shapes]
         y = torch.split(y, sizes, dim=1)

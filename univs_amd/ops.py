@@ -838,6 +838,41 @@ def transpose_last2(x):
     return out
 
 
+def tokens_from_nchw(xs, affines, lvl_pos):
+    """The encoder input of the pixel decoder from the levels' NCHW maps in one launch per level (include/univs_hip.h:
+    univs_transpose_ex_f32): xs[l] [T, C, H_l, W_l] float32 on the GPU, affines[l] [T * C, 2] or None (`group_norm_affine` of xs[l]: the
+    GroupNorm of `input_proj` applied on the way through), lvl_pos [1, S, C] or None -> (src_flatten [T, S, C], src_flatten + lvl_pos or
+    None): `torch.cat([x.flatten(2).transpose(1, 2) ...], 1)` and the first layer's `with_pos_embed` (msdeformattn.py:168-188, :61-63)
+    without the concatenation and the add as passes of their own.  None when a level is not covered (HW or C not a multiple of 4)."""
+    T, C = xs[0].shape[:2]
+    hws = [int(x.shape[2]) * int(x.shape[3]) for x in xs]
+    S = sum(hws)
+    if any((not x.is_cuda) or x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[:2]) != (T, C) or hw % 4 != 0
+           for x, hw in zip(xs, hws)) or C % 4 != 0 or T > 65535 or needs_grad(*xs):
+        return None
+    if lvl_pos is not None and (tuple(lvl_pos.shape[-2:]) != (S, C) or lvl_pos.numel() != S * C or lvl_pos.dtype != torch.float32
+                                or not lvl_pos.is_contiguous()):
+        raise RuntimeError("tokens_from_nchw: lvl_pos must be contiguous float32 [1, S, C]")
+    src = torch.empty((T, S, C), dtype=torch.float32, device=xs[0].device)
+    q0 = torch.empty_like(src) if lvl_pos is not None else None
+    lib = _lib.load()
+    r0 = 0
+    with _on(src):
+        for x, aff, hw in zip(xs, affines, hws):
+            x = x.contiguous()
+            if aff is not None and (aff.dtype != torch.float32 or tuple(aff.shape) != (T * C, 2) or not aff.is_contiguous()):
+                raise RuntimeError("tokens_from_nchw: affine must be contiguous float32 [T * C, 2]")
+            off = r0 * C * 4
+            rc = lib.univs_transpose_ex_f32(_ptr(x), T, C, hw, 0, _ptr(aff) if aff is not None else None, _ptr(src) + off, S * C,
+                                            (_ptr(lvl_pos) + off) if lvl_pos is not None else None,
+                                            (_ptr(q0) + off) if q0 is not None else None, _stream_ptr(src))
+            if rc == _lib.ERR_NOT_IMPLEMENTED:
+                return None
+            _lib.check(rc, "tokens_from_nchw")
+            r0 += hw
+    return src, q0
+
+
 def patch_merge_norm(x, weight, bias, eps=1e-5):
     """Swin PatchMerging up to its Linear in one pass (include/univs_hip.h: univs_patch_merge_norm_f32): x [B, H, W, C] float32 on the GPU
     -> LayerNorm over the 4 C channels of the 2 x 2 patches [B, ceil(H/2) * ceil(W/2), 4 C], channel order and zero padding of odd sizes as
