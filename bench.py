@@ -492,7 +492,7 @@ def run(args):
         t_msda = OpTimer(ops, "ms_deform_attn_forward", after=ops.msda_last_tiled_generation)
         t_msdas = OpTimer(ops, "msda_forward_strips", keep_args=6)       # one clip = six encoder layers
         t_mdec = OpTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)
-        t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
+        t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f, deferred=False: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
         t_res = OpTimer(ops, "bilinear_resample",
                         key=lambda x, size, addend=None: ("fpn" if addend is not None else "maskfeat",) + tuple(int(v) for v in size))
         t_pyr = OpTimer(ops, "bilinear_pyramid3")          # the three mask-feature resamplings of the prediction heads in one pass
@@ -619,8 +619,8 @@ def run(args):
                 4.0 * T * C * (H * W + kk[1] * kk[2]) for kk in t_res.events if kk[0] == "maskfeat") + (
                 4.0 * T * C * (H * W + sum(kk[1] * kk[2] for kk in t_mattn.events)) if t_pyr.events else 0.0)
             res["roofline_mask_decode_family"] = {
-                "what": "10 prediction-head calls per clip (1 full-resolution decode + 9 attention masks at 3 resolutions incl. "
-                        "the row reset, + the resampling of the mask features to the 3 resolutions: one pass).  `frac` is on the bytes "
+                "what": "10 prediction-head calls per clip (1 full-resolution decode + 9 attention masks at 3 resolutions -- their "
+                        "all-masked-row rule is applied inside the cross-attention kernel, no pass of its own -- + the resampling of the mask features to the 3 resolutions: one pass).  `frac` is on the bytes "
                         "these kernels move; `unfused_accounting` is SURVEY.md 8d's (ten full-resolution contractions), which the path "
                         "beats by construction: the attention masks are contracted at 1/8 - 1/32 resolution on pre-resampled features",
                 "bound": "hbm", "bytes_per_clip": actual, "seconds_per_clip": fam_t, "achieved": actual / fam_t / 1e9,
@@ -629,7 +629,7 @@ def run(args):
                 "unfused_accounting": {"bytes_per_clip": unfused, "achieved": unfused / fam_t / 1e9, "frac": unfused / fam_t / HBM_PEAK},
                 "ms_per_clip": {k: v * 1e3 for k, v in fam.items()}, "attn_mask_per_level": per_level,
                 "event_pair_ms_per_clip": {k: v * 1e3 for k, v in fam_events.items()},
-                "timing": "HIP events around each operator call (an attention-mask call = flag memset + contraction + row reset), " + ovh_note,
+                "timing": "HIP events around each operator call (an attention-mask call = the contraction; the rule for fully masked rows is applied by the cross-attention kernel that reads the mask; the last head's: flag memset + contraction + row reset), " + ovh_note,
                 "actual_bytes_per_clip_estimate": actual}
 
             if "roofline" in res:
@@ -669,6 +669,8 @@ def run(args):
     except Exception as e:  # pragma: no cover
         import traceback
         res["roofline_error"] = "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]
+        for t_ in locals().get("timers", []):
+            t_.enabled = False
 
     if world == 1:
         # informational: a steady-state clip of the same video (second clip, 10 visual-prompt entities in the memory

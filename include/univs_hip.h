@@ -312,11 +312,16 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
                            const float* b2, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
                            const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps, const float* post_add,
                            long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y, void* stream);
-/* the same with `residual_is_normed_x` (residual NULL, ln_weight given, y distinct from x): the residual is LN(x) itself -- the
- * post-norm chain `x1 = norm1(x); y = norm2(x1 + ffn(x1))` of an MSDeformAttn encoder layer (msdeformattn.py:124-133) with x = src +
- * output_proj(...) as the producing Linear's epilogue left it: norm1 costs no launch and no pass over memory of its own. */
+/* the same with `flags`:
+ *   UNIVS_MLP_RESIDUAL_IS_NORMED_X (residual NULL, ln_weight given, y distinct from x): the residual is LN(x) itself -- the post-norm
+ *     chain `x1 = norm1(x); y = norm2(x1 + ffn(x1))` of an MSDeformAttn encoder layer (msdeformattn.py:124-133) with x = src +
+ *     output_proj(...) as the producing Linear's epilogue left it: norm1 costs no launch and no pass over memory of its own;
+ *   UNIVS_MLP_DUAL_OUTPUT (post_ln_weight and y2 given, no post_add): y receives the finished rows UN-normalised and y2 their post-LN --
+ *     a Swin block's output together with the next block's `norm1` of it, or the stage's output norm (swin.py:286-293, :236, :664-672). */
+#define UNIVS_MLP_RESIDUAL_IS_NORMED_X 1
+#define UNIVS_MLP_DUAL_OUTPUT 2
 int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                              const float* b2, const float* residual, int residual_is_normed_x, const float* ln_weight,
+                              const float* b2, const float* residual, int flags, const float* ln_weight,
                               const float* ln_bias, float ln_eps, const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps,
                               const float* post_add, long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y,
                               void* stream);

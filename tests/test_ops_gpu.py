@@ -932,6 +932,18 @@ def test_mlp_fused_with_layer_norm(cuda, M, C, Hd):
     err2 = (two.double() - ref64).abs().max().item()
     print(f"mlp_fused + LN {M, C, Hd}: {err:.2e} (ATen fp32 {err32:.2e}, LN kernel + fused MLP {err2:.2e})")
     assert err < max(4.0 * err32, 2e-5), (err, err32)
+    if C <= 256:
+        # dual output: the block's result and the NEXT LayerNorm of it (the next block's norm1 / the stage's output norm) from one launch
+        g2 = (1.0 + 0.2 * synth.normal(f"mlpln/g2/{C}", (C,))).to(cuda)
+        b2n = (0.1 * synth.normal(f"mlpln/b2n/{C}", (C,))).to(cuda)
+        pair = ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "gelu", residual=xd, ln=(gd, bd, 1e-5), post_ln=(g2, b2n, 1e-5), dual=True)
+        assert pair is not None and torch.equal(pair[0], y)
+        n64 = F.layer_norm(y.double(), (C,), g2.double(), b2n.double(), 1e-5)
+        e_n = (pair[1].double() - n64).abs().max().item()
+        e_k = (ops.layer_norm(y, g2, b2n, 1e-5).double() - n64).abs().max().item()
+        assert e_n < max(4.0 * e_k, 2e-5), (e_n, e_k)
+        with pytest.raises(RuntimeError):
+            ops.mlp_fused(xd, w1d, b1d, w2d, b2d, "gelu", residual=xd, dual=True)
 
 
 @pytest.mark.parametrize("N,S,C,Hd", [(2, 9660, 256, 1024), (3, 1111, 256, 512), (1, 4000, 192, 384)], ids=lambda v: str(v))

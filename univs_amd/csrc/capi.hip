@@ -265,7 +265,7 @@ int univs_mlp_presplit_f32(const float* x, const void* w1p, const float* w1inv, 
 }
 
 int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
-                              const float* b2, const float* residual, int residual_is_normed_x, const float* ln_weight,
+                              const float* b2, const float* residual, int flags, const float* ln_weight,
                               const float* ln_bias, float ln_eps, const float* post_ln_weight, const float* post_ln_bias, float post_ln_eps,
                               const float* post_add, long long post_add_rows, float* y2, long long M, int C, int Hd, int act, float* y,
                               void* stream) {
@@ -279,13 +279,13 @@ int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1in
     set_error("univs_mlp_presplit_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  if (residual_is_normed_x && (residual || !ln_weight || x == y)) {
-    set_error("univs_mlp_presplit_f32: residual_is_normed_x needs ln_weight, no residual pointer and y distinct from x (the normalised "
-              "rows are parked in y)");
+  if ((flags & ~3) || ((flags & 1) && (residual || !ln_weight || x == y)) || ((flags & 2) && (!post_ln_weight || !y2 || post_add || (flags & 1)))) {
+    set_error("univs_mlp_presplit_f32: flags=%d: UNIVS_MLP_RESIDUAL_IS_NORMED_X needs ln_weight, no residual pointer and y distinct from x "
+              "(the normalised rows are parked in y); UNIVS_MLP_DUAL_OUTPUT needs post_ln_weight and y2, no post_add, and excludes the other", flags);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   const int rc = univs::mlp_f16x3_f32(x, w1p, w1inv, b1, w2p, w2inv, b2, residual, ln_weight, ln_bias, ln_eps, post_ln_weight, post_ln_bias,
-                                      post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, residual_is_normed_x,
+                                      post_ln_eps, post_add, post_add_rows, y2, y, M, C, Hd, act, flags,
                                       static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_mlp_presplit_f32: shape M=%lld C=%d Hd=%d (or alignment) is not covered (C in 96 / 128 / 192 / 256 / 384, Hd %% 32 == 0, "

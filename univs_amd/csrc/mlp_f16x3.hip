@@ -55,6 +55,8 @@ struct MlpArgs {
   float pln_eps;
   int padd_rows;
   int M, Hd, nwg;
+  int dual;             // with pln_g and Y2: Y receives the finished rows UN-normalised and Y2 their post-LN (the Swin block's output and the
+                        // next block's norm1 / the stage's output norm of it: swin.py:286-293, :236, :664-672); no padd
   int res_normed;       // with ln_g, Res == null: the residual is LN(x) -- the post-norm chain x1 = norm1(.), y = norm2(x1 + mlp(x1)) of the
                         // encoder layer (msdeformattn.py:124-133).  The normalised rows are parked in Y when the x tile is made and
                         // read back for the epilogue (same wave, through L2) instead of living in 16 CT C / 64 more registers.
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
             v += res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
           acc2[ob][ct] = v;
+          if (a.dual) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
           sm += (v[0] + v[1]) + (v[2] + v[3]);
         }
         const float mean = ml_row_sum(sm) * (1.0f / C);
@@ -496,6 +499,10 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
           const f32x4 bt = *reinterpret_cast<const f32x4*>(plnb_lds + f);
           const f32x4 y = (acc2[ob][ct] * rstd) * gm + bt;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+          if (a.dual) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), y2rs, offc, 0, 0);
+            continue;
+          }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), yrs, offc, 0, 0);
           if (a.Y2) {
             f32x4 y2 = y;
@@ -567,12 +574,14 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
 int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const float* b1, const void* w2p, const float* w2inv,
                   const float* b2, const float* residual, const float* ln_w, const float* ln_b, float ln_eps, const float* pln_w,
                   const float* pln_b, float pln_eps, const float* post_add, long long post_add_rows, float* y2, float* y, long long M,
-                  int C, int Hd, int act, int residual_is_normed_x, hipStream_t st) {
+                  int C, int Hd, int act, int flags, hipStream_t st) {
+  const int residual_is_normed_x = flags & 1, dual = (flags >> 1) & 1;
   if (M <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if ((act != ML_ACT_RELU && act != ML_ACT_GELU) || Hd < 32 || Hd % 32 != 0 || M < 2048 || M * (long long)C * 4 >= 0x7FFFFFFFLL ||
       mis(x) || mis(w1p) || mis(w2p) || mis(y) || mis(residual) || mis(w1inv) || mis(w2inv) || mis(b1) || mis(b2) || (ln_b && !ln_w) ||
       mis(post_add) || mis(y2) || (pln_b && !pln_w) || ((post_add || y2) && !pln_w) || (residual_is_normed_x && (residual || !ln_w || x == y)) ||
+      (dual && (!pln_w || !y2 || post_add || residual_is_normed_x)) || (flags & ~3) ||
       (post_add && (!y2 || post_add_rows < 1 ||
       post_add_rows * (long long)C * 4 >= 0x7FFFFFFFLL)))
     return UNIVS_ERR_NOT_IMPLEMENTED;
@@ -581,7 +590,7 @@ int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const flo
   a.W2p = reinterpret_cast<const u32x4*>(w2p); a.w2inv = w2inv; a.b2 = b2; a.Res = residual; a.Y = y;
   a.ln_g = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
   a.pln_g = pln_w; a.pln_b = pln_b; a.pln_eps = pln_eps; a.padd = post_add; a.padd_rows = (int)post_add_rows; a.Y2 = y2;
-  a.M = (int)M; a.Hd = Hd; a.res_normed = residual_is_normed_x ? 1 : 0;
+  a.M = (int)M; a.Hd = Hd; a.res_normed = residual_is_normed_x ? 1 : 0; a.dual = dual;
   switch (C) {
     case 96: return ml_launch<3, 2, 4>(a, act, st);
     case 128: return ml_launch<4, 1, 8>(a, act, st);

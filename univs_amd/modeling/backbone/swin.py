@@ -44,13 +44,18 @@ class Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = nn.Linear(hidden_features, out_features)
 
-    def fused(self, x, residual=None, norm=None):
+    def fused(self, x, residual=None, norm=None, post_norm=None):
         """Both Linears, the GELU, the shortcut add and (with `norm`, an nn.LayerNorm applied to x first) the block's norm2 in
-        ONE kernel (csrc/mlp_f16x3.hip): stages with C <= 256.  None when the shape is not covered or the fusion is off."""
+        ONE kernel (csrc/mlp_f16x3.hip): stages with C <= 256.  None when the shape is not covered or the fusion is off.
+        `post_norm` (an nn.LayerNorm): returns the pair (y, post_norm(y)) -- the next block's norm1, or the stage's output norm,
+        from the same launch."""
         if not (SWITCHES.fused_mlp and SWITCHES.swin_fused_linear and (SWITCHES.swin_fused_parts & 6) == 6 and x.is_cuda
                 and x.shape[-1] <= SWITCHES.fused_mlp_max_c):
             return None
         ln = None if norm is None else (norm.weight, norm.bias, norm.eps)
+        if post_norm is not None:
+            return ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual, ln=ln,
+                                 post_ln=(post_norm.weight, post_norm.bias, post_norm.eps), dual=True)
         return ops.mlp_fused(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "gelu", residual=residual, ln=ln)
 
     def forward(self, x, residual=None):
@@ -164,7 +169,9 @@ class SwinTransformerBlock(nn.Module):
         self.H = None
         self.W = None
 
-    def forward(self, x, mask_matrix):
+    def forward(self, x, mask_matrix, normed=None, next_norm=None):
+        """`normed`: norm1(x) when the caller already has it; `next_norm` (an nn.LayerNorm): the block returns (y, next_norm(y)) --
+        (y, None) where the fused MLP kernel that provides it does not apply."""
         B, L, C = x.shape
         H, W = self.H, self.W
         assert L == H * W, "input feature has wrong size"
@@ -173,10 +180,17 @@ class SwinTransformerBlock(nn.Module):
         if x.is_cuda and SWITCHES.fused_mlp:
             # x = shortcut + attn branch from the proj Linear's epilogue; then x + mlp(norm2(x)) in ONE launch where the fused
             # MLP covers the width (its x tile sits in registers: the LayerNorm costs no pass over memory), else norm2 + Mlp
-            x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
+            x = self.attn.forward_image(normed if normed is not None else layer_norm(self.norm1, x), H, W, self.shift_size,
                                         mask_matrix if self.shift_size > 0 else None, residual=shortcut).reshape(B, H * W, C)
+            if next_norm is not None and not torch.is_grad_enabled():
+                pair = self.mlp.fused(x, residual=x, norm=self.norm2, post_norm=next_norm)
+                if pair is not None:
+                    return pair
             y = self.mlp.fused(x, residual=x, norm=self.norm2)
-            return y if y is not None else self.mlp(layer_norm(self.norm2, x), residual=x)
+            y = y if y is not None else self.mlp(layer_norm(self.norm2, x), residual=x)
+            return y if next_norm is None else (y, None)
+        if normed is not None or next_norm is not None:
+            raise RuntimeError("SwinTransformerBlock: normed / next_norm belong to the fused GPU path")
         x = self.attn.forward_image(layer_norm(self.norm1, x), H, W, self.shift_size,
                                     mask_matrix if self.shift_size > 0 else None)
         # residual add and norm2 in one pass: x = shortcut + attn branch, h = norm2(x)
@@ -243,11 +257,32 @@ class BasicLayer(nn.Module):
             self._mask_cache[key] = m
         return m
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, out_norm=None):
+        """`out_norm` (an nn.LayerNorm, GPU inference): also returns out_norm(x_out) as a 7th element (None where the last block's fused
+        kernel does not provide it) -- the stage's output norm (swin.py:664-672) from the launch that produced x_out."""
         attn_mask = self._shift_mask(H, W, x.device)
-        for blk in self.blocks:
+        chain = x.is_cuda and SWITCHES.fused_mlp and not torch.is_grad_enabled()
+        normed, x_normed = None, None
+        for i, blk in enumerate(self.blocks):
             blk.H, blk.W = H, W
-            x = blk(x, attn_mask)
+            if chain:
+                # a block's fused MLP kernel also writes the NEXT block's norm1 of its output (or the stage's output norm)
+                nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else out_norm
+                if nxt is not None:
+                    x, n_ = blk(x, attn_mask, normed=normed, next_norm=nxt)
+                else:
+                    x, n_ = blk(x, attn_mask, normed=normed), None
+                if i + 1 < len(self.blocks):
+                    normed = n_
+                else:
+                    x_normed = n_
+            else:
+                x = blk(x, attn_mask)
+        if out_norm is not None:
+            if self.downsample is not None:
+                x_down = self.downsample(x, H, W)
+                return x, H, W, x_down, (H + 1) // 2, (W + 1) // 2, x_normed
+            return x, H, W, x, H, W, x_normed
         if self.downsample is not None:
             x_down = self.downsample(x, H, W)
             return x, H, W, x_down, (H + 1) // 2, (W + 1) // 2
@@ -348,9 +383,12 @@ class SwinTransformer(nn.Module):
             x, Wh, Ww = self.patch_embed.tokens(x)
         outs = {}
         for i in range(self.num_layers):
-            x_out, H, W, x, Wh, Ww = self.layers[i](x, Wh, Ww)
+            if i in self.out_indices and x.is_cuda and not torch.is_grad_enabled():
+                x_out, H, W, x, Wh, Ww, x_normed = self.layers[i](x, Wh, Ww, out_norm=getattr(self, f"norm{i}"))
+            else:
+                (x_out, H, W, x, Wh, Ww), x_normed = self.layers[i](x, Wh, Ww), None
             if i in self.out_indices:
-                x_out = layer_norm(getattr(self, f"norm{i}"), x_out)
+                x_out = x_normed if x_normed is not None else layer_norm(getattr(self, f"norm{i}"), x_out)
                 # tokens -> NCHW (swin.py:676-683 permute + contiguous): an LDS tile transpose on the GPU
                 outs[f"res{i + 2}"] = ops.transpose_last2(x_out).view(-1, self.num_features[i], H, W)
         return outs

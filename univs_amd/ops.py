@@ -341,7 +341,7 @@ def presplit_weights(weight, conv=False, mode=None):
 MLP_WIDTHS = (96, 128, 192, 256, 384)
 
 
-def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post_add=None, residual_normed=False):
+def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post_add=None, residual_normed=False, dual=False):
     """act(LN(x) W1^T + b1) W2^T + b2 (+ residual) in ONE kernel (include/univs_hip.h: univs_mlp_presplit_f32; csrc/mlp_f16x3.hip):
     the encoder FFN (msdeformattn.py:87-91) and the Swin Mlp + shortcut (swin.py:35-58, :291-293).  Both products use the
     three-product fp16 arithmetic of `linear_fused`; the [M, Hd] hidden activations stay in registers.  `act`: 'relu' | 'gelu'.
@@ -352,6 +352,8 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
     returns the pair (y, y + post_add), the second being the next layer's `with_pos_embed(src, pos)`.
     `residual_normed=True` (with `ln`, without `residual`): the residual is LN(x) itself -- `x1 = norm1(x); norm2(x1 + ffn(x1))`, the
     whole tail of the encoder layer behind `src + output_proj(...)` (msdeformattn.py:124-133) in one launch.
+    `dual=True` (with `post_ln`, without `post_add`): returns (y, post_ln(y)) with y the finished rows UN-normalised -- a Swin block's
+    output and the next block's `norm1` of it (or the stage's output norm) from the same launch.
     Returns None when the shape is not covered (C not in 96 / 128 / 192 / 256 / 384, Hd % 32, fewer than 2048 rows, autograd needed):
     the caller keeps two `linear_fused` calls."""
     C = x.shape[-1]
@@ -361,6 +363,8 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
         return None
     if residual_normed and (ln is None or residual is not None):
         raise RuntimeError("mlp_fused: residual_normed needs ln and excludes residual")
+    if dual and (post_ln is None or post_add is not None or residual_normed):
+        raise RuntimeError("mlp_fused: dual needs post_ln and excludes post_add / residual_normed")
     if (not x.is_cuda or x.dtype != torch.float32 or w1.dtype != torch.float32 or w2.dtype != torch.float32 or C not in MLP_WIDTHS
             or tuple(w1.shape) != (Hd, C) or tuple(w2.shape) != (C, Hd) or Hd % 32 != 0 or M < 2048 or M * C * 4 >= 2 ** 31 - 1
             or ((1 if C == 384 else 2) * 64 * C + 2 * Hd + 6 * C) * 4 > 160 * 1024):
@@ -401,13 +405,13 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
             raise RuntimeError(f"mlp_fused: residual must be float32 of x's shape on the GPU (got {tuple(residual.shape)})")
         r = residual.contiguous()
     y = torch.empty((M, C), dtype=torch.float32, device=x.device)
-    y2 = torch.empty((M, C), dtype=torch.float32, device=x.device) if pa is not None else None
+    y2 = torch.empty((M, C), dtype=torch.float32, device=x.device) if (pa is not None or dual) else None
     with _on(x):
         w1p, w1inv = presplit_weights(w1)
         w2p, w2inv = presplit_weights(w2, mode="mlp2")
         rc = _lib.load().univs_mlp_presplit_v2_f32(_ptr(x2), _ptr(w1p), _ptr(w1inv), _ptr(b1) if b1 is not None else None, _ptr(w2p),
                                                 _ptr(w2inv), _ptr(b2) if b2 is not None else None, _ptr(r) if r is not None else None,
-                                                1 if residual_normed else 0, _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
+                                                (1 if residual_normed else 0) | (2 if dual else 0), _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
                                                 _ptr(pw) if pw is not None else None, _ptr(pb) if pb is not None else None, float(peps),
                                                 _ptr(pa) if pa is not None else None, parows, _ptr(y2) if y2 is not None else None,
                                                 M, C, Hd, _ACTS[act], _ptr(y), _stream_ptr(x2))
