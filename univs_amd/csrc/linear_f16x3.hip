@@ -33,7 +33,7 @@ namespace univs {
 
 constexpr int L3_THREADS = 512;   // 8 waves, two per SIMD
 constexpr int L3_TILE_M = 32;     // rows of x per wave tile (two 16-column MFMA tiles)
-constexpr int L3_MAX_RB = 9;     // 144 features of K = 256 fill the LDS: the encoder's 288-column projection in two passes over x, not three
+constexpr int L3_MAX_RB = 8;
 enum { L3_EPI_NONE = 0, L3_EPI_RELU = 1, L3_EPI_GELU = 2, L3_EPI_RESIDUAL = 3, L3_EPI_BLOCKED = 4 };   // = LS_EPI_*
 
 // LDS: Wsp [K/32][4 k-groups][2 parts][16 RB features] 16 B | bias[R] | winv[R] | zero tail (16 x 16 B) | wmax[R]
@@ -351,8 +351,7 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
     UNIVS_L3_RB(5);
     UNIVS_L3_RB(6);
     UNIVS_L3_RB(7);
-    UNIVS_L3_RB(8);
-    default: UNIVS_L3_RB(9);
+    default: UNIVS_L3_RB(8);
   }
 #undef UNIVS_L3_RB
 #undef UNIVS_L3
