@@ -145,7 +145,8 @@ typedef struct UnivsConfig {
   int linear_rows_per_pass; /* kernel benchmarks: output features per pass of the three-product Linears (a multiple of 16, <= 128;
                              0 = as many as fit: 128 for the streamed kernel, the LDS capacity for the W-resident one) */
   int linear_grid_x;      /* kernel benchmarks: workgroups along the rows of the three-product Linears (0 = by shape) */
-  int reserved[4];
+  int xattn_segments;     /* kernel benchmarks: key segments per (batch entry, head, query chunk) of univs_cross_attention_f32 (0 = by shape) */
+  int reserved[3];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);

@@ -224,7 +224,7 @@ class UnivsConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
                                             "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "window_attn_v1",
                                             "linear_terms", "linear_ablate", "mask_decode_chunked", "mask_decode_wave_tiles",
-                                            "linear_rows_per_pass", "linear_grid_x")] + [("reserved", ctypes.c_int * 4)]
+                                            "linear_rows_per_pass", "linear_grid_x", "xattn_segments")] + [("reserved", ctypes.c_int * 3)]
 
 
 def get_config() -> dict:
