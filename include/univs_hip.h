@@ -291,6 +291,23 @@ int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv
                                int W, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * y[M, N] = act((x [+ x_add]) W[f_off : f_off + N]^T + bias) [+ residual] [-> LayerNorm] for FEW rows (small_linear.hip): the per-token
+ * Linears of the UniVS decoder on its Q' T query tokens with the elementwise steps around them in the same launch.
+ * Replaces (univs/modeling/transformer_decoder/transformer_layers.py):
+ *   `q = in_proj_q(tgt + query_pos)`                                  (:30-46, :95-115; x_add = query_pos, f_off selects the rows
+ *                                                                      of in_proj_weight: q 0, k E, v 2 E)
+ *   `tgt = norm(tgt + out_proj(attn))`, `tgt = norm(tgt + linear2(h))` (:42-46, :106-110, :160-166; residual = tgt, ln_* = norm)
+ *   `h = relu(linear1(tgt))`, the mask-embedding MLP                   (:150-166, :205-217; relu = 1)
+ * Three-product fp16 arithmetic of univs_linear_fused_f32 (fp32-accurate); LayerNorm with exact two-pass statistics.
+ *   wp, winv   univs_presplit_weights_f32(W [n_w, K], n_w, K, 0, ...) of the WHOLE weight matrix; bias [n_w] | NULL
+ *   x, x_add | NULL [M, K]; residual | NULL [M, N]; ln_weight | NULL, ln_bias | NULL [N] (with ln_weight: N == 256); y [M, N]
+ *   K % 32 == 0, N % 16 == 0, f_off % 4 == 0, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_small_linear_presplit_f32(const float* x, const float* x_add, const void* wp, const float* winv, const float* bias, int n_w,
+                                    int f_off, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
+                                    long long M, int N, int K, int relu, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y[M, C] = act(LN(x)[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16
  * arithmetic of univs_linear_fused_f32 in both products; the [M, Hd] hidden activations stay in registers (they are neither
  * written to nor read from memory).  LN: with ln_weight != NULL the rows of x first go through nn.LayerNorm(C) (weight, bias or

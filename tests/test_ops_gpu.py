@@ -1079,6 +1079,89 @@ def test_tokens_from_nchw(cuda):
     assert ops.tokens_from_nchw([xs[0][..., :9]], [None], None) is None          # H * W % 4 != 0
 
 
+@pytest.mark.parametrize("M,K,Nw,rows,add,relu,res,ln", [
+    (500, 256, 768, (0, 256), True, False, False, False),      # cross-attention q = in_proj_q(tgt + query_pos)
+    (500, 256, 768, (0, 512), True, False, False, False),      # self-attention q, k in one projection
+    (500, 256, 768, (512, 256), False, False, False, False),   # self-attention v
+    (500, 256, 256, None, False, False, True, True),           # norm(tgt + out_proj(attn))
+    (550, 256, 2048, None, False, True, False, False),         # relu(linear1(tgt))
+    (500, 2048, 256, None, False, False, True, True),          # norm(tgt + linear2(h))
+    (2000, 256, 256, None, False, True, False, False),         # mask-embedding MLP at config 5's length
+    (7, 64, 48, (16, 32), True, True, True, False), (1, 32, 16, None, False, False, False, False), (4096, 256, 256, None, True, False, True, True),
+], ids=lambda v: str(v))
+def test_small_linear_matches_torch(cuda, M, K, Nw, rows, add, relu, res, ln):
+    """ops.small_linear (csrc/small_linear.hip: a few-rows Linear with `x + x_add` in front and ReLU / residual / LayerNorm behind, rows of
+    a packed weight selected by offset) == the torch expression in fp64 to fp32 rounding (transformer_layers.py:30-46, :95-115, :150-166)."""
+    F = torch.nn.functional
+    tag = f"sl/{M}x{K}x{Nw}"
+    x = synth.normal(tag + "/x", (M, K))
+    x[::3] *= 30.0
+    xa = synth.normal(tag + "/xa", (M, K))
+    w = synth.normal(tag + "/w", (Nw, K), std=K ** -0.5)
+    b = synth.normal(tag + "/b", (Nw,), std=0.5)
+    f0, N = (0, Nw) if rows is None else rows
+    r = synth.normal(tag + "/r", (M, N))
+    g_ = 1.0 + 0.2 * synth.normal(tag + "/g", (N,))
+    be = 0.1 * synth.normal(tag + "/be", (N,))
+    xd, xad, wd, bd, rd, gd, bed = (t.to(cuda) for t in (x, xa, w, b, r, g_, be))
+    y = ops.small_linear(xd, wd, bd, rows=rows, x_add=xad if add else None, relu=relu, residual=rd if res else None,
+                         ln=(gd, bed, 1e-5) if ln else None)
+    assert y is not None and tuple(y.shape) == (M, N)
+
+    def ref(dt):
+        c = lambda t: t.to(dt)
+        t = F.linear(c(xd) + c(xad) if add else c(xd), c(wd)[f0:f0 + N], c(bd)[f0:f0 + N])
+        if relu:
+            t = F.relu(t)
+        if res:
+            t = t + c(rd)
+        return F.layer_norm(t, (N,), c(gd), c(bed), 1e-5) if ln else t
+    ref64, ref32 = ref(torch.float64), ref(torch.float32)
+    scale = max(1.0, ref64.abs().max().item())
+    err, err32 = (y.double() - ref64).abs().max().item() / scale, (ref32.double() - ref64).abs().max().item() / scale
+    assert err < max(4.0 * err32, 2e-6), (err, err32)
+    # leading dimensions are kept; no bias; shapes that are not covered
+    y3 = ops.small_linear(xd.view(1, M, K), wd, None, rows=rows)
+    assert tuple(y3.shape) == (1, M, N)
+    assert ops.small_linear(torch.zeros(5000, K, device=cuda), wd, bd) is None           # too many rows (the tall kernels' job)
+    assert ops.small_linear(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd) is None or (K - 8) % 32 == 0
+
+
+def test_small_linear_module_paths(cuda):
+    """layers.MultiheadAttention / FFNLayer / MLP through the few-rows kernel == the library GEMM + elementwise launches they replace
+    (SWITCHES.small_linear off) to fp32 rounding: self-attention with positional queries and a mask, cross-attention with precomputed
+    key / value projections, the post-norm FFN, the three-layer mask-embedding MLP."""
+    from univs_amd import layers
+    from univs_amd.modeling.transformer_decoder import transformer_layers as tl
+    from univs_amd.switches import override
+    E, Hh, L, S = 256, 8, 500, 920
+    sa = tl.SelfAttentionLayer(E, Hh).to(cuda).eval()
+    ca = tl.CrossAttentionLayer(E, Hh).to(cuda).eval()
+    ffn = tl.FFNLayer(E, 2048).to(cuda).eval()
+    mlp = layers.MLP(E, E, E, 3).to(cuda).eval()
+    with torch.no_grad():
+        for mod, nm in ((sa, "sa"), (ca, "ca"), (ffn, "ffn"), (mlp, "mlp")):
+            for n_, p_ in mod.named_parameters():
+                p_.copy_((synth.normal(f"slm/{nm}/{n_}", tuple(p_.shape), std=0.06) + (1.0 if n_.endswith("norm.weight") else 0.0)).to(cuda))
+        tgt = synth.normal("slm/tgt", (L, 1, E)).to(cuda)
+        pos = synth.normal("slm/pos", (L, 1, E)).to(cuda)
+        mem = synth.normal("slm/mem", (S, 1, E)).to(cuda)
+        msk = (torch.rand(L, L, generator=torch.Generator().manual_seed(2)) < 0.3).to(cuda)
+        msk[torch.arange(L), torch.arange(L)] = False
+        cm = (torch.rand(1, L, S, generator=torch.Generator().manual_seed(4)) < 0.5).to(cuda)
+
+        def run():
+            a = sa(tgt, tgt_mask=msk, query_pos=pos)
+            b = ca(a, mem, memory_mask=cm, query_pos=pos)
+            c = ffn(b)
+            return a, b, c, mlp(c)
+        small = run()
+        with override(small_linear=False):
+            plain = run()
+    for s_, p_, nm in zip(small, plain, ("self-attention", "cross-attention", "ffn", "mlp")):
+        assert (s_ - p_).abs().max().item() < 3e-5, (nm, (s_ - p_).abs().max().item())
+
+
 def test_mlp_fused_row_scaling_and_uncovered_shapes(cuda):
     """Rows of x over 80 binades, zero rows, hidden rows whose magnitude jumps between chunks (the running scale of the hidden
     activations is lowered with an exact rescaling of the output accumulators), Inf / NaN confined to their row; shapes the

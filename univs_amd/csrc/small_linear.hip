@@ -1,0 +1,203 @@
+// y[M, N] = act((x [+ xadd]) W^T + b) [+ residual] [-> LayerNorm] for FEW rows (M <= a few thousand): the per-token Linears of the
+// UniVS decoder on its Q' T = 500 ... 2 000 query tokens (univs/modeling/transformer_decoder/transformer_layers.py: the in / out
+// projections of SelfAttentionLayer :30-46 and CrossAttentionLayer :95-115, FFNLayer :150-166, the mask-embedding MLP :205-217).
+// The library runs each of them as a tuned GEMM of 8 - 13 us (launch- and latency-bound: 33 MFLOP) with the elementwise steps around
+// it -- `tgt + query_pos` in front, `norm(tgt + .)` behind -- as launches of their own: ~100 GEMMs + ~60 elementwise / LayerNorm
+// launches per clip.
+//
+// Arithmetic: the three-product fp16 scheme of linear_f16x3.hip (two fp16 parts per operand behind power-of-two row scales, three
+// v_mfma_f32_16x16x32_f16 per fp32 product, fp32 accumulation: ~2^-22 per product); W pre-split once per weight tensor
+// (gemm_f16x3_stream.hip: presplit_f16x3, the layout [(k/8) * 2 + part][feature] of 16-byte units), x split on the fly.
+// Organisation: everything here is latency: a workgroup = 8 waves = 16 rows x 256 features (32 per wave: two MFMA feature blocks),
+// the A fragments come straight from the pre-split image in global memory (L2-resident: the same 256 KB for every workgroup) --
+// four 16-byte loads per k-step and lane, requested SL_AHEAD k-steps ahead so that a K = 256 product is two round trips to L2; the
+// 16 x K tile of x is read twice (row maxima, then split: L1 hits).  Epilogue: bias, ReLU, residual, and -- when the workgroup
+// holds whole rows (N == 256) -- nn.LayerNorm with exact two-pass statistics across the eight waves (two LDS exchanges).
+#include "common.h"
+#include "f16x3.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace univs {
+
+constexpr int SL_WAVES = 8;
+constexpr int SL_AHEAD = 4;     // k-steps of A fragments in flight
+
+struct SlArgs {
+  const float* X;       // [M, K]
+  const float* Xadd;    // [M, K] or null: the operand is X + Xadd (`with_pos_embed`)
+  const u32x4* Wp;      // pre-split W [Nw, K]: unit ((k / 8) * 2 + part) * Nw + feature
+  const float* winv;    // [Nw]
+  const float* bias;    // [Nw] or null
+  const float* Res;     // [M, N] or null
+  const float* ln_g;    // [N] or null (then N == 256)
+  const float* ln_b;    // [N] or null
+  float ln_eps;
+  float* Y;             // [M, N]
+  int M, N, K, Nw, f_off, relu;   // features [f_off, f_off + N) of the pre-split matrix
+};
+
+typedef unsigned sl_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sl_row_sum(float v) {          // over the four lanes (lane >> 4) that hold one row
+  const sl_u2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float r1 = __uint_as_float(s1.x) + __uint_as_float(s1.y);
+  const sl_u2 s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+  return __uint_as_float(s2.x) + __uint_as_float(s2.y);
+}
+
+__global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const SlArgs a) {
+  __shared__ float red[2][SL_WAVES][16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int M = a.M, N = a.N, K = a.K, KS = K >> 5;
+  const int row0 = blockIdx.x * 16;
+  const int f0 = blockIdx.y * (32 * SL_WAVES) + wave * 32;     // this wave's 32 features (within [0, N))
+  const bool with_ln = a.ln_g != nullptr;                      // uniform; then N == 256 and every wave has features
+  if (f0 >= N && !with_ln) return;                              // (no barrier below without the LayerNorm)
+  const bool f_ok1 = f0 + 16 < N;                               // second feature block inside N (N % 16 == 0)
+
+  // ---- x: my row (clamped), my 8 k-values of a k-step at column 32 ks + 8 g
+  const int m = min(row0 + j, M - 1);
+  const float* xr = a.X + (long long)m * K + 8 * g;
+  const float* xa = a.Xadd ? a.Xadd + (long long)m * K + 8 * g : nullptr;
+  auto load_x = [&](int ks, f32x4& v0, f32x4& v1) __attribute__((always_inline)) {
+    v0 = *reinterpret_cast<const f32x4*>(xr + 32 * ks);
+    v1 = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
+    if (xa) {
+      v0 += *reinterpret_cast<const f32x4*>(xa + 32 * ks);
+      v1 += *reinterpret_cast<const f32x4*>(xa + 32 * ks + 4);
+    }
+  };
+  // ---- A fragments: units ((4 ks + g) * 2 + part) * Nw + f_off + f0 + 16 q + j
+  const u32x4* wl = a.Wp + (size_t)(g * 2) * a.Nw + a.f_off + min(f0, N - 16) + j;
+  const size_t kstep_units = (size_t)8 * a.Nw;
+  u32x4 afr[SL_AHEAD][2][2];                                    // [stage][feature block][part]
+  auto load_a = [&](int ks, u32x4 (&d)[2][2]) __attribute__((always_inline)) {
+    const u32x4* p = wl + (size_t)ks * kstep_units;
+    d[0][0] = p[0];
+    d[0][1] = p[a.Nw];
+    d[1][0] = f_ok1 ? p[16] : p[0];
+    d[1][1] = f_ok1 ? p[a.Nw + 16] : p[a.Nw];
+  };
+#pragma unroll
+  for (int u = 0; u < SL_AHEAD; ++u)
+    if (u < KS) load_a(u, afr[u]);
+
+  // ---- pass 1: exact row maximum of the operand
+  unsigned mx = 0u;
+  for (int ks = 0; ks < KS; ++ks) {
+    f32x4 v0, v1;
+    load_x(ks, v0, v1);
+    mx = max(mx, l3_absmax8(v0, v1));
+  }
+  mx = l3_row_max(mx);
+  float sx, sx_inv;
+  l3_scale(mx, 14, sx, sx_inv);
+
+  // ---- pass 2: the product
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 xv0, xv1;
+  load_x(0, xv0, xv1);
+  const int KSA = (KS + SL_AHEAD - 1) / SL_AHEAD * SL_AHEAD;
+#pragma unroll 1
+  for (int kb = 0; kb < KSA; kb += SL_AHEAD) {
+#pragma unroll
+    for (int u = 0; u < SL_AHEAD; ++u) {
+      const int ks = kb + u;
+      if (ks < KS) {                                            // uniform
+        f16x8 bh, bm;
+        l3_split8(xv0, xv1, sx, bh, bm);
+        if (ks + 1 < KS) load_x(ks + 1, xv0, xv1);
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[u][0][0]), am0 = __builtin_bit_cast(f16x8, afr[u][0][1]);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[u][1][0]), am1 = __builtin_bit_cast(f16x8, afr[u][1][1]);
+        if (ks + SL_AHEAD < KS) load_a(ks + SL_AHEAD, afr[u]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, bh, acc[0], 0, 0, 0);   // smallest terms first
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, bh, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bm, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bm, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D[i = feature][j = row]: a lane holds features f0 + 16 q + 4 g ... + 3 of row j
+  const int row = row0 + j;
+  const bool row_ok = row < M;
+  f32x4 v[2];
+  float sm = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = f0 + 16 * q + 4 * g;
+    const bool ok = f < N;                                      // (N % 4 == 0)
+    const int fw = a.f_off + (ok ? f : 0);
+    const f32x4 wi = *reinterpret_cast<const f32x4*>(a.winv + fw);
+    f32x4 t = (acc[q] * sx_inv) * wi;
+    if (a.bias) t += *reinterpret_cast<const f32x4*>(a.bias + fw);
+    if (a.relu) t = __builtin_elementwise_maximum(t, (f32x4){0.f, 0.f, 0.f, 0.f});   // NaN-propagating, as torch.relu
+    if (a.Res && ok) t += *reinterpret_cast<const f32x4*>(a.Res + (long long)m * N + f);
+    v[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sm += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+  }
+  if (with_ln) {
+    // nn.LayerNorm over the row's 256 values: 8 in this lane, 32 in this wave (its four lanes of the row), the rest in the other waves
+    const float inv_n = 1.0f / (float)N;
+    const float ws = sl_row_sum(sm);
+    if (g == 0) red[0][wave][j] = ws;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < SL_WAVES; ++w) tot += red[0][w][j];
+    const float mean = tot * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      v[q] -= mean;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sq = fmaf(v[q][e], v[q][e], sq);
+    }
+    const float wq = sl_row_sum(sq);
+    if (g == 0) red[1][wave][j] = wq;
+    __syncthreads();
+    float tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < SL_WAVES; ++w) tq += red[1][w][j];
+    const float rstd = 1.0f / sqrtf(tq * inv_n + a.ln_eps);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = f0 + 16 * q + 4 * g;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_g + f);
+      f32x4 y = (v[q] * rstd) * gm;
+      if (a.ln_b) y += *reinterpret_cast<const f32x4*>(a.ln_b + f);
+      v[q] = y;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = f0 + 16 * q + 4 * g;
+    if (row_ok && f < N) *reinterpret_cast<f32x4*>(a.Y + (long long)row * N + f) = v[q];
+  }
+}
+
+// returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
+int small_linear_f32(const float* x, const float* xadd, const void* wp, const float* winv, const float* bias, int n_w, int f_off,
+                     const float* residual, const float* ln_g, const float* ln_b, float ln_eps, float* y, long long M, int N, int K,
+                     int relu, hipStream_t st) {
+  if (M <= 0 || N <= 0) return UNIVS_OK;
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (K < 32 || K % 32 != 0 || N % 16 != 0 || n_w % 4 != 0 || f_off % 4 != 0 || f_off < 0 || f_off + N > n_w || M > 16LL * 65535 ||
+      (ln_g && N != 32 * SL_WAVES) || (ln_b && !ln_g) || mis(x) || mis(xadd) || mis(wp) || mis(winv) || mis(bias) || mis(residual) ||
+      mis(ln_g) || mis(ln_b) || mis(y) || M * (long long)std::max(N, K) * 4 >= 0x7FFFFFFFLL)
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  SlArgs a{};
+  a.X = x; a.Xadd = xadd; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = bias; a.Res = residual;
+  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.Y = y;
+  a.M = (int)M; a.N = N; a.K = K; a.Nw = n_w; a.f_off = f_off; a.relu = relu ? 1 : 0;
+  dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 32 * SL_WAVES - 1) / (32 * SL_WAVES)));
+  hipLaunchKernelGGL(small_linear_kernel, grid, dim3(64 * SL_WAVES), 0, st, a);
+  return check_launch("small_linear_f32");
+}
+
+}  // namespace univs

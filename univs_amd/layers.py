@@ -130,31 +130,49 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
 
     def forward(self, query, key, value, attn_mask: Optional[torch.Tensor] = None, need_weights=False,
-                average_attn_weights=True, kv=None):
+                average_attn_weights=True, kv=None, query_add=None, residual=None, norm=None):
         """`kv` = (k, v) [S, N, E]: the key / value projections when the caller already has them (the decoder computes the K and V
-        of all layers that attend to one feature level with ONE Linear each; `key` / `value` are then ignored)."""
+        of all layers that attend to one feature level with ONE Linear each; `key` / `value` are then ignored).
+        `query_add`: the query (and, where `key is query`, the key) operand is `query + query_add` -- the layer's `with_pos_embed`
+        inside the projection kernel; `residual` + `norm` (an nn.LayerNorm): the first result is `norm(residual + out_proj(.))` --
+        the post-norm layer's tail inside the output projection's kernel (transformer_layers.py:42-46, :106-110)."""
         L, N, E = query.shape
         S = key.shape[0] if kv is None else kv[0].shape[0]
         h, d = self.num_heads, self.head_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        lin = linear     # tall projections (cross-attention K / V of the 1/8-resolution memory: 73 600 rows) take the fp16
-        #                  three-product kernel (62 vs 90 us in the tuned library GEMM); short ones stay on the library
+        small = query.is_cuda and _small(query, w, b)
+
+        def lin(x, r0, n, add=None):
+            # rows [r0, r0 + n) of the packed in-projection.  Few rows: one launch with the position add inside (ops.small_linear);
+            # tall projections (cross-attention K / V of the 1/8-resolution memory: 73 600 rows) take the fp16 three-product kernel
+            if small and x.numel() // E <= 4096:
+                from . import ops
+                y = ops.small_linear(x, w, b, rows=(r0, n), x_add=add)
+                if y is not None:
+                    return y
+            return linear(x if add is None else x + add, w[r0:r0 + n], b[r0:r0 + n])
         if kv is not None:
-            q = lin(query, w[:E], b[:E])
+            q = lin(query, 0, E, query_add)
             k, v = kv
-        elif query is key and key is value:
-            q, k, v = lin(query, w, b).chunk(3, dim=-1)
+        elif query is key and key is value and query_add is None:
+            q, k, v = lin(query, 0, 3 * E).chunk(3, dim=-1)
         else:
             if query is key:      # self-attention with positional queries (q = k = tgt + pos, v = tgt): q and k in one projection
-                q, k = lin(query, w[:2 * E], b[:2 * E]).chunk(2, dim=-1)
-                v = lin(value, w[2 * E:], b[2 * E:])
+                q, k = lin(query, 0, 2 * E, query_add).chunk(2, dim=-1)
+                v = lin(value, 2 * E, E)
             else:
-                q = lin(query, w[:E], b[:E])
+                q = lin(query, 0, E, query_add)
                 if key is value:
-                    k, v = lin(key, w[E:], b[E:]).chunk(2, dim=-1)
+                    k, v = lin(key, E, 2 * E).chunk(2, dim=-1)
                 else:
-                    k = lin(key, w[E:2 * E], b[E:2 * E])
-                    v = lin(value, w[2 * E:], b[2 * E:])
+                    k = lin(key, E, E)
+                    v = lin(value, 2 * E, E)
+
+        def project(out):
+            if norm is None:
+                y = linear(out, self.out_proj.weight, self.out_proj.bias)
+                return y if residual is None else residual + y
+            return linear_norm(out, self.out_proj, residual, norm)
         if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 256 and L <= 2048
                 and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8)
                                            and ((attn_mask.dim() == 3 and attn_mask.shape[0] == N) or (attn_mask.dim() == 2 and N == 1))))):
@@ -165,7 +183,7 @@ class MultiheadAttention(nn.Module):
             m3 = attn_mask.view(1, L, S) if (attn_mask is not None and attn_mask.dim() == 2) else attn_mask
             out = ops.cross_attention(q, k, v, m3, h, 1.0 / math.sqrt(d))
             if out is not None:
-                return self.out_proj(out), None
+                return project(out), None
         if attn_mask is not None and not isinstance(attn_mask, torch.Tensor):
             attn_mask = attn_mask.materialize()                  # ops.DeferredMask: the paths below read the reference's tensor
         # [L, N, h, d] -> [N, h, L, d]
@@ -189,7 +207,7 @@ class MultiheadAttention(nn.Module):
             attn = torch.softmax(scores, dim=-1)
         out = torch.matmul(attn, v)  # [N, h, L, d]
         out = out.permute(2, 0, 1, 3).reshape(L, N, E)
-        out = self.out_proj(out)
+        out = project(out)
         if need_weights:
             return out, (attn.mean(dim=1) if average_attn_weights else attn)
         return out, None
@@ -207,7 +225,7 @@ class MLP(nn.Module):
     def forward(self, x):
         for i, layer in enumerate(self.layers):
             # hidden layers: the ReLU rides in the GEMM epilogue on the GPU (linear_act: one launch instead of GEMM + bias + clamp)
-            x = linear_act(x, layer, F.relu) if i < self.num_layers - 1 else layer(x)
+            x = linear_act(x, layer, F.relu) if i < self.num_layers - 1 else linear(x, layer.weight, layer.bias)
         return x
 
 
@@ -226,6 +244,11 @@ def linear(x, weight, bias=None):
     """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 or K % 96 == 0 (the MSDeformAttn token projections:
     96 600 rows x 256 -> 256 / 288) take the split kernels on the matrix cores (fp32-accurate: ops.linear_fused),
     everything else ATen."""
+    if x.is_cuda and _small(x, weight, bias):
+        from . import ops
+        y = ops.small_linear(x, weight, bias)
+        if y is not None:
+            return y
     if SWITCHES.split_linear and x.is_cuda:
         from . import ops
         y = ops.linear_split(x, weight, bias)
@@ -234,11 +257,34 @@ def linear(x, weight, bias=None):
     return F.linear(x, weight, bias)
 
 
+def _small(x, weight, bias=None):
+    """the few-rows Linear kernel (ops.small_linear) applies: whole weight tensors only (its split is cached per tensor object --
+    slices of a parameter are passed as (parameter, rows) by the callers that have them)"""
+    return (SWITCHES.small_linear and x.dtype == torch.float32 and weight._base is None and (bias is None or bias._base is None)
+            and x.numel() // max(x.shape[-1], 1) <= 4096 and not torch.is_grad_enabled())
+
+
+def linear_norm(x, lin, residual, norm):
+    """norm(residual + lin(x)) for nn.Linear / nn.LayerNorm modules: one launch for few rows (ops.small_linear), else the Linear and
+    the residual LayerNorm kernel"""
+    if x.is_cuda and _small(x, lin.weight, lin.bias):
+        from . import ops
+        y = ops.small_linear(x, lin.weight, lin.bias, residual=residual, ln=(norm.weight, norm.bias, norm.eps))
+        if y is not None:
+            return y
+    return layer_norm(norm, linear(x, lin.weight, lin.bias), residual=residual)
+
+
 def linear_act(x, linear, activation):
     """activation(linear(x)).  For ReLU on the GPU the activation rides in the GEMM epilogue (hipBLASLt via
     ATen's `_addmm_activation`: bit-identical to relu(linear(x)), one pass over the [tokens, d_ffn]
     activations less -- 0.17 ms per encoder layer at 720p)."""
     if activation is F.relu and x.is_cuda and x.dtype == torch.float32 and linear.bias is not None:
+        if _small(x, linear.weight, linear.bias):
+            from . import ops
+            y = ops.small_linear(x, linear.weight, linear.bias, relu=True)
+            if y is not None:
+                return y
         if SWITCHES.split_linear:
             from . import ops
             y = ops.linear_split(x, linear.weight, linear.bias, relu=True)

@@ -5,7 +5,7 @@ from typing import Optional
 
 from torch import Tensor, nn
 
-from ...layers import MLP, MultiheadAttention, get_activation_fn, layer_norm, linear_act  # noqa: F401  (MLP re-exported)
+from ...layers import MLP, MultiheadAttention, get_activation_fn, layer_norm, linear, linear_act, linear_norm  # noqa: F401  (MLP re-exported)
 
 
 def _with_pos(t, pos):
@@ -37,9 +37,13 @@ class SelfAttentionLayer(nn.Module):
             q = _with_pos(t2, query_pos)
             k = q if full else _with_pos(kv2, kv_pos)
             return tgt + self.self_attn(q, k, kv2, attn_mask=tgt_mask)[0]
+        if full:
+            # q = k = tgt + query_pos inside the projection kernel, norm(tgt + out_proj(.)) inside the output projection's
+            return self.self_attn(tgt, tgt, tgt, attn_mask=tgt_mask, query_add=query_pos, residual=tgt, norm=self.norm)[0] \
+                if query_pos is not None else self.self_attn(tgt, tgt, tgt, attn_mask=tgt_mask, residual=tgt, norm=self.norm)[0]
         q = _with_pos(tgt, query_pos)
-        k = q if full else _with_pos(kv, kv_pos)
-        return layer_norm(self.norm, self.self_attn(q, k, kv, attn_mask=tgt_mask)[0], residual=tgt)
+        k = _with_pos(kv, kv_pos)
+        return self.self_attn(q, k, kv, attn_mask=tgt_mask, residual=tgt, norm=self.norm)[0]
 
 
 class CrossAttentionLayer(nn.Module):
@@ -63,9 +67,14 @@ class CrossAttentionLayer(nn.Module):
         src = layer_norm(self.norm, tgt) if self.normalize_before else tgt
         # nn.MultiheadAttention's default averages the returned weights over heads; the reference
         # never passes `average_attn_weights` through, so neither do we (transformer_layers.py:101-105)
-        out, w = self.multihead_attn(_with_pos(src, query_pos), key if (key is not None or kv is not None) else _with_pos(memory, pos),
-                                     memory, attn_mask=memory_mask, need_weights=self.need_weights, kv=kv)
-        tgt = tgt + out if self.normalize_before else layer_norm(self.norm, out, residual=tgt)
+        kk = key if (key is not None or kv is not None) else _with_pos(memory, pos)
+        if self.normalize_before:
+            out, w = self.multihead_attn(_with_pos(src, query_pos), kk, memory, attn_mask=memory_mask, need_weights=self.need_weights, kv=kv)
+            tgt = tgt + out
+        else:
+            # `tgt + query_pos` inside the q projection, norm(tgt + out_proj(.)) inside the output projection (few rows: one launch each)
+            tgt, w = self.multihead_attn(src, kk, memory, attn_mask=memory_mask, need_weights=self.need_weights, kv=kv,
+                                         query_add=query_pos, residual=tgt, norm=self.norm)
         return (tgt, w) if self.need_weights else tgt
 
 
@@ -81,4 +90,4 @@ class FFNLayer(nn.Module):
     def forward(self, tgt):
         if self.normalize_before:
             return tgt + self.linear2(linear_act(layer_norm(self.norm, tgt), self.linear1, self.activation))
-        return layer_norm(self.norm, self.linear2(linear_act(tgt, self.linear1, self.activation)), residual=tgt)
+        return linear_norm(linear_act(tgt, self.linear1, self.activation), self.linear2, tgt, self.norm)

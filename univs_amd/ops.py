@@ -421,6 +421,59 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
     return (y.view(x.shape), y2.view(x.shape)) if y2 is not None else y.view(x.shape)
 
 
+SMALL_LINEAR_MAX_ROWS = 4096
+
+
+def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residual=None, ln=None):
+    """act((x [+ x_add]) W[rows]^T + bias[rows]) [+ residual] [-> LayerNorm] for a FEW tokens in one launch (include/univs_hip.h:
+    univs_small_linear_presplit_f32; csrc/small_linear.hip): the decoder's per-token Linears with `tgt + query_pos` in front and
+    `norm(tgt + .)` behind (transformer_layers.py:30-46, :95-115, :150-166, :205-217).  `weight` [Nw, K] is split once and cached
+    (as a whole: `rows` = (first, count) selects output features, e.g. the q / k / v thirds of `in_proj_weight`; `bias` [Nw] whole
+    too); `ln` = (weight, bias, eps) needs 256 output features.  Returns None when not covered (more than 4096 rows, K % 32, N % 16,
+    autograd needed): the caller keeps F.linear and the separate elementwise launches."""
+    K = x.shape[-1]
+    M = x.numel() // max(K, 1)
+    Nw = weight.shape[0]
+    f_off, N = (0, Nw) if rows is None else (int(rows[0]), int(rows[1]))
+    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.dim() != 2 or weight.shape[1] != K
+            or M < 1 or M > SMALL_LINEAR_MAX_ROWS or K % 32 != 0 or N % 16 != 0 or f_off % 4 != 0 or f_off + N > Nw
+            or needs_grad(x, weight, bias, x_add, residual) or (ln is not None and N != 256)):
+        return None
+    x2 = x.contiguous().view(M, K)
+    xa = None
+    if x_add is not None:
+        if x_add.dtype != torch.float32 or not x_add.is_cuda or tuple(x_add.shape) != tuple(x.shape):
+            return None
+        xa = x_add.contiguous()
+    r = None
+    if residual is not None:
+        if residual.dtype != torch.float32 or not residual.is_cuda or residual.numel() != M * N or residual.shape[-1] != N:
+            return None
+        r = residual.contiguous()
+    if bias is not None and (bias.dtype != torch.float32 or tuple(bias.shape) != (Nw,) or not bias.is_contiguous()):
+        return None
+    lw = lb = None
+    leps = 0.0
+    if ln is not None:
+        lw, lb, leps = ln
+        for t_ in (lw, lb):
+            if t_ is not None and (t_.dtype != torch.float32 or tuple(t_.shape) != (N,) or not t_.is_cuda or not t_.is_contiguous()):
+                return None
+        if lw is None:
+            return None
+    y = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    with _on(x):
+        wp, winv = presplit_weights(weight)
+        rc = _lib.load().univs_small_linear_presplit_f32(
+            _ptr(x2), _ptr(xa) if xa is not None else None, _ptr(wp), _ptr(winv), _ptr(bias) if bias is not None else None, Nw, f_off,
+            _ptr(r) if r is not None else None, _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
+            M, N, K, 1 if relu else 0, _ptr(y), _stream_ptr(x2))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "small_linear")
+    return y
+
+
 def linear_fused(x, weight, bias=None, act=None, residual=None):
     """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [the erf form; erf to 4.7e-7 absolute]) or `residual`
     (a tensor of the output's shape that is added) -- for float32 on the GPU through the three-product fp16 kernels (fp32-accurate:

@@ -41,6 +41,9 @@ class Switches:
     # encoder layer: norm1 evaluated inside the fused FFN kernel (on the x tile; its result is also the FFN's residual) instead of a
     # LayerNorm launch of its own
     fused_norm1: bool = True
+    # the decoder's per-token Linears (a few hundred to a few thousand rows) with `tgt + query_pos` in front and `norm(tgt + .)` behind
+    # in one launch each (csrc/small_linear.hip); False: library GEMMs + elementwise / LayerNorm launches
+    small_linear: bool = True
     # decoder cross-attention core (scores, mask, softmax, P V) as one pass over the keys (csrc/cross_attn.hip); False: two
     # library GEMMs around the masked-softmax kernel
     fused_cross_attention: bool = True
@@ -62,7 +65,7 @@ SWITCHES = Switches(
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
-    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True))
+    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
