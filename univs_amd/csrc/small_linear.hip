@@ -22,7 +22,8 @@
 namespace univs {
 
 constexpr int SL_WAVES = 8;
-constexpr int SL_AHEAD = 4;     // k-steps of A fragments in flight
+constexpr int SL_AHEAD = 4;     // k-steps of A fragments in flight (8 would cover K = 256 in one round trip but spills: 256 registers per lane)
+constexpr int SL_XB = 8;        // k-steps of x per batch of loads
 
 struct SlArgs {
   const float* X;       // [M, K]
@@ -36,6 +37,8 @@ struct SlArgs {
   float ln_eps;
   float* Y;             // [M, N]
   int M, N, K, Nw, f_off, relu;   // features [f_off, f_off + N) of the pre-split matrix
+  int add_features;               // Xadd applies to output features < add_features only (a multiple of 32; 0: to all) -- q, k = in_proj(tgt +
+                                  // pos) and v = in_proj(tgt) of a self-attention in one launch
 };
 
 typedef unsigned sl_u2 __attribute__((ext_vector_type(2)));
@@ -58,16 +61,26 @@ __global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const SlArg
   if (f0 >= N && !with_ln) return;                              // (no barrier below without the LayerNorm)
   const bool f_ok1 = f0 + 16 < N;                               // second feature block inside N (N % 16 == 0)
 
-  // ---- x: my row (clamped), my 8 k-values of a k-step at column 32 ks + 8 g
+  // ---- x: my row (clamped), my 8 k-values of a k-step at column 32 ks + 8 g.  Everything in this kernel is latency, so loads go out
+  // in batches: SL_XB k-steps of x at a time (all of it for K <= 256: read once and kept), SL_AHEAD k-steps of A fragments ahead
   const int m = min(row0 + j, M - 1);
   const float* xr = a.X + (long long)m * K + 8 * g;
-  const float* xa = a.Xadd ? a.Xadd + (long long)m * K + 8 * g : nullptr;
-  auto load_x = [&](int ks, f32x4& v0, f32x4& v1) __attribute__((always_inline)) {
-    v0 = *reinterpret_cast<const f32x4*>(xr + 32 * ks);
-    v1 = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
+  const float* xa = (a.Xadd && (a.add_features == 0 || f0 < a.add_features)) ? a.Xadd + (long long)m * K + 8 * g : nullptr;   // wave-uniform
+  f32x4 xb[SL_XB][2];
+  auto load_xb = [&](int kb) __attribute__((always_inline)) {   // k-steps kb .. kb + SL_XB - 1 (those < KS)
+#pragma unroll
+    for (int u = 0; u < SL_XB; ++u)
+      if (kb + u < KS) {
+        xb[u][0] = *reinterpret_cast<const f32x4*>(xr + 32 * (kb + u));
+        xb[u][1] = *reinterpret_cast<const f32x4*>(xr + 32 * (kb + u) + 4);
+      }
     if (xa) {
-      v0 += *reinterpret_cast<const f32x4*>(xa + 32 * ks);
-      v1 += *reinterpret_cast<const f32x4*>(xa + 32 * ks + 4);
+#pragma unroll
+      for (int u = 0; u < SL_XB; ++u)
+        if (kb + u < KS) {
+          xb[u][0] += *reinterpret_cast<const f32x4*>(xa + 32 * (kb + u));
+          xb[u][1] += *reinterpret_cast<const f32x4*>(xa + 32 * (kb + u) + 4);
+        }
     }
   };
   // ---- A fragments: units ((4 ks + g) * 2 + part) * Nw + f_off + f0 + 16 q + j
@@ -81,38 +94,51 @@ __global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const SlArg
     d[1][0] = f_ok1 ? p[16] : p[0];
     d[1][1] = f_ok1 ? p[a.Nw + 16] : p[a.Nw];
   };
+  load_xb(0);
 #pragma unroll
   for (int u = 0; u < SL_AHEAD; ++u)
     if (u < KS) load_a(u, afr[u]);
+  // the epilogue's operands, requested now
+  const int row = row0 + j;
+  const bool row_ok = row < M;
+  f32x4 e_wi[2], e_bi[2], e_res[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = f0 + 16 * q + 4 * g;
+    const bool ok = f < N;                                      // (N % 4 == 0)
+    const int fw = a.f_off + (ok ? f : 0);
+    e_wi[q] = *reinterpret_cast<const f32x4*>(a.winv + fw);
+    e_bi[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + fw) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    e_res[q] = (a.Res && ok) ? *reinterpret_cast<const f32x4*>(a.Res + (long long)m * N + f) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- pass 1: exact row maximum of the operand
   unsigned mx = 0u;
-  for (int ks = 0; ks < KS; ++ks) {
-    f32x4 v0, v1;
-    load_x(ks, v0, v1);
-    mx = max(mx, l3_absmax8(v0, v1));
+  for (int kb = 0; kb < KS; kb += SL_XB) {
+    if (kb > 0) load_xb(kb);
+#pragma unroll
+    for (int u = 0; u < SL_XB; ++u)
+      if (kb + u < KS) mx = max(mx, l3_absmax8(xb[u][0], xb[u][1]));
   }
   mx = l3_row_max(mx);
   float sx, sx_inv;
   l3_scale(mx, 14, sx, sx_inv);
 
-  // ---- pass 2: the product
+  // ---- pass 2: the product (K <= 32 SL_XB: x is still in registers)
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  f32x4 xv0, xv1;
-  load_x(0, xv0, xv1);
-  const int KSA = (KS + SL_AHEAD - 1) / SL_AHEAD * SL_AHEAD;
+  static_assert(SL_XB % SL_AHEAD == 0, "the ring slot of a k-step is a compile-time constant inside a batch");
 #pragma unroll 1
-  for (int kb = 0; kb < KSA; kb += SL_AHEAD) {
+  for (int kb = 0; kb < KS; kb += SL_XB) {
+    if (KS > SL_XB) load_xb(kb);
 #pragma unroll
-    for (int u = 0; u < SL_AHEAD; ++u) {
+    for (int u = 0; u < SL_XB; ++u) {
       const int ks = kb + u;
       if (ks < KS) {                                            // uniform
         f16x8 bh, bm;
-        l3_split8(xv0, xv1, sx, bh, bm);
-        if (ks + 1 < KS) load_x(ks + 1, xv0, xv1);
-        const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[u][0][0]), am0 = __builtin_bit_cast(f16x8, afr[u][0][1]);
-        const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[u][1][0]), am1 = __builtin_bit_cast(f16x8, afr[u][1][1]);
-        if (ks + SL_AHEAD < KS) load_a(ks + SL_AHEAD, afr[u]);
+        l3_split8(xb[u][0], xb[u][1], sx, bh, bm);
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[u % SL_AHEAD][0][0]), am0 = __builtin_bit_cast(f16x8, afr[u % SL_AHEAD][0][1]);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[u % SL_AHEAD][1][0]), am1 = __builtin_bit_cast(f16x8, afr[u % SL_AHEAD][1][1]);
+        if (ks + SL_AHEAD < KS) load_a(ks + SL_AHEAD, afr[u % SL_AHEAD]);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, bh, acc[0], 0, 0, 0);   // smallest terms first
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, bh, acc[1], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bm, acc[0], 0, 0, 0);
@@ -124,20 +150,15 @@ __global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const SlArg
   }
 
   // ---- epilogue: D[i = feature][j = row]: a lane holds features f0 + 16 q + 4 g ... + 3 of row j
-  const int row = row0 + j;
-  const bool row_ok = row < M;
   f32x4 v[2];
   float sm = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int f = f0 + 16 * q + 4 * g;
-    const bool ok = f < N;                                      // (N % 4 == 0)
-    const int fw = a.f_off + (ok ? f : 0);
-    const f32x4 wi = *reinterpret_cast<const f32x4*>(a.winv + fw);
-    f32x4 t = (acc[q] * sx_inv) * wi;
-    if (a.bias) t += *reinterpret_cast<const f32x4*>(a.bias + fw);
+    const bool ok = f < N;
+    f32x4 t = (acc[q] * sx_inv) * e_wi[q] + e_bi[q];
     if (a.relu) t = __builtin_elementwise_maximum(t, (f32x4){0.f, 0.f, 0.f, 0.f});   // NaN-propagating, as torch.relu
-    if (a.Res && ok) t += *reinterpret_cast<const f32x4*>(a.Res + (long long)m * N + f);
+    t += e_res[q];
     v[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
     sm += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
   }
@@ -184,17 +205,17 @@ __global__ __launch_bounds__(64 * SL_WAVES) void small_linear_kernel(const SlArg
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
 int small_linear_f32(const float* x, const float* xadd, const void* wp, const float* winv, const float* bias, int n_w, int f_off,
                      const float* residual, const float* ln_g, const float* ln_b, float ln_eps, float* y, long long M, int N, int K,
-                     int relu, hipStream_t st) {
+                     int relu, int add_features, hipStream_t st) {
   if (M <= 0 || N <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (K < 32 || K % 32 != 0 || N % 16 != 0 || n_w % 4 != 0 || f_off % 4 != 0 || f_off < 0 || f_off + N > n_w || M > 16LL * 65535 ||
-      (ln_g && N != 32 * SL_WAVES) || (ln_b && !ln_g) || mis(x) || mis(xadd) || mis(wp) || mis(winv) || mis(bias) || mis(residual) ||
+      (ln_g && N != 32 * SL_WAVES) || (ln_b && !ln_g) || add_features < 0 || add_features % 32 != 0 || mis(x) || mis(xadd) || mis(wp) || mis(winv) || mis(bias) || mis(residual) ||
       mis(ln_g) || mis(ln_b) || mis(y) || M * (long long)std::max(N, K) * 4 >= 0x7FFFFFFFLL)
     return UNIVS_ERR_NOT_IMPLEMENTED;
   SlArgs a{};
   a.X = x; a.Xadd = xadd; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = bias; a.Res = residual;
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.Y = y;
-  a.M = (int)M; a.N = N; a.K = K; a.Nw = n_w; a.f_off = f_off; a.relu = relu ? 1 : 0;
+  a.M = (int)M; a.N = N; a.K = K; a.Nw = n_w; a.f_off = f_off; a.relu = relu ? 1 : 0; a.add_features = add_features;
   dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 32 * SL_WAVES - 1) / (32 * SL_WAVES)));
   hipLaunchKernelGGL(small_linear_kernel, grid, dim3(64 * SL_WAVES), 0, st, a);
   return check_launch("small_linear_f32");

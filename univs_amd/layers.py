@@ -158,8 +158,15 @@ class MultiheadAttention(nn.Module):
             q, k, v = lin(query, 0, 3 * E).chunk(3, dim=-1)
         else:
             if query is key:      # self-attention with positional queries (q = k = tgt + pos, v = tgt): q and k in one projection
-                q, k = lin(query, 0, 2 * E, query_add).chunk(2, dim=-1)
-                v = lin(value, 2 * E, E)
+                qkv = None
+                if small and query_add is not None and value is query and E % 32 == 0:
+                    from . import ops   # ... and v in the same launch: the position embedding enters the first 2 E features only
+                    qkv = ops.small_linear(query, w, b, x_add=query_add, add_features=2 * E)
+                if qkv is not None:
+                    q, k, v = qkv.chunk(3, dim=-1)
+                else:
+                    q, k = lin(query, 0, 2 * E, query_add).chunk(2, dim=-1)
+                    v = lin(value, 2 * E, E)
             else:
                 q = lin(query, 0, E, query_add)
                 if key is value:
