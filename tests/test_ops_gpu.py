@@ -1085,7 +1085,7 @@ def test_tokens_from_nchw(cuda):
     (500, 256, 768, (512, 256), False, False, False, False),   # self-attention v
     (500, 256, 256, None, False, False, True, True),           # norm(tgt + out_proj(attn))
     (550, 256, 2048, None, False, True, False, False),         # relu(linear1(tgt))
-    (500, 2048, 256, None, False, False, True, True),          # norm(tgt + linear2(h))
+    (500, 512, 256, None, False, False, True, True),           # (K = 512: the widest the wrapper routes here)
     (2000, 256, 256, None, False, True, False, False),         # mask-embedding MLP at config 5's length
     (7, 64, 48, (16, 32), True, True, True, False), (1, 32, 16, None, False, False, False, False), (4096, 256, 256, None, True, False, True, True),
 ], ids=lambda v: str(v))

@@ -422,6 +422,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
 
 
 SMALL_LINEAR_MAX_ROWS = 4096
+SMALL_LINEAR_MAX_K = 512       # a wave walks K alone, four k-steps of weights ahead: 76 us at K = 2048 (the library: 18)
 
 
 def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residual=None, ln=None, add_features=0):
@@ -430,14 +431,14 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
     `norm(tgt + .)` behind (transformer_layers.py:30-46, :95-115, :150-166, :205-217).  `weight` [Nw, K] is split once and cached
     (as a whole: `rows` = (first, count) selects output features, e.g. the q / k / v thirds of `in_proj_weight`; `bias` [Nw] whole
     too); `ln` = (weight, bias, eps) needs 256 output features; `add_features`: x_add enters the first add_features outputs only (a
-    multiple of 32: q, k and v of a self-attention in one launch).  Returns None when not covered (more than 4096 rows, K % 32, N % 16,
+    multiple of 32: q, k and v of a self-attention in one launch).  Returns None when not covered (more than 4096 rows, K % 32, K > 512, N % 16,
     autograd needed): the caller keeps F.linear and the separate elementwise launches."""
     K = x.shape[-1]
     M = x.numel() // max(K, 1)
     Nw = weight.shape[0]
     f_off, N = (0, Nw) if rows is None else (int(rows[0]), int(rows[1]))
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.dim() != 2 or weight.shape[1] != K
-            or M < 1 or M > SMALL_LINEAR_MAX_ROWS or K % 32 != 0 or N % 16 != 0 or f_off % 4 != 0 or f_off + N > Nw
+            or M < 1 or M > SMALL_LINEAR_MAX_ROWS or K % 32 != 0 or K > SMALL_LINEAR_MAX_K or N % 16 != 0 or f_off % 4 != 0 or f_off + N > Nw
             or needs_grad(x, weight, bias, x_add, residual) or (ln is not None and N != 256) or add_features % 32 != 0):
         return None
     x2 = x.contiguous().view(M, K)
