@@ -1085,9 +1085,10 @@ def test_tokens_from_nchw(cuda):
     (500, 256, 768, (512, 256), False, False, False, False),   # self-attention v
     (500, 256, 256, None, False, False, True, True),           # norm(tgt + out_proj(attn))
     (550, 256, 2048, None, False, True, False, False),         # relu(linear1(tgt))
-    (500, 512, 256, None, False, False, True, True),           # (K = 512: the widest the wrapper routes here)
+    (300, 128, 256, None, True, True, True, True),
     (2000, 256, 256, None, False, True, False, False),         # mask-embedding MLP at config 5's length
     (7, 64, 48, (16, 32), True, True, True, False), (1, 32, 16, None, False, False, False, False), (4096, 256, 256, None, True, False, True, True),
+    (500, 256, 768, (0, 768), "qk", False, False, False),     # q, k (with the position embedding) and v (without) in one launch
 ], ids=lambda v: str(v))
 def test_small_linear_matches_torch(cuda, M, K, Nw, rows, add, relu, res, ln):
     """ops.small_linear (csrc/small_linear.hip: a few-rows Linear with `x + x_add` in front and ReLU / residual / LayerNorm behind, rows of
@@ -1105,12 +1106,15 @@ def test_small_linear_matches_torch(cuda, M, K, Nw, rows, add, relu, res, ln):
     be = 0.1 * synth.normal(tag + "/be", (N,))
     xd, xad, wd, bd, rd, gd, bed = (t.to(cuda) for t in (x, xa, w, b, r, g_, be))
     y = ops.small_linear(xd, wd, bd, rows=rows, x_add=xad if add else None, relu=relu, residual=rd if res else None,
-                         ln=(gd, bed, 1e-5) if ln else None)
+                         ln=(gd, bed, 1e-5) if ln else None, add_features=512 if add == "qk" else 0)
     assert y is not None and tuple(y.shape) == (M, N)
 
     def ref(dt):
         c = lambda t: t.to(dt)
-        t = F.linear(c(xd) + c(xad) if add else c(xd), c(wd)[f0:f0 + N], c(bd)[f0:f0 + N])
+        if add == "qk":
+            t = torch.cat([F.linear(c(xd) + c(xad), c(wd)[:512], c(bd)[:512]), F.linear(c(xd), c(wd)[512:], c(bd)[512:])], -1)
+        else:
+            t = F.linear(c(xd) + c(xad) if add else c(xd), c(wd)[f0:f0 + N], c(bd)[f0:f0 + N])
         if relu:
             t = F.relu(t)
         if res:

@@ -422,7 +422,7 @@ def mlp_fused(x, w1, b1, w2, b2, act, residual=None, ln=None, post_ln=None, post
 
 
 SMALL_LINEAR_MAX_ROWS = 4096
-SMALL_LINEAR_MAX_K = 512       # a wave walks K alone, four k-steps of weights ahead: 76 us at K = 2048 (the library: 18)
+SMALL_LINEAR_MAX_K = 256       # (a wave walks K alone, four k-steps of weights ahead: 76 us at K = 2048 against the library's 18)
 
 
 def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residual=None, ln=None, add_features=0):
@@ -431,7 +431,7 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
     `norm(tgt + .)` behind (transformer_layers.py:30-46, :95-115, :150-166, :205-217).  `weight` [Nw, K] is split once and cached
     (as a whole: `rows` = (first, count) selects output features, e.g. the q / k / v thirds of `in_proj_weight`; `bias` [Nw] whole
     too); `ln` = (weight, bias, eps) needs 256 output features; `add_features`: x_add enters the first add_features outputs only (a
-    multiple of 32: q, k and v of a self-attention in one launch).  Returns None when not covered (more than 4096 rows, K % 32, K > 512, N % 16,
+    multiple of 32: q, k and v of a self-attention in one launch).  Returns None when not covered (more than 4096 rows, K % 32, K > 256, N % 16,
     autograd needed): the caller keeps F.linear and the separate elementwise launches."""
     K = x.shape[-1]
     M = x.numel() // max(K, 1)
