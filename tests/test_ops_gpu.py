@@ -1053,6 +1053,13 @@ def test_deferred_attention_mask(cuda, T, Q, h, w):
             b = ops.cross_attention(q, k, v, eager, H, 32 ** -0.5)
             assert a is not None and torch.equal(a, b)
         assert torch.equal(dm.materialize(), eager)
+    # a deferred mask has to be consumed before the next one of its kind is produced: a stale one raises instead of reading flags
+    # that a newer generation has overwritten
+    first = ops.mask_decode_attn(med, feat, deferred=True)
+    second = ops.mask_decode_attn(med, feat, deferred=True)
+    with pytest.raises(RuntimeError):
+        first.materialize()
+    assert torch.equal(second.materialize(), eager)
 
 
 def test_tokens_from_nchw(cuda):

@@ -589,12 +589,15 @@ def mask_decode(mask_embed, mask_features):
 class DeferredMask:
     """An attention mask [T, Q, hw] (uint8, 1 = key masked out) whose all-masked-row rule (...decoder_univs.py:390) has NOT been applied
     to the bytes: row r counts only where flags[r] == gen, elsewhere every key is visible (include/univs_hip.h:
-    univs_mask_decode_attn_deferred_f32).  `cross_attention` consumes it as it is; `materialize()` gives the reference's bool tensor."""
-    __slots__ = ("mask", "flags", "gen", "_bool")
+    univs_mask_decode_attn_deferred_f32).  `cross_attention` consumes it as it is; `materialize()` gives the reference's bool tensor.
+    The flags buffer is shared by the masks of one (device, stream, row count): a mask has to be consumed before the NEXT deferred mask
+    of that kind is produced (the decoder's order: a layer's cross-attention runs before the next prediction head) -- consuming a
+    stale one raises instead of reading flags a newer generation has overwritten."""
+    __slots__ = ("mask", "flags", "gen", "_bool", "_entry")
     dtype = torch.bool
 
-    def __init__(self, mask, flags, gen):
-        self.mask, self.flags, self.gen, self._bool = mask, flags, gen, None
+    def __init__(self, mask, flags, gen, entry=None):
+        self.mask, self.flags, self.gen, self._bool, self._entry = mask, flags, gen, None, entry
 
     @property
     def shape(self):
@@ -607,8 +610,14 @@ class DeferredMask:
     def dim(self):
         return self.mask.dim()
 
+    def check_fresh(self):
+        if self._bool is None and self._entry is not None and self._entry[1] != self.gen:
+            raise RuntimeError("DeferredMask: a newer deferred mask of the same shape was produced on this stream before this one was "
+                               "consumed (its row flags are gone); materialize() it first, or ask for the eager form")
+
     def materialize(self):
         if self._bool is None:
+            self.check_fresh()
             T, Q, hw = self.mask.shape
             with _on(self.mask):
                 _lib.check(_lib.load().univs_attn_mask_rows_reset(_ptr(self.mask), _ptr(self.flags), self.gen, T * Q, hw,
@@ -647,7 +656,7 @@ def mask_decode_attn(mask_embed, feat_lowres, deferred=False):
             rc = _lib.load().univs_mask_decode_attn_deferred_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w, _ptr(mask),
                                                                  _ptr(e[0]), e[1], _stream_ptr(mask_embed))
         _lib.check(rc, "mask_decode_attn")
-        return DeferredMask(mask, e[0], e[1])
+        return DeferredMask(mask, e[0], e[1], e)
     ws = torch.empty((max(T * Q, 1),), dtype=torch.int32, device=mask_embed.device)
     with _on(mask_embed):
         rc = _lib.load().univs_mask_decode_attn_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w,
@@ -1077,7 +1086,11 @@ def cross_attention(q, k, v, mask, num_heads, scale):
     if isinstance(mask, DeferredMask):
         if tuple(mask.shape) != (N, L, S) or S % 4 != 0:
             return None
-        mask, flags, gen = mask.mask, mask.flags, mask.gen
+        if mask._bool is not None:                               # already made explicit: the bytes are the reference's tensor
+            mask = mask._bool.view(torch.uint8)
+        else:
+            mask.check_fresh()
+            mask, flags, gen = mask.mask, mask.flags, mask.gen
     elif mask is not None:
         if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8) or S % 4 != 0 or not mask.is_cuda:
             return None
