@@ -387,8 +387,10 @@ __global__ __launch_bounds__(256) void xattn_merge(const float* __restrict__ ws,
   const float* base = ws + ((((long long)chunk * N * H + nh) * nseg) * Lp + ql) * XA_PART;
   const long long pstride = (long long)Lp * XA_PART;
   float M = -INFINITY;
+#pragma unroll 8                                                 // (independent loads in flight: the kernel is pure latency)
   for (int p = 0; p < nseg; ++p) M = fmaxf(M, base[p * pstride + 32]);
   float acc = 0.f, l = 0.f;
+#pragma unroll 8
   for (int p = 0; p < nseg; ++p) {
     const float f = __builtin_amdgcn_exp2f(base[p * pstride + 32] - M);
     acc = fmaf(base[p * pstride + c], f, acc);
