@@ -303,11 +303,13 @@ int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv
  *   x, x_add | NULL [M, K]; residual | NULL [M, N]; ln_weight | NULL, ln_bias | NULL [N] (with ln_weight: N == 256); y [M, N]
  *   add_features: x_add enters the first add_features output features only (a multiple of 32; 0 = all) -- a self-attention's
  *                 q, k = in_proj(tgt + query_pos) and v = in_proj(tgt) as ONE launch over the packed in-projection
- *   K % 32 == 0, N % 16 == 0, f_off % 4 == 0, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
+ *   out_T > 0 (no residual / LayerNorm): the M rows are (q, t) pairs, q-major, t < out_T; the result of row (q, t) is stored at row
+ *                 (t, q): `mask_embed(decoder_output)` [Q', T, C] handed on as [T, Q', C] without a transposed copy
+ *   K % 32 == 0, K <= 256, N % 16 == 0, f_off % 4 == 0, 16-byte aligned pointers; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
  * ------------------------------------------------------------------------------------------- */
 int univs_small_linear_presplit_f32(const float* x, const float* x_add, const void* wp, const float* winv, const float* bias, int n_w,
                                     int f_off, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
-                                    long long M, int N, int K, int relu, int add_features, float* y, void* stream);
+                                    long long M, int N, int K, int relu, int add_features, int out_T, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y[M, C] = act(LN(x)[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16

@@ -1134,6 +1134,12 @@ def test_small_linear_matches_torch(cuda, M, K, Nw, rows, add, relu, res, ln):
     # leading dimensions are kept; no bias; shapes that are not covered
     y3 = ops.small_linear(xd.view(1, M, K), wd, None, rows=rows)
     assert tuple(y3.shape) == (1, M, N)
+    if M % 5 == 0 and not res and not ln:
+        # rows as (q, t) pairs handed back as [t, q]: the mask embeddings' layout change inside the kernel's store
+        yt = ops.small_linear(xd.view(M // 5, 5, K), wd, bd, rows=rows, x_add=xad.view(M // 5, 5, K) if add is True else None, relu=relu,
+                              transpose01=True)
+        if add is True or not add:
+            assert tuple(yt.shape) == (5, M // 5, N) and yt.is_contiguous() and torch.equal(yt, y.view(M // 5, 5, N).transpose(0, 1))
     assert ops.small_linear(torch.zeros(5000, K, device=cuda), wd, bd) is None           # too many rows (the tall kernels' job)
     assert ops.small_linear(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd) is None or (K - 8) % 32 == 0
 

@@ -74,7 +74,7 @@ int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const v
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
 int small_linear_f32(const float*, const float*, const void*, const float*, const float*, int, int, const float*, const float*, const float*,
-                     float, float*, long long, int, int, int, int, hipStream_t);
+                     float, float*, long long, int, int, int, int, int, hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
 int conv1x1_f16x3_f32(const float*, const void*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int window_attention_image_f16mma(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
@@ -297,7 +297,7 @@ int univs_mlp_presplit_v2_f32(const float* x, const void* w1p, const float* w1in
 
 int univs_small_linear_presplit_f32(const float* x, const float* x_add, const void* wp, const float* winv, const float* bias, int n_w,
                                     int f_off, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
-                                    long long M, int N, int K, int relu, int add_features, float* y, void* stream) {
+                                    long long M, int N, int K, int relu, int add_features, int out_T, float* y, void* stream) {
   clear_sticky_error();
   if (M < 0 || N < 0 || K < 1 || n_w < 1 || f_off < 0 || f_off + N > n_w) {
     set_error("univs_small_linear_presplit_f32: bad arguments M=%lld N=%d K=%d n_w=%d f_off=%d", M, N, K, n_w, f_off);
@@ -309,7 +309,7 @@ int univs_small_linear_presplit_f32(const float* x, const float* x_add, const vo
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   const int rc = univs::small_linear_f32(x, x_add, wp, winv, bias, n_w, f_off, residual, ln_weight, ln_bias, ln_eps, y, M, N, K, relu,
-                                         add_features, static_cast<hipStream_t>(stream));
+                                         add_features, out_T, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_small_linear_presplit_f32: M=%lld N=%d K=%d not covered (K %% 32 == 0, N %% 16 == 0, f_off %% 4 == 0, with a LayerNorm "
               "N == 256, M <= 1 048 560, 16-byte aligned pointers)", M, N, K);

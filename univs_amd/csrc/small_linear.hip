@@ -41,6 +41,8 @@ struct SlArgs {
   float ln_eps;
   float* Y;             // [M, N]
   int M, N, K, Nw, f_off, relu;   // features [f_off, f_off + N) of the pre-split matrix
+  int out_T;                      // > 0: rows are (q, t) pairs, q-major with T = out_T; row (q, t) of the result is stored at (t, q) -- the
+                                  // mask embeddings [Q', T, C] handed on as [T, Q', C] (...decoder_univs.py:527) without a copy of its own
   int add_features;               // Xadd applies to output features < add_features only (a multiple of 32; 0: to all) -- q, k = in_proj(tgt +
                                   // pos) and v = in_proj(tgt) of a self-attention in one launch
 };
@@ -224,27 +226,28 @@ __global__ __launch_bounds__(64 * SL_WAVES, 3) void small_linear_kernel(const Sl
       v[q] = y;
     }
   }
+  const int orow = a.out_T > 0 ? (row % a.out_T) * (M / a.out_T) + row / a.out_T : row;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int f = f0 + 16 * q + 4 * g;
-    if (row_ok && f < N) *reinterpret_cast<f32x4*>(a.Y + (long long)row * N + f) = v[q];
+    if (row_ok && f < N) *reinterpret_cast<f32x4*>(a.Y + (long long)orow * N + f) = v[q];
   }
 }
 
 // returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered
 int small_linear_f32(const float* x, const float* xadd, const void* wp, const float* winv, const float* bias, int n_w, int f_off,
                      const float* residual, const float* ln_g, const float* ln_b, float ln_eps, float* y, long long M, int N, int K,
-                     int relu, int add_features, hipStream_t st) {
+                     int relu, int add_features, int out_T, hipStream_t st) {
   if (M <= 0 || N <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (K < 32 || K % 32 != 0 || K > SL_KMAX || N % 16 != 0 || n_w % 4 != 0 || f_off % 4 != 0 || f_off < 0 || f_off + N > n_w || M > 16LL * 65535 ||
-      (ln_g && N != 32 * SL_WAVES) || (ln_b && !ln_g) || add_features < 0 || add_features % 32 != 0 || mis(x) || mis(xadd) || mis(wp) || mis(winv) || mis(bias) || mis(residual) ||
+      (ln_g && N != 32 * SL_WAVES) || (ln_b && !ln_g) || add_features < 0 || add_features % 32 != 0 || out_T < 0 || (out_T > 0 && (M % out_T != 0 || residual || ln_g)) || mis(x) || mis(xadd) || mis(wp) || mis(winv) || mis(bias) || mis(residual) ||
       mis(ln_g) || mis(ln_b) || mis(y) || M * (long long)std::max(N, K) * 4 >= 0x7FFFFFFFLL)
     return UNIVS_ERR_NOT_IMPLEMENTED;
   SlArgs a{};
   a.X = x; a.Xadd = xadd; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = bias; a.Res = residual;
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.Y = y;
-  a.M = (int)M; a.N = N; a.K = K; a.Nw = n_w; a.f_off = f_off; a.relu = relu ? 1 : 0; a.add_features = add_features;
+  a.M = (int)M; a.N = N; a.K = K; a.Nw = n_w; a.f_off = f_off; a.relu = relu ? 1 : 0; a.add_features = add_features; a.out_T = out_T;
   dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 32 * SL_WAVES - 1) / (32 * SL_WAVES)));
   const size_t lds = (size_t)2 * 2 * (K / 32) * 64 * 16;        // two operand tiles (x + x_add, x), two parts each
   hipLaunchKernelGGL(small_linear_kernel, grid, dim3(64 * SL_WAVES), lds, st, a);

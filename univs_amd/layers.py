@@ -229,11 +229,20 @@ class MLP(nn.Module):
         h = [hidden_dim] * (num_layers - 1)
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
-    def forward(self, x):
+    def forward(self, x, transpose01=False):
+        """`transpose01`: x is [A, B, C]; the result comes back as [B, A, C'] -- contiguous where the last Linear's kernel writes it that
+        way (few rows on the GPU), a transposed view otherwise"""
         for i, layer in enumerate(self.layers):
             # hidden layers: the ReLU rides in the GEMM epilogue on the GPU (linear_act: one launch instead of GEMM + bias + clamp)
-            x = linear_act(x, layer, F.relu) if i < self.num_layers - 1 else linear(x, layer.weight, layer.bias)
-        return x
+            if i < self.num_layers - 1:
+                x = linear_act(x, layer, F.relu)
+            elif transpose01 and x.is_cuda and x.dim() == 3 and _small(x, layer.weight, layer.bias):
+                from . import ops
+                y = ops.small_linear(x, layer.weight, layer.bias, transpose01=True)
+                return y if y is not None else linear(x, layer.weight, layer.bias).transpose(0, 1)
+            else:
+                x = linear(x, layer.weight, layer.bias)
+        return x.transpose(0, 1) if transpose01 else x
 
 
 def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):

@@ -432,7 +432,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             outputs_class = mean_over_frames(outputs_class)
             outputs_class = torch.einsum("bqc,bkc->bqk", outputs_class, clip_exp)
 
-        mask_embed = self.mask_embed(decoder_qt).transpose(0, 1)    # [T, Q', C] (a view; made contiguous below)
+        mask_embed = self.mask_embed(decoder_qt, transpose01=True)  # [T, Q', C] (written that way by the last Linear's kernel, or a view)
         outputs_reid = [None] * bs
         if self.prompt_as_queries and task == "grounding":
             assert len(targets) == 1, "Only support bacth size is 1 now"

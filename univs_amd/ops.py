@@ -425,13 +425,14 @@ SMALL_LINEAR_MAX_ROWS = 4096
 SMALL_LINEAR_MAX_K = 256       # (a wave walks K alone, four k-steps of weights ahead: 76 us at K = 2048 against the library's 18)
 
 
-def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residual=None, ln=None, add_features=0):
+def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residual=None, ln=None, add_features=0, transpose01=False):
     """act((x [+ x_add]) W[rows]^T + bias[rows]) [+ residual] [-> LayerNorm] for a FEW tokens in one launch (include/univs_hip.h:
     univs_small_linear_presplit_f32; csrc/small_linear.hip): the decoder's per-token Linears with `tgt + query_pos` in front and
     `norm(tgt + .)` behind (transformer_layers.py:30-46, :95-115, :150-166, :205-217).  `weight` [Nw, K] is split once and cached
     (as a whole: `rows` = (first, count) selects output features, e.g. the q / k / v thirds of `in_proj_weight`; `bias` [Nw] whole
     too); `ln` = (weight, bias, eps) needs 256 output features; `add_features`: x_add enters the first add_features outputs only (a
-    multiple of 32: q, k and v of a self-attention in one launch).  Returns None when not covered (more than 4096 rows, K % 32, K > 256, N % 16,
+    multiple of 32: q, k and v of a self-attention in one launch); `transpose01` (x [A, B, K], no residual / LayerNorm): the result comes
+    back as [B, A, N] contiguous (the mask embeddings [Q', T, C] -> [T, Q', C]).  Returns None when not covered (more than 4096 rows, K % 32, K > 256, N % 16,
     autograd needed): the caller keeps F.linear and the separate elementwise launches."""
     K = x.shape[-1]
     M = x.numel() // max(K, 1)
@@ -439,7 +440,8 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
     f_off, N = (0, Nw) if rows is None else (int(rows[0]), int(rows[1]))
     if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or weight.dim() != 2 or weight.shape[1] != K
             or M < 1 or M > SMALL_LINEAR_MAX_ROWS or K % 32 != 0 or K > SMALL_LINEAR_MAX_K or N % 16 != 0 or f_off % 4 != 0 or f_off + N > Nw
-            or needs_grad(x, weight, bias, x_add, residual) or (ln is not None and N != 256) or add_features % 32 != 0):
+            or needs_grad(x, weight, bias, x_add, residual) or (ln is not None and N != 256) or add_features % 32 != 0
+            or (transpose01 and (x.dim() != 3 or residual is not None or ln is not None))):
         return None
     x2 = x.contiguous().view(M, K)
     xa = None
@@ -463,13 +465,14 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
                 return None
         if lw is None:
             return None
-    y = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    oshape = (x.shape[1], x.shape[0], N) if transpose01 else tuple(x.shape[:-1]) + (N,)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
     with _on(x):
         wp, winv = presplit_weights(weight)
         rc = _lib.load().univs_small_linear_presplit_f32(
             _ptr(x2), _ptr(xa) if xa is not None else None, _ptr(wp), _ptr(winv), _ptr(bias) if bias is not None else None, Nw, f_off,
             _ptr(r) if r is not None else None, _ptr(lw) if lw is not None else None, _ptr(lb) if lb is not None else None, float(leps),
-            M, N, K, 1 if relu else 0, int(add_features), _ptr(y), _stream_ptr(x2))
+            M, N, K, 1 if relu else 0, int(add_features), int(x.shape[1]) if transpose01 else 0, _ptr(y), _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "small_linear")
