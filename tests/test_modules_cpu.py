@@ -173,3 +173,50 @@ def test_g2_msdeformattn_layer_matches_reference(golden_dir):
     pd = helpers.build_pixel_decoder(cases.HEAD_CASE["shapes"])
     with cpu_ops(), torch.no_grad():
         helpers.check_g2(pd, g, "cpu")
+
+
+def test_attention_layers_match_torch_nn():
+    """layers.MultiheadAttention with the arguments the decoder layers now pass (`query_add`: the position embedding added inside the
+    projection; `residual` + `norm`: the post-norm tail inside the output projection; precomputed key / value projections) against
+    torch.nn.MultiheadAttention + nn.LayerNorm composed as the reference composes them (transformer_layers.py:30-46, :95-115), and
+    layers.MLP(transpose01=True) against its own transposed result -- the host-side wiring of the few-rows kernels, on the CPU path."""
+    from univs_amd import layers
+    from univs_amd.modeling.transformer_decoder import transformer_layers as tl
+    torch.manual_seed(0)
+    E, H, L, S, N = 64, 2, 10, 24, 3
+    ref = torch.nn.MultiheadAttention(E, H).eval()
+    norm = torch.nn.LayerNorm(E).eval()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.2, 0.2)
+    tgt, pos = torch.randn(L, N, E), torch.randn(L, N, E)
+    mem, mpos = torch.randn(S, N, E), torch.randn(S, N, E)
+    with cpu_ops(), torch.no_grad():
+        # self-attention, post-norm: norm(tgt + attn(q = k = tgt + pos, v = tgt))
+        sa = tl.SelfAttentionLayer(E, H).eval()
+        sa.self_attn.load_state_dict(ref.state_dict())
+        sa.norm.load_state_dict(norm.state_dict())
+        mask = torch.rand(L, L) < 0.3
+        mask[torch.arange(L), torch.arange(L)] = False
+        want = norm(tgt + ref(tgt + pos, tgt + pos, tgt, attn_mask=mask)[0])
+        assert (sa(tgt, tgt_mask=mask, query_pos=pos) - want).abs().max() < 1e-5
+        assert (sa(tgt, tgt_mask=mask) - norm(tgt + ref(tgt, tgt, tgt, attn_mask=mask)[0])).abs().max() < 1e-5
+        # cross-attention, post-norm, per-frame masks shared by the heads; key = memory + pos given; then with precomputed K / V projections
+        ca = tl.CrossAttentionLayer(E, H).eval()
+        ca.multihead_attn.load_state_dict(ref.state_dict())
+        ca.norm.load_state_dict(norm.state_dict())
+        cm = torch.rand(N, L, S) < 0.4
+        cm[:, :, 0] = False
+        want = norm(tgt + ref(tgt + pos, mem + mpos, mem, attn_mask=cm.repeat_interleave(H, 0))[0])
+        got = ca(tgt, mem, memory_mask=cm, pos=mpos, query_pos=pos)
+        assert (got - want).abs().max() < 1e-5
+        w, b = ref.in_proj_weight, ref.in_proj_bias
+        kv = (torch.nn.functional.linear(mem + mpos, w[E:2 * E], b[E:2 * E]), torch.nn.functional.linear(mem, w[2 * E:], b[2 * E:]))
+        assert (ca(tgt, mem, memory_mask=cm, query_pos=pos, kv=kv) - want).abs().max() < 1e-5
+        # the FFN's post-norm tail and the mask-embedding MLP's transposed result
+        ffn = tl.FFNLayer(E, 128).eval()
+        x = torch.randn(L, N, E)
+        want = ffn.norm(x + ffn.linear2(torch.relu(ffn.linear1(x))))
+        assert (ffn(x) - want).abs().max() < 1e-5
+        mlp = layers.MLP(E, E, 32, 3).eval()
+        assert torch.equal(mlp(x, transpose01=True), mlp(x).transpose(0, 1))
