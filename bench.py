@@ -288,9 +288,10 @@ def run(args):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "arithmetic": "fp32 I/O and fp32 accumulation everywhere; Linears / MLPs / 3x3 convolution / 7x7 window attention multiply on "
-                      "the fp16 matrix cores as THREE products of two-part fp16 splits (f16x3: ~22-bit effective mantissa, error <= "
-                      "2^-21.7 per product); mask decode as six bf16 products (bf16x6); decoder attention GEMMs in the library's fp32",
+        "arithmetic": "fp32 I/O and fp32 accumulation everywhere; Linears / MLPs / 1x1 and 3x3 convolutions / 7x7 window attention / the "
+                      "decoder's attention (scores and P V) and per-token Linears multiply on the fp16 matrix cores as THREE products of "
+                      "two-part fp16 splits (f16x3: ~22-bit effective mantissa, error <= 2^-21.7 per product); mask decode as six bf16 "
+                      "products (bf16x6); the decoder FFN's second Linear and the class head in the library's fp32",
         "data": "synthetic",
         "config": {"workload": "BASELINE config 2: Swin-T UniVS, T=5 @ 720p (736x1280 padded), 100 queries, "
                                "first clip (no prompt queries); one clip per GPU",
