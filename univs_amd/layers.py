@@ -88,6 +88,18 @@ class Conv2d(nn.Conv2d):
         return x
 
 
+def to_device_async(t, device):
+    """Host tensor -> device without blocking the host on the stream: a pageable H2D copy is issued in stream order and waited for, i.e.
+    the host stalls until everything enqueued before it has run (the decoder's `frame_indices.to(device)` waited for the whole backbone
+    and pixel decoder: 3.7 of the 13 ms a clip took to enqueue, profiles/r04_host_cprofile_step_v1.txt).  Pinned staging + non_blocking."""
+    device = torch.device(device)
+    if t.device == device:
+        return t
+    if device.type != "cuda" or t.is_cuda:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def get_norm(norm, out_channels):
     """detectron2.layers.get_norm for the values the hot path uses ("GN" = GroupNorm(32), "" = none)."""
     if norm is None or norm == "":

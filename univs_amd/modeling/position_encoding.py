@@ -14,6 +14,8 @@ import math
 import torch
 from torch import nn
 
+from ..layers import to_device_async
+
 
 def _dim_t(num_feats, temperature, device):
     i = torch.arange(num_feats, dtype=torch.float32, device=device)
@@ -160,7 +162,7 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
     def _z(self, b, t, dev, t_indices):
         if t_indices is None:
             t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
-        return t_indices.to(dev) / self.num_max_frames * self.scale  # [b, t]
+        return to_device_async(t_indices, dev) / self.num_max_frames * self.scale  # [b, t]
 
     def forward(self, x, t_indices=None, mask=None):
         assert x.dim() == 5 and mask is None
@@ -183,5 +185,5 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
         assert t_indices.nelement() == 1 or t_indices.nelement() == t, "Unvalid length for frame indices"
         if t_indices.nelement() == 1:
             t_indices = t_indices.reshape(1).repeat(t)
-        z = t_indices.to(dev).reshape(t) / self.num_max_frames * self.scale
+        z = to_device_async(t_indices, dev).reshape(t) / self.num_max_frames * self.scale
         return self._points(z, xy_embed_normalized)

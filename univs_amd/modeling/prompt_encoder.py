@@ -19,7 +19,7 @@ Known quirk kept on purpose: the "avoid NaN" block multiplies by `isblank` inste
 import torch
 import torch.nn.functional as F
 
-from ..layers import point_sample
+from ..layers import point_sample, to_device_async
 from ..switches import SWITCHES
 from .position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
 
@@ -64,20 +64,13 @@ def convert_mask_to_box(masks):
     return out.reshape(*shape[:-2], 4) if len(shape) > 2 else out[0]
 
 
-def _to_device_async(t, device):
-    """Host tensor -> device without blocking the host on the stream (pinned staging + non_blocking copy)."""
-    if device.type != "cuda":
-        return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
-
-
 def _ints_to_device(vals, device):
     """python ints / 0-dim tensors -> int64 [len] on `device` without a blocking copy (a pageable H2D copy waits for the
     whole stream; `int()` of a device tensor does too)."""
     if all(isinstance(v, torch.Tensor) and v.device == device for v in vals):
         return torch.stack([v.reshape(()) for v in vals]).to(torch.int64)
     if all(not (isinstance(v, torch.Tensor) and v.is_cuda) for v in vals):
-        return _to_device_async(torch.tensor([int(v) for v in vals], dtype=torch.int64), device)
+        return to_device_async(torch.tensor([int(v) for v in vals], dtype=torch.int64), device)
     return torch.stack([torch.as_tensor(v).reshape(()).to(device, non_blocking=True) for v in vals]).to(torch.int64)
 
 
@@ -290,8 +283,8 @@ class VisualPromptEncoder:
             assert self._replay, "sampler replay: more get_mask_prompt calls than recorded draws"
             point_idx, replay_feat_idx = self._replay.popleft()
             assert point_idx.shape[0] == n and replay_feat_idx.shape[0] == n, "sampler replay: entity count differs from the recording"
-            point_idx = _to_device_async(point_idx.to(torch.int64), device)
-            replay_feat_idx = _to_device_async(replay_feat_idx.to(torch.int64), device)
+            point_idx = to_device_async(point_idx.to(torch.int64), device)
+            replay_feat_idx = to_device_async(replay_feat_idx.to(torch.int64), device)
             counts = [None] * (2 * n)
             point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
         elif self.sampler_rng == "device":
@@ -369,8 +362,8 @@ class VisualPromptEncoder:
             rec = [self._replay.popleft() for _ in range(Fk)]
             assert all(r[0].shape[0] == n and tuple(r[1].shape) == (n, R) for r in rec), \
                 "sampler replay: entity count differs from the recording"
-            point_idx = _to_device_async(torch.cat([r[0].to(torch.int64) for r in rec]), device)
-            dense_idx = _to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
+            point_idx = to_device_async(torch.cat([r[0].to(torch.int64) for r in rec]), device)
+            dense_idx = to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
             empty = (dense_idx[:, :1] < 0).view(-1, 1, 1)
             dense_idx = dense_idx.clamp(min=0)
         elif self.sampler_rng == "device":
@@ -402,7 +395,7 @@ class VisualPromptEncoder:
                         rows_d.append(torch.cat([torch.arange(c).repeat(int(R / c) + 1)[:R], torch.zeros(1, dtype=torch.int64)]))
                     else:
                         rows_d.append(torch.cat([torch.randperm(c)[:R], torch.zeros(1, dtype=torch.int64)]))
-            tab = _to_device_async(torch.cat([torch.stack(rows_d), torch.stack(rows_p)], dim=1), device)   # one transfer
+            tab = to_device_async(torch.cat([torch.stack(rows_d), torch.stack(rows_p)], dim=1), device)   # one transfer
             point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), tab[:, R + 1:], pre["rowcnt"].reshape(N, h))[:, 0]
             dense_idx = _kth_true(m, tab[:, :R])
             empty = (tab[:, R] != 0).view(-1, 1, 1)
@@ -520,7 +513,7 @@ class VisualPromptEncoder:
                 ranks = (u * cnt[:, None]).long().clamp(max=cnt[:, None] - 1)
             else:
                 # same generator calls, in the same order, as the reference's per-entity loop (prompt_encoder.py:463-474)
-                ranks = _to_device_async(torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]), device)
+                ranks = to_device_async(torch.stack([torch.randperm(int(c)).repeat(num_points)[:num_points] for c in counts]), device)
             idx = _kth_true_2d(sel, ranks, rowcnt)                 # [n, num_points] flat pixel indices
             point_coords = torch.stack([((idx % w).float() + 0.5) / w, ((idx // w).float() + 0.5) / h], dim=-1)
         else:
@@ -578,7 +571,7 @@ class VisualPromptEncoder:
                 rows.append(torch.randperm(c)[:R])
         # one async transfer: the rank table plus a column flagging empty entities
         host = torch.cat([torch.stack(rows), torch.tensor([[int(int(c) == 0)] for c in counts], dtype=torch.int64)], dim=1)
-        dev_tab = _to_device_async(host, m.device)
+        dev_tab = to_device_async(host, m.device)
         idx = _kth_true(m, dev_tab[:, :R])                        # [n, R] flat feature-map indices
         empty = (dev_tab[:, R] != 0).view(-1, 1, 1)
         self._last_dense = (idx, empty.view(-1))

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
-from ...layers import Conv2d, fp32_region
+from ...layers import Conv2d, fp32_region, to_device_async
 from ...registry import TRANSFORMER_DECODER_REGISTRY, configurable
 from ...switches import SWITCHES
 from ..position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
@@ -235,7 +235,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             targets = [{"task": "detection", "dataset_name": self.default_dataset_name, "prompt_type": "visual",
                         "num_frames": t_total, "first_frame_idx": 0, "frame_indices": torch.arange(t_total, device=dev)}]
         if "frame_indices" in targets[0]:
-            frame_indices = torch.stack([tv["frame_indices"] for tv in targets]).to(dev)
+            frame_indices = to_device_async(torch.stack([tv["frame_indices"] for tv in targets]), dev)   # (no host stall on the stream)
         else:
             frame_indices = torch.arange(t_total, device=dev)[None].repeat(bs, 1)
         if fs is not None:
