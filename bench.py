@@ -38,7 +38,12 @@ import subprocess
 import sys
 import time
 
-import torch
+# dmabuf IPC: RCCL (and CUDA-tensor sharing across processes) needs it on this host driver.  Set before the HIP / HSA runtime
+# can initialise -- i.e. before `import torch` -- so that it holds however the ranks were started (the driver's
+# `python -m torch.distributed.run ... bench.py`, our own relaunch, or a single process).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -87,6 +92,7 @@ def init_distributed(args):
                          f"{args.gpus} GPUs")
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (see the top of the file; kept here for callers that import this function)
         # one process per GPU on one node: share the host cores instead of N x all-cores thread pools
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         if args.dry_run:

@@ -661,7 +661,10 @@ def test_cross_attention_ranges_and_module_path(cuda):
     k = synth.normal("xa2/k", (S, N, E))
     v = synth.normal("xa2/v", (S, N, E))
     scale = 32 ** -0.5
-    for name, sq, sk, sv, tol in (("large v", 1.0, 1.0, 1.0e6, 2e-5), ("large k, small q", 1.0e-5, 1.0e5, 1.0, 2e-5),
+    # small v: a block whose |v| < 2^-4 throughout is range-scaled UP; the scale is undone in fp32 on the block's P V' (ADVICE r04:
+    # undoing it on the probabilities flushed them to fp16 subnormals -- 10 % error at |v| ~ 1e-2, zeros at 1e-5)
+    for name, sq, sk, sv, tol in (("large v", 1.0, 1.0, 1.0e6, 2e-5), ("small v 1e-2", 1.0, 1.0, 1.0e-2, 2e-5), ("small v 1e-3", 1.0, 1.0, 1.0e-3, 2e-5),
+                                  ("small v 1e-6", 1.0, 1.0, 1.0e-6, 2e-5), ("large k, small q", 1.0e-5, 1.0e5, 1.0, 2e-5),
                                   ("large q, small k", 3.0e5, 2.0e-6, 1.0, 2e-5), ("sharp scores", 6.0, 6.0, 1.0, 1e-4)):
         a = [(q * sq).to(cuda), (k * sk).to(cuda), (v * sv).to(cuda)]
         got = ops.cross_attention(a[0], a[1], a[2], None, H, scale)
@@ -669,6 +672,14 @@ def test_cross_attention_ranges_and_module_path(cuda):
         err = ((got.double() - ref).abs().max() / ref.abs().max()).item()
         print(f"cross attention, {name}: relative max error {err:.2e}")
         assert torch.isfinite(got).all() and err < tol, (name, err)
+    # v with scaled and unscaled 32-key blocks side by side in every segment (magnitude by key block)
+    blk = (torch.arange(S) // 32) % 3
+    vmix = v * torch.tensor([1.0, 1.0e-3, 3.0e-6])[blk].view(S, 1, 1)
+    got = ops.cross_attention(q.to(cuda), k.to(cuda), vmix.to(cuda), None, H, scale)
+    ref = _xattn_reference(q.to(cuda), k.to(cuda), vmix.to(cuda), None, H, scale)
+    err = ((got.double() - ref).abs().max() / ref.abs().max()).item()
+    print(f"cross attention, mixed v blocks: relative max error {err:.2e}")
+    assert err < 2e-5, err
     # k / v as column slices of wider projections (one Linear for the keys of several layers): same result as dense copies
     wide_k = torch.cat([synth.normal("xa2/wk0", (S, N, E)), k, synth.normal("xa2/wk2", (S, N, E))], -1).to(cuda)
     wide_v = torch.cat([v, synth.normal("xa2/wv1", (S, N, 2 * E))], -1).to(cuda)
@@ -725,7 +736,10 @@ def test_window_attention_f16x3_out_of_range_operands(cuda, B, H, W, ws, shift, 
     assert torch.isfinite(ok).all()
     # (tolerance of "k and v beyond 65504": its scores are ~700 x larger than usual, ~2 000 in the exp2 domain, where fp32's own
     # resolution of a score is 1.2e-4 -- both kernels carry that error against the exact result)
-    for name, sq, sk, sv, tol in (("large v", 1.0, 1.0, 1.0e6, 2e-5), ("large k, small q", 1.0e-5, 1.0e5, 1.0, 2e-5),
+    # small v: a block whose |v| < 2^-4 throughout is range-scaled UP; the scale is undone in fp32 on the block's P V' (ADVICE r04:
+    # undoing it on the probabilities flushed them to fp16 subnormals -- 10 % error at |v| ~ 1e-2, zeros at 1e-5)
+    for name, sq, sk, sv, tol in (("large v", 1.0, 1.0, 1.0e6, 2e-5), ("small v 1e-2", 1.0, 1.0, 1.0e-2, 2e-5), ("small v 1e-3", 1.0, 1.0, 1.0e-3, 2e-5),
+                                  ("small v 1e-6", 1.0, 1.0, 1.0e-6, 2e-5), ("large k, small q", 1.0e-5, 1.0e5, 1.0, 2e-5),
                                   ("large q, small k", 3.0e5, 2.0e-6, 1.0, 2e-5), ("k and v beyond 65504", 1.0e-2, 7.0e4, 7.0e4, 5e-4),
                                   ("one huge channel", 1.0, 1.0, 1.0, 2e-5)):
         q2 = qkv.clone()

@@ -31,20 +31,57 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(HERE, "..", "include"), *srcs, "-o", LIB + ".tmp"]
+def _flags(defines=()):
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+            "-I", os.path.join(HERE, "..", "include"), *[f"-D{d}" for d in defines]]
+
+
+def build(force=False, verbose=True, lib=LIB, defines=(), tag=""):
+    """One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one link.
+    `defines` / `tag` / `lib`: instrumented builds of the same sources for timing experiments (tools/gpu_runs)."""
+    if not force and not defines and not needs_build():
+        return lib
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "_obj" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def compile_one(s):
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [hipcc, *_flags(defines), "-c", src, "-o", obj]
+        if verbose:
+            print("[univs_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", *objs, "-o", lib + ".tmp"]
     if verbose:
         print("[univs_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
+ABLATIONS = {"nosplit": ("UNIVS_ABLATE_NOSPLIT",), "nomfma": ("UNIVS_ABLATE_NOMFMA",),
+             "nosplit_nomfma": ("UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA")}
+
+
+def build_ablation(name, verbose=False):
+    """libunivs_hip_<name>.so beside the product library: the same sources with a timing-experiment define (csrc/f16x3.h).
+    Loaded through UNIVS_HIP_LIB by tools/kbench.py; never by the product."""
+    lib = os.path.join(HERE, f"libunivs_hip_{name}.so")
+    return build(force=False, verbose=verbose, lib=lib, defines=ABLATIONS[name], tag="_" + name)
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--ablate" in sys.argv:
+        print(build_ablation(sys.argv[sys.argv.index("--ablate") + 1]))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

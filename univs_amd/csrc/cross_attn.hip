@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       }
     }
 
+    const bool v_scaled = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sv_inv)) != 0x3f800000;   // scalar
     // ---- V^T fragments of this iteration: B[channel 16 half + j][k-slots: keys 4 g + e, 16 + 4 g + e], two parts
     __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): this wave's LDS writes are visible to its own reads
     __builtin_amdgcn_wave_barrier();
@@ -338,18 +339,20 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
         for (int r = 0; r < 4; ++r) {
           const float e = __builtin_amdgcn_exp2f(sc[kb][r] - mref[qb]);   // exp2(-inf) = 0 for masked keys
           part += e;
-          pv[4 * kb + r] = e * sv_inv;                           // V's range scale undone on the probabilities (exact)
+          pv[4 * kb + r] = e;                                    // in (0, 2^8]: never scaled (V's range scale is undone in fp32 below)
         }
       lsum[qb] += part;
       f16x8 ph, pm;                                              // P[query 16 qb + j][k-slots: block A keys 4 g + e, block B keys 4 g + e]
       xa_split8(pv, ph, pm);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        f32x4 o = oacc[qb][hf];
+        // A range-scaled V block (wave-uniform, rare) accumulates P V' apart and joins O times 1 / scale in fp32: undoing the
+        // scale on P instead pushed the probabilities into fp16's subnormals whenever |v| < 2^-4 over a whole block.
+        f32x4 o = v_scaled ? (f32x4){0.f, 0.f, 0.f, 0.f} : oacc[qb][hf];
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pm, vh[hf], o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vm[hf], o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[hf], o, 0, 0, 0);
-        oacc[qb][hf] = o;
+        oacc[qb][hf] = v_scaled ? oacc[qb][hf] + o * sv_inv : o;
       }
     }
   }

@@ -18,8 +18,25 @@ __device__ __forceinline__ void l3_scale(unsigned maxbits, int t, float& s, floa
   inv = __builtin_bit_cast(float, (unsigned)(127 - t + e) << 23);
 }
 
+// Timing experiments only (instrumented builds, `python -m univs_amd.build --ablate nosplit|nomfma|nosplit_nomfma`; results WRONG):
+//   UNIVS_ABLATE_NOSPLIT -- the x operand is taken as if it arrived pre-split (its 32 bytes per lane reinterpreted as the two fp16x8
+//   parts, no row maximum, no conversions): what a consumer of producer-side (hi, lo) activations would execute;
+//   UNIVS_ABLATE_NOMFMA  -- the matrix instructions are dropped (operands kept alive).
+#ifdef UNIVS_ABLATE_NOMFMA
+__device__ __forceinline__ f32x4 l3_fake_mfma(f16x8 a, f16x8 b, f32x4 c) {
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) l3_fake_mfma(a, b, c)
+#endif
+
 // 8 consecutive k of one row, scaled -> the two fp16x8 parts (round to nearest even)
 __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h, f16x8& m) {
+#ifdef UNIVS_ABLATE_NOSPLIT
+  h = __builtin_bit_cast(f16x8, v0);
+  m = __builtin_bit_cast(f16x8, v1);
+  return;
+#endif
   const float x[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -30,6 +47,9 @@ __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h,
 }
 
 __device__ __forceinline__ unsigned l3_absmax8(f32x4 v0, f32x4 v1) {
+#ifdef UNIVS_ABLATE_NOSPLIT
+  return 0x3f800000u;
+#endif
   const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
   const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
   return __builtin_bit_cast(unsigned, fmaxf(a, b));        // non-negative floats order like their bit patterns
@@ -55,6 +75,9 @@ __device__ __forceinline__ float l3_gelu(float x) {
 
 // maximum over the four lanes (k-groups, lane >> 4) that hold one row of the B operand
 __device__ __forceinline__ unsigned l3_row_max(unsigned v) {
+#ifdef UNIVS_ABLATE_NOSPLIT
+  return v;
+#endif
   const auto s1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   const unsigned r1 = max(s1[0], s1[1]);
   const auto s2 = __builtin_amdgcn_permlane16_swap(r1, r1, false, false);
