@@ -282,6 +282,15 @@ int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv,
                               long long M, int N, int K, int act, float* y, void* stream);
 int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
                                float* y, void* stream);
+/* The W-RESIDENT kernel of univs_linear_fused_f32 / univs_linear_blocked_f32 (K <= 768; linear_f16x3.hip) on the pre-split image
+ * (mode 0 of univs_presplit_weights_f32): staging a workgroup's slab of W in LDS becomes a copy.  Splitting the slab inside every
+ * workgroup -- what the raw-weight entries do -- measured 13 - 15 us at the head of every launch (profiles/r05_gemm_phase_trace_v1.txt).
+ * Same arguments, coverage and results (bit for bit) as the raw-weight entries with (wp, winv) in place of `weight`; replaces the
+ * same call sites (ms_deform_attn.py:95-113, swin.py:137-141, :163, :35-58). */
+int univs_linear_resident_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,
+                                       long long M, int N, int K, int act, float* y, void* stream);
+int univs_linear_blocked_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, long long M, int N, int K,
+                                      int rows_per_batch, int col_block, float* y, void* stream);
 /* univs_conv1x1_presplit_f32: y = conv2d(x, w [Cout, Cin, 1, 1], bias) (stride 1, no padding) on contiguous float32 NCHW tensors
  *   through the same kernel (tap addressing with the centre tap alone); (wp, winv) = univs_presplit_weights_f32(w, Cout, Cin, 0),
  *   bias [Cout] or NULL rides in the epilogue.  Covered: Cin % 96 == 0 or Cin % 128 == 0, Cout % 16 == 0, T*H*W >= 4096.

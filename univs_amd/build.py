@@ -69,7 +69,8 @@ def build(force=False, verbose=True, lib=LIB, defines=(), tag=""):
 
 
 ABLATIONS = {"nosplit": ("UNIVS_ABLATE_NOSPLIT",), "nomfma": ("UNIVS_ABLATE_NOMFMA",),
-             "nosplit_nomfma": ("UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA")}
+             "nosplit_nomfma": ("UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA"), "trace": ("UNIVS_TRACE_GEMM",),
+             "trace_nosplit_nomfma": ("UNIVS_TRACE_GEMM", "UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA")}
 
 
 def build_ablation(name, verbose=False):

@@ -38,7 +38,8 @@ int msda_forward_tiled2_f32(const float*, const LevelTable&, const float*, const
                             int, float*, hipStream_t);
 int mask_decode_f32(const float*, const float*, int, int, int, long long, float*, hipStream_t);
 int transpose_f32(const float*, float*, long long, int, int, long long, long long, const float*, const float*, float*, hipStream_t);
-int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0);
+int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0,
+                     const float* winv = nullptr);
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
 int mask_decode_last_impl();
@@ -332,6 +333,53 @@ int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv,
   const int rc = univs::linear_f16x3_stream_f32(x, wp, winv, bias, residual, y, M, N, K, residual ? 3 : act,
                                                 static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_linear_presplit_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
+  return rc;
+}
+
+int univs_linear_resident_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, const float* residual,
+                                       long long M, int N, int K, int act, float* y, void* stream) {
+  clear_sticky_error();
+  if (M < 0 || N < 0 || K < 1 || act < 0 || act > 2 || (act != 0 && residual)) {
+    set_error("univs_linear_resident_presplit_f32: bad arguments M=%lld N=%d K=%d act=%d%s", M, N, K, act,
+              (act != 0 && residual) ? " (an activation and a residual exclude each other)" : "");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0 || N == 0) return UNIVS_OK;
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_linear_resident_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::linear_split_f32(x, static_cast<const float*>(wp), bias, residual, y, M, N, K, residual ? 3 : act,
+                                         static_cast<hipStream_t>(stream), 0, 0, winv);
+  if (rc == 1) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_linear_resident_presplit_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
+}
+
+int univs_linear_blocked_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, long long M, int N, int K,
+                                      int rows_per_batch, int col_block, float* y, void* stream) {
+  if (M < 0 || N < 1 || K < 1 || rows_per_batch < 1 || col_block < 4 || col_block % 4 != 0 || N % col_block != 0 ||
+      (M % rows_per_batch) != 0) {
+    set_error("univs_linear_blocked_presplit_f32: bad arguments M=%lld N=%d K=%d rows_per_batch=%d col_block=%d", M, N, K, rows_per_batch,
+              col_block);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return UNIVS_OK;
+  clear_sticky_error();
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_linear_blocked_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::linear_split_f32(x, static_cast<const float*>(wp), bias, nullptr, y, M, N, K, /*LS_EPI_BLOCKED=*/4,
+                                         static_cast<hipStream_t>(stream), rows_per_batch, col_block, winv);
+  if (rc > 0) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_linear_blocked_presplit_f32: shape M=%lld N=%d K=%d (or alignment) is not covered (K == 256, M >= 2048)", M, N, K);
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
   return rc;
 }
 

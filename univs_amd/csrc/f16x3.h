@@ -30,6 +30,38 @@ __device__ __forceinline__ f32x4 l3_fake_mfma(f16x8 a, f16x8 b, f32x4 c) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) l3_fake_mfma(a, b, c)
 #endif
 
+// UNIVS_TRACE_GEMM (instrumented build `--ablate trace`): s_memtime stamps of a few (workgroup, wave) pairs at the phase boundaries of
+// linear_f16x3 / gemm_f16x3_stream, read back through univs_debug_gemm_trace_{linear,stream} (tools/gemm_trace.py).
+#ifdef UNIVS_TRACE_GEMM
+#define UNIVS_GT_SLOTS 48
+#define UNIVS_GT_STAMPS 64
+#define UNIVS_GT_DECL(sym) static __device__ unsigned long long sym[UNIVS_GT_SLOTS * UNIVS_GT_STAMPS]
+// slot: workgroups x = {0, mid, last} of passes y = {0, last}, all 8 waves; -1 elsewhere
+#define UNIVS_GT_SLOT()                                                                                                     \
+  ((((int)blockIdx.x == 0 || (int)blockIdx.x == (int)gridDim.x / 2 || (int)blockIdx.x == (int)gridDim.x - 1) &&                \
+    ((int)blockIdx.y == 0 || (int)blockIdx.y == (int)gridDim.y - 1))                                                          \
+       ? ((((int)blockIdx.x == 0 ? 0 : (int)blockIdx.x == (int)gridDim.x - 1 ? 2 : 1) * 2 + ((int)blockIdx.y == 0 ? 0 : 1)) * 8 + \
+          (int)(threadIdx.x >> 6))                                                                                            \
+       : -1)
+#define UNIVS_GT(sym, slot, i)                                                                                  \
+  do {                                                                                                          \
+    if ((slot) >= 0 && (threadIdx.x & 63) == 0 && (i) < UNIVS_GT_STAMPS) sym[(slot) * UNIVS_GT_STAMPS + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define UNIVS_GT_REAL(sym, slot, i)                                                                             \
+  do {                                                                                                          \
+    if ((slot) >= 0 && (threadIdx.x & 63) == 0) sym[(slot) * UNIVS_GT_STAMPS + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define UNIVS_GT_VAL(sym, slot, i, v)                                                                           \
+  do {                                                                                                          \
+    if ((slot) >= 0 && (threadIdx.x & 63) == 0) sym[(slot) * UNIVS_GT_STAMPS + (i)] = (unsigned long long)(v);  \
+  } while (0)
+#else
+#define UNIVS_GT_SLOT() (-1)
+#define UNIVS_GT(sym, slot, i) do { } while (0)
+#define UNIVS_GT_REAL(sym, slot, i) do { } while (0)
+#define UNIVS_GT_VAL(sym, slot, i, v) do { } while (0)
+#endif
+
 // 8 consecutive k of one row, scaled -> the two fp16x8 parts (round to nearest even)
 __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h, f16x8& m) {
 #ifdef UNIVS_ABLATE_NOSPLIT

@@ -19,6 +19,9 @@
 
 namespace univs {
 
+#ifdef UNIVS_TRACE_GEMM
+UNIVS_GT_DECL(g_gs_trace);
+#endif
 constexpr int GS_THREADS = 512;
 constexpr int GS_TILE_M = 32;
 enum { GS_EPI_NONE = 0, GS_EPI_RELU = 1, GS_EPI_GELU = 2, GS_EPI_RESIDUAL = 3 };   // = LS_EPI_*
@@ -82,6 +85,9 @@ struct GsArgs {
 template <int RB, int RING, int XMODE>
 __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];
+  [[maybe_unused]] const int gts = UNIVS_GT_SLOT();
+  UNIVS_GT(g_gs_trace, gts, 0);
+  UNIVS_GT_REAL(g_gs_trace, gts, 62);
   constexpr int Rp = 16 * RB;
   constexpr int SLAB = RING * 4 * 2 * Rp;                        // 16-byte units per buffer
   const int n0 = blockIdx.y * a.rows_per_pass;
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
 #pragma unroll
   for (int u = 0; u < RING; ++u) load_x(raw[u], t_cur, u);
 
+  UNIVS_GT(g_gs_trace, gts, 2);
+  UNIVS_GT_VAL(g_gs_trace, gts, 63, rounds);
   int gq = 0;                                                    // k-groups done: slab gq is in buffer gq & 1
 #pragma unroll 1
   for (int rd = 0; rd < rounds; ++rd) {
@@ -295,6 +303,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
       }
       w_commit(bufc ^ 1, RING - 1);
     }
+    UNIVS_GT(g_gs_trace, gts, 3 + 2 * rd);
     // ---- epilogue: D[i = feature][j = row]: a lane holds four consecutive features of its two rows
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -334,9 +343,11 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
         }
       }
     }
+    UNIVS_GT(g_gs_trace, gts, 4 + 2 * rd);
     t_cur = t_next;
     tile_rows(wg0 + min(rd + 2, rounds - 1) * NWV + wave, t_next);
   }
+  UNIVS_GT_REAL(g_gs_trace, gts, 61);
 }
 
 static int gs_cus() {
@@ -454,3 +465,14 @@ int conv1x1_f16x3_f32(const float* x, const void* wp, const float* winv, const f
 }
 
 }  // namespace univs
+
+#ifdef UNIVS_TRACE_GEMM
+extern "C" int univs_debug_gemm_trace_stream(unsigned long long* out, int clear) {
+  if (clear) {
+    static unsigned long long zeros[UNIVS_GT_SLOTS * UNIVS_GT_STAMPS] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(univs::g_gs_trace), zeros, sizeof(zeros));
+  }
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(univs::g_gs_trace), sizeof(unsigned long long) * UNIVS_GT_SLOTS * UNIVS_GT_STAMPS);
+}
+#endif

@@ -31,21 +31,32 @@
 
 namespace univs {
 
+#ifdef UNIVS_TRACE_GEMM
+UNIVS_GT_DECL(g_l3_trace);
+#endif
 constexpr int L3_THREADS = 512;   // 8 waves, two per SIMD
 constexpr int L3_TILE_M = 32;     // rows of x per wave tile (two 16-column MFMA tiles)
 constexpr int L3_MAX_RB = 8;
+constexpr int L3_WPT = 24;        // PRE: 16-byte units of the W slab per thread (the host side checks that the slab fits)
 enum { L3_EPI_NONE = 0, L3_EPI_RELU = 1, L3_EPI_GELU = 2, L3_EPI_RESIDUAL = 3, L3_EPI_BLOCKED = 4 };   // = LS_EPI_*
 
 // LDS: Wsp [K/32][4 k-groups][2 parts][16 RB features] 16 B | bias[R] | winv[R] | zero tail (16 x 16 B) | wmax[R]
-template <int RB, int RING>   // RING: register stages of x (K / 32 is a multiple)
+// PRE: W is the pre-split image of presplit_f16x3 (gemm_f16x3_stream.hip: [(K / 8) x 2 parts][N] 16-byte units, `winv_g` its
+// inverse row scales) and staging the slab is a COPY.  Splitting the slab inside every workgroup (row maxima by LDS atomics,
+// then scale + split: two dependent sweeps over the slab) measured 28 - 32 k clocks = 13 - 15 us at the head of EVERY launch --
+// a quarter of an 18 400-row Swin stage-3 Linear, 30 % of a 96 600-row encoder projection (profiles/r05_gemm_phase_trace_v1.txt).
+template <int RB, int RING, bool PRE>   // RING: register stages of x (K / 32 is a multiple)
 __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __restrict__ X,      // [M, K]
-                                                               const float* __restrict__ W,      // [N, K]
+                                                               const float* __restrict__ W,      // [N, K] (PRE: the split image)
                                                                const float* __restrict__ bias,   // [N] or null
                                                                const float* __restrict__ Res,    // [M, N] (epi == RESIDUAL)
                                                                float* __restrict__ Y,            // [M, N]
                                                                int M, int N, int K, int rows_per_pass, int epi, int blk_rows,
-                                                               int blk_cols, int ablate) {
+                                                               int blk_cols, int ablate, const float* __restrict__ winv_g) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wsp[];
+  [[maybe_unused]] const int gts = UNIVS_GT_SLOT();
+  UNIVS_GT(g_l3_trace, gts, 0);
+  UNIVS_GT_REAL(g_l3_trace, gts, 62);
   const int n0 = blockIdx.y * rows_per_pass;
   const int R = min(rows_per_pass, N - n0);                      // a multiple of 4 (host-checked)
   constexpr int Rp = 16 * RB;                                    // rows of the LDS image (rows >= R are never written: their
@@ -76,6 +87,24 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
       vo[c] = ((unsigned)m * (unsigned)K + (unsigned)(8 * g)) * 4u;          // < 2^31 (host-checked)
     }
   };
+  // PRE: this pass's slab of the split image, requested FIRST and all at once (<= L3_WPT 16-byte units per thread), committed to LDS
+  // after the x ring has been requested behind it: vector memory returns in order, so the wait for the slab does not wait for x
+  // (requested behind x, each sweep of the copy waited for the first tiles' rows to arrive from HBM: 14 - 17 k clocks instead of ~4 k).
+  // run = (k-group of 8, part): R consecutive units of the image, N units apart; R threads per run, 512 / R runs per sweep.
+  [[maybe_unused]] u32x4 wcp[L3_WPT];
+  [[maybe_unused]] int wcp_runs = 0, wcp_rpi = 1, wcp_run0 = 0, wcp_rr = 0;
+  [[maybe_unused]] bool wcp_active = false;
+  if constexpr (PRE) {
+    const u32x4* Wp = reinterpret_cast<const u32x4*>(W) + n0;
+    wcp_runs = (K >> 3) * 2;
+    wcp_rpi = L3_THREADS / R;
+    wcp_run0 = tid / R;
+    wcp_rr = tid - wcp_run0 * R;
+    wcp_active = wcp_run0 < wcp_rpi;
+#pragma unroll
+    for (int u = 0; u < L3_WPT; ++u) wcp[u] = Wp[(size_t)min(wcp_run0 + u * wcp_rpi, wcp_runs - 1) * N + wcp_rr];
+    __builtin_amdgcn_sched_barrier(0);
+  }
   unsigned vo_cur[2], vo_next[2];
   tile_voff(0, vo_cur);
   tile_voff(min(1, max(ntiles, 1) - 1), vo_next);
@@ -93,6 +122,7 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  UNIVS_GT(g_l3_trace, gts, 1);
   // ---- this pass's rows of W -> LDS (fragment order), two sweeps: row maxima, then scale + split.  Work item = 8
   // consecutive k of one row; consecutive threads take consecutive ROWS (conflict-free 16-byte LDS writes; the reads of W
   // are 32-byte pieces of different rows, all L2 hits after the first workgroup)
@@ -101,30 +131,40 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
   for (int r = tid; r < R; r += L3_THREADS) {
     wmax_lds[r] = 0u;
     bias_lds[r] = bias ? bias[n0 + r] : 0.f;
+    if constexpr (PRE) winv_lds[r] = winv_g[n0 + r];
   }
   for (int i = tid; i < 64; i += L3_THREADS) tail[i] = 0u;
-  __syncthreads();
-  for (int idx = tid; idx < R * kch; idx += L3_THREADS) {
-    const int kc = idx / R, r = idx - kc * R;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8 + 4);
-    atomicMax(&wmax_lds[r], l3_absmax8(x0, x1));
+  if constexpr (PRE) {                                             // commit the slab requested at the top of the kernel
+#pragma unroll
+    for (int u = 0; u < L3_WPT; ++u)
+      if (wcp_active && wcp_run0 + u * wcp_rpi < wcp_runs) Wsp[(size_t)(wcp_run0 + u * wcp_rpi) * Rp + wcp_rr] = wcp[u];
   }
-  __syncthreads();
-  for (int idx = tid; idx < R * kch; idx += L3_THREADS) {
-    const int kc = idx / R, r = idx - kc * R;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8 + 4);
-    float s, inv;
-    l3_scale(wmax_lds[r], 14, s, inv);
-    f16x8 h, m;
-    l3_split8(x0, x1, s, h, m);
-    u32x4* dst = Wsp + (size_t)(kc * 2) * Rp + r;                // kc = ks * 4 + k-group
-    dst[0] = __builtin_bit_cast(u32x4, h);
-    dst[Rp] = __builtin_bit_cast(u32x4, m);
-    if (kc == 0) winv_lds[r] = inv;
+  if constexpr (!PRE) {
+    __syncthreads();
+    for (int idx = tid; idx < R * kch; idx += L3_THREADS) {
+      const int kc = idx / R, r = idx - kc * R;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8 + 4);
+      atomicMax(&wmax_lds[r], l3_absmax8(x0, x1));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < R * kch; idx += L3_THREADS) {
+      const int kc = idx / R, r = idx - kc * R;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(Wsrc + (size_t)r * K + kc * 8 + 4);
+      float s, inv;
+      l3_scale(wmax_lds[r], 14, s, inv);
+      f16x8 h, m;
+      l3_split8(x0, x1, s, h, m);
+      u32x4* dst = Wsp + (size_t)(kc * 2) * Rp + r;                // kc = ks * 4 + k-group
+      dst[0] = __builtin_bit_cast(u32x4, h);
+      dst[Rp] = __builtin_bit_cast(u32x4, m);
+      if (kc == 0) winv_lds[r] = inv;
+    }
   }
   __syncthreads();   // the only barrier of the main part
+  UNIVS_GT(g_l3_trace, gts, 2);
+  UNIVS_GT_VAL(g_l3_trace, gts, 63, ntiles);
   if (ntiles == 0) return;
 
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * N * 4), 0x00020000);
@@ -281,16 +321,20 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
     sx[0] = sx[1] = sx_inv[0] = sx_inv[1] = 1.0f;
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS; ks0 += RING) group(ks0, ks0 + RING >= KS);
+    UNIVS_GT(g_l3_trace, gts, 3 + 2 * tile);
     epilogue(tile);
+    UNIVS_GT(g_l3_trace, gts, 4 + 2 * tile);
     vo_cur[0] = vo_next[0];
     vo_cur[1] = vo_next[1];
     tile_voff(min(tile + 2, ntiles - 1), vo_next);
   }
+  UNIVS_GT_REAL(g_l3_trace, gts, 61);
 }
 
 // returns 1 if launched, 0 if the shape is not covered, < 0 on error.  Same contract as linear_split_f32 (W-stationary part).
+// `winv` != nullptr: `w` is the pre-split image (univs_presplit_weights_f32, mode 0) and `winv` its inverse row scales
 int linear_f16x3_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
-                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols) {
+                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols, const float* winv) {
   if (M <= 0 || N <= 0) return 1;
   if (epi < 0 || epi > L3_EPI_BLOCKED || (epi == L3_EPI_RESIDUAL) != (residual != nullptr)) return 0;
   if (epi == L3_EPI_BLOCKED && (blk_rows < 1 || blk_cols < 4 || blk_cols % 4 != 0 || N % blk_cols != 0 || M % blk_rows != 0))
@@ -299,7 +343,7 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
   if (K < 96 || ring == 0 || N % 4 != 0) return 0;
   if (M * (long long)N * 4 >= 0x7FFFFFFFLL || M * (long long)K * 4 >= 0x7FFFFFFFLL) return 0;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
-      (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15))
+      (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(winv) & 3))
     return 0;
   const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + inverse scales + zero tail + row maxima
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 4 + 12), 16 * L3_MAX_RB);
@@ -313,6 +357,7 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
   const int RB = (rows + 15) / 16;
   const long long WT = (M + L3_TILE_M - 1) / L3_TILE_M;
   if (WT < 64) return 0;                                   // too few rows to amortise the staging of W
+  if (winv && ((K >> 3) * 2 + (L3_THREADS / rows) - 1) / (L3_THREADS / rows) > L3_WPT) return 0;   // (cannot happen for K <= 768: <= 20 units)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
@@ -331,17 +376,22 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
   if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
   const size_t lds = (size_t)K * (16 * RB) * 4 + 12 * (size_t)rows + 256 + 16;
   dim3 grid((unsigned)gx, (unsigned)passes), block(L3_THREADS);
-#define UNIVS_L3(rb, rg)                                                                                             \
+#define UNIVS_L3(rb, rg, pre)                                                                                             \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3<rb, rg>),                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3<rb, rg, pre>),                                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-    hipLaunchKernelGGL((linear_f16x3<rb, rg>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K, rows, epi, \
-                       blk_rows, blk_cols, config().linear_ablate);                                                                          \
+    hipLaunchKernelGGL((linear_f16x3<rb, rg, pre>), grid, block, lds, st, x, w, bias, residual, y, (int)M, N, K, rows, epi, \
+                       blk_rows, blk_cols, config().linear_ablate, winv);                                                                          \
   } while (0)
-#define UNIVS_L3_RB(rb)                       \
-  case rb:                                    \
-    if (ring == 4) { UNIVS_L3(rb, 4); }       \
-    else { UNIVS_L3(rb, 3); }                 \
+#define UNIVS_L3_RB(rb)                                    \
+  case rb:                                                 \
+    if (winv) {                                            \
+      if (ring == 4) { UNIVS_L3(rb, 4, true); }            \
+      else { UNIVS_L3(rb, 3, true); }                      \
+    } else {                                               \
+      if (ring == 4) { UNIVS_L3(rb, 4, false); }           \
+      else { UNIVS_L3(rb, 3, false); }                     \
+    }                                                      \
     break
   switch (RB) {
     UNIVS_L3_RB(1);
@@ -360,3 +410,14 @@ int linear_f16x3_f32(const float* x, const float* w, const float* bias, const fl
 }
 
 }  // namespace univs
+
+#ifdef UNIVS_TRACE_GEMM
+extern "C" int univs_debug_gemm_trace_linear(unsigned long long* out, int clear) {
+  if (clear) {
+    static unsigned long long zeros[UNIVS_GT_SLOTS * UNIVS_GT_STAMPS] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(univs::g_l3_trace), zeros, sizeof(zeros));
+  }
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(univs::g_l3_trace), sizeof(unsigned long long) * UNIVS_GT_SLOTS * UNIVS_GT_STAMPS);
+}
+#endif

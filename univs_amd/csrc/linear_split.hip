@@ -248,11 +248,12 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_bf16x6(const float* __re
 }
 
 int linear_f16x3_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
-                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols);   // linear_f16x3.hip
+                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols, const float* winv);   // linear_f16x3.hip
 
 // returns 1 if launched, 0 if the shape is not covered (the caller uses the library GEMM), < 0 on error
+// `winv` != nullptr: `w` is the pre-split image of univs_presplit_weights_f32 (three-product kernel only)
 int linear_split_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, long long M, int N,
-                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols) {
+                     int K, int epi, hipStream_t st, int blk_rows, int blk_cols, const float* winv) {
   if (M <= 0 || N <= 0) return 1;
   if (epi < 0 || epi > LS_EPI_BLOCKED || (epi == LS_EPI_RESIDUAL) != (residual != nullptr)) return 0;
   if (epi == LS_EPI_BLOCKED && (K != 256 || blk_rows < 1 || blk_cols < 4 || blk_cols % 4 != 0 || N % blk_cols != 0 || M % blk_rows != 0))
@@ -266,7 +267,8 @@ int linear_split_f32(const float* x, const float* w, const float* bias, const fl
   // K >= 768: the weights are split once per tensor and streamed (gemm_f16x3_stream.hip: univs_linear_presplit_f32); this
   // entry splits W in every workgroup and only pays while the whole K of a useful number of features fits LDS
   if (K > 768) return 0;
-  if (config().linear_terms != 6) return linear_f16x3_f32(x, w, bias, residual, y, M, N, K, epi, st, blk_rows, blk_cols);   // default: three products
+  if (config().linear_terms != 6 || winv)
+    return linear_f16x3_f32(x, w, bias, residual, y, M, N, K, epi, st, blk_rows, blk_cols, winv);   // default: three products
   const long long lds_cap = 160 * 1024 - 2048;   // W slab + bias + the zeroed tail (see the staging loop)
   int r_cap = (int)std::min<long long>(lds_cap / ((long long)K * 6), 16 * LS_MAX_RB);
   r_cap -= r_cap % 4;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "msda_common.h"
@@ -30,6 +31,18 @@ struct GeoKey {
     return true;
   }
 };
+// Who may still read an entry's device tables: ONE event per stream that launched with it (a record on stream B must not
+// overwrite the record that guards stream A's launch), and a pin set when the entry is used while a stream is being
+// captured -- a hipGraph keeps raw pointers to the tables and replays at any later time, so a pinned entry is never evicted.
+struct GeoUse {
+  std::vector<std::pair<hipStream_t, hipEvent_t>> events;
+  bool pinned = false;
+  void destroy() {
+    for (auto& se : events)
+      if (se.second) (void)hipEventDestroy(se.second);
+    events.clear();
+  }
+};
 struct GeoEntry {
   GeoKey key;
   int4* table;       // device
@@ -37,35 +50,58 @@ struct GeoEntry {
   long long qmax;    // max queries of a tile
   long long win_px;  // max window pixels of a (tile, level)
   long long lvl_px[UNIVS_MAX_LEVELS];   // ... per level
-  hipEvent_t last_use = nullptr;        // recorded behind every launch that reads `table` (geo_mark_use)
+  GeoUse use;        // per-stream "last launch" events + the capture pin (geo_mark_use)
 };
 
 // Lifetime of a cached geometry: callers hold a shared_ptr for the duration of their launch call (an eviction by another host
-// thread cannot free the entry under them), every launch records `last_use` on its stream, and an evicted entry's device table
+// thread cannot free the entry under them), every launch records an event on ITS stream (GeoUse), and an evicted entry's device table
 // is freed only once that event has completed -- no hipDeviceSynchronize, nothing of another device is touched.  While a
 // stream is being captured a cache MISS returns nullptr (hipMalloc / hipMemcpy are illegal there): warm the cache with one
 // eager call per geometry before capturing.
+static inline std::mutex& geo_use_mutex() {
+  static std::mutex mu;
+  return mu;
+}
 template <class E>
 static inline void geo_mark_use(const std::shared_ptr<E>& e, hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
-  if (cs != hipStreamCaptureStatusNone) return;                 // (a replayed graph is ordered by its own stream; see graphs.py)
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!e->last_use && hipEventCreateWithFlags(&e->last_use, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    e->last_use = nullptr;
+  std::lock_guard<std::mutex> lock(geo_use_mutex());
+  if (cs != hipStreamCaptureStatusNone) {                       // (no event can be recorded here; the graph outlives this call)
+    e->use.pinned = true;
     return;
   }
-  (void)hipEventRecord(e->last_use, st);
+  hipEvent_t ev = nullptr;
+  for (auto& se : e->use.events)
+    if (se.first == st) ev = se.second;
+  if (!ev) {
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      e->use.pinned = true;                                     // cannot track this stream: keep the tables for good
+      return;
+    }
+    e->use.events.emplace_back(st, ev);
+  }
+  (void)hipEventRecord(ev, st);
 }
 template <class E>
-static inline bool geo_idle(const std::shared_ptr<E>& e) {       // nobody holds it and the GPU is done with it
+static inline bool geo_pinned(const std::shared_ptr<E>& e) {
+  std::lock_guard<std::mutex> lock(geo_use_mutex());
+  return e->use.pinned;
+}
+template <class E>
+static inline bool geo_idle(const std::shared_ptr<E>& e) {       // nobody holds it, no graph points at it, every stream is done with it
   if (e.use_count() > 1) return false;
-  if (!e->last_use) return true;
-  const hipError_t q = hipEventQuery(e->last_use);
-  if (q != hipSuccess) (void)hipGetLastError();
-  return q == hipSuccess;
+  std::lock_guard<std::mutex> lock(geo_use_mutex());
+  if (e->use.pinned) return false;
+  for (auto& se : e->use.events) {
+    const hipError_t q = hipEventQuery(se.second);
+    if (q != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  return true;
 }
 static inline bool geo_capturing(hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -95,7 +131,7 @@ static void axis_entry(int t, int ntile, int T, int Nq, int Nf, int R, int cap, 
 static void geo_free(GeoEntry* e) {
   if (!e) return;
   if (e->table) (void)hipFree(e->table);
-  if (e->last_use) (void)hipEventDestroy(e->last_use);
+  e->use.destroy();
   delete e;
 }
 
@@ -154,9 +190,9 @@ static std::shared_ptr<GeoEntry> geometry(const LevelTable& lv, int L, int fine,
     return nullptr;
   }
   std::shared_ptr<GeoEntry> sp(ge, geo_free);
-  if (cache.size() >= 32) {   // bounded (image datasets: many resolutions): retire the oldest entry OF THIS DEVICE
+  if (cache.size() >= 32) {   // bounded (image datasets: many resolutions): retire the oldest unpinned entry OF THIS DEVICE
     for (size_t i = 0; i < cache.size(); ++i)
-      if (cache[i]->key.dev == key.dev) {
+      if (cache[i]->key.dev == key.dev && !geo_pinned(cache[i])) {
         retired.push_back(cache[i]);
         cache.erase(cache.begin() + i);
         break;

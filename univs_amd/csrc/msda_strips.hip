@@ -405,7 +405,7 @@ struct S5Geo {
   size_t lds = 0;
   bool ok = false;
   unsigned long long stamp = 0;
-  hipEvent_t last_use = nullptr;   // recorded behind every launch that reads the tables (msda_geometry.h: geo_mark_use)
+  GeoUse use;                  // per-stream last-launch events + the capture pin (msda_geometry.h: geo_mark_use)
 };
 
 static void s5_free(S5Geo* g) {
@@ -413,7 +413,7 @@ static void s5_free(S5Geo* g) {
   if (g->tiles) (void)hipFree(g->tiles);
   if (g->pieces) (void)hipFree(g->pieces);
   if (g->qtable) (void)hipFree(g->qtable);
-  if (g->last_use) (void)hipEventDestroy(g->last_use);
+  g->use.destroy();
   delete g;
 }
 
@@ -455,7 +455,7 @@ static std::shared_ptr<S5Geo> s5_geometry(const LevelTable& lv, int L, int fine,
   if (cache.size() >= CACHE_MAX) {   // retire the least recently used geometry of THIS device (image datasets: many resolutions)
     size_t lru = cache.size();
     for (size_t i = 0; i < cache.size(); ++i)
-      if (cache[i]->key.dev == key.dev && (lru == cache.size() || cache[i]->stamp < cache[lru]->stamp)) lru = i;
+      if (cache[i]->key.dev == key.dev && !geo_pinned(cache[i]) && (lru == cache.size() || cache[i]->stamp < cache[lru]->stamp)) lru = i;
     if (lru < cache.size()) {
       retired.push_back(cache[lru]);
       cache.erase(cache.begin() + lru);

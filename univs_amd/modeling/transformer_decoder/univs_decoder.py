@@ -243,6 +243,8 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             self._frame_indices_all = frame_indices
             frame_indices = frame_indices[:, fs.local_slice(t)]
         mem_fused = [None] * self.num_feature_levels     # (memory, key) of a level from ONE kernel (ops.decoder_memory), where covered
+        pos_makers = {}                                  # level -> closure that materialises its position embedding on demand (local:
+                                                         # nothing of a forward pass outlives it on the module)
         for i in range(self.num_feature_levels):
             size_list.append(tuple(int(s) for s in x[i].shape[-2:]))
             xi = x[i].view(bs, t, -1, size_list[-1][0], size_list[-1][1])
@@ -260,14 +262,13 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             if mem_fused[i] is not None:
                 src.append(mem_fused[i][0])
                 pos.append(None)
-                pos_makers = self.__dict__.setdefault("_pos_makers", {})
                 pos_makers[i] = make_pos
             else:
                 pos.append(make_pos())
                 s = xin.flatten(2) + self.level_embed.weight[i][None, :, None]
                 src.append(s.permute(2, 0, 1))
         if any(m is not None for m in mem_fused):
-            pos = _LazyList(pos, self.__dict__.get("_pos_makers", {}))
+            pos = _LazyList(pos, pos_makers)
 
         query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bt, 1)
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bt, 1)
@@ -316,11 +317,11 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         # cross-attention inputs per level, contiguous and built once (every third layer reuses them)
         mem = [m[0] if m is not None else s_.contiguous() for m, s_ in zip(mem_fused, src)]
         mem_key = [m[1] if m is not None else (src[i_] + pos[i_]).contiguous() for i_, m in enumerate(mem_fused)]
-        self.__dict__.pop("_pos_makers", None)
         # key / value projections of the cross-attention: the layers i, i + L, i + 2 L, ... attend to the same level with
         # different weights -- ONE Linear per level for all their keys (N = 256 x layers), one for their values: the level's
         # memory is read once instead of once per layer; a layer takes its 256-column slice in place
-        kv_proj = self._cross_kv(mem, mem_key) if (mem[0].is_cuda and not self.transformer_cross_attention_layers[0].need_weights) else None
+        kv_proj = self._cross_kv(mem, mem_key) if (mem[0].is_cuda and not torch.is_grad_enabled()
+                                                   and not self.transformer_cross_attention_layers[0].need_weights) else None
         for i in range(self.num_layers):
             if self.prompt_as_queries and 0 < i < self.prompt_self_attn_layers:
                 output = self.forward_transformer_prompt_self_attention_layer(
@@ -601,7 +602,6 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             out.append(d.unsqueeze(2).repeat(1, 1, num_frames, 1))
         return out[1], out[0]
 
-    @torch.no_grad()
     def _cross_kv(self, mem, mem_key):
         """(k, v) per decoder layer: [HW_l, T, 256] column slices of one [HW_l, T, 256 n_l] projection per level and kind."""
         from ...layers import linear

@@ -236,9 +236,11 @@ def get_config() -> dict:
 def configure(**settings):
     """Set library settings by name (the others keep their current values); `configure()` with no argument restores the
     defaults.  Returns the previous settings (pass them back to restore)."""
+    global _LINEAR_TERMS
     prev = get_config()
     if not settings:
         _lib.check(_lib.load().univs_configure(None), "configure")
+        _LINEAR_TERMS = 3
         return prev
     c = UnivsConfig()
     c.size = ctypes.sizeof(UnivsConfig)
@@ -247,7 +249,11 @@ def configure(**settings):
             raise KeyError(f"configure: unknown setting {n!r} (known: {sorted(prev)})")
         setattr(c, n, int(v))
     _lib.check(_lib.load().univs_configure(ctypes.byref(c)), "configure")
+    _LINEAR_TERMS = 6 if int(c.linear_terms) == 6 else 3
     return prev
+
+
+_LINEAR_TERMS = 3        # mirror of UnivsConfig.linear_terms (all changes go through `configure`): the hot path does not query the library
 
 
 @contextlib.contextmanager
@@ -479,6 +485,13 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
     return y
 
 
+def _resident_presplit(weight, K):
+    """The W-resident Linear takes the cached split image of `weight` (SWITCHES.resident_presplit; three-product arithmetic; a whole,
+    contiguous tensor whose identity outlives the call -- views of parameters would be split again on every call)."""
+    return (SWITCHES.resident_presplit and K % 32 == 0 and weight._base is None and weight.is_contiguous()
+            and _LINEAR_TERMS != 6)
+
+
 def linear_fused(x, weight, bias=None, act=None, residual=None):
     """F.linear(x, weight, bias) with a fused epilogue -- `act` in (None, 'relu', 'gelu' [the erf form; erf to 4.7e-7 absolute]) or `residual`
     (a tensor of the output's shape that is added) -- for float32 on the GPU through the three-product fp16 kernels (fp32-accurate:
@@ -520,6 +533,13 @@ def linear_fused(x, weight, bias=None, act=None, residual=None):
             rc = _lib.load().univs_linear_presplit_f32(_ptr(x2), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None,
                                                        _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
                                                        _stream_ptr(x2))
+        if rc == _lib.ERR_NOT_IMPLEMENTED and _resident_presplit(weight, K):
+            # the W-resident kernel on the split image: staging the slab is a copy (13 - 15 us per launch less than splitting it in
+            # every workgroup); whole weight tensors only -- the split is cached per tensor object
+            wp, winv = presplit_weights(weight)
+            rc = _lib.load().univs_linear_resident_presplit_f32(_ptr(x2), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None,
+                                                                _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
+                                                                _stream_ptr(x2))
         if rc == _lib.ERR_NOT_IMPLEMENTED:
             rc = _lib.load().univs_linear_fused_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None,
                                                     _ptr(r) if r is not None else None, M, N, K, _ACTS[act], _ptr(y),
@@ -548,8 +568,13 @@ def linear_blocked(x, weight, bias, rows_per_batch, col_block):
     b = bias.contiguous() if bias is not None else None
     y = torch.empty((Mrows // rows, N // cb, rows, cb), dtype=torch.float32, device=x2.device)
     with _on(x2):
-        rc = _lib.load().univs_linear_blocked_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, Mrows, N, K, rows, cb,
-                                                  _ptr(y), _stream_ptr(x2))
+        if _resident_presplit(weight, K):
+            wp, winv = presplit_weights(weight)
+            rc = _lib.load().univs_linear_blocked_presplit_f32(_ptr(x2), _ptr(wp), _ptr(winv), _ptr(b) if b is not None else None, Mrows,
+                                                               N, K, rows, cb, _ptr(y), _stream_ptr(x2))
+        else:
+            rc = _lib.load().univs_linear_blocked_f32(_ptr(x2), _ptr(w), _ptr(b) if b is not None else None, Mrows, N, K, rows, cb,
+                                                      _ptr(y), _stream_ptr(x2))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "linear_blocked")
@@ -593,10 +618,11 @@ class DeferredMask:
     """An attention mask [T, Q, hw] (uint8, 1 = key masked out) whose all-masked-row rule (...decoder_univs.py:390) has NOT been applied
     to the bytes: row r counts only where flags[r] == gen, elsewhere every key is visible (include/univs_hip.h:
     univs_mask_decode_attn_deferred_f32).  `cross_attention` consumes it as it is; `materialize()` gives the reference's bool tensor.
-    The flags buffer is shared by the masks of one (device, stream, row count): a mask has to be consumed before the NEXT deferred mask
-    of that kind is produced (the decoder's order: a layer's cross-attention runs before the next prediction head) -- consuming a
-    stale one raises instead of reading flags a newer generation has overwritten."""
-    __slots__ = ("mask", "flags", "gen", "_bool", "_entry")
+    Flag buffers come from a ring of four per (device, stream, row count).  Before a buffer is handed to a new mask, the mask that
+    used it last -- if somebody still holds it and it was never made explicit -- is materialised (its bytes and flags are intact at
+    that point of the stream), so a held DeferredMask stays valid however many masks follow it; in the decoder's order (a layer's
+    cross-attention consumes its mask and drops it before the next prediction head) that never costs a launch."""
+    __slots__ = ("mask", "flags", "gen", "_bool", "_entry", "__weakref__")
     dtype = torch.bool
 
     def __init__(self, mask, flags, gen, entry=None):
@@ -614,9 +640,8 @@ class DeferredMask:
         return self.mask.dim()
 
     def check_fresh(self):
-        if self._bool is None and self._entry is not None and self._entry[1] != self.gen:
-            raise RuntimeError("DeferredMask: a newer deferred mask of the same shape was produced on this stream before this one was "
-                               "consumed (its row flags are gone); materialize() it first, or ask for the eager form")
+        if self._bool is None and self._entry is not None and self._entry[1] != self.gen:      # (cannot happen: see mask_decode_attn)
+            raise RuntimeError("DeferredMask: the row flags of this mask were overwritten by a newer generation")
 
     def materialize(self):
         if self._bool is None:
@@ -629,7 +654,16 @@ class DeferredMask:
         return self._bool
 
 
-_MASK_FLAGS = {}          # (device, stream, rows) -> [flags int32 zero-initialised, last generation]
+_MASK_FLAGS = {}          # (device, stream, rows) -> [next slot, [[flags int32 zero-initialised, last generation, weakref of its mask] x 4]]
+_MASK_RING = 4
+
+
+def _release_mask_flags(entry):
+    """The flags buffer of `entry` is about to serve a new generation: make its last mask explicit if it is still held."""
+    old = entry[2]() if entry[2] is not None else None
+    if old is not None and old._bool is None:
+        old.materialize()
+    entry[2] = None
 
 
 def mask_decode_attn(mask_embed, feat_lowres, deferred=False):
@@ -649,17 +683,29 @@ def mask_decode_attn(mask_embed, feat_lowres, deferred=False):
     mask = torch.empty((T, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
     if deferred and T * Q > 0 and not torch.cuda.is_current_stream_capturing():
         key = (mask_embed.device, _raw_stream(mask_embed.device.index), T * Q)
-        e = _MASK_FLAGS.get(key)
-        if e is None or e[1] >= 0x7FFFFFF0:
+        ring = _MASK_FLAGS.get(key)
+        if ring is None:
             if len(_MASK_FLAGS) > 64:
+                for r_ in _MASK_FLAGS.values():                   # masks still held elsewhere keep their meaning
+                    for e_ in r_[1]:
+                        _release_mask_flags(e_)
                 _MASK_FLAGS.clear()
-            e = _MASK_FLAGS[key] = [torch.zeros((T * Q,), dtype=torch.int32, device=mask_embed.device), 0]
+            ring = _MASK_FLAGS[key] = [0, [None] * _MASK_RING]
+        slot = ring[0]
+        ring[0] = (slot + 1) % _MASK_RING
+        e = ring[1][slot]
+        if e is not None:
+            _release_mask_flags(e)
+        if e is None or e[1] >= 0x7FFFFFF0:
+            e = ring[1][slot] = [torch.zeros((T * Q,), dtype=torch.int32, device=mask_embed.device), 0, None]
         e[1] += 1
         with _on(mask_embed):
             rc = _lib.load().univs_mask_decode_attn_deferred_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w, _ptr(mask),
                                                                  _ptr(e[0]), e[1], _stream_ptr(mask_embed))
         _lib.check(rc, "mask_decode_attn")
-        return DeferredMask(mask, e[0], e[1], e)
+        dm = DeferredMask(mask, e[0], e[1], e)
+        e[2] = weakref.ref(dm)
+        return dm
     ws = torch.empty((max(T * Q, 1),), dtype=torch.int32, device=mask_embed.device)
     with _on(mask_embed):
         rc = _lib.load().univs_mask_decode_attn_f32(_ptr(mask_embed), _ptr(feat_lowres), T, Q, C, h * w,

@@ -53,6 +53,9 @@ class Switches:
     # per tensor (csrc/gemm_f16x3_stream.hip; ops.presplit_weights caches the split); 0: only the W-resident kernels (K <= 768), which
     # split W in every workgroup; wider Linears and the convolution then go to the libraries
     presplit_kmin: int = 768
+    # the W-resident Linears (K <= 768) stage their slab of W from the split image cached per weight tensor (a copy) instead of
+    # splitting it in every workgroup of every launch (13 - 15 us per launch: profiles/r05_gemm_phase_trace_v1.txt)
+    resident_presplit: bool = True
     # prompt sampler draws: "reference" (the reference's host-side randperm order, bit-identical sampling) or "device"
     sampler: str = "reference"
     # hipGraph replay of the static parts of a clip (backbone, pixel decoder): see univs_amd/graphs.py
@@ -65,7 +68,8 @@ SWITCHES = Switches(
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
-    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True))
+    fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True),
+    resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True))
 if SWITCHES.sampler not in ("reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
 
