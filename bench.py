@@ -265,7 +265,10 @@ def run(args):
 
     @torch.no_grad()
     def step():
-        x = torch.nn.functional.pad((frames - mean) / std, (0, 0, 0, 16))   # 720 -> 736 rows
+        # normalise + pad (720 -> 736 rows): the drivers' pre-step (inference/video_entity.py: normalized_image_list), one pass
+        x = ops.normalize_pad(frames, mean, std, pad_to=(736, 1280))
+        if x is None:
+            x = torch.nn.functional.pad((frames - mean) / std, (0, 0, 0, 16))
         return head(swin(x), targets=targets())
 
     sync = torch.cuda.synchronize

@@ -489,6 +489,15 @@ int univs_upsample2x_add_f32(const float* in, const float* addend, const float* 
 int univs_group_norm_affine_f32(const float* x, const float* gamma, const float* beta, int N, int C, long long HW, int groups, float eps,
                                 float* ws, long long ws_floats, float* affine, void* stream);
 
+/* out[t, c, :H, :W] = (x[t, c] - mean[c]) / std[c], zeros in rows H..Hp-1 and columns W..Wp-1: the caller's pre-step of a clip
+ * (univs/inference/inference_video_entity.py:246-250: `self.normalizer(frame)` per frame, then `ImageList.from_tensors(images_norm,
+ * self.size_divisibility)`; detectron2 pads after normalising, so the padding is 0 in the normalised domain) as one pass instead of
+ * ATen's subtraction, division, fill and strided copy.  x [T, C, H, W] contiguous float32 (pixel values 0..255), mean / std [C]
+ * device pointers; arithmetic as ATen's (fp32 subtraction, then a true division): bit-identical to `F.pad((x - mean) / std, ...)`.
+ * UNIVS_ERR_NOT_IMPLEMENTED for more than 65535 planes. */
+int univs_normalize_pad_f32(const float* x, const float* mean, const float* std, long long T, int C, int H, int W, int Hp, int Wp, float* out,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bilinear resampling of image planes, align_corners = false (PyTorch semantics).
  * Replaces: F.interpolate(x, size=(Hout, Wout), mode="bilinear", align_corners=False) on the path of the

@@ -1328,6 +1328,26 @@ def test_linear_split_uncovered_shapes_return_none(cuda):
     assert tuple(y.shape) == (4096, 96)
 
 
+@pytest.mark.parametrize("T,H,W,div", [(5, 720, 1280, 32), (2, 37, 53, 32), (1, 64, 96, 0), (3, 33, 64, 32)], ids=lambda v: str(v))
+def test_normalize_pad_is_bit_identical(cuda, T, H, W, div):
+    """ops.normalize_pad == ImageList.from_tensors([(f - mean) / std ...], size_divisibility) of the clip loop's pre-step
+    (inference_video_entity.py:246-250) bit for bit: fp32 subtraction, true division, zero padding at the bottom / right; widths that
+    are not multiples of four; the driver helper takes it for same-size GPU frames and the per-frame path otherwise."""
+    from univs_amd.inference.video_entity import ImageList, normalized_image_list
+    x = (synth.uniform(f"np/x/{T}x{H}x{W}", (T, 3, H, W), 0.0, 255.0)).to(cuda)
+    mean = torch.tensor([123.675, 116.28, 103.53], device=cuda).view(3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375], device=cuda).view(3, 1, 1)
+    want = ImageList.from_tensors([(f - mean) / std for f in x], div).tensor
+    got = ops.normalize_pad(x, mean, std, div)
+    assert got is not None and got.shape == want.shape and torch.equal(got, want)
+    il = normalized_image_list(list(x), mean, std, div)
+    assert torch.equal(il.tensor, want) and il.image_sizes == [(H, W)] * T
+    ragged = [x[0], x[1][:, : H - 1]] if T > 1 else [x[0]]
+    il2 = normalized_image_list(ragged, mean, std, div)
+    assert torch.equal(il2.tensor, ImageList.from_tensors([(f - mean) / std for f in ragged], div).tensor)
+    assert ops.normalize_pad(x.cpu(), mean.cpu(), std.cpu(), div) is None
+
+
 @pytest.mark.parametrize("T,H,W,E,norm", [(2, 736, 1280, 96, True), (1, 64, 96, 96, True), (3, 36, 52, 128, True), (1, 72, 40, 192, False),
                                           (2, 20, 44, 96, False)], ids=lambda v: str(v))
 def test_patch_embed4_matches_torch(cuda, T, H, W, E, norm):

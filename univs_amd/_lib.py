@@ -72,6 +72,7 @@ SIGNATURES = {
     "univs_group_norm_affine_f32": (_I, [_P, _P, _P, _I, _I, _c.c_longlong, _I, _c.c_float, _P, _c.c_longlong, _P, _P]),
     "univs_bilinear_pyramid3_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P, _P, _P]),
     "univs_bilinear_resample_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P]),
+    "univs_normalize_pad_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _P, _P]),
     "univs_patch_merge_norm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _c.c_float, _P, _P]),
     "univs_layer_norm_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _c.c_float, _P, _P, _P]),
     "univs_layer_norm_add_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _c.c_longlong, _I, _c.c_float, _P, _P, _P, _P]),

@@ -53,6 +53,7 @@ int msda_prepare_f32(const float*, int, int, const float*, long long, const Leve
                      float*, float*, hipStream_t);
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
 int upsample2x_add_f32(const float*, const float*, const float*, float*, long long, int, int, hipStream_t);
+int normalize_pad_f32(const float*, float*, long long, int, int, int, int, int, const float*, const float*, hipStream_t);
 int group_norm_affine_f32(const float*, const float*, const float*, int, int, long long, int, float, float*, long long, float*, hipStream_t);
 int bilinear_pyramid3_f32(const float*, float*, float*, float*, long long, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
@@ -652,6 +653,23 @@ int univs_bilinear_resample_f32(const float* in, const float* addend, float* out
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return bilinear_resample_f32(in, addend, out, planes, Hin, Win, Hout, Wout, static_cast<hipStream_t>(stream));
+}
+
+int univs_normalize_pad_f32(const float* x, const float* mean, const float* std, long long T, int C, int H, int W, int Hp, int Wp, float* out,
+                            void* stream) {
+  clear_sticky_error();
+  if (T < 0 || C < 1 || H < 1 || W < 1 || Hp < H || Wp < W) {
+    set_error("univs_normalize_pad_f32: bad dimensions T=%lld C=%d %dx%d -> %dx%d", T, C, H, W, Hp, Wp);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0) return UNIVS_OK;
+  if (!x || !mean || !std || !out) {
+    set_error("univs_normalize_pad_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = normalize_pad_f32(x, out, T, C, H, W, Hp, Wp, mean, std, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_normalize_pad_f32: T * C = %lld planes not covered (<= 65535)", T * C);
+  return rc;
 }
 
 int univs_upsample2x_add_f32(const float* in, const float* addend, const float* addend_affine, float* out, long long planes, int Hin,

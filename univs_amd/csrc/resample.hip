@@ -221,4 +221,52 @@ int bilinear_resample_f32(const float* in, const float* addend, float* out, long
   return check_launch("bilinear_resample_f32");
 }
 
+// ---- (x - mean[c]) / std[c], zero-padded to [Hp, Wp]: the caller's pre-step of every clip (univs/inference/inference_video_entity.py:
+// 246-250 `self.normalizer(...)`, `ImageList.from_tensors(images_norm, self.size_divisibility)`) -- in ATen a subtraction, a
+// division, a fill and a strided copy (four passes, 75 us per 720p clip).  One pass: a thread writes four output pixels; the
+// arithmetic is ATen's (an fp32 subtraction, then a true division).
+__global__ __launch_bounds__(256) void normalize_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int Hp,
+                                                            int Wp, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv) {
+  const int wq = (Wp + 3) >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Hp * wq) return;
+  const int y = q / wq, x0 = (q - y * wq) * 4;
+  const long long plane = blockIdx.y;                            // t * C + c
+  const int c = (int)(plane % C);
+  const float m = mean ? mean[c] : (c == 0 ? m0 : c == 1 ? m1 : m2);
+  const float sd = stdv ? stdv[c] : (c == 0 ? s0 : c == 1 ? s1 : s2);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (y < H) {
+    const float* src = in + (plane * H + y) * (long long)W + x0;
+    if (x0 + 3 < W && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+      const float4 t = *reinterpret_cast<const float4*>(src);
+      v[0] = (t.x - m) / sd; v[1] = (t.y - m) / sd; v[2] = (t.z - m) / sd; v[3] = (t.w - m) / sd;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (x0 + e < W) v[e] = (src[e] - m) / sd;
+    }
+  }
+  float* dst = out + (plane * Hp + y) * (long long)Wp + x0;
+  if (x0 + 3 < Wp && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (x0 + e < Wp) dst[e] = v[e];
+  }
+}
+
+int normalize_pad_f32(const float* in, float* out, long long T, int C, int H, int W, int Hp, int Wp, const float* mean, const float* stdv,
+                      hipStream_t st) {
+  const long long planes = T * C;
+  if (planes <= 0) return UNIVS_OK;
+  if (planes > 65535 || Hp < H || Wp < W) return UNIVS_ERR_NOT_IMPLEMENTED;
+  const int wq = (Wp + 3) >> 2;
+  dim3 grid((unsigned)((Hp * wq + 255) / 256), (unsigned)planes);
+  hipLaunchKernelGGL(normalize_pad_kernel, grid, dim3(256), 0, st, in, out, C, H, W, Hp, Wp, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, mean, stdv);
+  return check_launch("normalize_pad_f32");
+}
+
 }  // namespace univs

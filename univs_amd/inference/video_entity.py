@@ -71,6 +71,18 @@ class ImageList:
         return ImageList(out, sizes)
 
 
+def normalized_image_list(frames, pixel_mean, pixel_std, size_divisibility):
+    """`ImageList.from_tensors([(f - mean) / std for f in frames], size_divisibility)` (inference_video_entity.py:246-250).  Frames of
+    one size on the GPU take ONE pass (ops.normalize_pad: bit-identical to the subtraction, the division and the padded copy)."""
+    if (len(frames) > 0 and frames[0].is_cuda and frames[0].dtype == torch.float32 and frames[0].dim() == 3
+            and all(f.shape == frames[0].shape for f in frames) and not torch.is_grad_enabled()):
+        from .. import ops
+        out = ops.normalize_pad(torch.stack(frames), pixel_mean, pixel_std, size_divisibility)
+        if out is not None:
+            return ImageList(out, [tuple(f.shape[-2:]) for f in frames])
+    return ImageList.from_tensors([(f - pixel_mean) / pixel_std for f in frames], size_divisibility)
+
+
 def _resize(masks, size):
     return F.interpolate(masks, size, mode="bilinear", align_corners=False)
 
@@ -171,7 +183,7 @@ class InferenceVideoEntity(nn.Module):
         "height", "width", "task", "dataset_name", "file_names", ...}].  `targets` defaults to what
         `model.prepare_targets.process_inference` builds (the reference's only mode); a prepared list may be passed."""
         frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
-        images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        images = normalized_image_list(frames, self.pixel_mean, self.pixel_std, self.size_divisibility)
         if targets is None:
             targets = model.prepare_targets.process_inference(batched_inputs, tuple(images.tensor.shape[-2:]), self.device,
                                                               getattr(model, "text_prompt_encoder", None),

@@ -120,9 +120,9 @@ class InferenceVideoVOS(nn.Module):
     def eval(self, model, batched_inputs, targets=None):
         """The reference's entry point (:203-241): normalise and pad the frames, build `targets` through
         `model.prepare_targets.process_inference` (unless a prepared list is passed), run the loop."""
-        from .video_entity import ImageList
+        from .video_entity import normalized_image_list
         frames = [f.to(self.device) for video in batched_inputs for f in video["image"]]
-        images = ImageList.from_tensors([(f - self.pixel_mean) / self.pixel_std for f in frames], self.size_divisibility)
+        images = normalized_image_list(frames, self.pixel_mean, self.pixel_std, self.size_divisibility)
         image_size = images.image_sizes[0]
         out_size = (batched_inputs[0].get("height", image_size[0]), batched_inputs[0].get("width", image_size[1]))
         if targets is None:

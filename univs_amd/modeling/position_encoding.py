@@ -164,15 +164,34 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
             t_indices = torch.arange(t, device=dev)[None, :].repeat(b, 1)
         return to_device_async(t_indices, dev) / self.num_max_frames * self.scale  # [b, t]
 
+    def temporal(self, t_indices, dev):
+        """pos_t [b, t, 2F] = sin / cos of the scaled frame indices: the temporal summand of `forward` / `forward_separable`, the same
+        for every feature level of a clip.  For HOST frame indices (what the clip loops pass: `torch.arange(i, i + T)`) the result is
+        cached by value -- a dozen tiny launches per level and clip otherwise (position_encoding.py:142-169 recomputes it per call)."""
+        def make():
+            dim_t_z = _dim_t(2 * self.num_pos_feats, self.temperature, dev)
+            z = to_device_async(t_indices, dev) / self.num_max_frames * self.scale
+            return _interleaved_sincos(z, dim_t_z)
+        if t_indices.is_cuda or torch.is_grad_enabled():
+            return make()
+        if not hasattr(self, "_t_cache"):
+            self._t_cache = _ShapeCache(cap=64)
+        key = (tuple(t_indices.shape), tuple(int(v) for v in t_indices.reshape(-1).tolist()), str(dev))
+        return self._t_cache.get(key, make)
+
     def forward(self, x, t_indices=None, mask=None):
         assert x.dim() == 5 and mask is None
         b, t, _, h, w = x.shape
         dev = x.device
         return self._compose(self._z(b, t, dev, t_indices), h, w, dev)
 
-    def forward_separable(self, x, t_indices=None):
-        """(yx [h*w, 2F], pos_t [b, t, 2F]) whose broadcast sum is `forward(x, t_indices)` (channels last)."""
+    def forward_separable(self, x, t_indices=None, pos_t=None):
+        """(yx [h*w, 2F], pos_t [b, t, 2F]) whose broadcast sum is `forward(x, t_indices)` (channels last).  `pos_t`: the result of
+        `temporal(t_indices, device)` where the caller already has it (one evaluation for all levels of a clip)."""
         b, t, _, h, w = x.shape
+        if pos_t is not None:
+            yx, _ = self._yx(h, w, x.device)
+            return yx.view(h * w, -1), pos_t
         return self.separable(self._z(b, t, x.device, t_indices), h, w, x.device)
 
     def forward_points_with_size(self, size, xy_embed_normalized, t_indices=None):

@@ -234,14 +234,23 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                                  "`predictor.default_dataset_name` first")
             targets = [{"task": "detection", "dataset_name": self.default_dataset_name, "prompt_type": "visual",
                         "num_frames": t_total, "first_frame_idx": 0, "frame_indices": torch.arange(t_total, device=dev)}]
+        frame_indices_host = None                        # the clip loops hand over host indices: the temporal embedding is cached by value
         if "frame_indices" in targets[0]:
-            frame_indices = to_device_async(torch.stack([tv["frame_indices"] for tv in targets]), dev)   # (no host stall on the stream)
+            fi = torch.stack([tv["frame_indices"] for tv in targets])
+            if not fi.is_cuda:
+                frame_indices_host = fi
+            frame_indices = to_device_async(fi, dev)   # (no host stall on the stream)
         else:
             frame_indices = torch.arange(t_total, device=dev)[None].repeat(bs, 1)
         if fs is not None:
             assert frame_indices.shape[1] == t_total, "targets['frame_indices'] must list the frames of ALL ranks"
             self._frame_indices_all = frame_indices
             frame_indices = frame_indices[:, fs.local_slice(t)]
+            if frame_indices_host is not None:
+                frame_indices_host = frame_indices_host[:, fs.local_slice(t)]
+        pos_t_clip = None                                # pos_t [b, t, 2F] of this clip, shared by the levels
+        if self.position_embedding_sin3d_type != "FixedT" and hasattr(self.pe_layer, "temporal") and not torch.is_grad_enabled():
+            pos_t_clip = self.pe_layer.temporal(frame_indices_host if frame_indices_host is not None else frame_indices, dev)
         mem_fused = [None] * self.num_feature_levels     # (memory, key) of a level from ONE kernel (ops.decoder_memory), where covered
         pos_makers = {}                                  # level -> closure that materialises its position embedding on demand (local:
                                                          # nothing of a forward pass outlives it on the module)
@@ -257,7 +266,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             if xin.is_cuda and bs == 1 and not torch.is_grad_enabled():
                 # NCHW -> [hw, t, C] + level embedding, and the same + position embedding, in one pass over the features; the
                 # position embedding itself is only materialised if the prompt encoder asks for it
-                yx, pz = self.pe_layer.forward_separable(xi) if fixed_t else self.pe_layer.forward_separable(xi, frame_indices)
+                yx, pz = self.pe_layer.forward_separable(xi) if fixed_t else self.pe_layer.forward_separable(xi, frame_indices, pos_t=pos_t_clip)
                 mem_fused[i] = ops.decoder_memory(xin, self.level_embed.weight[i], yx, pz[0])
             if mem_fused[i] is not None:
                 src.append(mem_fused[i][0])

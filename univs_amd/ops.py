@@ -786,6 +786,35 @@ def bilinear_resample(x, size, addend=None):
     return out
 
 
+def normalize_pad(x, mean, std, size_divisibility=0, pad_to=None):
+    """`F.pad((x - mean) / std, ...)` in one pass (include/univs_hip.h: univs_normalize_pad_f32): the pre-step of a clip
+    (inference_video_entity.py:246-250).  x [T, C, H, W] float32 on the GPU, mean / std [C] (any broadcastable shape with C elements);
+    rows / columns are zero-padded at the bottom / right up to a multiple of `size_divisibility` (or to `pad_to` = (Hp, Wp)).
+    Returns None when not covered (CPU tensors, autograd, other dtypes)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or needs_grad(x):
+        return None
+    T, C, H, W = x.shape
+    if pad_to is not None:
+        Hp, Wp = int(pad_to[0]), int(pad_to[1])
+    elif size_divisibility and size_divisibility > 1:
+        d = int(size_divisibility)
+        Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
+    else:
+        Hp, Wp = H, W
+    if T * C > 65535 or Hp < H or Wp < W or mean.numel() != C or std.numel() != C:
+        return None
+    xc = x.contiguous()
+    m = mean.reshape(C).to(device=x.device, dtype=torch.float32).contiguous()
+    s_ = std.reshape(C).to(device=x.device, dtype=torch.float32).contiguous()
+    out = torch.empty((T, C, Hp, Wp), dtype=torch.float32, device=x.device)
+    with _on(xc):
+        rc = _lib.load().univs_normalize_pad_f32(_ptr(xc), _ptr(m), _ptr(s_), T, C, H, W, Hp, Wp, _ptr(out), _stream_ptr(xc))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "normalize_pad")
+    return out
+
+
 def group_norm_affine(x, num_groups, weight, bias, eps=1e-5):
     """GroupNorm statistics of contiguous float32 NCHW `x` on the GPU as per-plane (scale, bias) pairs [N * C, 2] with
     F.group_norm(x) == x * scale + bias (include/univs_hip.h: univs_group_norm_affine_f32) -- for `upsample2x_add`, which applies
