@@ -232,3 +232,128 @@ def test_self_attention_rows_equal_rows_of_the_full_attention(pre_norm):
             assert (got - full[:, sl]).abs().max().item() < 2e-6
             assert seen[-1] == (Qn * (hi - lo), Qn * T)
     assert seen[0] == (Qn * T, Qn * T)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's sliding clip loop, frames of the video spread over the ranks (inference/video_entity.py: set_frame_shard)
+# ---------------------------------------------------------------------------------------------------
+LOOP_STATE_KEYS = ("logits", "masks", "mask_logits", "boxes", "embds", "ids", "first_appear_frame_idxs", "mask_quality_scores",
+                   "occurrence", "prompt_pe", "prompt_feats", "prompt_attn_masks", "frame_indices")
+
+
+def _loop_states(case, model, shard, **over):
+    """Runs the clip loop (sharded if `shard`); returns ({tag_key: tensor}, results, clip starts, pixel-decoder calls)."""
+    from tests import cases
+    from univs_amd.inference.video_entity import ImageList, InferenceVideoEntity
+    inf = InferenceVideoEntity(**cases.loop_kwargs(case, **over))
+    inf.set_frame_shard(shard)
+    dumps, calls = {}, []
+
+    def snapshot(tag, tv):
+        for k in LOOP_STATE_KEYS:
+            if k in tv:
+                dumps[f"{tag}_{k}"] = tv[k].detach().float().clone() if tv[k].dtype == torch.bool else tv[k].detach().clone()
+
+    def on_clip(i, targets):
+        snapshot(f"clip{len(calls)}_in", targets[0])
+        calls.append(int(i))
+    pd = model.sem_seg_head.pixel_decoder
+    pd_frames = []
+    orig = pd.forward_features
+    pd.forward_features = lambda f: (pd_frames.append(int(next(iter(f.values())).shape[0])), orig(f))[1]
+    try:
+        x = cases.preprocess(cases.loop_frames(case))
+        images = ImageList(x, [case["image_size"]] * case["n_frames"])
+        targets = cases.loop_targets(case)
+        with torch.no_grad():
+            torch.manual_seed(1)            # the prompt sampler draws from the CPU generator: same state on every rank
+            results = inf.inference_video(model, cases.loop_batched_inputs(case), images, targets, merge_results=False, on_clip=on_clip)
+    finally:
+        pd.forward_features = orig
+    snapshot("final", targets[0])
+    return dumps, results, calls, pd_frames
+
+
+def _clip_loop_worker(rank, world, port, case_over, kw_over):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import types
+        from oracle.cpu_path import cpu_ops
+        from tests import cases, helpers
+        from univs_amd.distributed import FrameShard
+        case = dict(cases.LOOP_CASE, **case_over)
+        model = types.SimpleNamespace(backbone=helpers.build_swin("cpu"), sem_seg_head=helpers.build_head(case, "cpu"))
+        kw = dict(stability_score_thresh=0.0, **kw_over)
+        with cpu_ops():
+            ref, ref_results, ref_calls, ref_pd = _loop_states(case, model, None, **kw)
+            got, results, calls, pd_frames = _loop_states(case, model, FrameShard(), **kw)
+        assert calls == ref_calls and len(calls) >= 2
+        # the stateless part really is spread: this rank ran backbone + pixel decoder on ITS frames only, once per frame ...
+        # (windows as the reference cuts them, :309-312: a new window starts with the first clip that reaches past the last one)
+        n, T, W = case["n_frames"], case["T"], 5
+        expect, win_end = [], 0
+        for i in ref_calls:
+            if i + T > win_end:
+                win_end = i + W
+                expect.append(len([f for f in range(i, min(win_end, n)) if f % world == rank]))
+        assert pd_frames == [e for e in expect if e], (pd_frames, expect, rank)
+        # ... where the unsharded loop runs the pixel decoder on every clip's frames
+        assert sum(ref_pd) == sum(min(case["T"], n - i) for i in ref_calls)
+        assert sorted(got) == sorted(ref)
+        for k in sorted(ref):
+            a, b = got[k], ref[k]
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            if a.numel() == 0:
+                continue
+            if k.endswith("_masks") and not k.endswith("attn_masks"):
+                logit = ref[k.replace("_masks", "_mask_logits")]
+                sure = logit.abs() > 1e-3                  # binarised logits: away from the decision boundary
+                assert torch.equal(a[sure], b[sure]), k
+            elif not a.dtype.is_floating_point:
+                assert torch.equal(a, b), k
+            else:
+                err = (a.double() - b.double()).abs().max().item()
+                assert err <= 2e-4 * max(1.0, b.abs().max().item()), (k, err)
+        assert len(results) == len(ref_results)
+        for ra, rb in zip(results, ref_results):
+            assert [r["obj_id"] for r in ra] == [r["obj_id"] for r in rb]
+            for x_, y_ in zip(ra, rb):
+                assert (torch.as_tensor(x_["score"]).double() - torch.as_tensor(y_["score"]).double()).abs().max().item() < 1e-4
+                assert (x_["masks"] != y_["masks"]).float().mean().item() < 1e-3
+        # every rank holds the same (replicated) state: compare a digest across the ranks
+        digest = torch.stack([got[k].double().sum() for k in sorted(got) if got[k].dtype.is_floating_point and got[k].numel()])
+        both = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(both, digest)
+        assert all((d - both[0]).abs().max().item() <= 1e-6 * max(1.0, both[0].abs().max().item()) for d in both)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_over,kw_over", [({}, {}), (dict(n_frames=8), dict(clip_stride=1))], ids=["g11a-7frames-stride2", "8frames-stride1"])
+def test_sharded_clip_loop_matches_single_process(case_over, kw_over):
+    """The reference's sliding clip loop (inference_video_entity.py:296-316; the 7-frame video of golden g11a) with the frames spread
+    over 2 ranks (frame f on rank f % 2: non-contiguous, unequal shares of every 3-frame clip): the per-video state at the entry of
+    every clip and at the end, and the emitted results == the single-process loop on every rank; backbone + pixel decoder run once per
+    owned frame and window.  Stride 1 makes the clips overlap by two frames."""
+    world = 2
+    mp.spawn(_clip_loop_worker, args=(world, _free_port(), case_over, kw_over), nprocs=world, join=True)
+
+
+def test_clip_shard_gather_orders_frames():
+    """ClipShard.all_gather_frames in a one-rank group (collective issued): identity; the position bookkeeping for cyclic owners."""
+    from univs_amd.distributed import ClipShard, cyclic_owners
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert cyclic_owners(3, 5, 2) == [1, 0, 1, 0, 1] and cyclic_owners(4, 3, 8) == [4, 5, 6]
+        cs = ClipShard([0, 0, 0], always_collective=True)
+        x = torch.arange(24.0).view(2, 3, 4)
+        assert torch.equal(cs.all_gather_frames(x, 1), x) and cs.local_slice(3) == slice(0, 3) and cs.total(3) == 3
+        with pytest.raises(AssertionError):
+            ClipShard([0, 1, 0])               # rank 1 does not exist in a one-rank group
+    finally:
+        dist.destroy_process_group()

@@ -56,6 +56,64 @@ class FrameShard:
         return x
 
 
+class ClipShard(FrameShard):
+    """The frames of ONE clip held by the ranks of a group in ARBITRARY ownership: `owners[p]` = group rank that holds clip position p.
+    What the sliding clip loop needs (inference/video_entity.py: frames are owned by absolute index, `f % world`, so a frame computed
+    once for a window serves every overlapping clip on the rank that made it): a rank's positions need not be contiguous nor equally
+    many.  Every rank of the group must own at least one position.  The interface is FrameShard's:
+      total(t_local) -> T; local_slice(t_local) -> a slice when the rank's positions are contiguous, else a list of positions;
+      all_gather_frames(x, dim): pads every rank's block to the largest count, ONE all_gather_into_tensor, then a gather of the valid
+      rows into clip order."""
+
+    def __init__(self, owners, group=None, always_collective=False):
+        super().__init__(group=group, always_collective=always_collective)
+        self.owners = [int(o) for o in owners]
+        self.t_total = len(self.owners)
+        assert self.t_total > 0 and all(0 <= o < self.world for o in self.owners), (self.owners, self.world)
+        self.positions = [[p for p, o in enumerate(self.owners) if o == r] for r in range(self.world)]
+        assert all(len(ps) > 0 for ps in self.positions), f"every rank of the group must own a frame of the clip (owners {self.owners})"
+        self.counts = [len(ps) for ps in self.positions]
+        self.max_count = max(self.counts)
+        self.local_positions = self.positions[self.rank]
+        # clip position p -> row of the padded rank-major gather
+        self._order = [self.owners[p] * self.max_count + self.positions[self.owners[p]].index(p) for p in range(self.t_total)]
+        self._order_cache = {}
+
+    def total(self, t_local: int) -> int:
+        assert t_local == len(self.local_positions), (t_local, self.local_positions)
+        return self.t_total
+
+    def local_slice(self, t_local: int):
+        ps = self.local_positions
+        assert t_local == len(ps), (t_local, ps)
+        if ps == list(range(ps[0], ps[0] + len(ps))):
+            return slice(ps[0], ps[0] + len(ps))
+        return list(ps)
+
+    def all_gather_frames(self, x: torch.Tensor, dim: int) -> torch.Tensor:
+        dim = dim % x.dim()
+        if self.world == 1 and not self.always_collective:
+            return x
+        n = x.shape[dim]
+        assert n == len(self.local_positions), (n, self.local_positions)
+        xm = x.movedim(dim, 0)
+        if n < self.max_count:
+            xm = torch.cat([xm, xm.new_zeros((self.max_count - n,) + tuple(xm.shape[1:]))], 0)
+        xm = xm.contiguous()
+        out = torch.empty((self.world * self.max_count,) + tuple(xm.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, xm, group=self.group)
+        idx = self._order_cache.get(x.device)
+        if idx is None:
+            idx = self._order_cache[x.device] = torch.tensor(self._order, dtype=torch.long).to(x.device, non_blocking=True)
+        return out.index_select(0, idx).movedim(0, dim)
+
+
+def cyclic_owners(first_frame: int, num_frames: int, world: int):
+    """Owner (group rank) of every position of the clip [first_frame, first_frame + num_frames) when frame f of the video belongs to
+    rank f % world: fixed per absolute frame, so overlapping clips and the memory pool agree on who holds a frame's features."""
+    return [(first_frame + p) % world for p in range(num_frames)]
+
+
 def shard_frames(tensor_or_dict, shard: FrameShard, t_total: int):
     """Slice dim 0 (frames) of a tensor / every tensor of a dict to this rank's block."""
     assert t_total % shard.world == 0, "frames must divide evenly over the ranks"

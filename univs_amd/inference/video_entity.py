@@ -141,6 +141,10 @@ class InferenceVideoEntity(nn.Module):
         # category ids (1-based, as the reference's metadata.thing_dataset_id_to_contiguous_id keys) that are "things"
         self.thing_dataset_ids = frozenset(int(c) for c in thing_dataset_ids)
         self.video_unified_inference_entities = video_unified_inference_entities
+        # see inference_video: overlapping clips of one window share the pixel decoder's per-frame outputs (False: once per clip, as the
+        # reference calls it)
+        self.pixel_decoder_once_per_window = True
+        self.frame_shard = None
         # {dataset name: (num_classes, start index)} slices of the class-embedding table; None = no slicing
         self.dataset_category_info = COMBINED_DATASETS_CATEGORY_INFO if dataset_category_info is None else dataset_category_info
 
@@ -210,7 +214,51 @@ class InferenceVideoEntity(nn.Module):
             return self.dataset_category_info[dataset_name]
         return self.dataset_category_info.get(dataset_name)
 
-    def inference_video(self, model, batched_inputs, images, targets, merge_results=True):
+    def set_frame_shard(self, shard):
+        """Run `inference_video` with the frames of the video spread over the ranks of `shard` (a univs_amd.distributed.FrameShard:
+        group, rank, world; None switches back).  Frame f belongs to rank f % world: a window's backbone + pixel decoder run on the
+        rank's own frames only -- ONCE per frame, whatever the clip stride (the reference's loop, and the unsharded one here, run the
+        pixel decoder once per CLIP: five times per frame at stride 1) -- and every clip's decoder runs on all ranks, each with the
+        clip's frames it owns (ClipShard: one all-gather of the query states per layer).  The per-video state `targets[0]` stays
+        REPLICATED: after a clip, the mask logits / embeddings of its frames are all-gathered and every rank does the same
+        book-keeping.  Needs world <= num_frames (every rank must own a frame of every clip; on a larger node the other ranks take
+        other videos).  SURVEY.md 8e; reference loop: inference_video_entity.py:296-316."""
+        self.frame_shard = shard
+
+    def _window_features(self, model, x, frames, shard):
+        """backbone + pixel decoder of `frames` (absolute indices) on the frames this rank owns -> ({frame: row}, outputs)."""
+        mine = [f for f in frames if f % shard.world == shard.rank]
+        if not mine:
+            return {}, None
+        feats = model.backbone(x[mine] if mine != list(range(mine[0], mine[0] + len(mine))) else x[mine[0]:mine[0] + len(mine)])
+        mf, bfe, _enc, ms = model.sem_seg_head.pixel_decoder.forward_features(feats)
+        return {f: k for k, f in enumerate(mine)}, (mf, bfe, list(ms))
+
+    def _sharded_clip(self, model, targets, first, n_clip, rows, pd, shard):
+        """The head's predictor on the clip [first, first + n_clip) whose frames are spread over the ranks -> the full-clip output dict
+        on every rank."""
+        from ..distributed import ClipShard, cyclic_owners
+        predictor = model.sem_seg_head.predictor
+        owners = cyclic_owners(first, n_clip, shard.world)
+        if len(set(owners)) < shard.world:
+            # (a clip shorter than num_frames only arises when the video ends inside it; the reference's own memory-pool update raises on
+            # such clips once entities exist, inference_video_entity.py:326-339 -- nothing to stay compatible with)
+            raise ValueError(f"frame-sharded clip loop: the clip at frame {first} has {n_clip} frames for {shard.world} ranks")
+        cs = ClipShard(owners, group=shard.group, always_collective=shard.always_collective)
+        k = [rows[first + p] for p in cs.local_positions]
+        sel = (lambda t: t[k[0]:k[0] + len(k)]) if k == list(range(k[0], k[0] + len(k))) else (lambda t: t[k])
+        mf, bfe, ms = pd
+        predictor.frame_shard = cs
+        try:
+            out = predictor([sel(lv) for lv in ms], sel(mf), sel(bfe) if bfe is not None else None, None, targets)
+        finally:
+            predictor.frame_shard = None
+        out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
+        out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
+        return out
+
+    def inference_video(self, model, batched_inputs, images, targets, merge_results=True, on_clip=None):
+        """`on_clip(first_frame_idx, targets)`: optional observer called at the entry of every clip (tests, tracing)."""
         x = images.tensor
         tv = targets[0]
         sub_task = tv["sub_task"]
@@ -228,6 +276,13 @@ class InferenceVideoEntity(nn.Module):
         is_last = False
         win_start = win_end = 0
         feats_window = None
+        shard = getattr(self, "frame_shard", None)
+        if shard is not None and shard.world == 1 and not shard.always_collective:
+            shard = None
+        if shard is not None and shard.world > T:
+            raise ValueError(f"frame-sharded clip loop: {shard.world} ranks for clips of {T} frames -- every rank must own a frame of "
+                             "every clip (give the loop a group of at most num_frames ranks; other ranks take other videos)")
+        win_rows, win_pd = {}, None
         for i in range(0, n_total, stride):
             if is_last and i + T > n_total:
                 break
@@ -235,12 +290,33 @@ class InferenceVideoEntity(nn.Module):
             tv["first_frame_idx"] = i
             tv["frame_indices"] = torch.arange(i, min(i + T, n_total))
 
-            if i + T > win_end:      # the backbone runs once per window of frames
-                win_start, win_end = i, i + self.num_frames_window_test
-                feats_window = model.backbone(x[win_start:win_end])
-            o = i - win_start
-            feats = {k: v[o:o + T] for k, v in feats_window.items()}
-            out = model.sem_seg_head(feats, targets=targets)
+            if on_clip is not None:
+                on_clip(i, targets)
+            if shard is not None:
+                if i + T > win_end:  # the window's frames: backbone AND pixel decoder, on their owners, once per frame
+                    win_start, win_end = i, i + self.num_frames_window_test
+                    win_rows, win_pd = self._window_features(model, x, list(range(win_start, min(win_end, n_total))), shard)
+                out = self._sharded_clip(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard)
+            else:
+                if i + T > win_end:      # the backbone runs once per window of frames
+                    win_start, win_end = i, i + self.num_frames_window_test
+                    feats_window = model.backbone(x[win_start:win_end])
+                    # windows longer than a clip: the pixel decoder too runs once per FRAME of the window (it is per-frame work; the
+                    # reference's loop repeats it for every clip a frame belongs to -- five times per frame at stride 1, :316)
+                    win_pd = None
+                    head = model.sem_seg_head
+                    if (self.pixel_decoder_once_per_window and self.num_frames_window_test > T and stride < T
+                            and hasattr(head, "pixel_decoder") and hasattr(head, "predictor")):
+                        mf, bfe, _enc, ms = head.pixel_decoder.forward_features(feats_window)
+                        win_pd = (mf, bfe, list(ms))
+                o = i - win_start
+                if win_pd is not None:
+                    mf, bfe, ms = win_pd
+                    out = model.sem_seg_head.predictor([lv[o:o + T] for lv in ms], mf[o:o + T], bfe[o:o + T] if bfe is not None else None,
+                                                       None, targets)
+                else:
+                    feats = {k: v[o:o + T] for k, v in feats_window.items()}
+                    out = model.sem_seg_head(feats, targets=targets)
             out.pop("aux_outputs", None)
 
             out["pred_logits"] = out["pred_logits"].sigmoid()

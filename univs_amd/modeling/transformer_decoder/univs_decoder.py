@@ -643,7 +643,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
 
     def _sa_mask_rows(self, mask, Qn, t_total, sl):
         """Rows of the [Q' T, Q' T] self-attention mask that belong to the frames `sl` (token order (q, t)): [Q' T_loc, Q' T]."""
-        key = ("rows", id(mask), Qn, t_total, sl.start, sl.stop)
+        key = ("rows", id(mask), Qn, t_total, (sl.start, sl.stop) if isinstance(sl, slice) else tuple(sl))
         m = self._sa_mask_cache.get(key)
         if m is None or m[0] is not mask:
             rows = mask.view(Qn, t_total, Qn * t_total)[:, sl].reshape(-1, Qn * t_total).contiguous()
