@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-frame-sharded", action="store_true", help="skip the config-3 frame-sharded measurement (N>1: one clip "
                     "of 5*N frames over the ranks; N=1: the 40-frame anchor under a one-rank RCCL group)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (Swin-L, 1080p) clip measurement at N = 1")
+    ap.add_argument("--no-sliding-loop", action="store_true", help="skip the sliding-clip-loop video measurement (config 3 as the reference runs it)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (Swin-B, 200 queries + text prompts) clip measurement at N = 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo plumbing check (tests): launcher, rendezvous, barrier-bracketed timing, max over "
                          "ranks, JSON line -- with a trivial step instead of the model")
@@ -475,6 +477,121 @@ def run(args):
             res["config5_swinl_1080p"] = {"error": repr(e)[:300]}
             if "wa" in locals():
                 setattr(ops, "window_attention_image", wa.orig)
+
+    # ---- BASELINE config 3 as the reference RUNS a long video (inference_video_entity.py:296-316): the sliding 5-frame clip loop with
+    # the prompt memory pool carried from clip to clip, over a 20-frame 720p video at the reference's default stride 1 (16 clips).
+    #   N = 1: (a) the reference's call pattern (window 5: backbone and pixel decoder once per CLIP), (b) one 20-frame window with the
+    #          pixel decoder once per FRAME (inference/video_entity.py: pixel_decoder_once_per_window);
+    #   N > 1: the frames of the video spread over min(N, 5) ranks (frame f on rank f % world: InferenceVideoEntity.set_frame_shard),
+    #          every clip's decoder on those ranks with one all-gather of the query states per layer, per-video state replicated.
+    if not args.no_sliding_loop:
+        try:
+            import types
+            from univs_amd.inference.video_entity import InferenceVideoEntity, normalized_image_list
+            NF = 20
+            vid = synth.synthetic_frames(NF, case["H"], case["W"], "cfg3/frames").to(dev)
+            model_ns = types.SimpleNamespace(backbone=swin, sem_seg_head=head)
+
+            def make_loop(window):
+                return InferenceVideoEntity(
+                    hidden_dim=256, num_queries=Q, overlap_threshold_entity=0.5, stability_score_thresh=0.5, size_divisibility=32,
+                    pixel_mean=synth.PIXEL_MEAN, pixel_std=synth.PIXEL_STD, num_frames=T, test_topk_per_image=100, apply_cls_thres=0.25,
+                    box_nms_thresh=0.85, num_frames_window_test=window, clip_stride=1, num_prev_frames_memory=5,
+                    video_unified_inference_entities="", temporal_consistency_threshold=0.25, detect_newly_object_threshold=0.1,
+                    detect_newly_interval_frames=1, custom_videos_enable=False).to(dev)
+
+            def run_video(loop):
+                torch.manual_seed(0)             # the prompt sampler's draws: the same on every rank
+                images = normalized_image_list(list(vid), loop.pixel_mean, loop.pixel_std, 32)
+                tg = [{"task": "detection", "dataset_name": "ytvis_2021_dev", "prompt_type": "visual", "num_frames": T,
+                       "video_len": NF, "sub_task": "vis"}]
+                with torch.no_grad():
+                    out = loop.inference_video(model_ns, [{"video_len": NF, "height": case["H"], "width": case["W"]}], images, tg,
+                                               merge_results=False)
+                n_ent = int(tg[0]["ids"].shape[0]) if "ids" in tg[0] else 0
+                return out, n_ent
+
+            def time_video(loop, reps=2):
+                run_video(loop)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    _, n_ent = run_video(loop)
+                sync()
+                return (time.perf_counter() - t0) / reps, n_ent
+            sl = {"workload": f"BASELINE config 3 as the reference runs it: {NF}-frame 720p video, sliding {T}-frame clips at stride 1 "
+                              f"({NF - T + 1} clips), visual-prompt memory pool carried between clips; 1 warm-up + 2 timed videos"}
+            if world == 1:
+                lp = make_loop(T)
+                lp.pixel_decoder_once_per_window = False
+                dt_ref, n_ent = time_video(lp)
+                sl["reference_call_pattern"] = {"window": T, "ms_per_video": dt_ref * 1e3, "frames_per_s": NF / dt_ref, "entities_at_end": n_ent,
+                                                "note": "backbone + pixel decoder once per clip (window = clip, :309-316)"}
+                lp = make_loop(NF)
+                dt_w, n_ent = time_video(lp)
+                sl["one_window"] = {"window": NF, "ms_per_video": dt_w * 1e3, "frames_per_s": NF / dt_w, "entities_at_end": n_ent,
+                                    "note": "backbone and pixel decoder once per frame of the window, decoder per clip"}
+            else:
+                from univs_amd.distributed import FrameShard
+                team = min(world, T)
+                import datetime
+                # a group of its own with a short timeout: a failure on one rank must not hang the others for the default ten minutes
+                grp = dist.new_group(ranks=list(range(team)), timeout=datetime.timedelta(seconds=180))
+                dts = 0.0
+                if rank < team:
+                    lp = make_loop(NF)
+                    lp.set_frame_shard(FrameShard(group=grp))
+                    dts, n_ent = time_video(lp)
+                    sl["entities_at_end"] = n_ent
+                tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dts = float(tt.item())
+                sl["frame_sharded"] = {"ranks_used": team, "ranks_idle": world - team, "window": NF, "ms_per_video": dts * 1e3,
+                                       "frames_per_s": NF / dts,
+                                       "note": "frame f on rank f % ranks_used: backbone + pixel decoder on owned frames, every clip's decoder "
+                                               "on all used ranks (ClipShard), targets[0] replicated; ranks beyond num_frames idle here "
+                                               "(they would take other videos)"}
+            res["sliding_clip_loop"] = sl
+        except Exception as e:  # pragma: no cover
+            import traceback
+            res["sliding_clip_loop"] = {"error": "".join(traceback.format_exception(type(e), e, e.__traceback__))[-600:]}
+            if world > 1:
+                pass
+
+    # ---- BASELINE config 4: Swin-B (12 x 12 windows), T=5 @ 720p, 200 learnable queries + 4 referring expressions: the text-prompt
+    # path (78 text tokens per expression cross-attend to the three feature levels, ...decoder_univs.py:760-793; ProCA; 'sep-blocked'
+    # self-attention).  Parity at this size: tests/test_modules_gpu.py (golden g14 / g14b); here its cost, on rank 0 at N = 1
+    if world == 1 and not args.no_config4:
+        try:
+            c4 = cases.CFG4
+            swin4 = helpers.build_swin(dev, variant=cases.SWIN_B)
+            head4 = helpers.build_head(c4, dev, return_aux=False, **cases.CFG4_DECODER)
+            tg4 = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.cfg4_targets(c4)[0].items()}
+
+            @torch.no_grad()
+            def step4():
+                x4 = ops.normalize_pad(frames, mean, std, pad_to=(736, 1280))
+                return head4(swin4(x4), targets=[dict(tg4)])
+            for _ in range(2):
+                step4()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step4()
+            sync()
+            dt4 = (time.perf_counter() - t0) / 5
+            t0 = time.perf_counter()
+            step4()
+            enq4 = time.perf_counter() - t0
+            sync()
+            res["config4_swinb_refvos"] = {
+                "workload": "BASELINE config 4: Swin-B (12 x 12 windows), T=5 @ 720p (736x1280 padded), 200 queries + 4 referring "
+                            "expressions (grounding: lang->vision cross-attention, ProCA, 'sep-blocked' self-attention); 2 warm-up + 5 timed clips",
+                "ms_per_clip": dt4 * 1e3, "frames_per_s": c4["T"] / dt4, "queries": c4["Q"] + c4["n_exp"], "host_enqueue_ms": enq4 * 1e3}
+            del swin4, head4
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            res["config4_swinb_refvos"] = {"error": repr(e)[:300]}
 
     if rank != 0:
         if world > 1:

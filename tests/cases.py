@@ -148,13 +148,6 @@ def swin_input(case=SWIN_CASE):
     return (frames - mean) / std
 
 
-def targets_grounding(case=HEAD_CASE, n_exp=3):
-    T = case["T"]
-    tv = targets_first_clip(case, task="grounding", prompt_type="text")[0]
-    tv["exp_word_feats"] = synth.normal("grounding/word", (n_exp, 77, T, 640))
-    tv["exp_sentence_feats"] = synth.normal("grounding/sent", (n_exp, T, 640))
-    tv["exp_word_len"] = [7] * n_exp
-    return [tv]
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -335,14 +328,7 @@ class ScriptedHead:
 # BASELINE config 4: Swin-B (window 12), T=5 @ 720p, 200 learnable queries + 4 referring expressions
 # (grounding, 'sep-blocked' self-attention mask, text prompts fused into the image features)
 # ---------------------------------------------------------------------------------------------------
-SWINB_SHAPES = {"res2": (128, 4), "res3": (256, 8), "res4": (512, 16), "res5": (1024, 32)}
-CFG4 = dict(name="cfg4", T=5, H=720, W=1280, Q=200, shapes=SWINB_SHAPES, n_exp=4)
-CFG4_DECODER = dict(text_to_image=True, sa_mask="sep-blocked")
-
-
-def cfg4_targets(case=CFG4):
-    tv = targets_grounding(case, n_exp=case["n_exp"])[0]
-    return [tv]
+from univs_amd.workloads import CFG4, CFG4_DECODER, SWINB_SHAPES, cfg4_targets, targets_grounding  # noqa: E402,F401
 
 
 # panoptic sub-task on the scripted scene: categories (1-based) of objects 0, 3, 4 are "things", the others "stuff"

@@ -105,6 +105,26 @@ def cfg2_frames(case=CFG2):
 # Swin-L (configs/univs_inf/vids/vis/univs_swinl_yt21_c1+univs.yaml:5-13) -- BASELINE config 5: T=10 @ 1080p (padded to
 # 1088x1920), 200 queries.  The reference's CPU run of the full clip needs > 100 GB, so the golden (g19) is the same
 # network on the first TWO frames; the T=10 run is checked through size-independent properties on the GPU.
+# BASELINE config 4: Swin-B (window 12), T=5 @ 720p, 200 learnable queries + 4 referring expressions (grounding, 'sep-blocked'
+# self-attention mask, text prompts fused into the image features: configs/univs_inf/vids/refvos/univs_swinb_refvos_davis_c1+univs.yaml)
+SWINB_SHAPES = {"res2": (128, 4), "res3": (256, 8), "res4": (512, 16), "res5": (1024, 32)}
+CFG4 = dict(name="cfg4", T=5, H=720, W=1280, Q=200, shapes=SWINB_SHAPES, n_exp=4)
+CFG4_DECODER = dict(text_to_image=True, sa_mask="sep-blocked")
+
+
+def targets_grounding(case=HEAD_CASE, n_exp=3):
+    T = case["T"]
+    tv = targets_first_clip(case, task="grounding", prompt_type="text")[0]
+    tv["exp_word_feats"] = synth.normal("grounding/word", (n_exp, 77, T, 640))
+    tv["exp_sentence_feats"] = synth.normal("grounding/sent", (n_exp, T, 640))
+    tv["exp_word_len"] = [7] * n_exp
+    return [tv]
+
+
+def cfg4_targets(case=CFG4):
+    return [targets_grounding(case, n_exp=case["n_exp"])[0]]
+
+
 CFG5 = dict(name="cfg5", T=10, H=1080, W=1920, Q=200, shapes=SWINL_SHAPES)
 CFG5_GOLDEN_T = 2
 
