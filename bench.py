@@ -521,16 +521,34 @@ def run(args):
                 return (time.perf_counter() - t0) / reps, n_ent
             sl = {"workload": f"BASELINE config 3 as the reference runs it: {NF}-frame 720p video, sliding {T}-frame clips at stride 1 "
                               f"({NF - T + 1} clips), visual-prompt memory pool carried between clips; 1 warm-up + 2 timed videos"}
+            enc_ = head.predictor.visual_prompt_sampler.visual_prompt_encoder
+            sl["sampler_default"] = enc_.sampler_rng
+
+            def with_sampler(mode, loop):
+                old_mode = enc_.sampler_rng
+                enc_.sampler_rng = mode
+                try:
+                    return time_video(loop)
+                finally:
+                    enc_.sampler_rng = old_mode
             if world == 1:
                 lp = make_loop(T)
                 lp.pixel_decoder_once_per_window = False
-                dt_ref, n_ent = time_video(lp)
-                sl["reference_call_pattern"] = {"window": T, "ms_per_video": dt_ref * 1e3, "frames_per_s": NF / dt_ref, "entities_at_end": n_ent,
-                                                "note": "backbone + pixel decoder once per clip (window = clip, :309-316)"}
+                dt_ref, n_ent = with_sampler("reference", lp)
+                sl["reference_call_pattern"] = {"window": T, "sampler": "reference", "ms_per_video": dt_ref * 1e3, "frames_per_s": NF / dt_ref,
+                                                "entities_at_end": n_ent,
+                                                "note": "the reference's algorithm call for call: backbone + pixel decoder once per clip (window = "
+                                                        "clip, :309-316), prompt pixels drawn by host-side randperm over every entity's candidates"}
                 lp = make_loop(NF)
-                dt_w, n_ent = time_video(lp)
-                sl["one_window"] = {"window": NF, "ms_per_video": dt_w * 1e3, "frames_per_s": NF / dt_w, "entities_at_end": n_ent,
-                                    "note": "backbone and pixel decoder once per frame of the window, decoder per clip"}
+                dt_w, n_ent = with_sampler("reference", lp)
+                sl["one_window_reference_sampler"] = {"window": NF, "sampler": "reference", "ms_per_video": dt_w * 1e3, "frames_per_s": NF / dt_w,
+                                                      "entities_at_end": n_ent,
+                                                      "note": "backbone and pixel decoder once per frame of the window, decoder per clip"}
+                # the library default on the GPU: the prompt sampler draws on the device (same distributions, another random stream, no host
+                # round trip, no host randperm over an entity's candidate pixels -- 4 ms each for a large mask at 720p)
+                dt_d, n_ent = with_sampler("device", lp)
+                sl["one_window"] = {"window": NF, "sampler": "device", "ms_per_video": dt_d * 1e3, "frames_per_s": NF / dt_d, "entities_at_end": n_ent,
+                                    "note": "the default configuration of this build (UNIVS_SAMPLER unset: 'auto' = device draws on the GPU)"}
             else:
                 from univs_amd.distributed import FrameShard
                 team = min(world, T)
@@ -821,8 +839,25 @@ def run(args):
                     prompted_clip()
                 torch.cuda.synchronize()
             dtp = (time.perf_counter() - t0) / 5
+            enc_p = head.predictor.visual_prompt_sampler.visual_prompt_encoder
             res["steady_state_with_prompts"] = {"ms_per_clip": dtp * 1e3, "frames_per_s": T / dtp, "entities": 10,
-                                                "queries": 110, "note": "second clip of a video, visual prompts"}
+                                                "queries": 110, "sampler": enc_p._rng(dev),
+                                                "note": "second clip of a video, visual prompts; the library's default sampler mode"}
+            if enc_p._rng(dev) != "reference":
+                old_mode = enc_p.sampler_rng
+                enc_p.sampler_rng = "reference"
+                try:
+                    with torch.no_grad():
+                        for _ in range(2):
+                            prompted_clip()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(5):
+                            prompted_clip()
+                        torch.cuda.synchronize()
+                    res["steady_state_with_prompts"]["reference_sampler_ms_per_clip"] = (time.perf_counter() - t0) / 5 * 1e3
+                finally:
+                    enc_p.sampler_rng = old_mode
         except Exception as e:  # pragma: no cover
             res["steady_state_with_prompts"] = {"error": str(e)[:200]}
 

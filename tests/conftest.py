@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The parity tests compare with states recorded inside the reference, whose prompt sampler draws through the host generator: they need
+# the reference's random stream (univs_amd/switches.py: sampler).  The library default on the GPU is the device-side sampler ("auto");
+# tests of that mode select it per encoder.  Set before univs_amd.switches is imported.
+os.environ.setdefault("UNIVS_SAMPLER", "reference")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

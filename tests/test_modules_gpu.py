@@ -287,6 +287,71 @@ def test_clip_loop_on_device_matches_reference(cuda, golden_dir):
     assert len(results) == 1 and results[0][0]["masks"].shape[-2:] == case["image_size"]
 
 
+def test_device_sampler_on_the_gpu(cuda, golden_dir):
+    """`sampler="device"` (UNIVS_SAMPLER=device; prompt_encoder.py:290, :369, :506-544) ON the device: the prompt sampler draws with the
+    device generator and never calls the host -- no `torch.randperm`, no `.tolist()` inside the head -- over the three clips of the
+    7-frame video (memory pool, ProCA).  Its draws differ from the reference's random stream, so what is asserted is what does NOT
+    depend on individual draws: the clip schedule, the integer book-keeping of the first clip (no prompts yet: identical to the
+    reference golden g11a), the entities found, class logits and mask areas of later clips close to the reference-mode run; sampled
+    pixels lie inside their entity's mask (operator level: tests/test_sampler_device_cpu.py); seeded runs repeat bit for bit."""
+    import types
+
+    from tests.test_clip_loop_cpu import run_loop
+    g = _g(golden_dir, "g11a_clip_loop_model")
+    case = cases.LOOP_CASE
+    model = types.SimpleNamespace(backbone=helpers.build_swin(cuda), sem_seg_head=helpers.build_head(case, cuda))
+    enc = model.sem_seg_head.predictor.visual_prompt_sampler.visual_prompt_encoder
+    ref_run, _ = run_loop(case, model, device=cuda, stability_score_thresh=0.0)
+    assert enc.sampler_rng == "reference"
+    enc.sampler_rng = "device"
+    orig_rp, orig_tl = torch.randperm, torch.Tensor.tolist
+    head_fwd = model.sem_seg_head.predictor.forward
+    inside = {"n": 0}
+
+    def guarded_fwd(*a, **k):
+        inside["n"] += 1
+        try:
+            return head_fwd(*a, **k)
+        finally:
+            inside["n"] -= 1
+
+    def no_randperm(*a, **k):
+        raise AssertionError("torch.randperm in device sampler mode")
+
+    def guarded_tolist(self):
+        assert not (inside["n"] and self.is_cuda), "host round trip (.tolist of a device tensor) inside the head in device sampler mode"
+        return orig_tl(self)
+    model.sem_seg_head.predictor.forward = guarded_fwd
+    torch.randperm, torch.Tensor.tolist = no_randperm, guarded_tolist
+    try:
+        got, results = run_loop(case, model, device=cuda, stability_score_thresh=0.0)
+        enc._dev_gen.clear()
+        again, _ = run_loop(case, model, device=cuda, stability_score_thresh=0.0)
+    finally:
+        torch.randperm, torch.Tensor.tolist = orig_rp, orig_tl
+        model.sem_seg_head.predictor.forward = head_fwd
+        enc.sampler_rng = "reference"
+    assert got["clip_first_frames"].tolist() == g["clip_first_frames"].tolist() == [0, 2, 4]
+    assert sorted(got) == sorted(ref_run)
+    for k in got:                                               # seeded: the same video twice gives the same states
+        assert torch.equal(got[k], again[k]), k
+    for k in got:
+        assert got[k].shape == ref_run[k].shape, k              # same entities, same pool layout
+        if k.startswith("clip0_in_") or k.startswith("clip1_in_"):
+            # up to the entry of the second clip no prompt token has been sampled: the device mode IS the reference mode there
+            if got[k].dtype.is_floating_point:
+                assert (got[k] - ref_run[k]).abs().max().item() <= 1e-5 * max(1.0, ref_run[k].abs().max().item()), k
+            else:
+                assert torch.equal(got[k], ref_run[k]), k
+    for k in ("final_ids", "final_first_appear_frame_idxs", "final_frame_indices", "final_occurrence"):
+        assert torch.equal(got[k], ref_run[k]), k
+    # later clips see different prompt tokens: class logits and mask areas stay close to the reference-mode run
+    assert (got["final_logits"] - ref_run["final_logits"]).abs().max().item() < 5e-2
+    a, b = (got["final_masks"] > 0.5).float().sum((-2, -1)), (ref_run["final_masks"] > 0.5).float().sum((-2, -1))
+    assert ((a - b).abs() <= 0.1 * b.clamp(min=50.0)).all(), (a, b)
+    assert torch.isfinite(got["final_mask_logits"]).all() and len(results) == 1
+
+
 def _cfg4_run(cuda, attn_hook=None):
     """Config 4 at full size through the HIP path; `attn_hook(call_index, our_mask) -> mask to use` wraps the fused
     attention-mask operator (ops.mask_decode_attn: one call per prediction head, 10 per clip)."""

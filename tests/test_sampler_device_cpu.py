@@ -80,6 +80,26 @@ def test_device_mode_is_seeded_and_uniform():
     assert counts.numel() == n_cand and (counts.float() - expect).abs().max() < 6 * expect ** 0.5 + 1
 
 
+def test_auto_mode_resolves_by_device():
+    """The default ("auto"): the reference's host draws for CPU tensors, the device generator for GPU tensors."""
+    from univs_amd.switches import Switches
+    assert Switches().sampler == "auto"
+    enc = VisualPromptEncoder(hidden_dim=256, num_frames=2, num_dense_points=R)
+    enc.sampler_rng = "auto"
+    assert enc._rng(torch.zeros(1)) == "reference" and enc._rng(torch.device("cpu")) == "reference"
+    assert enc._rng(torch.device("cuda", 0)) == "device"
+    enc.sampler_rng = "device"
+    assert enc._rng(torch.zeros(1)) == "device"
+    masks, feats, pos = scene()
+    enc.sampler_rng = "auto"
+    ref, _ = encoders()
+    torch.manual_seed(3)
+    a = enc.get_mask_prompt(feats, pos, masks, key_fid=0, key_fid_original=5)
+    torch.manual_seed(3)
+    b = ref.get_mask_prompt(feats, pos, masks, key_fid=0, key_fid_original=5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))          # on the CPU "auto" IS the reference mode
+
+
 def test_unknown_mode_is_rejected():
     from univs_amd.switches import override
     with override(sampler="fast"), pytest.raises(ValueError):

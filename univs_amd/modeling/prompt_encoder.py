@@ -161,9 +161,9 @@ class VisualPromptEncoder:
         # rank per point; uniform R-subset in random order via top-R of random keys), no host round trip; the random
         # stream differs from the reference's, everything that is not random (cyclic fill of small masks, fallbacks of
         # empty ones) is identical.
-        self.sampler_rng = SWITCHES.sampler          # "reference" | "device" (switches.py; settable per encoder)
-        if self.sampler_rng not in ("reference", "device"):
-            raise ValueError(f"sampler mode {self.sampler_rng!r} (expected 'reference' or 'device')")
+        self.sampler_rng = SWITCHES.sampler          # "auto" | "reference" | "device" (switches.py; settable per encoder)
+        if self.sampler_rng not in ("auto", "reference", "device"):
+            raise ValueError(f"sampler mode {self.sampler_rng!r} (expected 'auto', 'reference' or 'device')")
         self._dev_gen = {}
         self._replay = None
         # a list: every get_mask_prompt call (or key frame of get_mask_prompts) appends the pixels it sampled, in the format
@@ -183,6 +183,16 @@ class VisualPromptEncoder:
 
     def replay_pending(self):
         return 0 if self._replay is None else len(self._replay)
+
+    def _rng(self, where):
+        """The sampler mode in effect for tensors on `where` (a tensor or a device): "auto" = "device" on the GPU (draws from the device
+        generator: no host round trip, no host-side randperm over an entity's candidate pixels -- 4 ms each for a large mask at 720p,
+        82 -> 8 ms per clip in profiles/r05_video_loop_stages_v1.txt) and "reference" on the CPU (the reference's host `randperm`
+        calls in the reference's order: its random stream, draw for draw)."""
+        if self.sampler_rng != "auto":
+            return self.sampler_rng
+        dev = where.device if isinstance(where, torch.Tensor) else torch.device(where)
+        return "device" if dev.type == "cuda" else "reference"
 
     def _generator(self, device):
         g = self._dev_gen.get(str(device))
@@ -287,7 +297,7 @@ class VisualPromptEncoder:
             replay_feat_idx = to_device_async(replay_feat_idx.to(torch.int64), device)
             counts = [None] * (2 * n)
             point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
-        elif self.sampler_rng == "device":
+        elif self._rng(masks) == "device":
             counts = [None] * (2 * n)                        # sizes stay on the device
             point_coords = self.select_points_from_box_mask(h_img, w_img, masks=masks, boxes=boxes,
                                                             _prepared=(_pre["sel"], _pre["rowcnt"], None))
@@ -314,7 +324,7 @@ class VisualPromptEncoder:
         if enable_dense_prompt:
             fd, pd = self.get_dense_features(img_features, img_pos, feat_masks_binary, query_pe, query_feats,
                                              prompt_type="masks", is_train=is_train,
-                                             _counts=None if self.sampler_rng == "device" else counts[n:],
+                                             _counts=None if self._rng(masks) == "device" else counts[n:],
                                              _replay_idx=replay_feat_idx)
         if self.feature_reduce is not None:
             fd = self.feature_reduce(fd[:, :, 0].contiguous())[:, :, None].repeat(1, 1, fd.shape[2], 1)
@@ -366,7 +376,7 @@ class VisualPromptEncoder:
             dense_idx = to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
             empty = (dense_idx[:, :1] < 0).view(-1, 1, 1)
             dense_idx = dense_idx.clamp(min=0)
-        elif self.sampler_rng == "device":
+        elif self._rng(device) == "device":
             rowcnt = pre["rowcnt"].reshape(N, h)
             cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
             u = torch.rand((N, 1), device=device, generator=self._generator(device))
@@ -503,10 +513,10 @@ class VisualPromptEncoder:
                 f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
             if _prepared is None:
                 sel, rowcnt = self._select_candidates(masks, boxes, mask_thresh)
-                counts = None if self.sampler_rng == "device" else rowcnt.sum(1).tolist()   # the one host round trip
+                counts = None if self._rng(masks) == "device" else rowcnt.sum(1).tolist()   # the one host round trip
             else:
                 sel, rowcnt, counts = _prepared                   # get_mask_prompt shares one round trip
-            if self.sampler_rng == "device":
+            if self._rng(masks) == "device":
                 # a uniform candidate per point: rank = floor(u * count), count >= 1 by construction of `sel`
                 cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
                 u = torch.rand((n, num_points), device=device, generator=self._generator(device))
@@ -541,7 +551,7 @@ class VisualPromptEncoder:
             fd = torch.where(empty, query_feats[:, 0][:, None].expand(-1, R, -1), feats[idx])
             pd = torch.where(empty, query_pe[:, 0][:, None].expand(-1, R, -1), pos[idx])
             return (fd[:, :, None].repeat(1, 1, self.num_frames, 1), pd[:, :, None].repeat(1, 1, self.num_frames, 1))
-        if self.sampler_rng == "device":
+        if self._rng(m) == "device":
             assert not (prompt_type == "masks" and is_train), "training branch is out of scope"
             cnt = m.sum(1)                                                        # [n] on the device
             # masks with fewer than R pixels: all of them, cyclically, in pixel order (the reference's rule, :240-246)
@@ -672,7 +682,7 @@ class VisualPromptSampler:
             m = masks_all[:, -T:][:, :U].to(device).transpose(0, 1)
             b = boxes_all[:, -T:][:, :U].to(device).transpose(0, 1)
             jobs["clip"] = [enc.annotation_prefix(m, b, h_img, w_img), None]
-        if enc.sampler_rng == "reference" and enc._replay is None:
+        if enc._rng(device) == "reference" and enc._replay is None:
             parts = [j[-2]["counts"].flatten() for j in (jobs["prev"], jobs["clip"]) if j is not None]
             if parts:
                 host = torch.cat(parts).tolist()                                   # ONE host round trip for the clip

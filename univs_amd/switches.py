@@ -56,8 +56,11 @@ class Switches:
     # the W-resident Linears (K <= 768) stage their slab of W from the split image cached per weight tensor (a copy) instead of
     # splitting it in every workgroup of every launch (13 - 15 us per launch: profiles/r05_gemm_phase_trace_v1.txt)
     resident_presplit: bool = True
-    # prompt sampler draws: "reference" (the reference's host-side randperm order, bit-identical sampling) or "device"
-    sampler: str = "reference"
+    # prompt sampler draws: "reference" (the reference's host-side randperm calls in its order: its random stream draw for draw; on a
+    # 720p video with a large entity ~70 ms of host time per clip), "device" (the same distributions drawn by the device generator, no
+    # host round trip), or "auto" (default): "device" for GPU tensors, "reference" on the CPU.  Parity runs against recorded reference
+    # states set "reference" (tests/conftest.py does, through UNIVS_SAMPLER) or replay the reference's draws.
+    sampler: str = "auto"
     # hipGraph replay of the static parts of a clip (backbone, pixel decoder): see univs_amd/graphs.py
     graphs: bool = False
 
@@ -66,12 +69,12 @@ SWITCHES = Switches(
     msda_strips=_flag("UNIVS_MSDA_STRIPS", True), split_linear=_flag("UNIVS_SPLIT_LINEAR", True),
     split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
-    sampler=os.environ.get("UNIVS_SAMPLER", "reference"), graphs=_flag("UNIVS_GRAPHS", False),
+    sampler=os.environ.get("UNIVS_SAMPLER", "auto"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
     fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True),
     resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True))
-if SWITCHES.sampler not in ("reference", "device"):
-    raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'reference' or 'device')")
+if SWITCHES.sampler not in ("auto", "reference", "device"):
+    raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'auto', 'reference' or 'device')")
 
 
 @contextlib.contextmanager
