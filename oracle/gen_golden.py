@@ -1145,6 +1145,45 @@ def g18_prepare_targets():
     save("g18_prepare_targets", **d)
 
 
+# ---------------------------------------------------------------------------------------------------
+# G21: on-disk VPS / VSS result formats (univs/evaluation/vps_evaluation.py:117-178, vss_evaluation.py:93-118)
+# ---------------------------------------------------------------------------------------------------
+@gen
+def g21_result_files():
+    import tempfile
+    from PIL import Image
+    E = rh.ref_evaluators()
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        gt = os.path.join(d, "gt.json")
+        with open(gt, "w") as f:
+            json.dump({"categories": list(cases.VPS_CATEGORIES.values())}, f)
+        ev = object.__new__(E.VPSEvaluator)
+        ev._metadata = types.SimpleNamespace(categories=cases.VPS_CATEGORIES)
+        ev._output_dir, ev.pan_gt_json_file, ev._predictions = os.path.join(d, "vps"), gt, []
+        os.makedirs(os.path.join(ev._output_dir, "pan_pred"), exist_ok=True)
+        inputs, outputs = cases.result_file_inputs(), cases.vps_result_outputs()
+        np.random.seed(7)                         # IdGenerator draws the second colour of a thing class from numpy's global generator
+        ev.process([inputs], outputs)
+        names = sorted(os.listdir(os.path.join(ev._output_dir, "pan_pred", "vid_0007")))
+        out["vps_png_names"] = np.array(json.dumps(names))
+        out["vps_png"] = np.stack([np.asarray(Image.open(os.path.join(ev._output_dir, "pan_pred", "vid_0007", n))) for n in names])
+        out["vps_record"] = np.array(json.dumps(ev._predictions[0], sort_keys=True, default=int))
+        ev._distributed, ev._do_evaluation = False, False
+        ev._logger = types.SimpleNamespace(warning=print)
+        ev.evaluate()
+        out["vps_pred_json"] = np.array(open(os.path.join(ev._output_dir, "pred.json")).read())
+        es = object.__new__(E.VSSEvaluator)
+        es._output_dir, es.ignore_val = os.path.join(d, "vss"), 255
+        es.contiguous_id_to_dataset_id = dict(cases.VSS_CONTIGUOUS_TO_DATASET)
+        es.process([inputs], cases.vss_result_outputs())
+        names = sorted(os.listdir(os.path.join(es._output_dir, "vid_0007")))
+        out["vss_png_names"] = np.array(json.dumps(names))
+        out["vss_png"] = np.stack([np.asarray(Image.open(os.path.join(es._output_dir, "vid_0007", n))) for n in names])
+    print("  ", out["vps_png"].shape, out["vss_png"].shape, len(str(out["vps_record"])))
+    save("g21_result_files", **out)
+
+
 def main():
     names = sys.argv[1:] or list(GENERATORS)
     for n in names:

@@ -371,3 +371,56 @@ def ref_prepare_targets():
         sys.modules[name] = m
         spec.loader.exec_module(m)
     return sys.modules[name].PrepareTargets
+
+
+def ref_evaluators():
+    """The reference's `VPSEvaluator` / `VSSEvaluator` classes (univs/evaluation/vps_evaluation.py, vss_evaluation.py) for their
+    `process` methods -- the on-disk result formats.  Stand-ins: detectron2's DatasetEvaluator / PathManager / MetadataCatalog /
+    comm (inert bases), tqdm, the metric modules the files import at the top (never called here), and `panopticapi.utils`, which is
+    absent from this image: `IdGenerator` / `rgb2id` are the restatement in univs_amd/inference/results.py (published algorithm) --
+    so the golden pins everything `process` does EXCEPT the library's own colour rule."""
+    import importlib.util
+    install()
+    from univs_amd.inference import results as ours
+    pa = _pkg("panopticapi")
+    pu = _pkg("panopticapi.utils")
+    pu.IdGenerator, pu.rgb2id = ours.IdGenerator, ours.rgb2id
+    pa.utils = pu
+    for name in ("detectron2.utils.comm", "detectron2.config", "detectron2.data", "detectron2.evaluation", "detectron2.utils.file_io"):
+        if name not in sys.modules:
+            _pkg(name)
+    sys.modules["detectron2.config"].CfgNode = getattr(sys.modules["detectron2.config"], "CfgNode", type("CfgNode", (), {}))
+    if not hasattr(sys.modules["detectron2.data"], "MetadataCatalog"):
+        sys.modules["detectron2.data"].MetadataCatalog = types.SimpleNamespace(get=lambda n: types.SimpleNamespace(name=n))
+    sys.modules["detectron2.evaluation"].DatasetEvaluator = type("DatasetEvaluator", (), {})
+
+    class _PM:
+        @staticmethod
+        def get_local_path(p):
+            return p
+
+        @staticmethod
+        def mkdirs(p):
+            os.makedirs(p, exist_ok=True)
+    sys.modules["detectron2.utils.file_io"].PathManager = _PM
+    if "tqdm" not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except ImportError:
+            t = _pkg("tqdm")
+            t.tqdm = lambda x, **k: x
+    ev = _pkg("_ref_evaluation", f"{REF_ROOT}/univs/evaluation")
+    for leaf, names in (("eval_vpq_vps", ("vpq_compute_parallel",)), ("eval_stquality_vps", ("STQuality",)), ("eval_utils_vss", ("Evaluator",))):
+        m = _pkg(f"_ref_evaluation.{leaf}")
+        for n in names:
+            setattr(m, n, None)
+        setattr(ev, leaf, m)
+    ns = types.SimpleNamespace()
+    for attr, fname in (("VPSEvaluator", "vps_evaluation"), ("VSSEvaluator", "vss_evaluation")):
+        name = f"_ref_evaluation.{fname}"
+        spec = importlib.util.spec_from_file_location(name, f"{REF_ROOT}/univs/evaluation/{fname}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        setattr(ns, attr, getattr(m, attr))
+    return ns

@@ -439,3 +439,43 @@ VIPOSEG_CASE = dict(SCRIPT_CASE, name="viposeg", K=3938)
 VIPOSEG_CLASS_START = 2924
 VIPOSEG_OBJECTS = [(VIPOSEG_CLASS_START + o[0],) + tuple(o[1:]) for o in SCRIPT_OBJECTS]
 VIPOSEG_STUFF_IDS = (6, 10)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (d) on-disk VPS / VSS result formats (univs_amd/inference/results.py <-> univs/evaluation/vps_evaluation.py, vss_evaluation.py)
+# ---------------------------------------------------------------------------------------------------
+VPS_CATEGORIES = {1: {"id": 1, "isthing": 0, "color": [120, 120, 120]}, 2: {"id": 2, "isthing": 1, "color": [180, 120, 120]},
+                  3: {"id": 3, "isthing": 1, "color": [6, 230, 230]}, 4: {"id": 4, "isthing": 0, "color": [80, 50, 50]},
+                  7: {"id": 7, "isthing": 1, "color": [4, 200, 3]}}
+
+
+def result_file_inputs(T=3):
+    return {"video_id": "vid_0007", "file_names": [f"datasets/vipseg/imgs/vid_0007/{10 + 2 * t:08d}.jpg" for t in range(T + 1)],
+            "frame_indices": list(range(T))}
+
+
+def vps_result_outputs(T=3, H=24, W=40):
+    """A scripted panoptic result: two things of one class (the second needs a random colour), a thing that leaves, a stuff region, an
+    id that never appears, unlabelled pixels (0)."""
+    pan = torch.zeros(T, H, W, dtype=torch.int64)
+    pan[:, :8] = 90                                  # stuff, class 1
+    pan[:, 10:20, 3:12] = 31                         # thing, class 2
+    pan[:, 12:22, 20:33] = 32                        # thing, class 2 again
+    pan[0, 2:6, 30:38] = 33                          # thing, class 7, first frame only
+    pan[1:, 20:24, 0:6] = 91                         # stuff, class 4, from the second frame on
+    infos = [{"id": 31, "isthing": True, "category_id": 2}, {"id": 32, "isthing": True, "category_id": 2},
+             {"id": 33, "isthing": True, "category_id": 7}, {"id": 34, "isthing": True, "category_id": 3},
+             {"id": 90, "isthing": False, "category_id": 1}, {"id": 91, "isthing": False, "category_id": 4}]
+    return {"image_size": (H, W), "pred_masks": pan, "segments_infos": infos, "task": "vps"}
+
+
+VSS_CONTIGUOUS_TO_DATASET = {0: 1, 1: 2, 2: 5, 3: 9}
+
+
+def vss_result_outputs(T=3, H=24, W=40):
+    sem = torch.zeros(T, H, W, dtype=torch.int64)
+    sem[:, 6:, :] = 2
+    sem[1:, 10:18, 8:30] = 3
+    sem[0, :3, :5] = 255                             # the ignore value
+    sem[2, 20:, 30:] = 1
+    return {"image_size": (H, W), "pred_masks": sem, "task": "vss"}

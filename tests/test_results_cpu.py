@@ -142,3 +142,53 @@ def test_vos_png_writers(tmp_path):
         "inference/Annotations/clipA/0/00001.png", "inference/Annotations/clipA/0/00002.png",
         "inference/Annotations/clipA/4/00001.png", "inference/Annotations/clipA/4/00002.png"]
     assert np.array_equal(np.array(Image.open(paths[3])), res["masks"][1, 1].numpy())
+
+
+def test_vps_and_vss_result_files_match_reference(golden_dir, tmp_path):
+    """The on-disk VPS / VSS formats (results.py: write_vps_predictions / write_vps_json / write_vss_predictions) against what the
+    REFERENCE's evaluators wrote for the same scripted results (golden g21: VPSEvaluator.process + evaluate and VSSEvaluator.process
+    run from the imported reference, univs/evaluation/vps_evaluation.py:117-205, vss_evaluation.py:93-118): file names, decoded PNG
+    pixels, the per-video segment records and pred.json byte for byte.  (panopticapi's colour rule itself is a restatement on both
+    sides: the package is absent from the image.)"""
+    import json
+
+    from PIL import Image
+
+    from tests import cases
+    from univs_amd.inference import results as R
+    g = np.load(os.path.join(golden_dir, "g21_result_files.npz"))
+    inputs = cases.result_file_inputs()
+    np.random.seed(7)
+    rec = R.write_vps_predictions(inputs, cases.vps_result_outputs(), str(tmp_path / "vps"), cases.VPS_CATEGORIES)
+    names = sorted(os.listdir(tmp_path / "vps" / "pan_pred" / "vid_0007"))
+    assert names == json.loads(str(g["vps_png_names"]))
+    png = np.stack([np.asarray(Image.open(tmp_path / "vps" / "pan_pred" / "vid_0007" / n)) for n in names])
+    assert png.dtype == np.uint8 and np.array_equal(png, g["vps_png"])
+    assert json.dumps(rec, sort_keys=True, default=int) == str(g["vps_record"])
+    path = R.write_vps_json([rec], str(tmp_path / "vps"))
+    assert open(path).read() == str(g["vps_pred_json"])
+    # the scene exercises: a second thing of one class (random colour, not the class colour), a segment absent from a frame (no record
+    # there), an id that never appears (no record at all), stuff colours, unlabelled pixels
+    ann = rec["annotations"]
+    assert [len(a["segments_info"]) for a in ann] == [4, 4, 4] and ann[0]["file_name"] == "00000010.jpg"
+    ids = [s["id"] for s in ann[1]["segments_info"]]
+    assert len(set(ids)) == len(ids) and R.rgb2id(cases.VPS_CATEGORIES[2]["color"]) in ids
+    assert (png[0][0, 0] == np.array(cases.VPS_CATEGORIES[1]["color"])).all() and (png[0][9, 0] == 0).all()
+    paths = R.write_vss_predictions(inputs, cases.vss_result_outputs(), str(tmp_path / "vss"), cases.VSS_CONTIGUOUS_TO_DATASET)
+    assert [os.path.basename(p) for p in paths] == json.loads(str(g["vss_png_names"]))
+    sem = np.stack([np.asarray(Image.open(p)) for p in paths])
+    assert sem.dtype == np.uint8 and np.array_equal(sem, g["vss_png"])
+    assert sem[0, 0, 0] == 255 and set(np.unique(sem).tolist()) == {0, 1, 4, 8, 255}
+
+
+def test_vps_driver_output_feeds_the_writer(tmp_path):
+    """`InferenceVideoEntity.vps_output_results` (the tensors) -> files: the driver's dict is what the writer takes."""
+    from tests import cases
+    from univs_amd.inference import results as R
+    out = cases.vps_result_outputs()
+    rec = R.write_vps_predictions(cases.result_file_inputs(), {k: out[k] for k in ("image_size", "pred_masks", "segments_infos")},
+                                  str(tmp_path), cases.VPS_CATEGORIES)
+    assert rec["video_id"] == "vid_0007" and len(rec["annotations"]) == 3
+    for a in rec["annotations"]:
+        for s_ in a["segments_info"]:
+            assert set(s_) == {"bbox", "area", "category_id", "iscrowd", "id"} and s_["area"] > 0

@@ -9,6 +9,9 @@
     calculate_mask_temporal_consistency_scores    univs/inference/comm.py:197-207
     vis_clip_instances_to_coco_json_video         univs/inference/comm.py:97-195   per-video YouTube-VIS style records
     write_vos_pngs / write_rvos_pngs              inference_video_vos.py:622-705   palette id maps / per-expression masks
+    write_vps_predictions / write_vps_json        univs/evaluation/vps_evaluation.py:117-205   VIPSeg layout: `pan_pred/<video>/<frame>.png`
+                                                  colour-coded panoptic maps + the `pred.json` segment records that VPQ / STQ read
+    write_vss_predictions                         univs/evaluation/vss_evaluation.py:93-118    VSPW layout: `<video>/<frame>.png` class ids
 
 pycocotools is a third-party dependency of the reference (un-pinned: INSTALL.md installs the latest release) and is absent
 from this image, so the RLE string coding is restated from its published algorithm (`rleToString` / `rleFrString` in
@@ -249,4 +252,126 @@ def write_rvos_pngs(output_dir: str, file_names: Sequence[str], first_frame_idx:
             paths.append(os.path.join(save_dir, _png_name(file_names[first_frame_idx + t])))
             img.save(paths[-1])
             img.close()
+    return paths
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# VPS (VIPSeg) and VSS (VSPW) result files
+# ------------------------------------------------------------------------------------------------------------------
+def rgb2id(color):
+    """panopticapi.utils.rgb2id (COCO panoptic format: id = R + 256 G + 256^2 B), for one colour or an [..., 3] array."""
+    if isinstance(color, np.ndarray) and color.ndim >= 1 and color.shape[-1] == 3 and color.ndim > 1:
+        c = color.astype(np.int32)
+        return c[..., 0] + 256 * c[..., 1] + 256 * 256 * c[..., 2]
+    return int(color[0]) + 256 * int(color[1]) + 256 * 256 * int(color[2])
+
+
+class IdGenerator:
+    """panopticapi.utils.IdGenerator, restated from its published algorithm (cocodataset/panopticapi, utils.py; the package is a
+    third-party dependency of the reference's VPSEvaluator and absent from this image: parity with the library UNPINNED): stuff
+    categories always get their own colour; the first segment of a thing category gets the category colour, further segments a
+    random colour within +-30 per channel of it (numpy's global generator, as the library) that is not taken yet."""
+
+    def __init__(self, categories):
+        self.taken_colors = set([0, 0, 0])
+        self.categories = categories
+        for category in self.categories.values():
+            if category["isthing"] == 0:
+                self.taken_colors.add(tuple(category["color"]))
+
+    def get_color(self, cat_id):
+        def random_color(base, max_dist=30):
+            new_color = base + np.random.randint(low=-max_dist, high=max_dist + 1, size=3)
+            return tuple(np.maximum(0, np.minimum(255, new_color)))
+        category = self.categories[cat_id]
+        if category["isthing"] == 0:
+            return category["color"]
+        base_color_array = category["color"]
+        base_color = tuple(base_color_array)
+        if base_color not in self.taken_colors:
+            self.taken_colors.add(base_color)
+            return base_color
+        while True:
+            color = random_color(base_color_array)
+            if color not in self.taken_colors:
+                self.taken_colors.add(color)
+                return color
+
+
+def write_vps_predictions(inputs: dict, outputs: dict, output_dir: str, categories: dict):
+    """One video's `vps_output_results` dict ({"image_size", "pred_masks" [T, H, W] segment ids, "segments_infos": [{"id", "isthing",
+    "category_id"}]}) -> `<output_dir>/pan_pred/<video>/<frame>.png` (RGB panoptic maps) and the video's record for `pred.json`:
+    {"annotations": [{"segments_info": [{"bbox", "area", "category_id", "iscrowd", "id"}], "file_name"}], "video_id"} -- what
+    `VPSEvaluator.process` writes / collects (univs/evaluation/vps_evaluation.py:117-178; the bbox is [x, y, x_max - x, y_max - y] as
+    there).  `inputs`: the batched input of the video ("file_names", "frame_indices"); `categories`: {category id: {"id", "isthing",
+    "color"}} (the dataset metadata's `categories`)."""
+    from PIL import Image
+    color_generator = IdGenerator(categories)
+    image_names = [inputs["file_names"][int(i)] for i in inputs["frame_indices"]]
+    video_id = image_names[0].split("/")[-2]
+    H, W = int(outputs["image_size"][0]), int(outputs["image_size"][1])
+    pan = outputs["pred_masks"]
+    pan = pan.cpu().numpy() if isinstance(pan, torch.Tensor) else np.asarray(pan)
+    pan_format = np.zeros((pan.shape[0], H, W, 3), dtype=np.uint8)
+    per_segment = []
+    for info in outputs["segments_infos"]:
+        sem = info["category_id"]
+        mask = pan == info["id"]
+        color = color_generator.get_color(sem)
+        pan_format[mask] = color
+        base = {"category_id": int(sem) - 1, "iscrowd": 0, "id": int(rgb2id(color))}
+        dts = []
+        for i in range(pan.shape[0]):
+            ys, xs = np.where(mask[i])
+            if len(ys) == 0:
+                dts.append(None)
+                continue
+            x, y = xs.min(), ys.min()
+            dts.append(dict({"bbox": [int(x), int(y), int(xs.max() - x), int(ys.max() - y)], "area": int(mask[i].sum())}, **base))
+        per_segment.append(dts)
+    save_dir = os.path.join(output_dir, "pan_pred", video_id)
+    os.makedirs(save_dir, exist_ok=True)
+    annotations = []
+    for i, name in enumerate(image_names):
+        img = Image.fromarray(pan_format[i])
+        img.save(os.path.join(save_dir, name.split("/")[-1].split(".")[0] + ".png"))
+        img.close()
+        annotations.append({"segments_info": [d[i] for d in per_segment if d[i] is not None], "file_name": name.split("/")[-1]})
+    return {"annotations": annotations, "video_id": video_id}
+
+
+def write_vps_json(predictions: Sequence[dict], output_dir: str) -> str:
+    """`VPSEvaluator.evaluate`'s file (vps_evaluation.py:196-199): {"annotations": [one record per video]} -> `<output_dir>/pred.json`."""
+    import json
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, "pred.json")
+    with open(path, "w") as f:
+        json.dump({"annotations": list(predictions)}, f)
+    return path
+
+
+def write_vss_predictions(inputs: dict, outputs: dict, output_dir: str, contiguous_id_to_dataset_id: dict, ignore_val: int = 255):
+    """One video's `vss_output_results` dict ({"image_size", "pred_masks" [T, H, W] contiguous class ids}) -> `<output_dir>/<video_id>/
+    <frame>.png`, uint8 class ids as VSPW's evaluation reads them: the dataset id of the class minus the smallest dataset id, 255 where
+    the prediction is the ignore value (`VSSEvaluator.process`, univs/evaluation/vss_evaluation.py:93-118)."""
+    from PIL import Image
+    video_id = str(inputs["video_id"])
+    image_names = [inputs["file_names"][int(i)] for i in inputs["frame_indices"]]
+    sem = outputs["pred_masks"]
+    sem = (sem.cpu().numpy() if isinstance(sem, torch.Tensor) else np.asarray(sem)).astype(np.uint8)
+    out = np.full_like(sem, 255, dtype=np.uint8)
+    lo = min(contiguous_id_to_dataset_id.values())
+    for cls_id in np.unique(sem):
+        if cls_id == ignore_val:
+            continue
+        out[sem == cls_id] = contiguous_id_to_dataset_id[int(cls_id)] - lo
+    assert len(image_names) == len(out), "Mismatch length between predicted and gt images"
+    save_dir = os.path.join(output_dir, video_id)
+    os.makedirs(save_dir, exist_ok=True)
+    paths = []
+    for i, name in enumerate(image_names):
+        img = Image.fromarray(out[i])
+        paths.append(os.path.join(save_dir, name.split("/")[-1].split(".")[0] + ".png"))
+        img.save(paths[-1])
+        img.close()
     return paths
