@@ -709,13 +709,13 @@ def run(args):
                                                          "achieved": (alg + prep) / sec / 1e9, "frac": (alg + prep) / sec / HBM_PEAK}
             # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
             # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
-            for fn in ("r04_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+            for fn in ("r05_msda_traffic.json", "r04_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
                         tr = json.load(f)
                     if abs(tr["algorithmic_bytes_per_launch"] - alg) < 1 and tr.get("tiled_generation", 2) == gen:
                         res["roofline"]["traffic"] = tr["fetch_bytes_corrected"] + tr["write_bytes"]
-                        res["roofline"]["traffic_source"] = f"profiles/{fn} (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                        res["roofline"]["traffic_source"] = f"profiles/{fn} (separate --pmc passes; reads = TCC_EA0_RDREQ_DRAM_32B x 32 B = 2 x FETCH_SIZE, calibrated on known byte counts: profiles/r05_fetch_size_calibration_v1.txt)"
                         break
                 except (OSError, KeyError, ValueError):
                     pass
