@@ -247,6 +247,8 @@ def _loop_states(case, model, shard, **over):
     from univs_amd.inference.video_entity import ImageList, InferenceVideoEntity
     inf = InferenceVideoEntity(**cases.loop_kwargs(case, **over))
     inf.set_frame_shard(shard)
+    if shard is None:
+        inf.pixel_decoder_once_per_window = False      # the comparison run: the reference's call pattern (pixel decoder per clip)
     dumps, calls = {}, []
 
     def snapshot(tag, tv):

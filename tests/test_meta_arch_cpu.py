@@ -43,8 +43,9 @@ def video(task, dataset, **extra):
 def test_detection_request_runs_the_entity_loop():
     model = make_model()
     calls = []
-    head = model.sem_seg_head.forward
-    model.sem_seg_head.forward = lambda f, targets=None, **k: (calls.append(targets[0]["first_frame_idx"]), head(f, targets=targets, **k))[1]
+    # (the loop calls the head's predictor per clip; the pixel decoder runs once for the 5-frame window: inference/video_entity.py)
+    pred = model.sem_seg_head.predictor.forward
+    model.sem_seg_head.predictor.forward = lambda *a, **k: (calls.append((a[4] if len(a) > 4 else k["targets"])[0]["first_frame_idx"]), pred(*a, **k))[1]
     with cpu_ops():
         torch.manual_seed(0)
         out = model(video("detection", "ytvis21", video_id=3))

@@ -54,7 +54,12 @@ struct XaArgs {
 };
 
 constexpr int XA_PART = 34;
-constexpr int XA_VS = 40;    // halves per channel row of the transposed V (32 keys + 8 of padding: conflict-free 8-byte accesses)
+#ifndef UNIVS_XA_VS
+#define UNIVS_XA_VS 36
+#endif
+// halves per channel row of the transposed V: 32 keys + 4 of padding = 4 x an odd number, so that the 16 lanes of an 8-byte read (one
+// channel row each) start in 16 distinct bank pairs (40 = 4 x 10, round 4's stride: rows j and j + 8 shared their banks, 33 - 45 % conflict cycles)
+constexpr int XA_VS = UNIVS_XA_VS;
 
 // largest magnitude of the wave -> (power of two that brings it into [2^14, 2^15), its inverse), wave-uniform
 __device__ __forceinline__ void xa_wave_scale(float mx, float& s, float& inv) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
     ss_inv = sq_inv * sk_inv;
 
     // ---- V: 4 keys x 4 channels per lane, transposed into LDS as two fp16 planes
-    float sv_inv = 1.0f;
+    float sv_inv = 1.0f, sv_fwd = 1.0f;
     {
       float mv = 0.f;
 #pragma unroll
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       if (xa_out_of_range(mv, 0.0625f)) {
         float sv;
         xa_wave_scale(mv, sv, sv_inv);
+        sv_fwd = sv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           vr[e].x *= sv;
@@ -346,13 +352,18 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       xa_split8(pv, ph, pm);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        // A range-scaled V block (wave-uniform, rare) accumulates P V' apart and joins O times 1 / scale in fp32: undoing the
-        // scale on P instead pushed the probabilities into fp16's subnormals whenever |v| < 2^-4 over a whole block.
-        f32x4 o = v_scaled ? (f32x4){0.f, 0.f, 0.f, 0.f} : oacc[qb][hf];
+        // A range-scaled V block (wave-uniform): O is taken into the block's units (x scale, a power of two: exact), P V' accumulates
+        // onto it, and O returns (x 1 / scale, exact) -- the fp32 accumulation of the unscaled products, in place.  Undoing the scale on
+        // P instead pushed the probabilities into fp16's subnormals whenever |v| < 2^-4 over a whole block; a separate
+        // accumulator for the block cost 14 - 30 registers and spilled at seven / eight query blocks (xattn_partial<7>: 49 -> 97 us).
+        // (x scale <= 2^54 cannot overflow unless one head holds values 2^70 apart: O <= 2^8 x keys x max |v|.)
+        f32x4 o = oacc[qb][hf];
+        if (v_scaled) o *= sv_fwd;
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pm, vh[hf], o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vm[hf], o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[hf], o, 0, 0, 0);
-        oacc[qb][hf] = v_scaled ? oacc[qb][hf] + o * sv_inv : o;
+        if (v_scaled) o *= sv_inv;
+        oacc[qb][hf] = o;
       }
     }
   }

@@ -17,7 +17,9 @@
 //   * a wave = one window at a time.  Scores are computed transposed, S^T = K (Q scale)^T, so that a lane holds
 //     S[query n][keys jb*16 + 4g .. + 3]: softmax runs over registers and the four 16-lane groups, and the fp16
 //     probabilities are already the A operand of P V;
-//   * V is staged per wave in LDS as fp16, TRANSPOSED ([head channel][key], row stride NP + 8 halves: conflict-free 8-byte
+//   * V is staged per wave in LDS as fp16, TRANSPOSED ([head channel][key], row stride NP + 4 halves = 4 x an odd number: the 16
+//     lanes of one 8-byte read -- one channel row each -- then start in 16 distinct bank pairs; NP + 8, round 3's stride, is 4 x an even
+//     number and rows n and n + 8 met in the same banks: 45 % of the LDS index cycles were conflicts, profiles/r04_pmc_by_kernel_v1.txt
 //     reads): the B operand of P V is V[keys 4g .. 4g+3][channel n], four keys of ONE channel per lane.  The transpose is
 //     done in registers on the way in: a lane loads 4 keys x 4 channels (four 16-byte loads) and writes four 8-byte rows;
 //   * with 12 x 12 windows (config 5) every tile is full: 144 tokens = 9 blocks of 16, no padded key or query exists.
@@ -38,6 +40,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // waves per workgroup: 8; 4 for the three-product kernel on 12 x 12 windows, whose two fp16 planes of V leave room for four
 // waves beside the bias table (144 x 148 x 4 + 4 x 2 x 32 x 152 x 2 = 163 072 B of the CU's 163 840)
 constexpr int wh_waves(int nb, int terms) { return (terms == 3 && nb > 6) ? 4 : 8; }
+#ifndef UNIVS_WH_VT_PAD
+#define UNIVS_WH_VT_PAD 4          // (8: round 3's stride, kept for A/B builds -- python -m univs_amd.build --ablate vtpad8)
+#endif
+constexpr int WH_VT_PAD = UNIVS_WH_VT_PAD;
 
 // TERMS = 1: fp16 operands (UNIVS_MMA_F16).  TERMS = 3: every operand as TWO fp16 parts (h = fp16(x), m = fp16(x - h)) and three
 // of the four part products -- fp32-accurate (<= 2^-21.7 per product, see linear_f16x3.hip) at 3/16 of the exact-f32 MFMA time
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(64 * wh_waves(NB, TERMS)) void window_attn_img_f16(
                                                                       const float* __restrict__ shift_mask, int B_, int nW,
                                                                       int nH, float scale, float* __restrict__ out,
                                                                       WinImage wi, int magic) {
-  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + 8, WH_WAVES = wh_waves(NB, TERMS);
+  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + WH_VT_PAD, WH_WAVES = wh_waves(NB, TERMS);
   constexpr int VR = (NB + 1) / 2;   // V staging rounds: lanes 0-31 take key block r, lanes 32-63 block r + VR
   constexpr float LOG2E = 1.4426950408889634f;
   const int Ntok = wi.ws * wi.ws;
@@ -381,7 +387,7 @@ static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias
                       int nH, float scale, float* out, const WinImage& wi, int n_cu, hipStream_t st) {
   constexpr int NP = 16 * NB;
   constexpr int WH_WAVES = wh_waves(NB, TERMS);
-  const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * (TERMS == 3 ? 2 : 1) * 32 * (NP + 8) * sizeof(_Float16);
+  const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * (TERMS == 3 ? 2 : 1) * 32 * (NP + WH_VT_PAD) * sizeof(_Float16);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
   // workgroups = resident slots rounded DOWN to a multiple of the head count: one extra workgroup would double the tail
   int gx = std::max(1, n_cu * per_cu / nH);

@@ -268,6 +268,25 @@ def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
 # through the hand-written fp32-accurate GEMM kernels (ops.linear_fused: three fp16 products, csrc/linear_f16x3.hip)
 
 
+_LIBRARY_FALLBACKS = set()
+
+
+def _note_library_linear(x, weight, what="F.linear"):
+    """Log ONCE per (K, N, rows bucket) that a GPU Linear left the hand-written three-product kernels for the library's plain-fp32
+    GEMM: the arithmetic differs in the last bits from the tested path (an odd checkpoint width must not change the
+    numerics silently).  `logging.getLogger("univs_amd")`, level INFO."""
+    if not x.is_cuda:
+        return
+    rows = x.numel() // max(int(x.shape[-1]), 1)
+    key = (what, int(x.shape[-1]), int(weight.shape[0]), rows.bit_length())
+    if key in _LIBRARY_FALLBACKS:
+        return
+    _LIBRARY_FALLBACKS.add(key)
+    import logging
+    logging.getLogger("univs_amd").info("Linear %d -> %d on %d rows runs on the library GEMM (%s): shape not covered by the "
+                                        "three-product kernels", key[1], key[2], rows, what)
+
+
 def linear(x, weight, bias=None):
     """F.linear; on the GPU, tall fp32 projections with K % 128 == 0 or K % 96 == 0 (the MSDeformAttn token projections:
     96 600 rows x 256 -> 256 / 288) take the split kernels on the matrix cores (fp32-accurate: ops.linear_fused),
@@ -282,6 +301,7 @@ def linear(x, weight, bias=None):
         y = ops.linear_split(x, weight, bias)
         if y is not None:
             return y
+    _note_library_linear(x, weight)
     return F.linear(x, weight, bias)
 
 
@@ -318,6 +338,7 @@ def linear_act(x, linear, activation):
             y = ops.linear_split(x, linear.weight, linear.bias, relu=True)
             if y is not None:
                 return y
+        _note_library_linear(x, linear.weight, "addmm + ReLU")
         y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], -1)
     return activation(linear(x))
