@@ -319,6 +319,15 @@ int univs_conv1x1_presplit_f32(const float* x, const void* wp, const float* winv
 int univs_small_linear_presplit_f32(const float* x, const float* x_add, const void* wp, const float* winv, const float* bias, int n_w,
                                     int f_off, const float* residual, const float* ln_weight, const float* ln_bias, float ln_eps,
                                     long long M, int N, int K, int relu, int add_features, int out_T, float* y, void* stream);
+/* y = L_n(act(... L_1(LN?(x)))) for up to three 256 -> 256 Linears on FEW rows in one launch: the mask-embedding MLP of a prediction head
+ * (univs/modeling/transformer_decoder/transformer_layers.py:205-217, called at ...decoder_univs.py:520 on `decoder_norm(output)`, :513).
+ *   wp / winv / bias / relu: `stages` entries each (univs_presplit_weights_f32 images of [256, 256] weights; bias entries may be NULL;
+ *   relu[s] != 0: ReLU behind stage s).  Between stages the rows stay in LDS: results are bit-identical to `stages` calls of
+ *   univs_small_linear_presplit_f32.  in_ln_weight != NULL: nn.LayerNorm(256) on the input rows first (two-pass statistics); x_normed
+ *   (NULL or [M, 256]) receives the normalised rows.  out_T as in univs_small_linear_presplit_f32.  UNIVS_ERR_NOT_IMPLEMENTED when not covered. */
+int univs_small_mlp_presplit_f32(const float* x, int stages, const void* const* wp, const float* const* winv, const float* const* bias,
+                                 const int* relu, const float* in_ln_weight, const float* in_ln_bias, float in_ln_eps, float* x_normed,
+                                 long long M, int out_T, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y[M, C] = act(LN(x)[M, C] W1^T + b1) W2^T + b2 (+ residual): a two-Linear MLP in one kernel (mlp_f16x3.hip), three-product fp16

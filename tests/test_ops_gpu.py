@@ -1316,6 +1316,48 @@ def test_linear_resident_presplit_is_bit_identical(cuda, M, K, N, act, res, bloc
     assert (got.double() - ref.reshape(got.shape)).abs().max().item() < 2e-6 * scale
 
 
+@pytest.mark.parametrize("M,A,stages", [(500, 100, 3), (17, 0, 3), (4000, 200, 2), (16, 0, 1), (1100, 0, 3)], ids=lambda v: str(v))
+def test_small_mlp_chain_is_bit_identical_to_separate_launches(cuda, M, A, stages):
+    """ops.small_mlp (csrc/small_linear.hip: small_chain_kernel -- up to three 256 -> 256 Linears of the mask-embedding MLP in ONE launch,
+    the hidden rows handed over through LDS) == the same chain of ops.small_linear launches BIT FOR BIT (same row maxima, scales, parts),
+    with the [A, B, C] -> [B, A, C] output order of the mask embeddings; with the `decoder_norm` LayerNorm inside the launch: the MLP output
+    and the normalised rows against F.layer_norm + the chain to fp32 rounding, deterministic run to run; rows over many binades."""
+    x = synth.normal(f"sm/x/{M}", (M, 256)) * torch.logspace(-4, 4, M).view(M, 1)
+    if A:
+        x = x.view(A, M // A, 256)
+    x = x.to(cuda)
+    lay = []
+    for i in range(stages):
+        w = synth.normal(f"sm/w{i}", (256, 256), std=1 / 16).to(cuda)
+        b = synth.normal(f"sm/b{i}", (256,)).to(cuda) if i != 1 else None
+        lay.append((w, b, i < stages - 1))
+    want = x
+    for i, (w, b, relu) in enumerate(lay):
+        want = ops.small_linear(want, w, b, relu=relu, transpose01=bool(A) and i == stages - 1)
+        assert want is not None
+    got = ops.small_mlp(x, lay, transpose01=bool(A))
+    assert got is not None and got.shape == want.shape and torch.equal(got, want)
+    # the LayerNorm in front, inside the launch
+    g_ = (1.0 + 0.3 * synth.normal("sm/g", (256,))).to(cuda)
+    b_ = (0.2 * synth.normal("sm/bb", (256,))).to(cuda)
+    r = ops.small_mlp(x, lay, in_ln=(g_, b_, 1e-5), want_normed=True, transpose01=bool(A))
+    assert r is not None
+    y, xn = r
+    ref_n = torch.nn.functional.layer_norm(x.double(), (256,), g_.double(), b_.double(), 1e-5)
+    assert xn.shape == x.shape and (xn.double() - ref_n).abs().max().item() < 5e-6
+    ref = ref_n
+    for w, b, relu in lay:
+        ref = torch.nn.functional.linear(ref, w.double(), b.double() if b is not None else None)
+        ref = ref.relu() if relu else ref
+    if A:
+        ref = ref.transpose(0, 1)
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    y2 = ops.small_mlp(x, lay, in_ln=(g_, b_, 1e-5), transpose01=bool(A))
+    assert torch.equal(y2, y)                                    # without the second output: the same rows; and run to run
+    assert ops.small_mlp(x.cpu(), [(w.cpu(), None, False) for w, _, _ in lay]) is None
+    assert ops.small_mlp(x[..., :128].contiguous(), lay) is None
+
+
 def test_linear_split_uncovered_shapes_return_none(cuda):
     x = torch.zeros(4096, 80, device=cuda)
     assert ops.linear_split(x, torch.zeros(96, 80, device=cuda)) is None                      # K % 96 and K % 128

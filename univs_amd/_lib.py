@@ -63,6 +63,7 @@ SIGNATURES = {
     "univs_attn_mask_rows_reset": (_I, [_P, _P, _c.c_uint32, _c.c_longlong, _c.c_longlong, _P]),
     "univs_cross_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_float, _P, _P, _P]),
     "univs_small_linear_presplit_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _c.c_float, _c.c_longlong, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_small_mlp_presplit_f32": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _c.c_longlong, _I, _P, _P]),
     "univs_mlp_presplit_v2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _c.c_float, _P, _P, _c.c_float, _P, _c.c_longlong, _P,
                                        _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_mlp_presplit_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _c.c_float, _P, _c.c_longlong, _P,

@@ -54,6 +54,8 @@ int msda_prepare_f32(const float*, int, int, const float*, long long, const Leve
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
 int upsample2x_add_f32(const float*, const float*, const float*, float*, long long, int, int, hipStream_t);
 int normalize_pad_f32(const float*, float*, long long, int, int, int, int, int, const float*, const float*, hipStream_t);
+int small_chain_f32(const float*, int, const void* const*, const float* const*, const float* const*, const int*, const float*, const float*,
+                    float, float*, float*, long long, int, hipStream_t);
 int group_norm_affine_f32(const float*, const float*, const float*, int, int, long long, int, float, float*, long long, float*, hipStream_t);
 int bilinear_pyramid3_f32(const float*, float*, float*, float*, long long, int, int, hipStream_t);
 int layer_norm_f32(const float*, const float*, const float*, const float*, long long, int, float, float*, float*, const float*, float*,
@@ -315,6 +317,26 @@ int univs_small_linear_presplit_f32(const float* x, const float* x_add, const vo
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_small_linear_presplit_f32: M=%lld N=%d K=%d not covered (K %% 32 == 0, N %% 16 == 0, f_off %% 4 == 0, with a LayerNorm "
               "N == 256, M <= 1 048 560, 16-byte aligned pointers)", M, N, K);
+  return rc;
+}
+
+int univs_small_mlp_presplit_f32(const float* x, int stages, const void* const* wp, const float* const* winv, const float* const* bias,
+                                 const int* relu, const float* in_ln_weight, const float* in_ln_bias, float in_ln_eps, float* x_normed,
+                                 long long M, int out_T, float* y, void* stream) {
+  clear_sticky_error();
+  if (M < 0 || stages < 1 || stages > 3 || out_T < 0) {
+    set_error("univs_small_mlp_presplit_f32: bad arguments M=%lld stages=%d out_T=%d", M, stages, out_T);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (M == 0) return UNIVS_OK;
+  if (!x || !y || !wp || !winv || !bias || !relu) {
+    set_error("univs_small_mlp_presplit_f32: NULL pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::small_chain_f32(x, stages, wp, winv, bias, relu, in_ln_weight, in_ln_bias, in_ln_eps, x_normed, y, M, out_T,
+                                        static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_small_mlp_presplit_f32: M=%lld not covered (M <= 1 048 560, out_T | M, 16-byte aligned pointers, x_normed / bias only with a LayerNorm)", M);
   return rc;
 }
 

@@ -254,4 +254,199 @@ int small_linear_f32(const float* x, const float* xadd, const void* wp, const fl
   return check_launch("small_linear_f32");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A CHAIN of up to three 256 -> 256 Linears on few rows in ONE launch: y = L3(act(L2(act(L1(LN?(x)))))) -- the mask-embedding MLP of every
+// prediction head (univs/modeling/transformer_decoder/transformer_layers.py:205-217 `MLP`, called at ...decoder_univs.py:520 on the
+// `decoder_norm`-ed queries): three launches of small_linear_kernel (8 us each, all of it launch ramp and latency) and a LayerNorm launch
+// per head, ten heads per clip.  Same workgroup shape (8 waves = 16 rows x 256 features) and the same arithmetic; between two stages the
+// 16 x 256 result goes back to LDS AS THE NEXT OPERAND: every lane holds 2 x 4 consecutive features of one row, the row maxima meet in
+// LDS (atomic max), the lane scales, splits and writes its two 8-byte halves of the B-fragment units -- the values, the row maximum, the
+// scale and the parts are what the next launch would have read back from memory and computed, so the chain is bit-identical to the
+// sequence of launches.  The next stage's first weight fragments are requested before the two barriers of the hand-over.
+// Optional nn.LayerNorm on the INPUT rows (`decoder_norm`): exact two-pass statistics over the staged tile, summed in a fixed order.
+struct SlChainArgs {
+  const float* X;       // [M, 256]
+  const u32x4* Wp[3];   // pre-split W_s [256, 256]
+  const float* winv[3];
+  const float* bias[3];
+  int relu[3];
+  int stages;
+  const float* in_g;    // LayerNorm on x (weight / bias / eps) or null
+  const float* in_b;
+  float in_eps;
+  float* Xn;            // [M, 256] or null: the normalised input rows (for the callers that need `decoder_norm(x)` itself)
+  float* Y;             // [M, 256] (out_T > 0: row (q, t) stored at (t, q))
+  int M, out_T;
+};
+
+__global__ __launch_bounds__(64 * SL_WAVES, 3) void small_chain_kernel(const SlChainArgs a) {
+  constexpr int K = 256, N = 256, KS = K >> 5;
+  __shared__ __attribute__((aligned(16))) u32x4 xs[2][2 * KS * 64];      // two operand tiles (ping-pong), [part][k-step][lane]
+  __shared__ unsigned rmax[3][16];
+  __shared__ float rstat[2][SL_WAVES][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int M = a.M;
+  const int row0 = blockIdx.x * 16;
+  const int f0 = wave * 32;
+
+  u32x4 afr[SL_AHEAD][2][2];
+  auto load_a = [&](const u32x4* wl, int ks, u32x4 (&d)[2][2]) __attribute__((always_inline)) {
+    const u32x4* p = wl + (size_t)ks * (8 * N);
+    d[0][0] = p[0];
+    d[0][1] = p[N];
+    d[1][0] = p[16];
+    d[1][1] = p[N + 16];
+  };
+  const size_t wl_off = (size_t)(g * 2) * N + f0 + j;
+#pragma unroll
+  for (int u = 0; u < SL_AHEAD; ++u) load_a(a.Wp[0] + wl_off, u, afr[u]);
+
+  if (tid < 48) (&rmax[0][0])[tid] = 0u;
+  __syncthreads();
+  // ---- stage-0 operand: slot s_ = tid (KS * 64 = 512 slots): row j_ = s_ & 15, columns 32 ks + 8 g_
+  {
+    const int s_ = tid;
+    const int ks = s_ >> 6, l_ = s_ & 63, j_ = l_ & 15, g_ = l_ >> 4;
+    const int mrow = min(row0 + j_, M - 1);
+    const long long off = (long long)mrow * K + 32 * ks + 8 * g_;
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(a.X + off), x1 = *reinterpret_cast<const f32x4*>(a.X + off + 4);
+    if (a.in_g) {
+      // nn.LayerNorm over the row: mean, then the centred second moment (two passes).  A row's 32 slots sit in the four lanes j_ + 16 g_
+      // of each of the 8 waves: lane sums by permlane swaps, wave sums through LDS, added in a fixed order (deterministic)
+      const float s4 = sl_row_sum(((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3])));
+      if (g_ == 0) rstat[0][ks][j_] = s4;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) tot += rstat[0][w][j_];
+      const float mean = tot * (1.0f / K);
+      x0 -= mean;
+      x1 -= mean;
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sq = fmaf(x0[e], x0[e], fmaf(x1[e], x1[e], sq));
+      const float q4 = sl_row_sum(sq);
+      if (g_ == 0) rstat[1][ks][j_] = q4;
+      __syncthreads();
+      float tq = 0.f;
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) tq += rstat[1][w][j_];
+      const float rstd = 1.0f / sqrtf(tq * (1.0f / K) + a.in_eps);
+      const int c = 32 * ks + 8 * g_;
+      x0 = (x0 * rstd) * *reinterpret_cast<const f32x4*>(a.in_g + c);
+      x1 = (x1 * rstd) * *reinterpret_cast<const f32x4*>(a.in_g + c + 4);
+      if (a.in_b) {
+        x0 += *reinterpret_cast<const f32x4*>(a.in_b + c);
+        x1 += *reinterpret_cast<const f32x4*>(a.in_b + c + 4);
+      }
+      if (a.Xn && row0 + j_ < M) {
+        *reinterpret_cast<f32x4*>(a.Xn + off) = x0;
+        *reinterpret_cast<f32x4*>(a.Xn + off + 4) = x1;
+      }
+    }
+    atomicMax(&rmax[0][j_], l3_absmax8(x0, x1));
+    __syncthreads();
+    float sc, inv;
+    l3_scale(rmax[0][j_], 14, sc, inv);
+    f16x8 h8, m8;
+    l3_split8(x0, x1, sc, h8, m8);
+    xs[0][s_] = __builtin_bit_cast(u32x4, h8);
+    xs[0][KS * 64 + s_] = __builtin_bit_cast(u32x4, m8);
+  }
+  __syncthreads();
+
+  const int row = row0 + j;
+  const bool row_ok = row < M;
+  f32x4 v[2];
+#pragma unroll 1
+  for (int st = 0; st < a.stages; ++st) {
+    float sc_, sx_inv;
+    l3_scale(rmax[st][j], 14, sc_, sx_inv);
+    const u32x4* xt = xs[st & 1] + lane;
+    const u32x4* wl = a.Wp[st] + wl_off;
+    f32x4 e_wi[2], e_bi[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = f0 + 16 * q + 4 * g;
+      e_wi[q] = *reinterpret_cast<const f32x4*>(a.winv[st] + f);
+      e_bi[q] = a.bias[st] ? *reinterpret_cast<const f32x4*>(a.bias[st] + f) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < KS; kb += SL_AHEAD) {
+#pragma unroll
+      for (int u = 0; u < SL_AHEAD; ++u) {
+        const int ks = kb + u;
+        const f16x8 bh = __builtin_bit_cast(f16x8, xt[ks * 64]), bm = __builtin_bit_cast(f16x8, xt[KS * 64 + ks * 64]);
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[u][0][0]), am0 = __builtin_bit_cast(f16x8, afr[u][0][1]);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[u][1][0]), am1 = __builtin_bit_cast(f16x8, afr[u][1][1]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am0, bh, acc[0], 0, 0, 0);   // smallest terms first
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am1, bh, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bm, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bm, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + SL_AHEAD < KS) load_a(wl, ks + SL_AHEAD, afr[u]);
+        else if (st + 1 < a.stages) load_a(a.Wp[st + 1] + wl_off, ks + SL_AHEAD - KS, afr[u]);   // the next stage's first fragments
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 t = (acc[q] * sx_inv) * e_wi[q] + e_bi[q];
+      if (a.relu[st]) t = __builtin_elementwise_maximum(t, (f32x4){0.f, 0.f, 0.f, 0.f});
+      v[q] = t;
+    }
+    if (st + 1 < a.stages) {
+      // hand-over: the result rows become the next operand tile (see the header)
+      atomicMax(&rmax[st + 1][j], l3_absmax8(v[0], v[1]));
+      __syncthreads();
+      float sc, inv;
+      l3_scale(rmax[st + 1][j], 14, sc, inv);
+      _Float16* dst = reinterpret_cast<_Float16*>(xs[(st + 1) & 1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 hh, mm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xsv = v[q][e] * sc;
+          hh[e] = (_Float16)xsv;
+          mm[e] = (_Float16)(xsv - (float)hh[e]);
+        }
+        const int unit = wave * 64 + (2 * q + (g >> 1)) * 16 + j;           // k-step = this wave's 32 features
+        *reinterpret_cast<h4*>(dst + (size_t)unit * 8 + 4 * (g & 1)) = hh;
+        *reinterpret_cast<h4*>(dst + (size_t)(KS * 64 + unit) * 8 + 4 * (g & 1)) = mm;
+      }
+      __syncthreads();
+    }
+  }
+  const int orow = a.out_T > 0 ? (row % a.out_T) * (M / a.out_T) + row / a.out_T : row;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = f0 + 16 * q + 4 * g;
+    if (row_ok) *reinterpret_cast<f32x4*>(a.Y + (long long)orow * N + f) = v[q];
+  }
+}
+
+int small_chain_f32(const float* x, int stages, const void* const* wp, const float* const* winv, const float* const* bias, const int* relu,
+                    const float* in_g, const float* in_b, float in_eps, float* xn, float* y, long long M, int out_T, hipStream_t st) {
+  if (M <= 0) return UNIVS_OK;
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (stages < 1 || stages > 3 || M > 16LL * 65535 || out_T < 0 || (out_T > 0 && M % out_T != 0) || mis(x) || mis(y) || mis(xn) || mis(in_g) ||
+      mis(in_b) || (in_b && !in_g) || (xn && !in_g) || M * 256LL * 4 >= 0x7FFFFFFFLL)
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  SlChainArgs a{};
+  a.X = x; a.stages = stages; a.in_g = in_g; a.in_b = in_b; a.in_eps = in_eps; a.Xn = xn; a.Y = y; a.M = (int)M; a.out_T = out_T;
+  for (int s_ = 0; s_ < stages; ++s_) {
+    if (!wp[s_] || !winv[s_] || mis(wp[s_]) || mis(winv[s_]) || mis(bias[s_])) return UNIVS_ERR_NOT_IMPLEMENTED;
+    a.Wp[s_] = reinterpret_cast<const u32x4*>(wp[s_]); a.winv[s_] = winv[s_]; a.bias[s_] = bias[s_]; a.relu[s_] = relu[s_] ? 1 : 0;
+  }
+  hipLaunchKernelGGL(small_chain_kernel, dim3((unsigned)((M + 15) / 16)), dim3(64 * SL_WAVES), 0, st, a);
+  return check_launch("small_chain_f32");
+}
+
 }  // namespace univs

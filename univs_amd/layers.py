@@ -241,9 +241,26 @@ class MLP(nn.Module):
         h = [hidden_dim] * (num_layers - 1)
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
-    def forward(self, x, transpose01=False):
+    def forward(self, x, transpose01=False, in_norm=None, want_normed=False):
         """`transpose01`: x is [A, B, C]; the result comes back as [B, A, C'] -- contiguous where the last Linear's kernel writes it that
-        way (few rows on the GPU), a transposed view otherwise"""
+        way (few rows on the GPU), a transposed view otherwise.  `in_norm` (an nn.LayerNorm): the MLP is applied to `in_norm(x)`; with
+        `want_normed` the call returns (y, in_norm(x)).  Few rows of 256 channels on the GPU: the whole chain -- LayerNorm included -- is
+        ONE launch (ops.small_mlp)."""
+        if (SWITCHES.small_mlp_chain and x.is_cuda and self.num_layers <= 3 and x.shape[-1] == 256 and not torch.is_grad_enabled()
+                and x.numel() // 256 <= 4096 and (in_norm is None or SWITCHES.small_mlp_norm)):
+            from . import ops
+            chain = [(l_.weight, l_.bias, i < self.num_layers - 1) for i, l_ in enumerate(self.layers)]
+            r = ops.small_mlp(x, chain, in_ln=None if in_norm is None else (in_norm.weight, in_norm.bias, in_norm.eps),
+                              want_normed=want_normed, transpose01=transpose01)
+            if r is not None:
+                return r
+        xn = None
+        if in_norm is not None:
+            x = xn = in_norm(x)
+        y = self._forward_layers(x, transpose01)
+        return (y, xn) if want_normed else y
+
+    def _forward_layers(self, x, transpose01):
         for i, layer in enumerate(self.layers):
             # hidden layers: the ReLU rides in the GEMM epilogue on the GPU (linear_act: one launch instead of GEMM + bias + clamp)
             if i < self.num_layers - 1:

@@ -424,8 +424,13 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
                 return x.view(bs, t, *x.shape[1:]).mean(1)
             return fs.all_reduce_sum(x.sum(0, keepdim=True)) / float(t_total)
 
-        decoder_qt = self.decoder_norm(output)                      # [Q', T, C], contiguous: the per-token MLPs run on this
-        decoder_output = decoder_qt.transpose(0, 1)                 # [T, Q', C] (a view)
+        # decoder_norm(output) [Q', T, C] feeds the mask-embedding MLP and -- only where class logits / re-id scores are formed -- the
+        # heads below: on the GPU norm + MLP are one launch (layers.MLP: ops.small_mlp), and the normalised rows are written out only
+        # where somebody reads them
+        need_normed = need_class or (self.prompt_as_queries and task == "grounding")
+        me = self.mask_embed(output, transpose01=True, in_norm=self.decoder_norm, want_normed=need_normed)
+        mask_embed_early, decoder_qt = me if need_normed else (me, None)
+        decoder_output = decoder_qt.transpose(0, 1) if decoder_qt is not None else None   # [T, Q', C] (a view)
         # class logits of the intermediate layers are only ever returned as aux outputs (the attention mask of the next
         # layer depends on the mask embedding alone): the 8 launches of this head run where their result is used
         outputs_class = self.vis2text_projection(decoder_output) if need_class else None
@@ -442,7 +447,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             outputs_class = mean_over_frames(outputs_class)
             outputs_class = torch.einsum("bqc,bkc->bqk", outputs_class, clip_exp)
 
-        mask_embed = self.mask_embed(decoder_qt, transpose01=True)  # [T, Q', C] (written that way by the last Linear's kernel, or a view)
+        mask_embed = mask_embed_early                               # [T, Q', C] (written that way by the last Linear's kernel, or a view)
         outputs_reid = [None] * bs
         if self.prompt_as_queries and task == "grounding":
             assert len(targets) == 1, "Only support bacth size is 1 now"

@@ -485,6 +485,52 @@ def small_linear(x, weight, bias=None, rows=None, x_add=None, relu=False, residu
     return y
 
 
+def small_mlp(x, layers_, in_ln=None, want_normed=False, transpose01=False):
+    """A chain of up to three 256 -> 256 Linears (ReLU between them as flagged) on a FEW tokens in ONE launch (include/univs_hip.h:
+    univs_small_mlp_presplit_f32; csrc/small_linear.hip: small_chain_kernel): the mask-embedding MLP of every prediction head
+    (transformer_layers.py:205-217).  `layers_` = [(weight [256, 256], bias [256] | None, relu: bool), ...]; bit-identical to the same
+    chain of `small_linear` calls.  `in_ln` = (weight, bias, eps): nn.LayerNorm(256) on the input rows inside the launch (`decoder_norm`,
+    ...decoder_univs.py:513); with `want_normed` the normalised rows come back too: (y, x_normed).  `transpose01` as in `small_linear`.
+    Returns None when not covered (the caller keeps the separate launches)."""
+    K = x.shape[-1]
+    M = x.numel() // max(K, 1)
+    n = len(layers_)
+    if (not x.is_cuda or x.dtype != torch.float32 or K != 256 or M < 1 or M > SMALL_LINEAR_MAX_ROWS or n < 1 or n > 3
+            or (transpose01 and x.dim() != 3) or (want_normed and in_ln is None)):
+        return None
+    for w, b, _ in layers_:
+        if (w.dtype != torch.float32 or tuple(w.shape) != (256, 256) or w._base is not None or not w.is_contiguous() or needs_grad(x, w, b)
+                or (b is not None and (b.dtype != torch.float32 or tuple(b.shape) != (256,) or not b.is_contiguous()))):
+            return None
+    x2 = x.contiguous().view(M, K)
+    lw = lb = None
+    leps = 0.0
+    if in_ln is not None:
+        lw, lb, leps = in_ln
+        for t_ in (lw, lb):
+            if t_ is not None and (t_.dtype != torch.float32 or tuple(t_.shape) != (256,) or not t_.is_cuda or not t_.is_contiguous()):
+                return None
+        if lw is None:
+            return None
+    oshape = (x.shape[1], x.shape[0], 256) if transpose01 else tuple(x.shape[:-1]) + (256,)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(x2) if want_normed else None
+    P3, I3 = ctypes.c_void_p * 3, ctypes.c_int * 3
+    with _on(x):
+        split = [presplit_weights(w) for w, _, _ in layers_]
+        wp = P3(*([_ptr(s_[0]) for s_ in split] + [None] * (3 - n)))
+        wi = P3(*([_ptr(s_[1]) for s_ in split] + [None] * (3 - n)))
+        bs = P3(*([(_ptr(b) if b is not None else None) for _, b, _ in layers_] + [None] * (3 - n)))
+        rl = I3(*([1 if r else 0 for _, _, r in layers_] + [0] * (3 - n)))
+        rc = _lib.load().univs_small_mlp_presplit_f32(_ptr(x2), n, wp, wi, bs, rl, _ptr(lw) if lw is not None else None,
+                                                      _ptr(lb) if lb is not None else None, float(leps), _ptr(xn) if xn is not None else None,
+                                                      M, int(x.shape[1]) if transpose01 else 0, _ptr(y), _stream_ptr(x2))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "small_mlp")
+    return (y, xn.view(x.shape)) if want_normed else y
+
+
 def _resident_presplit(weight, K):
     """The W-resident Linear takes the cached split image of `weight` (SWITCHES.resident_presplit; three-product arithmetic; a whole,
     contiguous tensor whose identity outlives the call -- views of parameters would be split again on every call)."""

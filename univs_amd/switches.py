@@ -53,6 +53,11 @@ class Switches:
     # per tensor (csrc/gemm_f16x3_stream.hip; ops.presplit_weights caches the split); 0: only the W-resident kernels (K <= 768), which
     # split W in every workgroup; wider Linears and the convolution then go to the libraries
     presplit_kmin: int = 768
+    # few-rows MLPs of 256-channel Linears (the mask-embedding MLP of every prediction head) as ONE launch, the hidden rows handed from
+    # stage to stage through LDS (csrc/small_linear.hip: small_chain_kernel; bit-identical to the separate launches); `small_mlp_norm`:
+    # the `decoder_norm` LayerNorm in front of it inside the same launch (its own fp32 rounding: not bit-identical to ATen's kernel)
+    small_mlp_chain: bool = True
+    small_mlp_norm: bool = True
     # the W-resident Linears (K <= 768) stage their slab of W from the split image cached per weight tensor (a copy) instead of
     # splitting it in every workgroup of every launch (13 - 15 us per launch: profiles/r05_gemm_phase_trace_v1.txt)
     resident_presplit: bool = True
@@ -72,7 +77,8 @@ SWITCHES = Switches(
     sampler=os.environ.get("UNIVS_SAMPLER", "auto"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
     fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True),
-    resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True))
+    resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True), small_mlp_chain=_flag("UNIVS_SMALL_MLP_CHAIN", True),
+    small_mlp_norm=_flag("UNIVS_SMALL_MLP_NORM", True))
 if SWITCHES.sampler not in ("auto", "reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'auto', 'reference' or 'device')")
 
