@@ -260,7 +260,8 @@ def run(args):
     T, Q = case["T"], case["Q"]
 
     def targets(frame_indices=None):
-        tv = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}
+        # (frame indices stay on the host, as the clip loops hand them over: inference_video_entity.py:307 `torch.arange(i, ...)`)
+        tv = {k: (v.to(dev) if isinstance(v, torch.Tensor) and k != "frame_indices" else v) for k, v in cases.targets_first_clip(case)[0].items()}
         if frame_indices is not None:
             tv["frame_indices"] = frame_indices
         return [tv]

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 swin, head = cases.build_model(dev)
 case = cases.CFG2
 x = cases.preprocess(cases.cfg2_frames()).to(dev)
-tg = lambda: [{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in cases.targets_first_clip(case)[0].items()}]  # noqa: E731
+tg = lambda: [{k: (v.to(dev) if isinstance(v, torch.Tensor) and k != "frame_indices" else v) for k, v in cases.targets_first_clip(case)[0].items()}]  # noqa: E731
 with torch.no_grad():
     for _ in range(2):
         head(swin(x), targets=tg())

@@ -79,6 +79,7 @@ struct GsArgs {
   int M, N, K, rows_per_pass, epi;
   int Cin, Cout, H, Wd, HW;      // conv (XMODE 1): X [T, Cin, H, W], Y [T, Cout, H, W]
   int tap0;                      // conv: first tap of the kernel (0: all nine taps of a 3 x 3; 4: the centre alone = a 1 x 1)
+  int remap;                     // XCD-aware (row range, pass) order (UnivsConfig.linear_ablate == 5 switches it off: A/B)
 };
 
 // LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp]
@@ -90,7 +91,14 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
   UNIVS_GT_REAL(g_gs_trace, gts, 62);
   constexpr int Rp = 16 * RB;
   constexpr int SLAB = RING * 4 * 2 * Rp;                        // 16-byte units per buffer
-  const int n0 = blockIdx.y * a.rows_per_pass;
+  // (row range, pass): every XCD takes a contiguous chunk of the (row range major, pass minor) sequence -- see linear_f16x3.hip
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.remap && gridDim.y > 1) {
+    const unsigned lw = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    bx = lw / gridDim.y;
+    by = lw - bx * gridDim.y;
+  }
+  const int n0 = by * a.rows_per_pass;
   const int R = min(a.rows_per_pass, a.N - n0);                  // a multiple of 4 (conv: of 16)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
   constexpr int NWV = GS_THREADS / 64;
 
   const int WT = (M + GS_TILE_M - 1) / GS_TILE_M;
-  const int wg0 = (int)((long long)WT * blockIdx.x / gridDim.x), wg1 = (int)((long long)WT * (blockIdx.x + 1) / gridDim.x);
+  const int wg0 = (int)((long long)WT * bx / gridDim.x), wg1 = (int)((long long)WT * (bx + 1) / gridDim.x);
   const int rounds = (wg1 - wg0 + NWV - 1) / NWV;                // every wave runs all rounds (barriers); idle tiles store nothing
   if (rounds == 0) return;
 
@@ -379,6 +387,7 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   if (XMODE == 1) rows = (rows + 15) & ~15;
   const int RB = (rows + 15) / 16;
   a.rows_per_pass = rows;
+  a.remap = cfg_.linear_ablate == 5 ? 0 : 1;
   const long long WT = ((long long)a.M + GS_TILE_M - 1) / GS_TILE_M;
   long long gx = std::max<long long>(1, gs_cus() / passes);
   gx = std::min(gx, std::max<long long>(1, WT / 8));

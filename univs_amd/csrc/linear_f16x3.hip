@@ -57,7 +57,16 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
   [[maybe_unused]] const int gts = UNIVS_GT_SLOT();
   UNIVS_GT(g_l3_trace, gts, 0);
   UNIVS_GT_REAL(g_l3_trace, gts, 62);
-  const int n0 = blockIdx.y * rows_per_pass;
+  // (row range, pass) of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id; the remap gives every XCD a CONTIGUOUS
+  // chunk of the sequence (row range major, pass minor): the passes of a row range -- which stream the same rows of x -- run on ONE XCD
+  // and meet in its L2, whatever the grid extents (with 12 passes over 21 row ranges every XCD used to fetch nearly all of x itself).
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (ablate != 5 && gridDim.y > 1) {
+    const unsigned lw = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    bx = lw / gridDim.y;
+    by = lw - bx * gridDim.y;
+  }
+  const int n0 = by * rows_per_pass;
   const int R = min(rows_per_pass, N - n0);                      // a multiple of 4 (host-checked)
   constexpr int Rp = 16 * RB;                                    // rows of the LDS image (rows >= R are never written: their
                                                                  // products only reach features that are never stored)
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(L3_THREADS, 1) void linear_f16x3(const float* __res
   // ---- this wave's row tiles: the workgroup owns a contiguous run, its waves take tiles round-robin
   const int WT = (M + L3_TILE_M - 1) / L3_TILE_M;
   constexpr int NWV = L3_THREADS / 64;
-  const int wg0 = (int)((long long)WT * blockIdx.x / gridDim.x), wg1 = (int)((long long)WT * (blockIdx.x + 1) / gridDim.x);
+  const int wg0 = (int)((long long)WT * bx / gridDim.x), wg1 = (int)((long long)WT * (bx + 1) / gridDim.x);
   const int wt0 = wg0 + wave;
   const int ntiles = wt0 < wg1 ? (wg1 - wt0 + NWV - 1) / NWV : 0;
 

@@ -179,10 +179,14 @@ class PositionEmbeddingSine3DArbitraryT(_Sine3DBase):
         key = (tuple(t_indices.shape), tuple(int(v) for v in t_indices.reshape(-1).tolist()), str(dev))
         return self._t_cache.get(key, make)
 
-    def forward(self, x, t_indices=None, mask=None):
+    def forward(self, x, t_indices=None, mask=None, pos_t=None):
+        """`pos_t`: the result of `temporal(t_indices, device)` where the caller already has it."""
         assert x.dim() == 5 and mask is None
         b, t, _, h, w = x.shape
         dev = x.device
+        if pos_t is not None:
+            yx, _ = self._yx(h, w, dev)
+            return (yx + pos_t[..., None, None, :]).movedim(-1, -3)
         return self._compose(self._z(b, t, dev, t_indices), h, w, dev)
 
     def forward_separable(self, x, t_indices=None, pos_t=None):

@@ -260,7 +260,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             fixed_t = self.position_embedding_sin3d_type == "FixedT"
 
             def make_pos(xi=xi, fixed_t=fixed_t):          # [b,t,C,h,w] -> [hw, bt, C]
-                p = self.pe_layer(xi) if fixed_t else self.pe_layer(xi, frame_indices)
+                p = self.pe_layer(xi) if fixed_t else self.pe_layer(xi, frame_indices, pos_t=pos_t_clip)
                 return p.flatten(3).flatten(0, 1).permute(2, 0, 1)
             xin = self.input_proj[i](x[i])
             if xin.is_cuda and bs == 1 and not torch.is_grad_enabled():
