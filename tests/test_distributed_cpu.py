@@ -359,3 +359,55 @@ def test_clip_shard_gather_orders_frames():
             ClipShard([0, 1, 0])               # rank 1 does not exist in a one-rank group
     finally:
         dist.destroy_process_group()
+
+
+def _vos_loop_worker(rank, world, port):
+    """The config-built model (tests/test_meta_arch_cpu.py) on a mask-prompted ('sot') request: the VOS driver with the frames spread over
+    the ranks == the single-process driver (id maps of every frame), on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle.cpu_path import cpu_ops
+        from tests.test_meta_arch_cpu import H, N_FRAMES, W, make_model, video
+        from univs_amd.distributed import FrameShard
+        from univs_amd.inference.video_vos import FrameAnnotations
+        model = make_model()
+        m = torch.zeros(1, H, W)
+        m[0, 10:40, 20:60] = 1
+        ann0 = FrameAnnotations((H, W), [7], m, torch.tensor([[20.0, 10.0, 60.0, 40.0]]), torch.tensor([0]))
+
+        def request():
+            anns = [ann0] + [FrameAnnotations((H, W)) for _ in range(N_FRAMES - 1)]
+            return video("sot", "ytbvos18_val", instances=anns, mask_palette=[0] * 768)
+        pd = model.sem_seg_head.pixel_decoder
+        frames_seen = []
+        orig = pd.forward_features
+        pd.forward_features = lambda f: (frames_seen.append(int(next(iter(f.values())).shape[0])), orig(f))[1]
+        with cpu_ops():
+            torch.manual_seed(0)
+            ref = torch.cat(model(request()))
+            n_ref = sum(frames_seen)
+            frames_seen.clear()
+            model.inference_video_vos.set_frame_shard(FrameShard())
+            torch.manual_seed(0)
+            got = torch.cat(model(request()))
+            model.inference_video_vos.set_frame_shard(None)
+        assert tuple(got.shape) == (N_FRAMES, H, W) and got.dtype == torch.uint8
+        assert (got != ref).float().mean().item() < 2e-3, (got != ref).float().mean().item()     # (pixels at a logit of ~0 may differ)
+        assert set(got.unique().tolist()) <= {0, 7} and torch.equal(got[0] == 7, m[0].bool())
+        owned = len([f for f in range(N_FRAMES) if f % world == rank])
+        assert owned <= sum(frames_seen) < n_ref, (frames_seen, n_ref)     # this rank ran the pixel decoder on its own frames only
+        both = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(both, got)
+        assert all(torch.equal(b, both[0]) for b in both)                     # the ranks agree exactly
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_vos_driver_matches_single_process():
+    """InferenceVideoVOS.set_frame_shard (inference_video_vos.py:243-284 with frame f on rank f % 2): backbone + pixel decoder on the owned
+    frames, every clip's decoder on both ranks (ClipShard), per-video state replicated; the id maps equal the single-process driver's."""
+    world = 2
+    mp.spawn(_vos_loop_worker, args=(world, _free_port()), nprocs=world, join=True)

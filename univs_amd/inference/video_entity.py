@@ -87,6 +87,52 @@ def _resize(masks, size):
     return F.interpolate(masks, size, mode="bilinear", align_corners=False)
 
 
+def window_features_on_owner(model, x, frames, shard):
+    """backbone + pixel decoder of `frames` (absolute indices of the video) on the frames THIS rank owns (frame f belongs to rank
+    f % world) -> ({frame: row}, (mask_features, mask_features_bfe_conv, multi_scale_features) of those rows)."""
+    mine = [f for f in frames if f % shard.world == shard.rank]
+    if not mine:
+        return {}, None
+    feats = model.backbone(x[mine] if mine != list(range(mine[0], mine[0] + len(mine))) else x[mine[0]:mine[0] + len(mine)])
+    mf, bfe, _enc, ms = model.sem_seg_head.pixel_decoder.forward_features(feats)
+    return {f: k for k, f in enumerate(mine)}, (mf, bfe, list(ms))
+
+
+def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard):
+    """The head's predictor on the clip [first, first + n_clip) whose frames are spread over the ranks of `shard` (ClipShard: one
+    all-gather of the query states per decoder layer) -> the full-clip output dict on every rank (mask logits and embeddings of the
+    clip's frames all-gathered; class / re-id logits are replicated by construction)."""
+    from ..distributed import ClipShard, cyclic_owners
+    predictor = model.sem_seg_head.predictor
+    owners = cyclic_owners(first, n_clip, shard.world)
+    if len(set(owners)) < shard.world:
+        # (a clip shorter than num_frames only arises when the video ends inside it; the reference's own memory-pool update raises on
+        # such clips once entities exist, inference_video_entity.py:326-339 -- nothing to stay compatible with)
+        raise ValueError(f"frame-sharded clip loop: the clip at frame {first} has {n_clip} frames for {shard.world} ranks")
+    cs = ClipShard(owners, group=shard.group, always_collective=shard.always_collective)
+    k = [rows[first + p] for p in cs.local_positions]
+    sel = (lambda t: t[k[0]:k[0] + len(k)]) if k == list(range(k[0], k[0] + len(k))) else (lambda t: t[k])
+    mf, bfe, ms = pd
+    predictor.frame_shard = cs
+    try:
+        out = predictor([sel(lv) for lv in ms], sel(mf), sel(bfe) if bfe is not None else None, None, targets)
+    finally:
+        predictor.frame_shard = None
+    out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
+    out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
+    return out
+
+
+def check_loop_shard(shard, num_frames):
+    """None for a one-rank shard without forced collectives; raises when the group is larger than a clip."""
+    if shard is not None and shard.world == 1 and not shard.always_collective:
+        return None
+    if shard is not None and shard.world > num_frames:
+        raise ValueError(f"frame-sharded clip loop: {shard.world} ranks for clips of {num_frames} frames -- every rank must own a frame of "
+                         "every clip (give the loop a group of at most num_frames ranks; other ranks take other videos)")
+    return shard
+
+
 class InferenceVideoEntity(nn.Module):
     @configurable
     def __init__(
@@ -225,38 +271,6 @@ class InferenceVideoEntity(nn.Module):
         other videos).  SURVEY.md 8e; reference loop: inference_video_entity.py:296-316."""
         self.frame_shard = shard
 
-    def _window_features(self, model, x, frames, shard):
-        """backbone + pixel decoder of `frames` (absolute indices) on the frames this rank owns -> ({frame: row}, outputs)."""
-        mine = [f for f in frames if f % shard.world == shard.rank]
-        if not mine:
-            return {}, None
-        feats = model.backbone(x[mine] if mine != list(range(mine[0], mine[0] + len(mine))) else x[mine[0]:mine[0] + len(mine)])
-        mf, bfe, _enc, ms = model.sem_seg_head.pixel_decoder.forward_features(feats)
-        return {f: k for k, f in enumerate(mine)}, (mf, bfe, list(ms))
-
-    def _sharded_clip(self, model, targets, first, n_clip, rows, pd, shard):
-        """The head's predictor on the clip [first, first + n_clip) whose frames are spread over the ranks -> the full-clip output dict
-        on every rank."""
-        from ..distributed import ClipShard, cyclic_owners
-        predictor = model.sem_seg_head.predictor
-        owners = cyclic_owners(first, n_clip, shard.world)
-        if len(set(owners)) < shard.world:
-            # (a clip shorter than num_frames only arises when the video ends inside it; the reference's own memory-pool update raises on
-            # such clips once entities exist, inference_video_entity.py:326-339 -- nothing to stay compatible with)
-            raise ValueError(f"frame-sharded clip loop: the clip at frame {first} has {n_clip} frames for {shard.world} ranks")
-        cs = ClipShard(owners, group=shard.group, always_collective=shard.always_collective)
-        k = [rows[first + p] for p in cs.local_positions]
-        sel = (lambda t: t[k[0]:k[0] + len(k)]) if k == list(range(k[0], k[0] + len(k))) else (lambda t: t[k])
-        mf, bfe, ms = pd
-        predictor.frame_shard = cs
-        try:
-            out = predictor([sel(lv) for lv in ms], sel(mf), sel(bfe) if bfe is not None else None, None, targets)
-        finally:
-            predictor.frame_shard = None
-        out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
-        out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
-        return out
-
     def inference_video(self, model, batched_inputs, images, targets, merge_results=True, on_clip=None):
         """`on_clip(first_frame_idx, targets)`: optional observer called at the entry of every clip (tests, tracing)."""
         x = images.tensor
@@ -276,12 +290,7 @@ class InferenceVideoEntity(nn.Module):
         is_last = False
         win_start = win_end = 0
         feats_window = None
-        shard = getattr(self, "frame_shard", None)
-        if shard is not None and shard.world == 1 and not shard.always_collective:
-            shard = None
-        if shard is not None and shard.world > T:
-            raise ValueError(f"frame-sharded clip loop: {shard.world} ranks for clips of {T} frames -- every rank must own a frame of "
-                             "every clip (give the loop a group of at most num_frames ranks; other ranks take other videos)")
+        shard = check_loop_shard(getattr(self, "frame_shard", None), T)
         win_rows, win_pd = {}, None
         for i in range(0, n_total, stride):
             if is_last and i + T > n_total:
@@ -295,8 +304,8 @@ class InferenceVideoEntity(nn.Module):
             if shard is not None:
                 if i + T > win_end:  # the window's frames: backbone AND pixel decoder, on their owners, once per frame
                     win_start, win_end = i, i + self.num_frames_window_test
-                    win_rows, win_pd = self._window_features(model, x, list(range(win_start, min(win_end, n_total))), shard)
-                out = self._sharded_clip(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard)
+                    win_rows, win_pd = window_features_on_owner(model, x, list(range(win_start, min(win_end, n_total))), shard)
+                out = sharded_clip_forward(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard)
             else:
                 if i + T > win_end:      # the backbone runs once per window of frames
                     win_start, win_end = i, i + self.num_frames_window_test

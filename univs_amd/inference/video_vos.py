@@ -131,7 +131,14 @@ class InferenceVideoVOS(nn.Module):
         targets[0]["video_len"] = len(frames)
         return self.inference_video_vos(model, batched_inputs, images, targets, image_size, out_size)
 
+    def set_frame_shard(self, shard):
+        """The clip loop with the frames of the video spread over the ranks of `shard` (frame f on rank f % world; backbone + pixel decoder
+        on the owned frames, every clip's decoder on all ranks through ClipShard, `targets[0]` replicated): see
+        InferenceVideoEntity.set_frame_shard.  None switches back."""
+        self.frame_shard = shard
+
     def inference_video_vos(self, model, batched_inputs, images, targets, image_size=None, out_size=None):
+        from .video_entity import check_loop_shard, sharded_clip_forward, window_features_on_owner
         x = images.tensor
         image_size = tuple(images.image_sizes[0])
         out_size = tuple(out_size) if out_size is not None else image_size
@@ -143,6 +150,8 @@ class InferenceVideoVOS(nn.Module):
         is_last = False
         win_start = win_end = 0
         feats_window = None
+        shard = check_loop_shard(getattr(self, "frame_shard", None), T)
+        win_rows, win_pd = {}, None
         for i in range(0, video_len, stride):
             if is_last and i + T > video_len:
                 break
@@ -150,13 +159,19 @@ class InferenceVideoVOS(nn.Module):
             tv["frame_indices"] = torch.arange(i, min(i + T, video_len))
             if i + T > win_end:
                 win_start, win_end = i, min(i + self.num_frames_window_test, video_len)
-                feats_window = model.backbone(x[win_start:win_end])
+                if shard is not None:    # backbone AND pixel decoder on the frames this rank owns, once per frame
+                    win_rows, win_pd = window_features_on_owner(model, x, list(range(win_start, win_end)), shard)
+                else:
+                    feats_window = model.backbone(x[win_start:win_end])
             # 1. annotations of objects that become visible in this clip; room for the clip's new frames
             self.write_targets_into_annotations_per_clip(targets, i, stride)
             # 2. the hot path
-            o = i - win_start
-            feats = {k: v[o:o + T] for k, v in feats_window.items()}
-            out = model.sem_seg_head(feats, targets=targets)
+            if shard is not None:
+                out = sharded_clip_forward(model, targets, i, min(T, video_len - i), win_rows, win_pd, shard)
+            else:
+                o = i - win_start
+                feats = {k: v[o:o + T] for k, v in feats_window.items()}
+                out = model.sem_seg_head(feats, targets=targets)
             out.pop("aux_outputs", None)
             # 3. predictions -> pseudo annotations (the prompts of the following frames)
             self.write_predictions_into_annotations_per_clip(out, image_size, targets, i, stride)
