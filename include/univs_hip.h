@@ -291,6 +291,11 @@ int univs_linear_resident_presplit_f32(const float* x, const void* wp, const flo
                                        long long M, int N, int K, int act, float* y, void* stream);
 int univs_linear_blocked_presplit_f32(const float* x, const void* wp, const float* winv, const float* bias, long long M, int N, int K,
                                       int rows_per_batch, int col_block, float* y, void* stream);
+/* univs_conv3x3_nhwc_presplit_f32: the same convolution on a CHANNELS-LAST operand x [T, H, W, Cin] (y stays NCHW [T, Cout, H, W]); same
+ *   weights image, same k order, bit-identical results: a lane's 8 input channels of a tap are 32 contiguous bytes (two 16-byte loads)
+ *   where the NCHW operand takes eight 4-byte loads a plane apart.  For producers that can write channels last (ops.upsample2x_add). */
+int univs_conv3x3_nhwc_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
+                                    float* y, void* stream);
 /* univs_conv1x1_presplit_f32: y = conv2d(x, w [Cout, Cin, 1, 1], bias) (stride 1, no padding) on contiguous float32 NCHW tensors
  *   through the same kernel (tap addressing with the centre tap alone); (wp, winv) = univs_presplit_weights_f32(w, Cout, Cin, 0),
  *   bias [Cout] or NULL rides in the epilogue.  Covered: Cin % 96 == 0 or Cin % 128 == 0, Cout % 16 == 0, T*H*W >= 4096.

@@ -1620,3 +1620,18 @@ def test_layer_norm_second_output(cuda):
         ops.layer_norm(x, w, b, 1e-5, post_add=p)
     with pytest.raises(RuntimeError):
         ops.layer_norm(x, w, b, 1e-5, residual=r, post_add=p[:, :1])                  # broadcast over rows: not covered
+
+
+def test_conv3x3_channels_last_operand_is_bit_identical(cuda):
+    """ops.conv3x3_nhwc (univs_conv3x3_nhwc_presplit_f32: the FPN convolution reading a channels-last operand, XMODE 2 of the streamed
+    kernel) == ops.conv3x3 on the NCHW tensor bit for bit (same weights image, same k order), borders included; uncovered shapes -> None."""
+    T, C, H, W = 2, 128, 46, 80
+    x = synth.normal("c3n/x", (T, C, H, W)).to(cuda)
+    w = synth.normal("c3n/w", (64, C, 3, 3), std=1 / 34).to(cuda)
+    want = ops.conv3x3(x, w)
+    got = ops.conv3x3_nhwc(x.permute(0, 2, 3, 1).contiguous(), w)
+    assert want is not None and got is not None and torch.equal(got, want)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    assert (got.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item() + 1e-6
+    assert ops.conv3x3_nhwc(x.permute(0, 2, 3, 1), w) is None                       # not contiguous as [T, H, W, C]
+    assert ops.conv3x3_nhwc(x[:, :96].permute(0, 2, 3, 1).contiguous(), w[:, :96].contiguous()) is None   # Cin % 128

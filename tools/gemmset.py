@@ -92,6 +92,12 @@ def main():
     t = timeit(lambda: ops.conv3x3(xc, wc), iters=10, warmup=3)
     fl = 2.0 * T * 184 * 320 * 256 * 2304
     rows.append(dict(name="fpn_conv3x3", us=round(t * 1e6, 1), per_clip=1, mfma_frac=round(3 * fl / t / 2.5e15, 3), hbm_frac=round(2 * xc.numel() * 4 / t / 8e12, 3)))
+    xn = xc.permute(0, 2, 3, 1).contiguous()
+    if hasattr(ops, "conv3x3_nhwc") and ops.conv3x3_nhwc(xn, wc) is not None:
+        same = bool(torch.equal(ops.conv3x3_nhwc(xn, wc), ops.conv3x3(xc, wc)))
+        t = timeit(lambda: ops.conv3x3_nhwc(xn, wc), iters=10, warmup=3)
+        rows.append(dict(name="fpn_conv3x3_nhwc_input", us=round(t * 1e6, 1), per_clip=0, mfma_frac=round(3 * fl / t / 2.5e15, 3), bit_identical_to_nchw=same))
+    del xn
     w1 = synth.normal("gs/conv/w1", (256, 256, 1, 1), std=1 / 16).to(dev)
     b1 = synth.normal("gs/conv/b1", (256,)).to(dev)
     t = timeit(lambda: ops.conv1x1(xc, w1, b1), iters=10, warmup=3)

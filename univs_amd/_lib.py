@@ -52,6 +52,7 @@ SIGNATURES = {
     "univs_presplit_weights_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "univs_linear_presplit_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_conv3x3_presplit_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_conv3x3_nhwc_presplit_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univs_linear_resident_presplit_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _P, _P]),
     "univs_linear_blocked_presplit_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P, _P]),
     "univs_conv1x1_presplit_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -54,6 +54,7 @@ int msda_prepare_f32(const float*, int, int, const float*, long long, const Leve
 int bilinear_resample_f32(const float*, const float*, float*, long long, int, int, int, int, hipStream_t);
 int upsample2x_add_f32(const float*, const float*, const float*, float*, long long, int, int, hipStream_t);
 int normalize_pad_f32(const float*, float*, long long, int, int, int, int, int, const float*, const float*, hipStream_t);
+int conv3x3_nhwc_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
 int small_chain_f32(const float*, int, const void* const*, const float* const*, const float* const*, const int*, const float*, const float*,
                     float, float*, float*, long long, int, hipStream_t);
 int group_norm_affine_f32(const float*, const float*, const float*, int, int, long long, int, float, float*, long long, float*, hipStream_t);
@@ -421,6 +422,24 @@ int univs_conv3x3_presplit_f32(const float* x, const void* wp, const float* winv
   const int rc = univs::conv3x3_f16x3_f32(x, wp, winv, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
     set_error("univs_conv3x3_presplit_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout %% 16, >= 4096 pixels)", T, Cin, Cout, H, W);
+  return rc;
+}
+
+int univs_conv3x3_nhwc_presplit_f32(const float* x, const void* wp, const float* winv, int T, int Cin, int Cout, int H, int W,
+                                    float* y, void* stream) {
+  clear_sticky_error();
+  if (T < 0 || Cin < 1 || Cout < 0 || H < 0 || W < 0) {
+    set_error("univs_conv3x3_nhwc_presplit_f32: bad dimensions T=%d Cin=%d Cout=%d H=%d W=%d", T, Cin, Cout, H, W);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if (T == 0 || Cout == 0 || H == 0 || W == 0) return UNIVS_OK;
+  if (!x || !wp || !winv || !y) {
+    set_error("univs_conv3x3_nhwc_presplit_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = univs::conv3x3_nhwc_f16x3_f32(x, wp, winv, y, T, Cin, Cout, H, W, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    set_error("univs_conv3x3_nhwc_presplit_f32: T=%d Cin=%d Cout=%d H=%d W=%d not covered (Cin %% 128, Cout %% 16, >= 4096 pixels)", T, Cin, Cout, H, W);
   return rc;
 }
 

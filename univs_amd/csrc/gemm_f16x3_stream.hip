@@ -22,7 +22,10 @@ namespace univs {
 #ifdef UNIVS_TRACE_GEMM
 UNIVS_GT_DECL(g_gs_trace);
 #endif
-constexpr int GS_THREADS = 512;
+#ifndef UNIVS_GS_THREADS
+#define UNIVS_GS_THREADS 512     // (256: timing experiment `--ablate gs256` -- two 4-wave workgroups per CU where their W buffers fit)
+#endif
+constexpr int GS_THREADS = UNIVS_GS_THREADS;
 constexpr int GS_TILE_M = 32;
 enum { GS_EPI_NONE = 0, GS_EPI_RELU = 1, GS_EPI_GELU = 2, GS_EPI_RESIDUAL = 3 };   // = LS_EPI_*
 
@@ -77,14 +80,14 @@ struct GsArgs {
   const float* Res;
   float* Y;
   int M, N, K, rows_per_pass, epi;
-  int Cin, Cout, H, Wd, HW;      // conv (XMODE 1): X [T, Cin, H, W], Y [T, Cout, H, W]
+  int Cin, Cout, H, Wd, HW;      // conv (XMODE 1): X [T, Cin, H, W], Y [T, Cout, H, W]; XMODE 2: X [T, H, W, Cin] (channels last), Y as XMODE 1
   int tap0;                      // conv: first tap of the kernel (0: all nine taps of a 3 x 3; 4: the centre alone = a 1 x 1)
   int remap;                     // XCD-aware (row range, pass) order (UnivsConfig.linear_ablate == 5 switches it off: A/B)
 };
 
 // LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp]
 template <int RB, int RING, int XMODE>
-__global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs a) {
+__global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_stream(const GsArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];
   [[maybe_unused]] const int gts = UNIVS_GT_SLOT();
   UNIVS_GT(g_gs_trace, gts, 0);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
   }
 
   // ---- x
-  const long long xbytes = XMODE == 0 ? (long long)M * K * 4 : (long long)(M / a.HW) * a.Cin * a.HW * 4;
+  const long long xbytes = XMODE == 0 ? (long long)M * K * 4 : (long long)(M / a.HW) * a.Cin * a.HW * 4;   // (XMODE 1 and 2: the same bytes)
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)xbytes, 0x00020000);
   const long long ybytes = XMODE == 0 ? (long long)M * N * 4 : (long long)(M / a.HW) * a.Cout * a.HW * 4;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)ybytes, 0x00020000);
@@ -167,6 +170,11 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
       if (XMODE == 0) {
         t.vo[c] = ((unsigned)m * (unsigned)K + (unsigned)(8 * g)) * 4u;
         t.py[c] = t.px[c] = 0;
+      } else if (XMODE == 2) {
+        const int f = m / a.HW, rem = m - f * a.HW;
+        t.py[c] = rem / a.Wd;
+        t.px[c] = rem - t.py[c] * a.Wd;
+        t.vo[c] = ((unsigned)m * (unsigned)a.Cin + (unsigned)(8 * g)) * 4u;   // pixel m, channels 8 g ..: 32 contiguous bytes
       } else {
         const int f = m / a.HW, rem = m - f * a.HW;
         t.py[c] = rem / a.Wd;
@@ -176,13 +184,26 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
     }
   };
   f32x4 raw[RING][2][2];                                         // [stage][column tile][8 k-values]
-  const int kspt = XMODE == 1 ? a.Cin >> 5 : 1;                  // k-steps per tap
+  const int kspt = XMODE != 0 ? a.Cin >> 5 : 1;                  // k-steps per tap
   auto load_x = [&](f32x4 (&buf)[2][2], const TileRows& t, int ks) __attribute__((always_inline)) {
     if (XMODE == 0) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         buf[c][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, t.vo[c], ks * 128, 0));
         buf[c][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, t.vo[c] + 16u, ks * 128, 0));
+      }
+    } else if (XMODE == 2) {
+      // channels last: 8 input channels of tap ks / kspt at my (shifted) pixel are 32 contiguous bytes -- two 16-byte loads per
+      // column tile where the NCHW operand takes eight 4-byte loads; taps outside the image read 0 (offset out of range)
+      const int tap_ = ks / kspt, cb = (ks - tap_ * kspt) * 32;  // uniform
+      const int tap = tap_ + a.tap0;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bool inb = (unsigned)(t.py[c] + dy) < (unsigned)a.H && (unsigned)(t.px[c] + dx) < (unsigned)a.Wd;
+        const unsigned vo = inb ? t.vo[c] + (unsigned)((dy * a.Wd + dx) * a.Cin * 4) : 0xFFFFFFE0u;
+        buf[c][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, cb * 4, 0));
+        buf[c][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 16u, cb * 4, 0));
       }
     } else {
       // 8 input channels (a plane apart) of tap ks / kspt at my pixel; taps outside the image read 0 (offset out of range)
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(GS_THREADS, 1) void gemm_f16x3_stream(const GsArgs 
       const int m = tt * GS_TILE_M + 16 * c + j;
       const bool row_ok = tile_ok && m < M;
       int fr = 0, rem = 0;
-      if (XMODE == 1) {
+      if (XMODE != 0) {
         fr = min(m, M - 1) / a.HW;
         rem = min(m, M - 1) - fr * a.HW;
       }
@@ -384,16 +405,18 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   const int passes = (a.N + r_cap - 1) / r_cap;
   int rows = (a.N + passes - 1) / passes;
   rows = (rows + 3) & ~3;
-  if (XMODE == 1) rows = (rows + 15) & ~15;
+  if (XMODE != 0) rows = (rows + 15) & ~15;
   const int RB = (rows + 15) / 16;
   a.rows_per_pass = rows;
   a.remap = cfg_.linear_ablate == 5 ? 0 : 1;
   const long long WT = ((long long)a.M + GS_TILE_M - 1) / GS_TILE_M;
   long long gx = std::max<long long>(1, gs_cus() / passes);
-  gx = std::min(gx, std::max<long long>(1, WT / 8));
+  gx = std::min(gx, std::max<long long>(1, WT / (GS_THREADS / 64)));
   if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;     // the passes of a row range share an XCD (linear_f16x3.hip)
   if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
   const size_t lds = (size_t)2 * ring * 8 * (16 * RB) * 16 + 8 * (size_t)(16 * RB);
+  if (GS_THREADS < 512 && cfg_.linear_grid_x <= 0 && lds * (512 / GS_THREADS) <= 156 * 1024)      // (experiment: several workgroups per CU)
+    gx = std::min<long long>(gx * (512 / GS_THREADS), std::max<long long>(1, WT / (GS_THREADS / 64)));
   dim3 grid((unsigned)gx, (unsigned)passes), block(GS_THREADS);
 #define UNIVS_GS(rb, rg)                                                                                          \
   do {                                                                                                            \
@@ -451,6 +474,23 @@ int conv3x3_f16x3_f32(const float* x, const void* wp, const float* winv, float* 
   a.Cin = Cin; a.Cout = Cout; a.H = H; a.Wd = W; a.HW = H * W;
   a.tap0 = 0;
   return gs_launch<1>(a, 4, st);
+}
+
+// the same convolution on a CHANNELS-LAST operand x [T, H, W, Cin] (output NCHW as above): see XMODE 2 in the kernel
+int conv3x3_nhwc_f16x3_f32(const float* x, const void* wp, const float* winv, float* y, int T, int Cin, int Cout, int H, int W,
+                           hipStream_t st) {
+  if (T <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UNIVS_OK;
+  const long long M = (long long)T * H * W;
+  if (Cin % 128 != 0 || Cout % 16 != 0 || M < 4096 || M * std::max(Cin, Cout) * 4 >= 0x7FFFFFFFLL ||
+      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wp) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (reinterpret_cast<uintptr_t>(winv) & 15))
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  GsArgs a{};
+  a.X = x; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = nullptr; a.Res = nullptr; a.Y = y;
+  a.M = (int)M; a.N = Cout; a.K = 9 * Cin; a.epi = GS_EPI_NONE;
+  a.Cin = Cin; a.Cout = Cout; a.H = H; a.Wd = W; a.HW = H * W;
+  a.tap0 = 0;
+  return gs_launch<2>(a, 4, st);
 }
 
 // y = conv2d(x, w [Cout, Cin, 1, 1], bias) on NCHW tensors: the same kernel with the centre tap alone (K = Cin; w pre-split as a

@@ -929,6 +929,24 @@ def conv3x3(x, weight):
     return y
 
 
+def conv3x3_nhwc(x_nhwc, weight):
+    """`conv3x3` on a channels-last operand x [T, H, W, Cin] (contiguous) -> NCHW [T, Cout, H, W], bit-identical to
+    conv3x3(x.permute(0, 3, 1, 2)) (include/univs_hip.h: univs_conv3x3_nhwc_presplit_f32).  None when not covered."""
+    if (not x_nhwc.is_cuda or x_nhwc.dtype != torch.float32 or weight.dtype != torch.float32 or x_nhwc.dim() != 4 or not x_nhwc.is_contiguous()
+            or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x_nhwc.shape[3] or needs_grad(x_nhwc, weight) or SWITCHES.presplit_kmin <= 0):
+        return None
+    T, H, W, Cin = x_nhwc.shape
+    Cout = weight.shape[0]
+    y = torch.empty((T, Cout, H, W), dtype=torch.float32, device=x_nhwc.device)
+    with _on(x_nhwc):
+        wp, winv = presplit_weights(weight, conv=True)
+        rc = _lib.load().univs_conv3x3_nhwc_presplit_f32(_ptr(x_nhwc), _ptr(wp), _ptr(winv), T, Cin, Cout, H, W, _ptr(y), _stream_ptr(x_nhwc))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "conv3x3_nhwc")
+    return y
+
+
 def conv1x1(x, weight, bias=None):
     """F.conv2d(x, weight, bias) for a 1 x 1 kernel (stride 1, no padding), float32 NCHW on the GPU, through the three-product fp16
     streamed GEMM (include/univs_hip.h: univs_conv1x1_presplit_f32) with the bias in the epilogue: the lateral, mask-feature and
