@@ -556,15 +556,22 @@ def run(args):
                 import datetime
                 # a group of its own with a short timeout: a failure on one rank must not hang the others for the default ten minutes
                 grp = dist.new_group(ranks=list(range(team)), timeout=datetime.timedelta(seconds=180))
-                dts = 0.0
+                dts, failure = 0.0, None
                 if rank < team:
-                    lp = make_loop(NF)
-                    lp.set_frame_shard(FrameShard(group=grp))
-                    dts, n_ent = time_video(lp)
-                    sl["entities_at_end"] = n_ent
+                    try:         # (a failing rank still reaches the world-wide reduction below: nobody waits for it in vain)
+                        lp = make_loop(NF)
+                        lp.set_frame_shard(FrameShard(group=grp))
+                        dts, n_ent = time_video(lp)
+                        sl["entities_at_end"] = n_ent
+                    except Exception as e_:  # pragma: no cover
+                        failure, dts = e_, float("inf")
                 tt = torch.tensor([dts], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dts = float(tt.item())
+                if failure is not None:
+                    raise failure
+                if dts == float("inf"):
+                    raise RuntimeError("the frame-sharded sliding clip loop failed on another rank")
                 sl["frame_sharded"] = {"ranks_used": team, "ranks_idle": world - team, "window": NF, "ms_per_video": dts * 1e3,
                                        "frames_per_s": NF / dts,
                                        "note": "frame f on rank f % ranks_used: backbone + pixel decoder on owned frames, every clip's decoder "
@@ -574,8 +581,6 @@ def run(args):
         except Exception as e:  # pragma: no cover
             import traceback
             res["sliding_clip_loop"] = {"error": "".join(traceback.format_exception(type(e), e, e.__traceback__))[-600:]}
-            if world > 1:
-                pass
 
     # ---- BASELINE config 4: Swin-B (12 x 12 windows), T=5 @ 720p, 200 learnable queries + 4 referring expressions: the text-prompt
     # path (78 text tokens per expression cross-attend to the three feature levels, ...decoder_univs.py:760-793; ProCA; 'sep-blocked'
