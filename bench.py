@@ -29,6 +29,11 @@ per launch), `roofline_mask_decode` (the full-resolution l
 (the ten prediction-head calls of a clip under the un-fused op-boundary accounting of SURVEY.md section 8d: 4.197 GB per
 clip over the summed time of every kernel the fused implementation runs for them), `roofline_window_attn` (per Swin
 stage), and `cpu_baseline` (rank 0, N=1 only: the CPU oracle path on the host cores, 1 warm-up + 3 timed clips, median).
+Informational objects (never `value`): `steady_state_with_prompts` (second clip of a video, 10 entities), `config4_swinb_refvos`
+(BASELINE config 4: Swin-B, 200 queries + 4 referring expressions), `config5_swinl_1080p`, `frame_sharded_n1` (one 40-frame clip under a
+one-rank RCCL group) and `sliding_clip_loop` (config 3 as the reference RUNS a long video: the sliding 5-frame clip loop with the prompt
+memory pool over a 20-frame video -- at N = 1 in the reference's call pattern and in this build's default; at N > 1 with the frames of
+the video spread over min(N, 5) ranks, InferenceVideoEntity.set_frame_shard).
 """
 import argparse
 import ctypes
