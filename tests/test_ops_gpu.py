@@ -1635,3 +1635,33 @@ def test_conv3x3_channels_last_operand_is_bit_identical(cuda):
     assert (got.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item() + 1e-6
     assert ops.conv3x3_nhwc(x.permute(0, 2, 3, 1), w) is None                       # not contiguous as [T, H, W, C]
     assert ops.conv3x3_nhwc(x[:, :96].permute(0, 2, 3, 1).contiguous(), w[:, :96].contiguous()) is None   # Cin % 128
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,act,res", [(18400, 1536, 384, None, True), (4600, 3072, 768, None, True), (18400, 384, 384, None, True),
+                                           (4600, 768, 2304, None, False), (4600, 768, 3072, "gelu", False), (18400, 768, 384, None, False),
+                                           (4600, 1536, 768, None, False), (18399, 768, 200, "relu", False), (2049, 384, 132, None, True), (4100, 576, 260, None, False), (4100, 1152, 256, None, True),
+                                           (73600, 384, 192, None, False)], ids=lambda v: str(v))
+def test_linear_tile_kernel_is_bit_identical_to_the_pass_kernel(cuda, M, K, N, act, res):
+    """The wide-K Linear tiled in two dimensions (gemm_f16x3_tile.hip: x split once per workgroup and shared through LDS) == the row-range x
+    pass kernel (gemm_f16x3_stream.hip: every pass re-reads and re-splits x), bit for bit -- the same scales (running row maxima), the same
+    parts and the same products in the same order per output; UnivsConfig.linear_ablate = 6 switches the tiled kernel off."""
+    x = synth.normal(f"gt/x/{M}x{K}", (M, K)).to(cuda)
+    x = x * torch.logspace(-2, 2, K, device=cuda).view(1, K)                      # the running row scale has to move along k
+    w = (synth.normal(f"gt/w/{N}x{K}", (N, K), std=K ** -0.5) * torch.logspace(-3, 3, N).view(N, 1)).to(cuda)
+    b = synth.normal(f"gt/b/{N}", (N,)).to(cuda)
+    r = synth.normal(f"gt/r/{M}x{N}", (M, N)).to(cuda) if res else None
+    with ops.configured(linear_ablate=6):
+        want = ops.linear_fused(x, w, b, act=act, residual=r)
+    got = ops.linear_fused(x, w, b, act=act, residual=r)
+    assert want is not None and got is not None
+    assert torch.equal(got, want)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if act == "relu":
+        ref = ref.relu()
+    if res:
+        ref = ref + r.double()
+    scale = (x.double().abs() @ w.double().abs().t()).max().item()
+    assert (got.double() - ref).abs().max().item() < 2e-6 * scale

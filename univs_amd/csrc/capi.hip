@@ -78,6 +78,8 @@ int mlp_f16x3_f32(const float*, const void*, const float*, const float*, const v
                   int, int, int, int, hipStream_t);
 int linear_f16x3_stream_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
                             hipStream_t);
+int linear_f16x3_tile_f32(const float*, const void*, const float*, const float*, const float*, float*, long long, int, int, int,
+                          hipStream_t);
 int small_linear_f32(const float*, const float*, const void*, const float*, const float*, int, int, const float*, const float*, const float*,
                      float, float*, long long, int, int, int, int, int, hipStream_t);
 int conv3x3_f16x3_f32(const float*, const void*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -354,8 +356,13 @@ int univs_linear_presplit_f32(const float* x, const void* wp, const float* winv,
     set_error("univs_linear_presplit_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = univs::linear_f16x3_stream_f32(x, wp, winv, bias, residual, y, M, N, K, residual ? 3 : act,
-                                                static_cast<hipStream_t>(stream));
+  // the two-dimensional tiling where it applies (gemm_f16x3_tile.hip; UnivsConfig.linear_ablate == 6 switches it off: A / B), else the
+  // row-range x pass kernel -- bit-identical results
+  int rc = UNIVS_ERR_NOT_IMPLEMENTED;
+  if (config().linear_ablate != 6)
+    rc = univs::linear_f16x3_tile_f32(x, wp, winv, bias, residual, y, M, N, K, residual ? 3 : act, static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED)
+    rc = univs::linear_f16x3_stream_f32(x, wp, winv, bias, residual, y, M, N, K, residual ? 3 : act, static_cast<hipStream_t>(stream));
   if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_linear_presplit_f32: shape M=%lld N=%d K=%d (or alignment) is not covered", M, N, K);
   return rc;
 }

@@ -451,17 +451,35 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
     for (int ct = 0; ct < CT; ++ct) {
       const int m = row0 + 16 * ct + j;
       const unsigned rowoff = m < M ? (unsigned)m * (unsigned)C * 4u : 0xFFFFFFF0u;   // out of range: loads give 0, stores are dropped
+      // the residual values of a row come in batches of up to RBAT blocks, requested together: a load inside the per-block loop is
+      // compiled into load / wait / store, one memory latency per block
+      constexpr int RBAT = NOB < 8 ? NOB : 8;
+      f32x4 resv[RBAT];
+      auto load_res = [&](int ob0) __attribute__((always_inline)) {
+        if (with_res) {
+#pragma unroll
+          for (int q = 0; q < RBAT; ++q) {
+            const int f = min(ob0 + q, NOB - 1) * 16 + 4 * g;
+            const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+            // (parked rows: written by other lanes of this wave -> glc, from L2)
+            resv[q] = res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
+                                 : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < RBAT; ++q) resv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      };
       if (!with_pln) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
+          if (ob % RBAT == 0) load_res(ob);
           const int f = ob * 16 + 4 * g;
           const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (with_res)                                           // (parked rows: written by other lanes of this wave -> glc, from L2)
-            v += res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
-                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          if (with_res) v += resv[ob % RBAT];
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
         }
       } else {
@@ -470,14 +488,13 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
         float sm = 0.f;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
+          if (ob % RBAT == 0) load_res(ob);
           const int f = ob * 16 + 4 * g;
           const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
           const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
           f32x4 v = (acc2[ob][ct] * sh_inv[ct]) * wi + bi;
           const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
-          if (with_res)                                           // (parked rows: written by other lanes of this wave -> glc, from L2)
-            v += res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
-                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+          if (with_res) v += resv[ob % RBAT];
           acc2[ob][ct] = v;
           if (a.dual) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
           sm += (v[0] + v[1]) + (v[2] + v[3]);
