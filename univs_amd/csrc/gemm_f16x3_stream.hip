@@ -85,7 +85,7 @@ struct GsArgs {
   int remap;                     // XCD-aware (row range, pass) order (UnivsConfig.linear_ablate == 5 switches it off: A/B)
 };
 
-// LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp] | one dump unit
+// LDS: 2 x [RING][4 k-groups][2 parts][16 RB] 16 B | bias[Rp] | winv[Rp]
 template <int RB, int RING, int XMODE>
 __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_stream(const GsArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 Wst[];
@@ -122,45 +122,38 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
     winv_lds[r] = r < R ? a.winv[n0 + r] : 0.f;
   }
 
-  // ---- W: copy of the pre-split image.  Slab q of this pass = RING * 8 runs of R consecutive 16-byte units; a thread moves units
-  // tid + 512 (u UPS + v), its share u of a slab at stage u of a group.  The share of slab gq + 2 is REQUESTED at stage u of group gq and
-  // COMMITTED at stage u of group gq + 1 (into the buffer group gq read): a full group between request and use, as for x.  Every load
-  // of the loop is unconditional (lanes without a unit read out of range = 0 and write a dump slot): with loads under branches hipcc
-  // loses its count of outstanding vector-memory operations and drains them all (`s_waitcnt vmcnt(0)`) in front of every commit --
-  // the ISA of the first version did, four times per group, so that nothing was ever more than one k-step ahead and a k-step cost one
-  // memory latency (2 520 clocks at 64 features per pass with or without the split and the matrix instructions:
-  // profiles/r05_gemm_phase_trace_v1.txt).
+  // ---- W: copy of the pre-split image.  Slab q of this pass = RING * 8 runs of R consecutive 16-byte units; a thread moves
+  // units tid + 512 v, two per k-step of the group before (fetch at stage u, commit at stage u + 1).
+  // (The fetches sit under lane conditions, and hipcc answers loads under branches with `s_waitcnt vmcnt(0)` in front of every commit:
+  // nothing is ever more than a k-step ahead.  A branch-free form with a full group of lead -- round 5, profiles/r05_gemm_tile_v1.txt --
+  // measured the same at 64 features per pass and 10 % WORSE for the convolution (24 more registers at 128 features: spills), because
+  // what bounds this kernel is the L2 -> CU stream of the passes' x re-reads, not the latency of the slab: the wide-K Linears went to
+  // gemm_f16x3_tile.hip instead and this form stayed.)
   constexpr int UNITS = RING * 8 * Rp;                           // per slab (rows >= R of a short last pass are skipped)
   constexpr int UPT = (UNITS + GS_THREADS - 1) / GS_THREADS;     // units per thread and slab (8 at 128 features)
   constexpr int UPS = (UPT + RING - 1) / RING;                   // per stage
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.Wp), 0, (int)((long long)(K >> 3) * 2 * N * 16), 0x00020000);
-  const int slab_bytes = RING * 8 * N * 16;
-  constexpr int DUMP = 2 * SLAB + Rp / 2;                        // one unit behind bias / winv
-  u32x4 wreg[RING][UPS];
+  u32x4 wreg[UPS];
   auto w_fetch = [&](int q, int u) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < UPS; ++v) {
       const int i = tid + GS_THREADS * (u * UPS + v);
       const int run = i / Rp, rr = i - run * Rp;
-      const bool ok = u * UPS + v < UPT && i < UNITS && rr < R;
-      const unsigned vo = ok ? (unsigned)((run * N + n0 + rr) * 16) : 0xFFFFFFF0u;
-      wreg[u][v] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, q * slab_bytes, 0));
+      wreg[v] = (u32x4){0u, 0u, 0u, 0u};
+      if (u * UPS + v < UPT && i < UNITS && rr < R) wreg[v] = a.Wp[(size_t)(q * RING * 8 + run) * N + n0 + rr];
     }
   };
   auto w_commit = [&](int buf, int u) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < UPS; ++v) {
       const int i = tid + GS_THREADS * (u * UPS + v);
-      if (u * UPS + v < UPT) Wst[i < UNITS ? buf * SLAB + i : DUMP] = wreg[u][v];
+      if (u * UPS + v < UPT && i < UNITS) Wst[buf * SLAB + i] = wreg[v];
     }
   };
 #pragma unroll
-  for (int u = 0; u < RING; ++u) w_fetch(0, u);                  // slab 0 -> buffer 0
-#pragma unroll
-  for (int u = 0; u < RING; ++u) w_commit(0, u);
-#pragma unroll
-  for (int u = 0; u < RING; ++u) w_fetch(KG > 1 ? 1 : 0, u);     // slab 1: committed during group 0
+  for (int u = 0; u < RING; ++u) {                               // slab 0 -> buffer 0
+    w_fetch(0, u);
+    w_commit(0, u);
+  }
 
   // ---- x
   const long long xbytes = XMODE == 0 ? (long long)M * K * 4 : (long long)(M / a.HW) * a.Cin * a.HW * 4;   // (XMODE 1 and 2: the same bytes)
@@ -280,23 +273,13 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
 #pragma unroll 1
     for (int q = 0; q < KG; ++q, ++gq) {
       __syncthreads();                                           // slab gq is complete; the other buffer is free
-      const int bufc = gq & 1;
-      int q2 = q + 2;                                            // (q + 2) mod KG, KG >= 1
-      q2 = q2 >= KG ? q2 - KG : q2;
-      q2 = q2 >= KG ? q2 - KG : q2;
+      const int bufc = gq & 1, qn = (q + 1 == KG) ? 0 : q + 1;
       const bool last_group = q + 1 == KG;
       const unsigned a_buf = a_lane + (unsigned)(bufc * SLAB * 16);
       read_batch(afr[0], a_buf, 0);
-      TileRows t_ref;                                            // rows of the k-steps requested in this group
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        t_ref.vo[c] = last_group ? t_next.vo[c] : t_cur.vo[c];
-        t_ref.py[c] = last_group ? t_next.py[c] : t_cur.py[c];
-        t_ref.px[c] = last_group ? t_next.px[c] : t_cur.px[c];
-      }
 #pragma unroll
       for (int u = 0; u < RING; ++u) {
-        w_commit(bufc ^ 1, u);                                   // slab gq + 1, requested a group ago
+        if (u > 0) w_commit(bufc ^ 1, u - 1);
         // ---- the running row scale (linear_f16x3.hip)
         bool need = false;
         int enew[2];
@@ -325,8 +308,9 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
         l3_split8(raw[u][0][0], raw[u][0][1], s0, bh[0], bm[0]);
         l3_split8(raw[u][1][0], raw[u][1][1], s1, bh[1], bm[1]);
         __builtin_amdgcn_sched_barrier(0);
-        w_fetch(q2, u);                                          // slab gq + 2
-        load_x(raw[u], t_ref, last_group ? u : q * RING + u + RING);   // the ring runs RING k-steps ahead, across tiles
+        w_fetch(qn, u);                                          // the next slab, two units per stage
+        if (last_group) load_x(raw[u], t_next, u);               // the ring runs RING k-steps ahead, across tiles
+        else load_x(raw[u], t_cur, q * RING + u + RING);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -351,6 +335,7 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      w_commit(bufc ^ 1, RING - 1);
     }
     UNIVS_GT(g_gs_trace, gts, 3 + 2 * rd);
     // ---- epilogue: D[i = feature][j = row]: a lane holds four consecutive features of its two rows
@@ -363,8 +348,8 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
         fr = min(m, M - 1) / a.HW;
         rem = min(m, M - 1) - fr * a.HW;
       }
-      // the residual rows of this column tile, requested together (one load, one wait, one store at a time -- what the compiler makes
-      // of a load inside the per-block loop -- was RB memory latencies per column tile)
+      // the residual rows of this column tile, requested in batches (a load inside the per-block loop is compiled into load / wait /
+      // store -- one memory latency per block)
       constexpr int RBAT = RB > 4 ? (RB + 1) / 2 : RB;           // (in two halves at RB > 4: registers)
       [[maybe_unused]] f32x4 resv[RBAT];
       auto load_res = [&](int rb0) __attribute__((always_inline)) {
@@ -452,7 +437,7 @@ static int gs_launch(const GsArgs& a0, int ring, hipStream_t st) {
   gx = std::min(gx, std::max<long long>(1, WT / (GS_THREADS / 64)));
   if (gx >= 8 && (gx - gx % 8) * 10 >= gx * 9) gx -= gx % 8;     // the passes of a row range share an XCD (linear_f16x3.hip)
   if (cfg_.linear_grid_x > 0) gx = std::min<long long>(cfg_.linear_grid_x, WT);
-  const size_t lds = (size_t)2 * ring * 8 * (16 * RB) * 16 + 8 * (size_t)(16 * RB) + 16;
+  const size_t lds = (size_t)2 * ring * 8 * (16 * RB) * 16 + 8 * (size_t)(16 * RB);
   if (GS_THREADS < 512 && cfg_.linear_grid_x <= 0 && lds * (512 / GS_THREADS) <= 156 * 1024)      // (experiment: several workgroups per CU)
     gx = std::min<long long>(gx * (512 / GS_THREADS), std::max<long long>(1, WT / (GS_THREADS / 64)));
   dim3 grid((unsigned)gx, (unsigned)passes), block(GS_THREADS);
