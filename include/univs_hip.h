@@ -137,7 +137,11 @@ typedef struct UnivsConfig {
   int linear_ablate;      /* timing experiments on linear_f16x3 (results then only valid for inputs already in fp16's range):
                              1 = no row-maximum pass over x (scale 1); 2 / 3 / 4 = univs_mlp_presplit_f32 (encoder FFN and Swin stage-1
                              shapes) without its MFMAs / without the LDS reads of the weight fragments / without the activation
-                             and split of the hidden activations: results are then WRONG, kernel benchmarks only */
+                             and split of the hidden activations: results are then WRONG, kernel benchmarks only;
+                             6 = univs_linear_presplit_f32 keeps the row-range x pass kernel (gemm_f16x3_stream) where it would take the
+                             two-dimensional tiling (gemm_f16x3_tile; bit-identical results: A / B runs); 7 / 8 / 9 = that kernel with 2 / 3 / 4
+                             k-steps of loads in flight where K allows (kernel benchmarks; with linear_grid_x = 3..5 as its CT and
+                             linear_rows_per_pass = 128 / 192 / 256 as its feature-tile width) */
   int mask_decode_chunked;/* 1: the exact-f32 mask kernel always in its chunked form (kernel benchmarks; default 0: small maps with
                              C == 256 request every row of their columns at once, skinny_gemm_f32_oneshot) */
   int mask_decode_wave_tiles; /* split-bf16 mask decode: column tiles a wave should get before a workgroup is added (default 1;
@@ -269,6 +273,9 @@ int univs_attn_mask_rows_reset(uint8_t* attn_mask, const uint32_t* row_flags, ui
  *   wp     N * K * 4 bytes, 16-byte aligned (out);  winv [N] fp32 (out)
  * univs_linear_presplit_f32 : y = act(x W^T + bias) (+ residual), arguments as univs_linear_fused_f32 with (wp, winv) in place
  *   of w; K % 128 == 0 or K % 96 == 0, N % 4 == 0, M >= 2048.  UNIVS_ERR_NOT_IMPLEMENTED when the shape is not covered.
+ *   Two kernels behind it with bit-identical results: for K >= 384, K % 64 == 0, N >= 128 the two-dimensional tiling
+ *   (gemm_f16x3_tile.hip: x is split once per workgroup and shared by its waves through LDS), else the row-range x pass kernel
+ *   (gemm_f16x3_stream.hip); UnivsConfig.linear_ablate = 6 forces the latter.
  * univs_conv3x3_presplit_f32: y = conv2d(x, w, bias=None, stride=1, padding=1) for a 3 x 3 kernel on contiguous float32 NCHW
  *   tensors, x [T, Cin, H, W] -> y [T, Cout, H, W], as a GEMM with tap addressing of x (the FPN output convolution of the
  *   pixel decoder, mask2former/modeling/pixel_decoder/msdeformattn.py:227-232, :352; its GroupNorm + ReLU stay separate).
