@@ -69,22 +69,39 @@ __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h,
   m = __builtin_bit_cast(f16x8, v1);
   return;
 #endif
-  const float x[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
+  // Two instructions per value, written into the packed halves directly: h = fp16(v s) and m = fp16(v s - h) as mixed-precision FMAs
+  // (v_fma_mix{lo,hi}_f16: fp32 sources v and s, the third source 0 or -h read as fp16 from the half just written; one rounding each).
+  // The same values as the mul / cvt / cvt-back / sub / cvt chain hipcc makes of the plain expression -- s is a power of two, so v s
+  // is exact, and v s - fp16(v s) is exact in fp32 -- at 2 instead of ~3.4 vector instructions per value: the split is a fifth of the
+  // vector work of every three-product kernel, and vector work does not overlap the matrix pipe (profiles/r05_gemm_negative_results_v2.txt).
+  const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  u32x4 hu, mu;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const _Float16 hh = (_Float16)x[e];
-    h[e] = hh;
-    m[e] = (_Float16)(x[e] - (float)hh);                   // exact difference, then rounded
+  for (int p = 0; p < 4; ++p) {
+    unsigned hp, mp;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hp), "=&v"(mp)
+        : "v"(x[2 * p]), "v"(x[2 * p + 1]), "v"(s));
+    hu[p] = hp;
+    mu[p] = mp;
   }
+  h = __builtin_bit_cast(f16x8, hu);
+  m = __builtin_bit_cast(f16x8, mu);
 }
 
 __device__ __forceinline__ unsigned l3_absmax8(f32x4 v0, f32x4 v1) {
 #ifdef UNIVS_ABLATE_NOSPLIT
   return 0x3f800000u;
 #endif
-  const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
-  const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
-  return __builtin_bit_cast(unsigned, fmaxf(a, b));        // non-negative floats order like their bit patterns
+  // max |.| of eight values in four instructions (v_max3_f32 with |.| source modifiers)
+  float t1, t2, r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t1) : "v"(v0.x), "v"(v0.y), "v"(v0.z));
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t2) : "v"(v0.w), "v"(v1.x), "v"(v1.y));
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(v1.z), "v"(v1.w), "v"(t1));
+  return __builtin_bit_cast(unsigned, fmaxf(r, t2));       // non-negative floats order like their bit patterns
 }
 
 // nn.GELU() (approximate = 'none'): x * 0.5 * (1 + erf(x / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7;
