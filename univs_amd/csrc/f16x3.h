@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace univs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -61,6 +63,16 @@ __device__ __forceinline__ f32x4 l3_fake_mfma(f16x8 a, f16x8 b, f32x4 c) {
 #define UNIVS_GT_REAL(sym, slot, i) do { } while (0)
 #define UNIVS_GT_VAL(sym, slot, i, v) do { } while (0)
 #endif
+
+// f(integral_constant<int, I>) for I = I0 .. N - 1: loops whose index has to be a compile-time constant (immediate offsets of asm
+// statements; `#pragma unroll` is a hint and its index is not a constant expression)
+template <int I, int N, class F>
+__device__ __forceinline__ void l3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    l3_static_for<I + 1, N>(f);
+  }
+}
 
 // 8 consecutive k of one row, scaled -> the two fp16x8 parts (round to nearest even)
 __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h, f16x8& m) {

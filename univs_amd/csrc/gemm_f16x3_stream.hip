@@ -235,13 +235,20 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
   const unsigned a_lane = (unsigned)((g * 2 * Rp + j) * 16);
   const unsigned a_kstep = (unsigned)(8 * Rp * 16);
   const unsigned a_part = (unsigned)(Rp * 16);
-  auto read_batch = [&](u32x4 (&d)[BSZ][2], unsigned base, int b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < BSZ; ++q) {
-      const int rb = min(b * BSZ + q, RB - 1);
-      const unsigned ah = base + (unsigned)(rb * 256);
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(d[q][0]), "=&v"(d[q][1]) : "v"(ah), "v"(ah + a_part) : "memory");
-    }
+  // (the block and part offsets of a read are immediates of the instruction: linear_f16x3.hip)
+  auto read_batch = [&](u32x4 (&d)[BSZ][2], unsigned base, auto bc) __attribute__((always_inline)) {
+    constexpr int b = decltype(bc)::value;
+    l3_static_for<0, BSZ>([&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int rb = b * BSZ + q < RB ? b * BSZ + q : RB - 1;
+      u32x4& dh = d[q][0];
+      u32x4& dm = d[q][1];
+      const unsigned aa = base;
+      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                   : "=&v"(dh), "=&v"(dm)
+                   : "v"(aa), "n"(rb * 256), "n"(rb * 256 + Rp * 16)
+                   : "memory");
+    });
   };
   auto wait_batch = [&](u32x4 (&d)[BSZ][2]) __attribute__((always_inline)) {
     if constexpr (BSZ == 1)
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
       const int bufc = gq & 1, qn = (q + 1 == KG) ? 0 : q + 1;
       const bool last_group = q + 1 == KG;
       const unsigned a_buf = a_lane + (unsigned)(bufc * SLAB * 16);
-      read_batch(afr[0], a_buf, 0);
+      read_batch(afr[0], a_buf, std::integral_constant<int, 0>{});
 #pragma unroll
       for (int u = 0; u < RING; ++u) {
         if (u > 0) w_commit(bufc ^ 1, u - 1);
@@ -312,11 +319,11 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
         if (last_group) load_x(raw[u], t_next, u);               // the ring runs RING k-steps ahead, across tiles
         else load_x(raw[u], t_cur, q * RING + u + RING);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        l3_static_for<0, NB>([&](auto bc) __attribute__((always_inline)) {
+          constexpr int b = decltype(bc)::value;
           wait_batch(afr[b & 1]);
-          if (b + 1 < NB) read_batch(afr[(b + 1) & 1], a_buf + (unsigned)u * a_kstep, b + 1);
-          else if (u + 1 < RING) read_batch(afr[0], a_buf + (unsigned)(u + 1) * a_kstep, 0);
+          if constexpr (b + 1 < NB) read_batch(afr[(b + 1) & 1], a_buf + (unsigned)u * a_kstep, std::integral_constant<int, b + 1>{});
+          else if (u + 1 < RING) read_batch(afr[0], a_buf + (unsigned)(u + 1) * a_kstep, std::integral_constant<int, 0>{});
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int qq = 0; qq < BSZ; ++qq) {
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(GS_THREADS, 512 / GS_THREADS) void gemm_f16x3_strea
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
       }
       w_commit(bufc ^ 1, RING - 1);
     }
