@@ -68,7 +68,7 @@ def build(force=False, verbose=True, lib=LIB, defines=(), tag=""):
     return lib
 
 
-ABLATIONS = {"nosplit": ("UNIVS_ABLATE_NOSPLIT",), "nomfma": ("UNIVS_ABLATE_NOMFMA",),
+ABLATIONS = {"plainsplit": ("UNIVS_SPLIT_PLAIN",), "nosplit": ("UNIVS_ABLATE_NOSPLIT",), "nomfma": ("UNIVS_ABLATE_NOMFMA",),
              "nosplit_nomfma": ("UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA"), "trace": ("UNIVS_TRACE_GEMM",), "vtpad8": ("UNIVS_WH_VT_PAD=8", "UNIVS_XA_VS=40"), "gs256": ("UNIVS_GS_THREADS=256",),
              "trace_nosplit_nomfma": ("UNIVS_TRACE_GEMM", "UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA")}
 

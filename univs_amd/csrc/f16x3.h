@@ -81,6 +81,18 @@ __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h,
   m = __builtin_bit_cast(f16x8, v1);
   return;
 #endif
+#ifdef UNIVS_SPLIT_PLAIN   // (A / B: the plain expression, ~3.4 vector instructions per value as hipcc compiles it; same values)
+  {
+    const float xp[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 hh = (_Float16)xp[e];
+      h[e] = hh;
+      m[e] = (_Float16)(xp[e] - (float)hh);                  // exact difference, then rounded
+    }
+    return;
+  }
+#endif
   // Two instructions per value, written into the packed halves directly: h = fp16(v s) and m = fp16(v s - h) as mixed-precision FMAs
   // (v_fma_mix{lo,hi}_f16: fp32 sources v and s, the third source 0 or -h read as fp16 from the half just written; one rounding each).
   // The same values as the mul / cvt / cvt-back / sub / cvt chain hipcc makes of the plain expression -- s is a power of two, so v s
@@ -107,6 +119,13 @@ __device__ __forceinline__ void l3_split8(f32x4 v0, f32x4 v1, float s, f16x8& h,
 __device__ __forceinline__ unsigned l3_absmax8(f32x4 v0, f32x4 v1) {
 #ifdef UNIVS_ABLATE_NOSPLIT
   return 0x3f800000u;
+#endif
+#ifdef UNIVS_SPLIT_PLAIN
+  {
+    const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+    const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+    return __builtin_bit_cast(unsigned, fmaxf(a, b));
+  }
 #endif
   // max |.| of eight values in four instructions (v_max3_f32 with |.| source modifiers)
   float t1, t2, r;
