@@ -172,3 +172,28 @@ def test_window_attention_three_product_error_model():
     p16 = np.exp(s16 - s16.max(1, keepdims=True))
     o16 = (p16.astype(np.float16).astype(np.float64) @ v.astype(np.float16).astype(np.float64)) / p16.sum(1, keepdims=True)
     assert np.abs(o16 - o64).max() > 50 * np.abs(o3 - o64).max()
+
+
+def test_split_as_two_single_rounding_fmas_gives_the_same_parts():
+    """csrc/f16x3.h l3_split8 computes h = fp16(v * s) and m = fp16(v * s - h) as two mixed-precision FMAs with ONE rounding each
+    (v_fma_mix{lo,hi}_f16), where the plain expression rounds v * s to fp32 first, subtracts in fp32 and rounds again.  The two agree
+    bit for bit because s is a power of two (v * s is exact in fp32) and x - fp16(x) is exact in fp32 whenever fp16(x) is finite:
+    checked here in float64 (which holds every intermediate exactly) over values across fp16's whole range, incl. its subnormals."""
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal(200000) * np.exp2(rng.integers(-40, 8, 200000))).astype(np.float32)
+    v[:8] = [0.0, -0.0, 1.0, -1.0, 2.0 ** -30, 65504.0 / 4096, 3.0e-9, -7.7]
+    for e in (12, 4, 0, -6):                                   # the scale places a row's maximum near 2^12; smaller ones for the tail
+        s = np.float32(2.0 ** e)
+        exact = v.astype(np.float64) * float(s)                # exact product
+        keep = np.abs(exact) < 60000.0                         # (the kernels' scale keeps every element below fp16's maximum)
+        xs32 = (v * s).astype(np.float32)
+        assert np.array_equal(xs32.astype(np.float64)[keep], exact[keep])                  # v * s exact in fp32
+        h_chain = xs32.astype(np.float16)
+        h_fma = exact.astype(np.float16)                       # one rounding from the exact product
+        assert np.array_equal(h_chain[keep].view(np.uint16), h_fma[keep].view(np.uint16))
+        d32 = (xs32 - h_chain.astype(np.float32)).astype(np.float32)
+        d_exact = exact - h_fma.astype(np.float64)
+        assert np.array_equal(d32.astype(np.float64)[keep], d_exact[keep])                 # the difference is exact in fp32
+        m_chain = d32.astype(np.float16)
+        m_fma = d_exact.astype(np.float16)                     # one rounding from the exact difference
+        assert np.array_equal(m_chain[keep].view(np.uint16), m_fma[keep].view(np.uint16))

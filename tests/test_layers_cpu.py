@@ -43,3 +43,33 @@ def test_library_fallback_is_logged_once(caplog):
         layers._note_library_linear(torch.zeros(3, 100), w)
     recs = [r for r in caplog.records if r.name == "univs_amd"]
     assert len(recs) == 1 and "100 -> 7" in recs[0].getMessage()
+
+
+def test_packed_in_projection_rows_are_cached_whole_tensors_without_autograd():
+    """MultiheadAttention._packed_rows: under no_grad the K / V rows of the packed in-projection are contiguous copies made once per
+    weight version (whole tensors: the fp16 three-product Linear finds their split image in its cache), refreshed when the parameter
+    changes in place or moves; with autograd the views of the parameter are returned so that gradients reach it."""
+    import torch
+    from oracle.cpu_path import cpu_ops
+    from univs_amd.layers import MultiheadAttention
+    torch.manual_seed(0)
+    mha = MultiheadAttention(32, 4)
+    with torch.no_grad():
+        w1, b1 = mha._packed_rows(32, 32)
+        w2, b2 = mha._packed_rows(32, 32)
+        assert w1 is w2 and b1 is b2 and w1._base is None and w1.is_contiguous()
+        assert torch.equal(w1, mha.in_proj_weight[32:64]) and torch.equal(b1, mha.in_proj_bias[32:64])
+        mha.in_proj_weight.mul_(2.0)                              # an in-place update (load_state_dict, an optimizer step)
+        w3, _ = mha._packed_rows(32, 32)
+        assert w3 is not w1 and torch.equal(w3, mha.in_proj_weight[32:64])
+        q = torch.randn(5, 2, 32)
+        k = torch.randn(7, 2, 32)
+        with cpu_ops():
+            out_cached = mha(q, k, k + 1.0)[0]
+    wv, bv = mha._packed_rows(32, 32)                             # autograd on: views of the parameters
+    assert wv._base is not None and wv.requires_grad
+    with cpu_ops():
+        out_views = mha(q, k, k + 1.0)[0]
+    assert torch.allclose(out_cached, out_views.detach(), atol=1e-6)
+    out_views.sum().backward()
+    assert mha.in_proj_weight.grad is not None and mha.in_proj_weight.grad[32:].abs().sum() > 0
