@@ -294,10 +294,12 @@ int linear_f16x3_tile_f32(const float* x, const void* wp, const float* winv, con
       const double t_full = occ == 2 ? ks * 2.0 * std::max(mfma, std::max(ldsc, mem)) + 6000.0 : t_alone;
       const long long full = wgs / ((long long)ncu * occ), rem = wgs - full * ncu * occ;
       const double t = full * t_full + (rem == 0 ? 0.0 : rem > ncu ? t_full : t_alone);
-      if (t < best_t) { best_t = t; best_ct = ct; best_rb = rb; best_nf = nf; best_tf = tf; best_occ = occ; }
+      if (t < best_t) { best_t = t; best_ct = ct; best_rb = rb; best_nf = nf; best_tf = tf; best_occ = (occ == 2 && wgs > ncu) ? 2 : 1; }
     }
   if (best_ct == 0) return UNIVS_ERR_NOT_IMPLEMENTED;
   if (best_ct == 5 && best_rb == 4 && nslot == 4) nslot = K % 96 == 0 ? 3 : 2;                                    // (registers)
+  // (two workgroups per CU only where there are more workgroups than CUs; otherwise the same tile with the deeper load pipeline:
+  //  4 600 x 3072 -> 768 on 128 x 128 tiles, 216 workgroups: 95 us with 3-4 k-steps in flight, 105 with 2)
   if (best_occ == 2) nslot = 2;                                                                                    // (128 registers)
   GtArgs a{};
   a.X = x; a.Wp = reinterpret_cast<const u32x4*>(wp); a.winv = winv; a.bias = bias; a.Res = residual; a.Y = y;
@@ -315,7 +317,7 @@ int linear_f16x3_tile_f32(const float* x, const void* wp, const float* winv, con
 #define UNIVS_GT_RB(ct, rb)                                                        \
   do {                                                                             \
     constexpr int oc = ((ct == 3 && rb <= 3) || (ct == 4 && rb == 2)) ? 2 : 1;     \
-    if (oc == 2) UNIVS_GT_K(ct, rb, 2, oc);                                        \
+    if (oc == 2 && best_occ == 2) UNIVS_GT_K(ct, rb, 2, oc);                       \
     else if (nslot == 4) UNIVS_GT_K(ct, rb, 4, 1);                                 \
     else if (nslot == 3) UNIVS_GT_K(ct, rb, 3, 1);                                 \
     else UNIVS_GT_K(ct, rb, 2, 1);                                                 \
