@@ -62,6 +62,12 @@ def test_packed_in_projection_rows_are_cached_whole_tensors_without_autograd():
         mha.in_proj_weight.mul_(2.0)                              # an in-place update (load_state_dict, an optimizer step)
         w3, _ = mha._packed_rows(32, 32)
         assert w3 is not w1 and torch.equal(w3, mha.in_proj_weight[32:64])
+        from univs_amd import ops
+        mha.in_proj_weight.data.add_(1.0)                         # through `.data`: no version bump -> ops.invalidate_presplit() is the call
+        assert mha._packed_rows(32, 32)[0] is w3
+        ops.invalidate_presplit()
+        w4, _ = mha._packed_rows(32, 32)
+        assert w4 is not w3 and torch.equal(w4, mha.in_proj_weight[32:64])
         q = torch.randn(5, 2, 32)
         k = torch.randn(7, 2, 32)
         with cpu_ops():

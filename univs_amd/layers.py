@@ -148,7 +148,8 @@ class MultiheadAttention(nn.Module):
         w, b = self.in_proj_weight, self.in_proj_bias
         if torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad)):
             return w[r0:r0 + n], (None if b is None else b[r0:r0 + n])
-        key = (r0, n, w._version, w.data_ptr(), None if b is None else b._version)
+        from . import ops   # (writes through `.data` bump no version counter: ops.invalidate_presplit() is the documented call after them)
+        key = (r0, n, w._version, w.data_ptr(), None if b is None else b._version, ops.presplit_generation())
         cache = self.__dict__.setdefault("_row_cache", {})
         hit = cache.get((r0, n))
         if hit is None or hit[0] != key:

@@ -293,10 +293,18 @@ _PRESPLIT = {}      # (id(weight tensor), mode) -> (weak reference to it, (versi
 PRESPLIT_MODES = {"linear": 0, "conv": 1, "mlp2": 2}    # include/univs_hip.h: univs_presplit_weights_f32 `conv`
 
 
+_PRESPLIT_GENERATION = [0]   # bumped by invalidate_presplit: derived caches (layers.MultiheadAttention._packed_rows) key on it
+
+
+def presplit_generation():
+    return _PRESPLIT_GENERATION[0]
+
+
 def invalidate_presplit(weight=None):
     """Drop the cached splits of `weight` (all of them without an argument).  The cache notices in-place updates that bump the
     tensor's version counter (load_state_dict, optimizer steps, `weight.copy_`) and new storages; writes through `weight.data`
     (common in checkpoint / EMA code) bump a DIFFERENT counter and leave the address unchanged -- after those, call this."""
+    _PRESPLIT_GENERATION[0] += 1
     if weight is None:
         _PRESPLIT.clear()
         return
