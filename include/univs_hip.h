@@ -113,6 +113,16 @@ int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_
                                   const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S,
                                   int M, int D, int L, int Lq, int P, float* out, void* stream);
 
+/* The same operator one generation later (csrc/msda_heads.hip; what MSDeformAttn.forward runs since round 6): a lane owns a
+ * sample of a FULL head, one 8-wave workgroup per CU with the windows of a 12 x 8 tile resident (<= 160 KB of LDS), the
+ * workgroups of an XCD walk adjacent tile columns in lockstep so that shared halo columns come from HBM once.  Operands as
+ * univs_msda_forward_strips_f32 except
+ *   value_hm [N][M][S][32]      value_proj's output in blocks of 32 channels (one head): univs_linear_blocked_f32(..., S, 32).
+ * Covered: D == 32, P == 4, 1 <= L <= 4, Lq == S; otherwise UNIVS_ERR_NOT_IMPLEMENTED. */
+int univs_msda_forward_heads_f32(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S,
+                                 int M, int D, int L, int Lq, int P, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Process-wide settings.  The library reads NO environment variable: everything that selects an implementation or a
  * tuning parameter is set here (0 / negative = the default).  univs_configure(NULL) restores the defaults.  Settings
@@ -126,7 +136,7 @@ typedef struct UnivsConfig {
   int msda_strip_w;       /* msda_strips: tile width in pixels of the finest level (default 12) */
   int msda_strip_h;       /* msda_strips: tile height (default 8; lowered until the windows fit 80 KB of LDS) */
   int msda_halo;          /* LDS-tiled kernels: sampling offsets covered by the windows, pixels (default 6) */
-  int msda_grid;          /* LDS-tiled kernels: workgroups launched (default: 4 x CUs for msda_strips, 1 x CUs for msda_tiled2) */
+  int msda_grid;          /* LDS-tiled kernels: workgroups launched (default: 4 x CUs for msda_strips, 1 x CUs for msda_heads / msda_tiled2) */
   int mask_decode_impl;   /* 0 by size, 1 exact-f32 MFMA kernel, 2 split-bf16 kernel wherever its preconditions hold */
   int mask_decode_ct;     /* split-bf16 mask decode: 4 = the 64-column kernel (default 2: 32 columns) */
   int mask_decode_ablate; /* timing experiments: 1 memory side only, 2 compute side only (results are then meaningless) */
@@ -150,7 +160,9 @@ typedef struct UnivsConfig {
                              0 = as many as fit: 128 for the streamed kernel, the LDS capacity for the W-resident one) */
   int linear_grid_x;      /* kernel benchmarks: workgroups along the rows of the three-product Linears (0 = by shape) */
   int xattn_segments;     /* kernel benchmarks: key segments per (batch entry, head, query chunk) of univs_cross_attention_f32 (0 = by shape) */
-  int reserved[3];
+  int msda_sched;         /* msda_heads: 0 / 2 = the workgroups of an XCD walk adjacent tile columns in lockstep rounds (default),
+                             1 = one contiguous range of the (plane, column, row) sequence per workgroup (generation 5's rule; A / B runs) */
+  int reserved[2];
 } UnivsConfig;
 int univs_configure(const UnivsConfig* cfg);
 int univs_get_config(UnivsConfig* out);
@@ -161,7 +173,8 @@ int univs_msda_set_impl(int impl);
 /* Which implementation the last univs_msda_forward_f32 call on this thread launched: 1 generic,
  * 2 LDS-tiled, 0 none yet.  Lets tests assert that a fast path really ran (no silent fallback). */
 int univs_msda_last_impl(void);
-/* Generation of the LDS-tiled kernel the last MSDA forward call on this thread launched: 5 = strips at half a head per
+/* Generation of the LDS-tiled kernel the last MSDA forward call on this thread launched: 6 = a full head per lane-sample
+ * (msda_heads.hip, head-major operands), 5 = strips at half a head per
  * workgroup (msda_strips.hip, head-major operands), 2 = producer / consumer waves (msda_tiled2.hip, standard layouts),
  * 0 = none (generic kernel). */
 int univs_msda_last_tiled_generation(void);

@@ -176,14 +176,85 @@ def test_msda_strips_cfg2_and_cfg5_size(cuda):
         assert np.abs(got[:1, sub].cpu().numpy() - want).max() < 3e-5
 
 
-@pytest.mark.parametrize("N,S,CB", [(5, 19320, 16), (5, 19320, 36), (2, 4200, 48), (3, 2352, 16)], ids=str)
+@pytest.mark.parametrize("case", [c for c in cases.MSDA_CASES if c["encoder"] and c["D"] == 32], ids=lambda c: c["name"])
+def test_msda_heads_matches_reference_sequence(cuda, case):
+    """Generation 6 (msda_heads.hip: a full head per lane-sample, one workgroup per CU, lockstep column segments) == the
+    reference's sequence softmax / reference + offset / normaliser -> ms_deform_attn_forward, evaluated by the oracle, == our
+    two-operator path on the standard layouts and == generation 5; ragged pyramids, four levels (finest first), a single
+    level, far offsets (global fallback); both scheduling policies, other tilings and ragged grids."""
+    from oracle import cpu_path
+    value, shapes, lsi, proj, n_off, ref = _fused_inputs(case)
+    M, L, P = value.shape[2], len(shapes), case["P"]
+    want = cpu_path.msda_forward_fused(value, proj, n_off, ref, shapes, lsi, P).numpy()
+    vhm, qhm = ops.msda_pack_heads(value.to(cuda), proj.to(cuda), n_off, shapes, P)
+    ref_q = ref[:, :, 0].contiguous().to(cuda)                       # one reference point per query
+    got = ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P)
+    assert got is not None and ops.msda_last_impl() == 2 and ops.msda_last_tiled_generation() == 6
+    loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+    with ops.configured(msda_impl=1):
+        two = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
+        assert ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P) is None     # generic forced: the caller's fallback
+    for cfg in (dict(msda_sched=1), dict(msda_strip_w=8, msda_strip_h=6, msda_grid=7), dict(msda_grid=24), dict(msda_grid=40, msda_sched=1),
+                dict(msda_strip_w=16, msda_strip_h=6)):
+        with ops.configured(**cfg):                                                   # schedules / tilings / ragged workgroup splits
+            alt = ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert alt is not None and (alt - got).abs().max().item() < 2e-6, cfg
+    v5, q5 = ops.msda_pack_head_major(value.to(cuda), proj.to(cuda), n_off, shapes, P)
+    gen5 = ops.msda_forward_strips(v5, q5, ref_q, shapes, lsi, M, P)
+    torch.cuda.synchronize()
+    err = np.abs(got.cpu().numpy() - want).max()
+    print(f"heads {case['name']}: max abs err vs oracle {err:.2e}, vs generic kernel {(got - two).abs().max().item():.2e}, "
+          f"vs generation 5 {(got - gen5).abs().max().item():.2e}")
+    assert err < 3e-5
+    assert (got - two).abs().max().item() < 3e-5
+    assert (got - gen5).abs().max().item() < 1e-5
+
+
+def test_msda_heads_cfg2_and_cfg5_size(cuda):
+    """Generation 6 at the bench geometries (720p: S = 19 320, 5 frames as the clip runs it; 1080p: S = 42 840, 2 frames): ==
+    generic kernel on the standard layouts; linearity in value; oracle C on every 23rd query of the first frame; both schedules."""
+    for shapes, N in (([(23, 40), (46, 80), (92, 160)], 5), ([(34, 60), (68, 120), (136, 240)], 2)):
+        case = dict(name=f"strips{shapes[0][0]}", shapes=shapes, N=N, M=8, D=32, P=4, encoder=True, far=False)
+        value, shapes_, lsi, proj, n_off, ref = _fused_inputs(case)
+        M, L, P = 8, 3, 4
+        vhm, qhm = ops.msda_pack_heads(value.to(cuda), proj.to(cuda), n_off, shapes, P)
+        ref_q = ref[:, :, 0].contiguous().to(cuda)
+        got = ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert got is not None and ops.msda_last_tiled_generation() == 6
+        loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
+        with ops.configured(msda_impl=1):
+            generic = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)
+        assert (got - generic).abs().max().item() < 3e-5
+        with ops.configured(msda_sched=1):
+            assert (ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P) - got).abs().max().item() < 2e-6
+        got2 = ops.msda_forward_heads(2.0 * vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert (got2 - 2.0 * got).abs().max().item() < 1e-5
+        sub = np.arange(0, loc.shape[1], 23)
+        want = c_ops.msda_forward(value[:1].numpy(), shapes, lsi, loc[:1, sub].contiguous().cpu().numpy(),
+                                  attn[:1, sub].contiguous().cpu().numpy())
+        assert np.abs(got[:1, sub].cpu().numpy() - want).max() < 3e-5
+
+
+def test_msda_heads_uncovered_geometry_and_bad_shapes(cuda):
+    vhm = torch.zeros(1, 2, 6, 32, device=cuda)        # M = 2
+    ref = torch.zeros(1, 6, 2, device=cuda)
+    assert ops.msda_forward_heads(vhm, torch.zeros(1, 2, 6, 3 * 1 * 3, device=cuda), ref, [(2, 3)], [0], 2, 3) is None   # P = 3
+    with pytest.raises(RuntimeError):
+        ops.msda_forward_heads(vhm, torch.zeros(1, 2, 6, 11, device=cuda), ref, [(2, 3)], [0], 2, 4)                    # row width
+    with pytest.raises(RuntimeError):
+        ops.msda_forward_heads(vhm, torch.zeros(1, 2, 6, 12, device=cuda), ref, [(2, 3)], [1], 2, 4)                    # level table
+    with pytest.raises(RuntimeError):
+        ops.msda_forward_heads(torch.zeros(1, 4, 6, 16, device=cuda), torch.zeros(1, 2, 6, 12, device=cuda), ref, [(2, 3)], [0], 2, 4)   # gen-5 layout
+
+
+@pytest.mark.parametrize("N,S,CB", [(5, 19320, 16), (5, 19320, 32), (5, 19320, 36), (2, 4200, 48), (3, 2352, 16)], ids=str)
 @pytest.mark.parametrize("terms", [6, 3], ids=["bf16x6", "f16x3"])
 def test_linear_blocked_matches_standard_layout(cuda, linear_terms, terms, N, S, CB):
     """The Linear with the column-blocked epilogue (head-major operands of the strips kernel) == the standard-layout Linear,
     permuted: bit for bit (same arithmetic, different store addresses)."""
     linear_terms(terms)
     K = 256
-    Nf = 256 if CB == 16 else 8 * CB
+    Nf = 256 if CB in (16, 32) else 8 * CB
     x = synth.normal("linblk/x", (N, S, K)).to(cuda)
     w = synth.normal("linblk/w", (Nf, K), std=0.05).to(cuda)
     b = synth.normal("linblk/b", (Nf,)).to(cuda)

@@ -1,0 +1,306 @@
+// Host emulation of msda_heads.hip's data flow (tables -> segments -> row pieces -> circular row windows in LDS -> sample
+// records -> gathers in the lane-specific corner / chunk order -> point reduction -> output channels; global fallback for
+// samples that leave the window) against a plain double-precision bilinear reference (ms_deform_im2col_cuda.cuh:38-89,
+// 242-304) on the STANDARD layouts.  It compiles the SAME table builders and record function the kernel uses
+// (csrc/msda_heads_geom.h: s6_build_host, s6_build_segments, s6_record), re-creates the head-major operand layouts the Linear
+// epilogues write, and checks on the way that (a) every ds_read_b128 lane group of the gather touches 16 different 16-byte
+// slots (bank-conflict-free by construction), (b) no LDS byte is read before the current segment wrote it (stale circular
+// rows), (c) every (plane, tile) is covered by exactly one segment under both scheduling policies, (d) the division by two
+// FMAs equals the IEEE quotient.
+//   hipcc -O2 -std=c++17 -I include tools/heads_emulate.cpp -o /tmp/heads_emulate && /tmp/heads_emulate
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../univs_amd/csrc/msda_heads_geom.h"
+
+namespace univs { void set_error(const char*, ...) {} }
+using namespace univs;
+
+struct Case { const char* name; std::vector<std::pair<int, int>> shapes; int N, M, TH, TW, R; float off_std; int nwg, policy; };
+
+static double ref_sample(const std::vector<float>& value, int S, int M, int n, int m, int start, int H, int W, float x, float y,
+                         double aw, int ch) {
+  const float him = y * H - 0.5f, wim = x * W - 0.5f;
+  if (!(him > -1 && wim > -1 && him < H && wim < W)) return 0.0;
+  const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+  const double lh = him - h0, lw = wim - w0;
+  auto v = [&](int h, int w) -> double {
+    if (h < 0 || w < 0 || h >= H || w >= W) return 0.0;
+    return value[(((size_t)n * S + start + (size_t)h * W + w) * M + m) * 32 + ch];
+  };
+  return aw * ((1 - lh) * (1 - lw) * v(h0, w0) + (1 - lh) * lw * v(h0, w0 + 1) + lh * (1 - lw) * v(h0 + 1, w0) + lh * lw * v(h0 + 1, w0 + 1));
+}
+
+// the ds_read_b128 lane groups of gfx950 (MI355X_MICROARCH.md, LDS table)
+static const int GROUPS[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                  {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                  {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+
+int main() {
+  std::vector<Case> cases = {
+      {"cfg1", {{8, 14}, {16, 28}, {32, 56}}, 2, 8, 8, 12, 6, 2.0f, 16, 1},
+      {"cfg1-contig", {{8, 14}, {16, 28}, {32, 56}}, 2, 8, 8, 12, 6, 2.0f, 24, 0},
+      {"ragged", {{5, 7}, {9, 13}, {17, 25}}, 1, 8, 8, 12, 6, 2.0f, 16, 1},
+      {"L4-fine-first", {{32, 48}, {16, 24}, {8, 12}, {4, 6}}, 1, 4, 8, 12, 6, 2.5f, 8, 1},
+      {"L1", {{20, 33}}, 2, 1, 8, 12, 6, 3.0f, 2, 0},
+      {"L2-tiny-halo", {{12, 20}, {24, 40}}, 1, 2, 8, 12, 1, 3.0f, 16, 1},
+      {"two-px", {{2, 2}, {4, 4}, {8, 8}}, 1, 2, 8, 12, 6, 2.0f, 1, 0},
+      {"cfg2-slice", {{23, 40}, {46, 80}, {92, 160}}, 1, 2, 8, 12, 6, 2.0f, 16, 1},
+      {"cfg2-w16h6", {{23, 40}, {46, 80}, {92, 160}}, 1, 1, 6, 16, 6, 2.0f, 8, 0},
+      {"cfg5-slice", {{34, 60}, {68, 120}, {136, 240}}, 1, 1, 8, 12, 6, 2.0f, 32, 1},
+  };
+  int bad_total = 0;
+  for (const Case& c : cases) {
+    const int L = (int)c.shapes.size(), P = 4;
+    LevelTable lv{};
+    int S = 0, fine = 0;
+    for (int l = 0; l < L; ++l) {
+      lv.H[l] = c.shapes[l].first; lv.W[l] = c.shapes[l].second; lv.start[l] = S;
+      S += lv.H[l] * lv.W[l];
+      if (lv.H[l] * lv.W[l] > lv.H[fine] * lv.W[fine]) fine = l;
+    }
+    const int N = c.N, M = c.M;
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    // standard layouts: value [N][S][M][32]; raw projections: offsets [N][S][M][L][P][2] (pixels of the target level), logits
+    // [N][S][M][L][P]; reference points [S][L][2] (pixel centres of the query's own level)
+    std::vector<float> value((size_t)N * S * M * 32), off((size_t)N * S * M * L * P * 2), logit((size_t)N * S * M * L * P), ref((size_t)S * L * 2);
+    for (auto& v : value) v = nd(rng);
+    for (auto& v : off) v = nd(rng) * c.off_std;
+    for (auto& v : logit) v = nd(rng);
+    for (int lq = 0; lq < L; ++lq)
+      for (int i = 0; i < lv.H[lq] * lv.W[lq]; ++i)
+        for (int l = 0; l < L; ++l) {
+          ref[((size_t)(lv.start[lq] + i) * L + l) * 2 + 0] = ((i % lv.W[lq]) + 0.5f) / lv.W[lq];
+          ref[((size_t)(lv.start[lq] + i) * L + l) * 2 + 1] = ((i / lv.W[lq]) + 0.5f) / lv.H[lq];
+        }
+    // every 11th query: far offsets (misses, partly outside the image)
+    for (int n = 0; n < N; ++n)
+      for (int q = 0; q < S; ++q)
+        if (q % 11 == 5)
+          for (size_t i = 0; i < (size_t)M * L * P * 2; ++i) off[((size_t)n * S + q) * M * L * P * 2 + i] *= 5.f;
+    int order[4] = {0, 1, 2, 3};
+    std::sort(order, order + L, [&](int a, int b) {
+      const long long sa = (long long)lv.H[a] * lv.W[a], sb = (long long)lv.H[b] * lv.W[b];
+      return sa != sb ? sa > sb : a < b;
+    });
+    // head-major operands as the Linear epilogues write them: value [N][M][S][32], projections [N][M][S][P][3L]
+    std::vector<float> vhm((size_t)N * M * S * 32), qhm((size_t)N * M * S * P * 3 * L);
+    for (int n = 0; n < N; ++n)
+      for (int s = 0; s < S; ++s)
+        for (int m = 0; m < M; ++m) {
+          for (int ch = 0; ch < 32; ++ch)
+            vhm[(((size_t)n * M + m) * S + s) * 32 + ch] = value[(((size_t)n * S + s) * M + m) * 32 + ch];
+          for (int p = 0; p < P; ++p) {   // levels in SLOT order (largest first, ties by index), as ops.msda_pack_head_major
+            float* row = &qhm[((((size_t)n * M + m) * S + s) * P + p) * 3 * L];
+            for (int kk = 0; kk < L; ++kk) {
+              const int l = order[kk];
+              row[2 * kk] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2];
+              row[2 * kk + 1] = off[(((((size_t)n * S + s) * M + m) * L + l) * P + p) * 2 + 1];
+              row[2 * L + kk] = logit[((((size_t)n * S + s) * M + m) * L + l) * P + p];
+            }
+          }
+        }
+    S6Host g;
+    for (int TH = c.TH; TH >= 2; TH -= 2) {   // as msda_forward_heads_f32 chooses the tile height
+      s6_build_host(lv, L, fine, TH, c.TW, c.R, g);
+      if (g.ok && g.lds <= (size_t)S6_LDS_MAX) break;
+      g.ok = false;
+    }
+    if (!g.ok) { printf("%-14s tables not ok (qmax %lld lds %zu)\n", c.name, g.qmax, g.lds); ++bad_total; continue; }
+    std::vector<S6Seg> segs;
+    std::vector<int> begin;
+    const int grid = (int)std::min<long long>((long long)N * M * g.ntiles, c.nwg);
+    if (!s6_build_segments(N * M, g.tiles_x, g.tiles_y, grid, c.policy, 1.5, segs, begin)) { printf("%-14s segments not ok\n", c.name); ++bad_total; continue; }
+    std::vector<int> covered((size_t)N * M * g.ntiles, 0);
+    std::vector<float> out((size_t)N * S * M * 32, 0.f), cnt((size_t)N * S * M * 32, 0.f);
+    long long conflicts = 0, stale = 0, misses = 0, samples = 0, reads = 0, inexact_div = 0, nseg = 0, maxsteps = 0;
+    for (int wg = 0; wg < grid; ++wg) {
+      std::vector<float> lds(g.lds / 4, NAN);
+      std::vector<unsigned> stamp(g.lds / 16, 0xffffffffu);   // segment serial that wrote each 16-byte slot last
+      long long steps = 0;
+      for (int si = begin[wg]; si < begin[wg + 1]; ++si) {
+        const S6Seg sg = segs[(size_t)si];
+        if (sg.count <= 0) continue;
+        ++nseg;
+        steps += sg.count;
+        const unsigned serial = (unsigned)si;
+        const int hd = sg.plane, n = hd / M, m = hd % M;
+        if (sg.tile0 / g.tiles_y != (sg.tile0 + sg.count - 1) / g.tiles_y || hd < 0 || hd >= N * M || sg.tile0 < 0 || sg.tile0 + sg.count > g.ntiles) {
+          printf("%s: a segment leaves its column\n", c.name); ++bad_total; continue;
+        }
+        const float* vbase = &vhm[(size_t)hd * S * 32];
+        auto move_rows = [&](int tile, int which) {
+          for (int wave = 0; wave < S6_NW; ++wave)
+            for (int k = 0; k < S6_PCAP; ++k) {
+              const S6Piece pc = g.pieces[(((size_t)tile * 2 + which) * S6_NW + wave) * S6_PCAP + k];
+              for (int lane = 0; lane < 64; ++lane) {
+                const int lpx = lane >> 3, lch = lane & 7;
+                const unsigned lanebit = 1u << lpx;
+                float v[4] = {0, 0, 0, 0};
+                if (pc.c & lanebit) {
+                  const long long px = (long long)(pc.a & 0xffffffu) + lpx - S6_PX_BIAS;
+                  if (px < 0 || px >= S) { printf("piece pixel out of the frame\n"); ++bad_total; continue; }
+                  for (int e = 0; e < 4; ++e) v[e] = vbase[px * 32 + lch * 4 + e];
+                }
+                if ((pc.c >> 16) & lanebit) {
+                  const unsigned dst = pc.b + lpx * 128 + lch * 16;
+                  if (dst + 16 > g.lds) { printf("LDS store out of range\n"); ++bad_total; continue; }
+                  for (int e = 0; e < 4; ++e) lds[dst / 4 + e] = v[e];
+                  stamp[dst / 16] = serial;
+                }
+              }
+            }
+        };
+        move_rows(sg.tile0, 1);   // cold start: the whole windows of the segment's first tile
+        for (int tile = sg.tile0; tile < sg.tile0 + sg.count; ++tile) {
+          ++covered[(size_t)hd * g.ntiles + tile];
+          const S6Tile& t = g.tiles[tile];
+          for (int wave = 0; wave < S6_NW; ++wave) {
+            float acc[64][8][4];
+            for (auto& a : acc) for (auto& b : a) for (auto& x : b) x = 0.f;
+            int qg[64];
+            float xs[64][4], ys[64][4], as[64][4];
+            for (int lane = 0; lane < 64; ++lane) {
+              const int qi = lane & 15, pt = lane >> 4;
+              qg[lane] = g.qtab[(size_t)tile * S6_QCAP + wave * 16 + qi];
+              const float* row = &qhm[((((size_t)n * M + m) * S + qg[lane]) * P + pt) * 3 * L];
+              for (int kk = 0; kk < L; ++kk) {
+                const int l = g.lv.l[kk];
+                // the kernel's division: reciprocal multiply + exact-remainder correction; must equal the IEEE quotient
+                const float Wf = (float)g.lv.W[kk], Hf = (float)g.lv.H[kk];
+                if (g.lv.l[kk] != order[kk]) { printf("slot order mismatch\n"); ++bad_total; }
+                const float qx = row[2 * kk] * g.lv.rW[kk], qy = row[2 * kk + 1] * g.lv.rH[kk];
+                const float ox = fmaf(fmaf(-qx, Wf, row[2 * kk]), g.lv.rW[kk], qx), oy = fmaf(fmaf(-qy, Hf, row[2 * kk + 1]), g.lv.rH[kk], qy);
+                if (ox != row[2 * kk] / Wf || oy != row[2 * kk + 1] / Hf) ++inexact_div;
+                xs[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2] + ox;
+                ys[lane][kk] = ref[((size_t)qg[lane] * L + l) * 2 + 1] + oy;
+                as[lane][kk] = row[2 * L + kk];
+              }
+            }
+            for (int qi = 0; qi < 16; ++qi) {   // softmax over the L * P logits of the query (the 4 DPP rows)
+              float mx = -INFINITY, sum = 0.f;
+              for (int pt = 0; pt < 4; ++pt) for (int kk = 0; kk < L; ++kk) mx = fmaxf(mx, as[pt * 16 + qi][kk]);
+              for (int pt = 0; pt < 4; ++pt) for (int kk = 0; kk < L; ++kk) { as[pt * 16 + qi][kk] = expf(as[pt * 16 + qi][kk] - mx); sum += as[pt * 16 + qi][kk]; }
+              for (int pt = 0; pt < 4; ++pt) for (int kk = 0; kk < L; ++kk) as[pt * 16 + qi][kk] /= sum;
+            }
+            for (int kk = 0; kk < L; ++kk) {
+              S6Rec rec[64];
+              for (int lane = 0; lane < 64; ++lane) {
+                rec[lane] = s6_record(xs[lane][kk], ys[lane][kk], as[lane][kk], (float)g.lv.H[kk], (float)g.lv.W[kk], t.p0[kk], t.p1[kk],
+                                      g.lv.nr[kk], g.lv.pitch[kk], g.lv.next_d[kk], g.lv.wrap_d[kk], (unsigned)g.lv.reg[kk], lane & 15);
+                ++samples;
+              }
+              for (int k = 0; k < 4; ++k)
+                for (int j = 0; j < 8; ++j) {
+                  for (int gr = 0; gr < 4; ++gr) {   // (a) the 16 lanes of a ds_read_b128 group hit 16 different slots
+                    unsigned seen = 0;
+                    for (int i = 0; i < 16; ++i) {
+                      const unsigned addr = rec[GROUPS[gr][i]].a[k] ^ (unsigned)(j << 4);
+                      const unsigned slot = (addr >> 4) & 15u;
+                      if (seen & (1u << slot)) ++conflicts;
+                      seen |= 1u << slot;
+                    }
+                  }
+                  for (int lane = 0; lane < 64; ++lane) {
+                    const unsigned addr = rec[lane].a[k] ^ (unsigned)(j << 4);
+                    if (addr + 16 > g.lds || (addr & 15)) { printf("%s: LDS read out of range / misaligned\n", c.name); ++bad_total; continue; }
+                    ++reads;
+                    if (rec[lane].w[k] != 0.f) {
+                      // (b) a contributing read must see data of THIS segment's windows
+                      if (stamp[addr / 16] != serial) ++stale;
+                      for (int e = 0; e < 4; ++e) acc[lane][j][e] = fmaf(rec[lane].w[k], lds[addr / 4 + e], acc[lane][j][e]);
+                    }
+                  }
+                }
+              for (int lane = 0; lane < 64; ++lane)
+                if (!rec[lane].inwin && as[lane][kk] != 0.f && s6_inband(xs[lane][kk], ys[lane][kk], (float)g.lv.H[kk], (float)g.lv.W[kk])) {   // global fallback
+                  ++misses;
+                  const Footprint fp = footprint(g.lv.H[kk], g.lv.W[kk], xs[lane][kk], ys[lane][kk], as[lane][kk]);
+                  const float* vl = &vhm[((size_t)hd * S + g.lv.start[kk]) * 32];
+                  const unsigned orot = lane & 7;
+                  for (int ch = 0; ch < 32; ++ch) {
+                    const float tot = fp.w00 * vl[(size_t)(fp.h0 * g.lv.W[kk] + fp.w0) * 32 + ch] + fp.w01 * vl[(size_t)(fp.h0 * g.lv.W[kk] + fp.w1) * 32 + ch] +
+                                      fp.w10 * vl[(size_t)(fp.h1 * g.lv.W[kk] + fp.w0) * 32 + ch] + fp.w11 * vl[(size_t)(fp.h1 * g.lv.W[kk] + fp.w1) * 32 + ch];
+                    acc[lane][(ch / 4) ^ orot][ch % 4] += tot;   // chunk slot j holds channel chunk j ^ rot
+                  }
+                }
+            }
+            // point reduction: row r of the wave ends up with chunk slots 2 r, 2 r + 1 of each query = channel chunks slot ^ rot8
+            for (int qi = 0; qi < 16; ++qi)
+              for (int sl = 0; sl < 8; ++sl) {
+                const unsigned rot8 = qi & 7;
+                const unsigned ca = (unsigned)sl ^ rot8;
+                for (int e = 0; e < 4; ++e) {
+                  float tot = 0.f;
+                  for (int pt = 0; pt < 4; ++pt) tot += acc[pt * 16 + qi][sl][e];
+                  const size_t o = (((size_t)n * S + qg[qi]) * M + m) * 32 + ca * 4 + e;
+                  out[o] = tot;
+                  cnt[o] += 1.f;
+                }
+              }
+          }
+          if (tile + 1 < sg.tile0 + sg.count) move_rows(tile + 1, 0);   // the rows entering the next tile's windows
+        }
+      }
+      maxsteps = std::max(maxsteps, steps);
+    }
+    long long not_once = 0;
+    for (int v : covered) not_once += v != 1;
+    // compare with the double-precision reference on the standard layouts
+    double maxerr = 0;
+    long long uncovered = 0;
+    for (int n = 0; n < N; ++n)
+      for (int q = 0; q < S; q += (S > 6000 ? 7 : 1))
+        for (int m = 0; m < M; ++m) {
+          double lg[4][4], mx = -1e30, sum = 0;
+          for (int l = 0; l < L; ++l) for (int p = 0; p < P; ++p) mx = std::max(mx, (double)logit[((((size_t)n * S + q) * M + m) * L + l) * P + p]);
+          for (int l = 0; l < L; ++l) for (int p = 0; p < P; ++p) { lg[l][p] = exp((double)logit[((((size_t)n * S + q) * M + m) * L + l) * P + p] - mx); sum += lg[l][p]; }
+          for (int ch = 0; ch < 32; ch += 5) {
+            double r = 0;
+            for (int l = 0; l < L; ++l)
+              for (int p = 0; p < P; ++p) {
+                const float x = ref[((size_t)q * L + l) * 2] + off[(((((size_t)n * S + q) * M + m) * L + l) * P + p) * 2] / (float)lv.W[l];
+                const float y = ref[((size_t)q * L + l) * 2 + 1] + off[(((((size_t)n * S + q) * M + m) * L + l) * P + p) * 2 + 1] / (float)lv.H[l];
+                r += ref_sample(value, S, M, n, m, lv.start[l], lv.H[l], lv.W[l], x, y, lg[l][p] / sum, ch);
+              }
+            const size_t o = (((size_t)n * S + q) * M + m) * 32 + ch;
+            if (cnt[o] < 1.f) ++uncovered;
+            maxerr = std::max(maxerr, fabs(r - (double)out[o]));
+          }
+        }
+    long long zero_cnt = 0;
+    for (float v : cnt) zero_cnt += v < 1.f;
+    const bool ok = maxerr < 2e-5 && conflicts == 0 && stale == 0 && zero_cnt == 0 && uncovered == 0 && inexact_div == 0 && not_once == 0;
+    printf("%-14s tiles %3d (%dx%d) lds %6zu B qmax %3lld grid %3d policy %d segments %3lld max steps %3lld (ideal %.1f): max err %.2e, bank conflicts %lld, "
+           "stale reads %lld, unwritten outputs %lld, tiles not covered once %lld, inexact divisions %lld, misses %.3f %% of %lld samples  %s\n",
+           c.name, g.ntiles, g.tiles_x, g.tiles_y, g.lds, g.qmax, grid, c.policy, nseg, maxsteps, (double)N * M * g.ntiles / grid, maxerr, conflicts, stale,
+           zero_cnt, not_once, inexact_div, 100.0 * misses / std::max<long long>(samples, 1), samples, ok ? "ok" : "FAIL");
+    if (!ok) ++bad_total;
+  }
+  // the schedules of the benchmark geometries (no data): balance and segment counts
+  struct Sch { const char* name; int planes, tx, ty, grid; };
+  for (const Sch& s : {Sch{"cfg2 N=5", 40, 14, 12, 256}, Sch{"cfg2 N=1", 8, 14, 12, 256}, Sch{"cfg5 N=10", 80, 20, 17, 256}, Sch{"cfg1 N=2", 16, 5, 4, 256},
+                       Sch{"cfg2 N=40", 320, 14, 12, 256}})
+    for (int policy = 0; policy < 2; ++policy) {
+      std::vector<S6Seg> segs;
+      std::vector<int> begin;
+      const int grid = (int)std::min<long long>((long long)s.planes * s.tx * s.ty, s.grid);
+      const bool okb = s6_build_segments(s.planes, s.tx, s.ty, grid, policy, 1.5, segs, begin);
+      long long mx = 0, tot = 0, ns = 0, mxseg = 0;
+      for (int wg = 0; wg < grid; ++wg) {
+        long long st = 0, k = 0;
+        for (int si = begin[wg]; si < begin[wg + 1]; ++si) { const S6Seg sg = segs[(size_t)si]; st += sg.count; ++k; }
+        mx = std::max(mx, st); tot += st; ns += k; mxseg = std::max(mxseg, k);
+      }
+      printf("schedule %-10s policy %d: %s, steps total %lld (want %lld), max per workgroup %lld (ideal %.2f), segments %lld (max %lld per workgroup)\n", s.name,
+             policy, okb ? "ok" : "FAIL", tot, (long long)s.planes * s.tx * s.ty, mx, (double)s.planes * s.tx * s.ty / grid, ns, mxseg);
+      if (!okb || tot != (long long)s.planes * s.tx * s.ty) ++bad_total;
+    }
+  printf(bad_total ? "FAILED\n" : "all ok\n");
+  return bad_total ? 1 : 0;
+}

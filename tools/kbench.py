@@ -90,10 +90,24 @@ def main():
                     res["msda_strips" + tag] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
                                                     gen=ops.msda_last_tiled_generation(),
                                                     max_abs_diff_vs_generic=(got - want).abs().max().item())
+        # generation 6: a full head per lane-sample, one workgroup per CU, lockstep column segments
+        vh6, qh6 = ops.msda_pack_heads(value, proj, n_off, shapes, P_)
+        variants6 = (("", {}), ("_contig", dict(msda_sched=1))) if only_strips else (
+            ("", {}), ("_again", {}), ("_contig", dict(msda_sched=1)), ("_w16h6", dict(msda_strip_w=16, msda_strip_h=6)),
+            ("_w16h6_contig", dict(msda_strip_w=16, msda_strip_h=6, msda_sched=1)), ("_th6", dict(msda_strip_h=6)),
+            ("_w8", dict(msda_strip_w=8)), ("_r5", dict(msda_halo=5)), ("_grid512", dict(msda_grid=512)), ("_grid248", dict(msda_grid=248)))
+        for tag, cfg in variants6:
+            with ops.configured(**cfg):
+                got = ops.msda_forward_heads(vh6, qh6, refq, shapes, lsi, M_, P_)
+                if got is not None:
+                    t = timeit(lambda: ops.msda_forward_heads(vh6, qh6, refq, shapes, lsi, M_, P_))
+                    res["msda_heads" + tag] = dict(ms=t * 1e3, GBps=alg / t / 1e9, frac_hbm=alg / t / HBM_PEAK,
+                                                   gen=ops.msda_last_tiled_generation(),
+                                                   max_abs_diff_vs_generic=(got - want).abs().max().item())
         x_tok = synth.normal("kb/tok", (T, S, 256)).to(dev)
         w_v, b_v = synth.normal("kb/wv", (256, 256), std=0.05).to(dev), synth.normal("kb/bv", (256,)).to(dev)
         w_q, b_q = synth.normal("kb/wq", (288, 256), std=0.05).to(dev), synth.normal("kb/bq", (288,)).to(dev)
-        for nm, w_, b_, cb in (("value", w_v, b_v, 16), ("qproj", w_q, b_q, 36)):
+        for nm, w_, b_, cb in (("value", w_v, b_v, 16), ("value32", w_v, b_v, 32), ("qproj", w_q, b_q, 36)):
             res[f"linear_{nm}_standard"] = dict(ms=timeit(lambda: ops.linear_fused(x_tok, w_, b_)) * 1e3)
             res[f"linear_{nm}_blocked"] = dict(ms=timeit(lambda: ops.linear_blocked(x_tok, w_, b_, S, cb)) * 1e3)
     if not args.only or "mask" in args.only:

@@ -32,6 +32,7 @@ SIGNATURES = {
     "univs_msda_forward_f64": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_msda_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "univs_msda_forward_strips_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "univs_msda_forward_heads_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "univs_linear_blocked_f32": (_I, [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P, _P]),
     "univs_configure": (_I, [_P]),
     "univs_get_config": (_I, [_P]),

@@ -40,6 +40,8 @@ int mask_decode_f32(const float*, const float*, int, int, int, long long, float*
 int transpose_f32(const float*, float*, long long, int, int, long long, long long, const float*, const float*, float*, hipStream_t);
 int linear_split_f32(const float*, const float*, const float*, const float*, float*, long long, int, int, int, hipStream_t, int = 0, int = 0,
                      const float* winv = nullptr);
+int msda_forward_heads_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int, int, int,
+                           float*, hipStream_t);
 int msda_forward_strips_f32(const float*, const LevelTable&, const float*, const float*, long long, int, int, int, int, int,
                             int, int, float*, hipStream_t);
 int mask_decode_last_impl();
@@ -973,6 +975,41 @@ int univs_msda_forward_strips_f32(const float* value_hm, const int64_t* spatial_
   }
   if (rc == 0) {
     set_error("univs_msda_forward_strips_f32: geometry not covered (D == 32, P == 4, 1 <= L <= 4, Lq == S, windows within 80 KB of LDS)");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
+}
+
+int univs_msda_forward_heads_f32(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start,
+                                  const float* proj_hm, const float* ref_points, long long ref_batch_stride, int N, int S, int M,
+                                  int D, int L, int Lq, int P, float* out, void* stream) {
+  if (N < 0 || S < 0 || M < 1 || D < 0 || Lq < 0 || P < 1 || L < 1 || L > UNIVS_MAX_LEVELS || ref_batch_stride < 0) {
+    set_error("univs_msda_forward_heads_f32: bad dimensions N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", N, S, M, D, L, Lq, P);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)N * Lq * M * D == 0) return UNIVS_OK;
+  clear_sticky_error();
+  g_msda_gen = 0;
+  if (!value_hm || !proj_hm || !ref_points || !out) {
+    set_error("univs_msda_forward_heads_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  LevelTable lv;
+  int rc = make_levels(spatial_shapes, level_start, L, S, &lv, "univs_msda_forward_heads_f32");
+  if (rc != UNIVS_OK) return rc;
+  if (config().msda_impl == 1) {   // the generic kernel was forced: it has no head-major variant, the caller takes the two-operator path
+    set_error("univs_msda_forward_heads_f32: generic implementation forced (univs_msda_set_impl(1))");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  rc = msda_forward_heads_f32(value_hm, lv, proj_hm, ref_points, ref_batch_stride, N, S, M, D, L, Lq, P, out,
+                               static_cast<hipStream_t>(stream));
+  if (rc > 0) {
+    g_msda_last = 2;
+    g_msda_gen = 6;
+    return UNIVS_OK;
+  }
+  if (rc == 0) {
+    set_error("univs_msda_forward_heads_f32: geometry not covered (D == 32, P == 4, 1 <= L <= 4, Lq == S, windows within 160 KB of LDS)");
     return UNIVS_ERR_NOT_IMPLEMENTED;
   }
   return rc;

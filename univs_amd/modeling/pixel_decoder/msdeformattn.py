@@ -31,7 +31,8 @@ from ..position_encoding import PositionEmbeddingSine
 from ...switches import SWITCHES   # msda_strips (default True): the encoder's MSDeformAttn core on head-major operands
 # (csrc/msda_strips.hip): value_proj and the merged offset / logit projection store their outputs in the sampling kernel's
 # layouts (blocked Linear epilogue), the kernel handles half a head per workgroup with two workgroups per CU.  False: the
-# standard-layout operators (msda_prepare + ms_deform_attn_forward).
+# standard-layout operators (msda_prepare + ms_deform_attn_forward).  msda_heads (default True): generation 6 first
+# (csrc/msda_heads.hip: value in blocks of a full head, one workgroup per CU).
 
 
 def _shape_list(spatial_shapes):
@@ -98,11 +99,18 @@ class MSDeformAttn(nn.Module):
                 and input_padding_mask is None and self.d_model == 32 * M and query.dtype == torch.float32):
             shapes = _shape_list(input_spatial_shapes)
             order = tuple(ops.msda_level_order(shapes))
-            value_hm = ops.linear_blocked(input_flatten, self.value_proj.weight, self.value_proj.bias, Len_in, 16)
-            if value_hm is not None:
-                w_hm, b_hm = self._head_major_query_proj(order)
-                qp_hm = ops.linear_blocked(query, w_hm, b_hm, Len_q, 3 * L * P)
-                if qp_hm is not None:
+            w_hm, b_hm = self._head_major_query_proj(order)
+            qp_hm = ops.linear_blocked(query, w_hm, b_hm, Len_q, 3 * L * P)
+            if qp_hm is not None and SWITCHES.msda_heads:
+                # generation 6 (csrc/msda_heads.hip): value in blocks of one head, a lane owns a sample of a full head
+                value_hm = ops.linear_blocked(input_flatten, self.value_proj.weight, self.value_proj.bias, Len_in, 32)
+                if value_hm is not None:
+                    output = ops.msda_forward_heads(value_hm, qp_hm, ref_per_query, shapes, input_level_start_index, M, P)
+                    if output is not None:
+                        return self._project(output, residual)
+            if qp_hm is not None:
+                value_hm = ops.linear_blocked(input_flatten, self.value_proj.weight, self.value_proj.bias, Len_in, 16)
+                if value_hm is not None:
                     output = ops.msda_forward_strips(value_hm, qp_hm, ref_per_query, shapes, input_level_start_index, M, P)
                     if output is not None:
                         return self._project(output, residual)

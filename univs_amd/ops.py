@@ -191,6 +191,41 @@ def msda_pack_head_major(value, proj, n_off, spatial_shapes, num_points=4):
     return value_hm, row.reshape(N, M, S, P * 3 * L).contiguous()
 
 
+def msda_pack_heads(value, proj, n_off, spatial_shapes, num_points=4):
+    """Standard layouts -> the head-major operands of `msda_forward_heads` (torch copies: tests and tools; the hot path gets
+    them from `linear_blocked`): value [N, S, M, 32] -> [N, M, S, 32]; proj as `msda_pack_head_major`."""
+    _, qhm = msda_pack_head_major(value, proj, n_off, spatial_shapes, num_points)
+    return value.permute(0, 2, 1, 3).contiguous(), qhm
+
+
+def msda_forward_heads(value_hm, proj_hm, ref_points, spatial_shapes, level_start_index, num_heads, num_points=4):
+    """MSDeformAttn core (ms_deform_attn.py:100-116) on head-major operands, a full head per lane-sample (include/univs_hip.h:
+    univs_msda_forward_heads_f32; csrc/msda_heads.hip): value_hm [N, M, S, 32] and proj_hm [N, M, S, P*3L] as `linear_blocked`
+    writes them (levels of proj_hm in `msda_level_order`), ref_points [N or 1, S, 2] (one per query, shared by the levels).
+    Returns [N, S, M*32], or None when the geometry is not covered."""
+    _inference_only("msda_forward_heads", value_hm, proj_hm, ref_points)
+    _require_gpu("msda_forward_heads", value_hm, proj_hm, ref_points)
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (value_hm, proj_hm, ref_points)):
+        raise RuntimeError("msda_forward_heads: contiguous float32 operands only")
+    M, P = int(num_heads), int(num_points)
+    N, M1, S, D = value_hm.shape
+    sh, st, L = _host_shapes(spatial_shapes, level_start_index, S)
+    if M1 != M or D != 32 or tuple(proj_hm.shape) != (N, M, S, P * 3 * L) or tuple(ref_points.shape[1:]) != (S, 2) \
+            or ref_points.shape[0] not in (1, N):
+        raise RuntimeError("msda_forward_heads: inconsistent shapes")
+    if P != 4 or not (1 <= L <= 4):
+        return None
+    out = torch.empty((N, S, M * 32), dtype=torch.float32, device=value_hm.device)
+    rbs = 0 if ref_points.shape[0] == 1 else S * 2
+    with _on(value_hm):
+        rc = _lib.load().univs_msda_forward_heads_f32(_ptr(value_hm), sh, st, _ptr(proj_hm), _ptr(ref_points), rbs, N, S, M, 32,
+                                                      L, S, P, _ptr(out), _stream_ptr(value_hm))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "msda_forward_heads")
+    return out
+
+
 def msda_forward_strips(value_hm, proj_hm, ref_points, spatial_shapes, level_start_index, num_heads, num_points=4):
     """MSDeformAttn core (ms_deform_attn.py:100-116) on head-major operands (include/univs_hip.h:
     univs_msda_forward_strips_f32): value_hm [N, M*2, S, 16] and proj_hm [N, M, S, P*3L] as `linear_blocked` writes them
@@ -224,7 +259,7 @@ class UnivsConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("size", "msda_impl", "msda_strip_w", "msda_strip_h", "msda_halo", "msda_grid",
                                             "mask_decode_impl", "mask_decode_ct", "mask_decode_ablate", "window_attn_v1",
                                             "linear_terms", "linear_ablate", "mask_decode_chunked", "mask_decode_wave_tiles",
-                                            "linear_rows_per_pass", "linear_grid_x", "xattn_segments")] + [("reserved", ctypes.c_int * 3)]
+                                            "linear_rows_per_pass", "linear_grid_x", "xattn_segments", "msda_sched")] + [("reserved", ctypes.c_int * 2)]
 
 
 def get_config() -> dict:

@@ -23,6 +23,9 @@ class Switches:
     # the encoder's MSDeformAttn core on head-major operands (csrc/msda_strips.hip); False: msda_prepare + the standard-layout
     # operator (msda_tiled2.hip / generic)
     msda_strips: bool = True
+    # ... its sixth generation (csrc/msda_heads.hip: a lane owns a sample of a FULL head, one workgroup per CU, lockstep column
+    # segments); False: generation 5 (csrc/msda_strips.hip)
+    msda_heads: bool = True
     # token Linears on the hand-written fp32-accurate GEMM kernels (False: library GEMMs)
     split_linear: bool = True
     # the 3 x 3 FPN output convolution on the three-product fp16 kernel (False: MIOpen)
@@ -71,7 +74,7 @@ class Switches:
 
 
 SWITCHES = Switches(
-    msda_strips=_flag("UNIVS_MSDA_STRIPS", True), split_linear=_flag("UNIVS_SPLIT_LINEAR", True),
+    msda_strips=_flag("UNIVS_MSDA_STRIPS", True), msda_heads=_flag("UNIVS_MSDA_HEADS", True), split_linear=_flag("UNIVS_SPLIT_LINEAR", True),
     split_conv=_flag("UNIVS_SPLIT_CONV", True), swin_fused_linear=_flag("UNIVS_SWIN_FUSED_LINEAR", True),
     swin_fused_parts=int(os.environ.get("UNIVS_SWIN_FUSED_PARTS", "7")), linear_kmax=int(os.environ.get("UNIVS_LINEAR_KMAX", "4096")),
     sampler=os.environ.get("UNIVS_SAMPLER", "auto"), graphs=_flag("UNIVS_GRAPHS", False),
