@@ -647,6 +647,7 @@ def run(args):
 
         t_msda = OpTimer(ops, "ms_deform_attn_forward", after=ops.msda_last_tiled_generation)
         t_msdas = OpTimer(ops, "msda_forward_strips", keep_args=6)       # one clip = six encoder layers
+        t_msdah = OpTimer(ops, "msda_forward_heads", keep_args=6, after=ops.msda_last_tiled_generation)   # generation 6 (the default)
         t_mdec = OpTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)
         t_mattn = OpTimer(ops, "mask_decode_attn", key=lambda e, f, deferred=False: ("attn",) + shape_key(f), after=ops.mask_decode_last_impl)
         t_res = OpTimer(ops, "bilinear_resample",
@@ -654,7 +655,7 @@ def run(args):
         t_pyr = OpTimer(ops, "bilinear_pyramid3")          # the three mask-feature resamplings of the prediction heads in one pass
         t_win = OpTimer(ops, "window_attention_image",
                         key=lambda qkv, qb, bias, sm, H, W, ws, shift, scale, mma="f32": (int(H), int(W), int(qkv.shape[3]), int(qkv.shape[4])))
-        timers = [t_msda, t_msdas, t_mdec, t_mattn, t_res, t_pyr, t_win]
+        timers = [t_msda, t_msdas, t_msdah, t_mdec, t_mattn, t_res, t_pyr, t_win]
         PROF_STEPS = 5
         for t_ in timers:
             t_.enabled = True
@@ -685,7 +686,8 @@ def run(args):
 
         S = 23 * 40 + 46 * 80 + 92 * 160
         alg = 3200.0 * S * T   # bytes per launch (one launch = T frames of one encoder layer)
-        sec, n = t_msdas.seconds()
+        t_hm = t_msdah if set(t_msdah.notes.get("all", [])) == {6} else t_msdas     # the head-major operator that ran (generation 6, else 5)
+        sec, n = t_hm.seconds()
         fused = bool(n)          # the head-major operator also does msda_prepare's work
         sec_events = sec
         timing = f"HIP events around each launch in a separate pass of {PROF_STEPS} clips after the timed region"
@@ -694,15 +696,18 @@ def run(args):
             # the replay of the six launches back to back (operands warm in the memory-side cache) is reported next to it
             sec = net(sec_events)
             timing += "; " + ovh_note
-            sec_replay, n_r = t_msdas.replay()
-            t_msdas.args.clear()
+            sec_replay, n_r = t_hm.replay()
+            t_hm.args.clear()
         if not n:
             sec, n = t_msda.seconds()
             sec_events = sec
         if n:
             gens = set(t_msda.notes.get("all", []))
-            gen = 5 if fused else (max(gens) if gens else 0)
-            kname = {5: "msda_fwd_strips<3> (MSDeformAttn core on head-major operands: strips with resident row-circular windows at half a "
+            gen = (6 if t_hm is t_msdah else 5) if fused else (max(gens) if gens else 0)
+            kname = {6: "msda_fwd_heads<3> (MSDeformAttn core on head-major operands: a lane owns a sample of a full head, one 8-wave "
+                        "workgroup per CU with the windows of a 16 x 6 tile resident, the workgroups of an XCD walk adjacent tile columns "
+                        "in lockstep)",
+                     5: "msda_fwd_strips<3> (MSDeformAttn core on head-major operands: strips with resident row-circular windows at half a "
                         "head per workgroup, two workgroups per CU, a lane owns a sample)",
                      2: "msda_fwd_tiled2<3> (MSDeformAttn forward: LDS-tiled, persistent, producer/consumer waves)"}.get(gen, "msda_fwd_vec4 (generic)")
             res["roofline"] = {"kernel": kname + (" + fused msda_prepare" if fused else ""), "bound": "hbm",
@@ -720,7 +725,7 @@ def run(args):
                                                          "achieved": (alg + prep) / sec / 1e9, "frac": (alg + prep) / sec / HBM_PEAK}
             # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
             # measurement of the same kernel on the same geometry, corrected as the microarch guide prescribes
-            for fn in ("r05_msda_traffic.json", "r04_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+            for fn in ("r06_msda_traffic.json", "r05_msda_traffic.json", "r04_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
                         tr = json.load(f)

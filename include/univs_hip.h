@@ -133,8 +133,8 @@ int univs_msda_forward_heads_f32(const float* value_hm, const int64_t* spatial_s
 typedef struct UnivsConfig {
   int size;               /* sizeof(UnivsConfig) of the caller (versioning) */
   int msda_impl;          /* 0 auto, 1 generic direct-gather kernel, 2 LDS-tiled kernels where they apply */
-  int msda_strip_w;       /* msda_strips: tile width in pixels of the finest level (default 12) */
-  int msda_strip_h;       /* msda_strips: tile height (default 8; lowered until the windows fit 80 KB of LDS) */
+  int msda_strip_w;       /* msda_strips / msda_heads: tile width in pixels of the finest level (default 12 / 16) */
+  int msda_strip_h;       /* msda_strips / msda_heads: tile height (default 8 / 6; smaller tilings are tried until the windows fit the LDS) */
   int msda_halo;          /* LDS-tiled kernels: sampling offsets covered by the windows, pixels (default 6) */
   int msda_grid;          /* LDS-tiled kernels: workgroups launched (default: 4 x CUs for msda_strips, 1 x CUs for msda_heads / msda_tiled2) */
   int mask_decode_impl;   /* 0 by size, 1 exact-f32 MFMA kernel, 2 split-bf16 kernel wherever its preconditions hold */

@@ -334,7 +334,14 @@ def test_device_sampler_on_the_gpu(cuda, golden_dir):
     assert got["clip_first_frames"].tolist() == g["clip_first_frames"].tolist() == [0, 2, 4]
     assert sorted(got) == sorted(ref_run)
     for k in got:                                               # seeded: the same video twice gives the same states
-        assert torch.equal(got[k], again[k]), k
+        # (same draws -> same entities, same integer / boolean state bit for bit; floating-point state to rounding: on this
+        # 64 x 96 video the small Linears and convolutions run on the library, whose GEMMs are not run-to-run deterministic --
+        # 1e-5 on the stored mask logits in REFERENCE sampler mode too, tools/debug_loop_determinism.py)
+        assert got[k].shape == again[k].shape, k
+        if got[k].dtype.is_floating_point and got[k].numel():
+            assert (got[k] - again[k]).abs().max().item() <= 1e-4 * max(1.0, got[k].abs().max().item()), k
+        else:
+            assert torch.equal(got[k], again[k]), k
     for k in got:
         assert got[k].shape == ref_run[k].shape, k              # same entities, same pool layout
         if k.startswith("clip0_in_") or k.startswith("clip1_in_"):
@@ -571,7 +578,7 @@ def test_config5_fp16_window_attention_against_reference(cuda, golden_dir):
 def test_config5_full_clip_properties(cuda):
     """BASELINE config 5 at FULL size on the GPU (Swin-L, T=10 @ 1080p, 200 queries; the reference's CPU run of this clip
     needs > 100 GB): size-independent properties of the hot operators on the tensors the model really produces --
-    finite outputs; the head-major MSDeformAttn kernel (msda_strips.hip) covers the 1080p geometry and == the generic
+    finite outputs; the head-major MSDeformAttn kernel (msda_heads.hip) covers the 1080p geometry and == the generic
     kernel on the same layer's operands un-packed to the standard layouts; oracle C on every 37th query of the first
     layer; full-resolution mask decode == fp64 einsum on a strided subset; the first two frames' features == the T=2 run
     (frames are independent in the backbone)."""
@@ -581,11 +588,11 @@ def test_config5_full_clip_properties(cuda):
     head = helpers.build_head(case, cuda, return_aux=False)
     x = cases.preprocess(cases.cfg5_frames(case["T"])).to(cuda)
     seen = {"msda": [], "dec": []}
-    orig_strips, orig_dec = ops.msda_forward_strips, ops.mask_decode
+    orig_heads, orig_dec = ops.msda_forward_heads, ops.mask_decode
 
-    def strips_hook(vhm, qhm, ref_q, shapes, lsi, M, P=4):
-        out = orig_strips(vhm, qhm, ref_q, shapes, lsi, M, P)
-        assert out is not None and ops.msda_last_tiled_generation() == 5, "the head-major kernel must cover the 1080p geometry"
+    def heads_hook(vhm, qhm, ref_q, shapes, lsi, M, P=4):
+        out = orig_heads(vhm, qhm, ref_q, shapes, lsi, M, P)
+        assert out is not None and ops.msda_last_tiled_generation() == 6, "the head-major kernel must cover the 1080p geometry"
         if not seen["msda"]:
             seen["msda"].append((vhm, qhm, ref_q, shapes, lsi, out))
         return out
@@ -594,22 +601,22 @@ def test_config5_full_clip_properties(cuda):
         out = orig_dec(e, f)
         seen["dec"].append((e, f, out, ops.mask_decode_last_impl()))
         return out
-    ops.msda_forward_strips, ops.mask_decode = strips_hook, dec_hook
+    ops.msda_forward_heads, ops.mask_decode = heads_hook, dec_hook
     try:
         with torch.no_grad():
             feats = swin(x)
             out = head(feats, targets=_targets_to(cases.targets_first_clip(case), cuda))
     finally:
-        ops.msda_forward_strips, ops.mask_decode = orig_strips, orig_dec
+        ops.msda_forward_heads, ops.mask_decode = orig_heads, orig_dec
     pm = out["pred_masks"]
     assert tuple(pm.shape) == (1, 200, 10, 272, 480) and torch.isfinite(pm).all()
     assert torch.isfinite(out["pred_logits"]).all() and torch.isfinite(out["pred_embds"]).all()
     # MSDA: S = 34*60 + 68*120 + 136*240 = 42840 tokens per frame.  Un-pack the head-major operands to the standard layouts
     vhm, qhm, ref_q, shapes, lsi, got = seen["msda"][0]
-    N, M2, S, DH = vhm.shape
-    M, L, P = M2 // 2, len(shapes), 4
-    assert S == 42840 and N == 10
-    value = vhm.view(N, M, 2, S, DH).permute(0, 3, 1, 2, 4).reshape(N, S, M, 2 * DH).contiguous()
+    N, M, S, D = vhm.shape
+    L, P = len(shapes), 4
+    assert S == 42840 and N == 10 and D == 32
+    value = vhm.permute(0, 2, 1, 3).contiguous()
     order = ops.msda_level_order(shapes)
     q = qhm.view(N, M, S, P, 3 * L)
     off = torch.empty((N, S, M, L, P, 2), device=cuda)

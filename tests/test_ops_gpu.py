@@ -221,6 +221,8 @@ def test_msda_heads_cfg2_and_cfg5_size(cuda):
         ref_q = ref[:, :, 0].contiguous().to(cuda)
         got = ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P)
         assert got is not None and ops.msda_last_tiled_generation() == 6
+        for _ in range(3):      # run to run bit-identical (query slots that repeat a tile's last query compute but do not store)
+            assert torch.equal(got, ops.msda_forward_heads(vhm, qhm, ref_q, shapes, lsi, M, P))
         loc, attn = ops.msda_prepare(proj.to(cuda), n_off, ref.to(cuda), shapes, M, L, P)
         with ops.configured(msda_impl=1):
             generic = ops.ms_deform_attn_forward(value.to(cuda), shapes, lsi, loc, attn)

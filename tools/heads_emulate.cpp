@@ -142,13 +142,13 @@ int main() {
                 const int lpx = lane >> 3, lch = lane & 7;
                 const unsigned lanebit = 1u << lpx;
                 float v[4] = {0, 0, 0, 0};
-                if (pc.c & lanebit) {
+                if ((pc.a >> 24) & lanebit) {
                   const long long px = (long long)(pc.a & 0xffffffu) + lpx - S6_PX_BIAS;
                   if (px < 0 || px >= S) { printf("piece pixel out of the frame\n"); ++bad_total; continue; }
                   for (int e = 0; e < 4; ++e) v[e] = vbase[px * 32 + lch * 4 + e];
                 }
-                if ((pc.c >> 16) & lanebit) {
-                  const unsigned dst = pc.b + lpx * 128 + lch * 16;
+                if ((pc.b >> 24) & lanebit) {
+                  const unsigned dst = (pc.b & 0xffffffu) + lpx * 128 + lch * 16;
                   if (dst + 16 > g.lds) { printf("LDS store out of range\n"); ++bad_total; continue; }
                   for (int e = 0; e < 4; ++e) lds[dst / 4 + e] = v[e];
                   stamp[dst / 16] = serial;

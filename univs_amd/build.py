@@ -70,7 +70,11 @@ def build(force=False, verbose=True, lib=LIB, defines=(), tag=""):
 
 ABLATIONS = {"plainsplit": ("UNIVS_SPLIT_PLAIN",), "nosplit": ("UNIVS_ABLATE_NOSPLIT",), "nomfma": ("UNIVS_ABLATE_NOMFMA",),
              "nosplit_nomfma": ("UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA"), "trace": ("UNIVS_TRACE_GEMM",), "vtpad8": ("UNIVS_WH_VT_PAD=8", "UNIVS_XA_VS=40"), "gs256": ("UNIVS_GS_THREADS=256",),
-             "trace_nosplit_nomfma": ("UNIVS_TRACE_GEMM", "UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA")}
+             "trace_nosplit_nomfma": ("UNIVS_TRACE_GEMM", "UNIVS_ABLATE_NOSPLIT", "UNIVS_ABLATE_NOMFMA"),
+             # csrc/msda_heads.hip (S6_ABLATE bits): no gather stream / no row movement / no reduction + stores / no records
+             "heads_nostream": ("S6_ABLATE=1",), "heads_norows": ("S6_ABLATE=2",), "heads_noreduce": ("S6_ABLATE=4",),
+             "heads_norecords": ("S6_ABLATE=8",), "heads_nostream_norows": ("S6_ABLATE=3",), "heads_onlyrows": ("S6_ABLATE=13",),
+             "heads_skeleton": ("S6_ABLATE=15",), "heads_trace": ("S6_TRACE",)}
 
 
 def build_ablation(name, verbose=False):

@@ -32,6 +32,23 @@
 #include "config.h"
 #include "msda_dev.h"
 
+// Timing experiments (python -m univs_amd.build --ablate heads_*; results are then WRONG): S6_ABLATE bit 0 = no gather stream
+// (LDS reads + multiply-adds), bit 1 = no row movement in the steady state (loads + LDS commits), bit 2 = no point
+// reduction / output stores, bit 3 = no sample records (and no stream).
+#ifndef S6_ABLATE
+#define S6_ABLATE 0
+#endif
+// S6_TRACE (python -m univs_amd.build --ablate heads_trace): lane 0 of every wave keeps ten s_memtime stamps per item in
+// registers and stores them behind barrier B: g_s6_trace[workgroup][item serial < 48][wave][10], read back with
+// univs_dbg_s6_trace (tools/msda_trace6.py).
+#ifdef S6_TRACE
+#define S6_TRACE_ITEMS 48
+__device__ unsigned long long g_s6_trace[256 * S6_TRACE_ITEMS * 8 * 10];
+#define S6_STAMP(K) { __builtin_amdgcn_sched_barrier(0); stamp[K] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define S6_STAMP(K)
+#endif
+
 namespace univs {
 
 typedef float s6v4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte load that is only 4-byte aligned
@@ -50,7 +67,7 @@ template <int L>
 __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Levels lv, const S6Tile* __restrict__ tiles,
                                                                  const S6Piece* __restrict__ pieces,
                                                                  const int* __restrict__ qtab, const S6Seg* __restrict__ segs,
-                                                                 const int* __restrict__ seg_begin) {
+                                                                 const int* __restrict__ seg_begin, unsigned lds_dummy) {
   constexpr int P = 4, DH = S6_DH;
   extern __shared__ __attribute__((aligned(1024))) char lds6[];
   const unsigned lds_base = (unsigned)(unsigned long long)(T3_LDS char*)lds6;
@@ -65,41 +82,36 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
   auto hfield = [&](int hdv, int idx) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(hdv, idx); };
 
   // =========================== moving rows ===========================
-  // A piece = 8 pixels of one row of one level: lane (pixel = lane >> 3, chunk = lane & 7) moves 16 bytes.
+  // A piece = 8 pixels of one row of one level: lane (pixel = lane >> 3, chunk = lane & 7) moves 16 bytes.  Its descriptor is two
+  // dwords (msda_heads_geom.h: S6Piece): the pixel index with the load mask in the top byte, the LDS offset with the store mask
+  // in the top byte -- one v_readlane per request and per commit.  Masked-out lanes load from an offset outside the buffer
+  // (0, no memory traffic) and store into a 1-KB dummy region behind the windows: no branch, no exec-mask change.
   const int lpx = lane >> 3, lch = lane & 7;
   const unsigned lanepart_g = (unsigned)((lpx - S6_PX_BIAS) * (DH * 4) + lch * 16), lanepart_l = (unsigned)(lpx * 128 + lch * 16);
-  const unsigned lanebit = 1u << lpx;
+  const unsigned maskpos = 24u + (unsigned)lpx;
+  const unsigned dummy_l = lds_dummy + (unsigned)lane * 16u;
   t3v4 wreg[S6_PC];
   static_assert(S6_PCAP <= 64 && S6_PCAP % S6_PC == 0, "a wave fetches its piece list with one load; whole passes");
   auto piece_list = [&](int tile, int which) __attribute__((always_inline)) {   // lane k: piece k of my list
     const S6Piece* p = pieces + ((long long)(tile * 2 + which) * S6_NW + wave) * S6_PCAP + min(lane, S6_PCAP - 1);
-    return *reinterpret_cast<const s6u3*>(p);
+    return *reinterpret_cast<const t3u2*>(p);
   };
-  // Pass `pass` of a list: pieces [pass * S6_PC, +S6_PC).  No bounds: the host pads every list with no-op pieces (no column
-  // inside the level: the load returns 0 without touching memory; no column inside the pitch: nothing is stored).
-  auto load_rows = [&](const s6u3& list, unsigned hd, int pass) __attribute__((always_inline)) {
-    // one buffer resource over this (frame, head)'s value pixels; masked-out columns get an offset outside it -> 0
+  auto value_rsrc = [&](unsigned hd) __attribute__((always_inline)) {
+    // one buffer resource over this (frame, head)'s value pixels
     const unsigned long long pv = (unsigned long long)(a.vhm + (long long)hd * S * DH);
     const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pv), phi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0, (int)((long long)S * DH * 4), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < S6_PC; ++j) {
-      const unsigned pa = __builtin_amdgcn_readlane(list.x, pass * S6_PC + j);
-      const unsigned pc = __builtin_amdgcn_readlane(list.z, pass * S6_PC + j);
-      const unsigned off = (pc & lanebit) ? (pa & 0xffffffu) * (unsigned)(DH * 4) + lanepart_g : 0x80000000u;
-      wreg[j] = __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-    }
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo), 0,
+                                             (int)((long long)S * DH * 4), 0x00020000);
   };
-  auto commit_rows = [&](const s6u3& list, int pass, auto steady) __attribute__((always_inline)) {
-    // the rows have arrived (in the steady state they were waited for before the item's output stores were issued)
-    if constexpr (!decltype(steady)::value) __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-    for (int j = 0; j < S6_PC; ++j) {
-      const unsigned pb = __builtin_amdgcn_readlane(list.y, pass * S6_PC + j);
-      const unsigned pc = __builtin_amdgcn_readlane(list.z, pass * S6_PC + j);
-      if ((pc >> 16) & lanebit) *(T3_LDS t3v4*)((T3_LDS char*)lds6 + lanepart_l + pb) = wreg[j];
-    }
+  auto request = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned pa) __attribute__((always_inline)) {   // pa: uniform
+    const unsigned on = (unsigned)__builtin_amdgcn_sbfe((int)pa, maskpos, 1u);                      // all ones: my column is in the level
+    const unsigned off = (((pa & 0xffffffu) << 7) + lanepart_g) | ~on;                              // (~on: far outside the buffer)
+    return __builtin_bit_cast(t3v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+  };
+  auto commit = [&](unsigned pb, const t3v4& v) __attribute__((always_inline)) {                    // pb: uniform
+    const unsigned on = (unsigned)__builtin_amdgcn_sbfe((int)pb, maskpos, 1u);                      // all ones: my column is in the pitch
+    const unsigned adr = (((pb & 0xffffffu) + lanepart_l) & on) | (dummy_l & ~on);
+    *(T3_LDS t3v4*)((T3_LDS char*)lds6 + adr) = v;
   };
 
   // =========================== gathering ===========================
@@ -114,6 +126,7 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
 
   struct Inputs { float x[L], y[L], a[L]; };
   struct RawInputs { float v[3 * L]; float2 rp; };
+  struct Recs { unsigned ca[4 * L]; float cw[4 * L]; unsigned long long mm[L]; };
   // my (query, head, point)'s 3 L floats -- L offset pairs then L logits (slot order) -- and the query's reference point:
   // loads only; `finish_inputs` does the arithmetic an item later, when the loads have long arrived
   auto load_raw = [&](int n, int m, int qg, RawInputs& r) __attribute__((always_inline)) {
@@ -171,6 +184,52 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
 #pragma unroll
     for (int kk = 0; kk < L; ++kk) iv.a[kk] = iv.a[kk] * rs;
   };
+  // my sample's records at every level (msda_heads_geom.h: s6_record, shared with the host emulator) and the rare path's
+  // masks (evaluated HERE: a branch between reads and multiply-adds lets hipcc sink the latter into its successor)
+  auto make_records = [&](const Inputs& in, int hdv, Recs& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < L; ++kk) {
+      const S6Rec rec = s6_record(in.x[kk], in.y[kk], in.a[kk], Hf[kk], Wf[kk], (unsigned)hfield(hdv, HD_P0 + kk),
+                                  (unsigned)hfield(hdv, HD_P1 + kk), lv.nr[kk], lv.pitch[kk], lv.next_d[kk], lv.wrap_d[kk],
+                                  lds_base + (unsigned)lv.reg[kk], (unsigned)lane & 15u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r.ca[4 * kk + k] = rec.a[k]; r.cw[4 * kk + k] = rec.w[k]; }
+      r.mm[kk] = __ballot(!rec.inwin);
+      if (r.mm[kk] != 0)
+        r.mm[kk] = __ballot(!rec.inwin && in.a[kk] != 0.f && s6_inband(in.x[kk], in.y[kk], Hf[kk], Wf[kk]));
+    }
+  };
+  // sum the 4 points (DPP rows) of every query and store: after the two swap rounds row r of the wave holds the finished
+  // chunk slots 2 r and 2 r + 1 of each query = channel chunks (2 r) ^ rot8 and (2 r + 1) ^ rot8
+  // (`live`: my query slot is one of the tile's queries.  The slots behind them repeat the tile's last query -- same inputs, but a
+  // lane's corner ORDER depends on its lane bits, so a repeat may round differently: it computes and does not store, or two
+  // runs could differ in the last bit by which lane stored last.)
+  auto reduce_store = [&](const t3v4 (&acc)[8], int n, int m, int qg, bool live) __attribute__((always_inline)) {
+    if constexpr (S6_ABLATE & 4) {
+      if (acc[0].x == 1.2345f) a.out[lane] = acc[0].x + acc[1].y + acc[7].w;
+    } else {
+      float a32[32];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a32[4 * j] = acc[j].x; a32[4 * j + 1] = acc[j].y; a32[4 * j + 2] = acc[j].z; a32[4 * j + 3] = acc[j].w; }
+      float s16[16], t8[8];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        const t3u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a32[f]), __float_as_uint(a32[f + 16]), false, false);
+        s16[f] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const t3u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s16[f]), __float_as_uint(s16[f + 8]), false, false);
+        t8[f] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+      }
+      char* ob = reinterpret_cast<char*>(a.out + ((long long)n * S * M + m) * 32);                             // uniform
+      const unsigned oo = (unsigned)qg * (unsigned)(M * 128) + ((((unsigned)pt << 1) ^ rot8) << 4);          // < 2^32 (host-checked)
+      if (live) {
+        *reinterpret_cast<t3v4*>(ob + oo) = (t3v4){t8[0], t8[1], t8[2], t8[3]};
+        *reinterpret_cast<t3v4*>(ob + (oo ^ 16u)) = (t3v4){t8[4], t8[5], t8[6], t8[7]};
+      }
+    }
+  };
 
   // The gather is ONE stream over the item's 4 L corners (level-major): the reads of corner c + 2 are issued behind the
   // multiply-adds of corner c, four chunks at a time, into the register set those multiply-adds just freed (two sets of 8 x 16
@@ -204,6 +263,9 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
   }
 
   // ---- the workgroup's segments
+#ifdef S6_TRACE
+  int trace_serial = 0;
+#endif
   const int si0 = __builtin_amdgcn_readfirstlane(seg_begin[blockIdx.x]), si1 = __builtin_amdgcn_readfirstlane(seg_begin[blockIdx.x + 1]);
 #pragma unroll 1
   for (int si = si0; si < si1; ++si) {
@@ -214,30 +276,29 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
     const int tile0 = __builtin_amdgcn_readfirstlane(sp->tile0);
     const int n = (int)(hd / (unsigned)M), m = (int)(hd - (unsigned)n * (unsigned)M);
     const int tlast = tile0 + count - 1;
+    const __amdgpu_buffer_rsrc_t vrs = value_rsrc(hd);
 
-    // ---- prologue: the whole windows of the segment's first tile (a cold start), the first two query lists, the first inputs
+    // ---- prologue: the whole windows of the segment's first tile (a cold start), the first two query lists, the first inputs.
+    // ONE round trip: every piece of the list (S6_PCAP, no-op pieces included: they touch no memory) is requested before the
+    // first is waited for -- the accumulators and gather registers are dead here --, the inputs travel beside them.
     if (si > si0) __syncthreads();   // nobody gathers from the previous segment's windows any more
+    const t3u2 clist = piece_list(tile0, 1);
     int hdv = header(tile0);
     int qg_cur = my_query(tile0);
     int qg_nxt = my_query(min(tile0 + 1, tlast));
+    t3u2 rows = piece_list(min(tile0 + 1, tlast), 0);   // the rows entering the next tile's windows
+    if (count < 2) rows = (t3u2){0u, 0u};               // no next tile: no-op pieces
     Inputs in_cur;
     {
+      t3v4 creg[S6_PCAP];
+#pragma unroll
+      for (int j = 0; j < S6_PCAP; ++j) creg[j] = request(vrs, __builtin_amdgcn_readlane(clist.x, j));
       RawInputs r0;
       load_raw(n, m, qg_cur, r0);
       finish_inputs(r0, in_cur);
+#pragma unroll
+      for (int j = 0; j < S6_PCAP; ++j) commit(__builtin_amdgcn_readlane(clist.y, j), creg[j]);
     }
-    {
-      const s6u3 list = piece_list(tile0, 1);
-      const int n_cold = hfield(hdv, HD_NCOLD);
-      const int passes = (n_cold + S6_PC - 1) / S6_PC;
-#pragma unroll 1
-      for (int pass = 0; pass < passes; ++pass) {
-        load_rows(list, hd, pass);
-        commit_rows(list, pass, std::false_type{});
-      }
-    }
-    s6u3 rows = piece_list(min(tile0 + 1, tlast), 0);   // the rows entering the next tile's windows
-    if (count < 2) rows = (s6u3){0u, 0u, 0u};           // no next tile: no-op pieces
     __builtin_amdgcn_s_waitcnt(0x0F70);   // (see the wait before the output stores)
     __syncthreads();
 
@@ -245,44 +306,49 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
     for (int tile = tile0;; ++tile) {
       const bool has_next = tile < tlast;
       const int tnxt = min(tile + 1, tlast), tn2 = min(tile + 2, tlast);
-      // ---- 0. everything the NEXT item needs is requested here, ahead of this item's gathers: its inputs (the query list
-      // was fetched an item ago), the rows entering its windows (first pass; the piece list was fetched an item ago), its
-      // header, and the lists of the item after it.
+#ifdef S6_TRACE
+      unsigned long long stamp[10];
+#endif
+      S6_STAMP(0)
+      // ---- 0. the NEXT item's inputs are requested here (its query list was fetched an item ago); the rows entering its
+      // windows are requested inside the gather stream, its header and the lists of the item after it ahead of the last level
       RawInputs raw_nxt;
       load_raw(n, m, qg_nxt, raw_nxt);
-      load_rows(rows, hd, 0);
-      int hdv_nxt = 0, qg_n2 = 0;
-      s6u3 rows_n2 = {0u, 0u, 0u};
-      __builtin_amdgcn_sched_barrier(0);
-
-      // ---- A. my sample's records at every level (msda_heads_geom.h: s6_record, shared with the host emulator) and the rare
-      // path's masks (evaluated HERE: a branch between reads and multiply-adds lets hipcc sink the latter into its successor)
-      unsigned ca[4 * L];
-      float cw[4 * L];
-      unsigned long long mm[L];
+      if constexpr (!(S6_ABLATE & 2) && (S6_ABLATE & 9)) {   // (no stream to spread them over)
 #pragma unroll
-      for (int kk = 0; kk < L; ++kk) {
-        const S6Rec rec = s6_record(in_cur.x[kk], in_cur.y[kk], in_cur.a[kk], Hf[kk], Wf[kk], (unsigned)hfield(hdv, HD_P0 + kk),
-                                    (unsigned)hfield(hdv, HD_P1 + kk), lv.nr[kk], lv.pitch[kk], lv.next_d[kk], lv.wrap_d[kk],
-                                    lds_base + (unsigned)lv.reg[kk], (unsigned)lane & 15u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ca[4 * kk + k] = rec.a[k]; cw[4 * kk + k] = rec.w[k]; }
-        mm[kk] = __ballot(!rec.inwin);
-        if (mm[kk] != 0)
-          mm[kk] = __ballot(!rec.inwin && in_cur.a[kk] != 0.f && s6_inband(in_cur.x[kk], in_cur.y[kk], Hf[kk], Wf[kk]));
+        for (int j = 0; j < S6_PC; ++j) wreg[j] = request(vrs, __builtin_amdgcn_readlane(rows.x, j));
       }
+      int hdv_nxt = 0, qg_n2 = 0;
+      t3u2 rows_n2 = {0u, 0u};
+      __builtin_amdgcn_sched_barrier(0);
+      S6_STAMP(1)
+
+      // ---- A. my sample's records at every level
+      Recs rc;
+      make_records(in_cur, hdv, rc);
+      S6_STAMP(2)
 
       // ---- B. gather: 4 L corners x 8 chunks in one stream
       t3v4 acc[8];   // my sample's 32 channels, chunk slot j = channel chunk j ^ rot8; summed over corners and levels
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = (t3v4){0.f, 0.f, 0.f, 0.f};
-      {
+      if constexpr (S6_ABLATE & 9) {   // (keep the records alive)
+        unsigned keep = 0;
+        if constexpr (!(S6_ABLATE & 8)) {
+#pragma unroll
+          for (int c = 0; c < 4 * L; ++c) keep ^= rc.ca[c] ^ __float_as_uint(rc.cw[c]);
+        }
+        acc[0].x = __uint_as_float(keep);
+        hdv_nxt = header(tnxt);
+        qg_n2 = my_query(tn2);
+        rows_n2 = piece_list(tn2, 0);
+      } else {
         constexpr int NC = 4 * L;
         t3v4 d0[8], d1[8];
-        S6_READ4(ca[0], 0, d0);
-        S6_READ4(ca[0], 4, d0);
-        S6_READ4(ca[1], 0, d1);
-        S6_READ4(ca[1], 4, d1);
+        S6_READ4(rc.ca[0], 0, d0);
+        S6_READ4(rc.ca[0], 4, d0);
+        S6_READ4(rc.ca[1], 0, d1);
+        S6_READ4(rc.ca[1], 4, d1);
 #pragma unroll
         for (int c = 0; c < NC; c += 2) {
           if (c == NC - 4) {   // (ahead of the last level's corners: L2 hits)
@@ -290,26 +356,35 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
             qg_n2 = my_query(tn2);
             rows_n2 = piece_list(tn2, 0);
           }
+          if constexpr (!(S6_ABLATE & 2)) {   // the rows entering the next tile's windows: S6_PC requests spread over the stream
+            // (issued in one burst at the top, they -- 96 KB per CU with the inputs -- wait ~1.7k clocks for the vector-memory
+            // queue while every SIMD idles)
+            constexpr int per = (S6_PC + NC / 2 - 1) / (NC / 2);
+#pragma unroll
+            for (int j = (c / 2) * per; j < (c / 2 + 1) * per && j < S6_PC; ++j)
+              wreg[j] = request(vrs, __builtin_amdgcn_readlane(rows.x, j));
+          }
           if (c + 2 < NC) {   // 16 reads in flight before and after every step
-            S6_WAIT4(12, 0, d0); S6_FMA4(0, d0, cw[c]);     S6_READ4_DEP(ca[c + 2], 0, d0, acc);
-            S6_WAIT4(12, 4, d0); S6_FMA4(4, d0, cw[c]);     S6_READ4_DEP(ca[c + 2], 4, d0, acc);
-            S6_WAIT4(12, 0, d1); S6_FMA4(0, d1, cw[c + 1]); S6_READ4_DEP(ca[c + 3], 0, d1, acc);
-            S6_WAIT4(12, 4, d1); S6_FMA4(4, d1, cw[c + 1]); S6_READ4_DEP(ca[c + 3], 4, d1, acc);
+            S6_WAIT4(12, 0, d0); S6_FMA4(0, d0, rc.cw[c]);     S6_READ4_DEP(rc.ca[c + 2], 0, d0, acc);
+            S6_WAIT4(12, 4, d0); S6_FMA4(4, d0, rc.cw[c]);     S6_READ4_DEP(rc.ca[c + 2], 4, d0, acc);
+            S6_WAIT4(12, 0, d1); S6_FMA4(0, d1, rc.cw[c + 1]); S6_READ4_DEP(rc.ca[c + 3], 0, d1, acc);
+            S6_WAIT4(12, 4, d1); S6_FMA4(4, d1, rc.cw[c + 1]); S6_READ4_DEP(rc.ca[c + 3], 4, d1, acc);
           } else {
-            S6_WAIT4(12, 0, d0); S6_FMA4(0, d0, cw[c]);
-            S6_WAIT4(8, 4, d0);  S6_FMA4(4, d0, cw[c]);
-            S6_WAIT4(4, 0, d1);  S6_FMA4(0, d1, cw[c + 1]);
-            S6_WAIT4(0, 4, d1);  S6_FMA4(4, d1, cw[c + 1]);
+            S6_WAIT4(12, 0, d0); S6_FMA4(0, d0, rc.cw[c]);
+            S6_WAIT4(8, 4, d0);  S6_FMA4(4, d0, rc.cw[c]);
+            S6_WAIT4(4, 0, d1);  S6_FMA4(0, d1, rc.cw[c + 1]);
+            S6_WAIT4(0, 4, d1);  S6_FMA4(4, d1, rc.cw[c + 1]);
           }
         }
       }
+      S6_STAMP(3)
 
       // ---- C. rare: samples whose footprint leaves the tile's window -> the whole wave fetches the four corners from
       // global memory (lane = corner lane >> 4, channels 2 (lane & 15) and + 1), sums them over the corners and hands the 32
       // channels to the owning lane
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
-        unsigned long long m1 = mm[kk];
+        unsigned long long m1 = rc.mm[kk];
         if (m1 != 0) {
           const float* vl = a.vhm + ((long long)hd * S + lv.start[kk]) * DH + 2 * (lane & 15);
 #pragma unroll 1
@@ -346,48 +421,49 @@ __global__ __launch_bounds__(64 * S6_NW, 2) void msda_fwd_heads(S6Args a, S6Leve
       // the next item's locations and weights from its raw projections (loaded at the top of this item)
       Inputs in_nxt;
       finish_inputs(raw_nxt, in_nxt);
+      S6_STAMP(4)
 
-      __syncthreads();   // A: nobody reads the rows that are about to be replaced any more
       // Every load of this item -- the next tile's rows, inputs, header, the lists of the tile after it -- is waited for
       // HERE, before the output stores are issued, so that no later wait for one of them waits for the stores'
       // acknowledgements (thousands of clocks).
       __builtin_amdgcn_s_waitcnt(0x0F70);
-      commit_rows(rows, 0, std::true_type{});
-      if (has_next) {
-        const int passes = (hfield(hdv_nxt, HD_NENTER) + S6_PC - 1) / S6_PC;   // > 1 only for tall tiles
+      S6_STAMP(5)
+      __syncthreads();   // A: nobody reads the rows that are about to be replaced any more
+      S6_STAMP(6)
+      // the LDS stores of the entering rows are issued first (branch-free) and drain -- 13 clocks of the store path each,
+      // ~850 per item and CU -- under the point reduction's vector work
+      if constexpr (!(S6_ABLATE & 2)) {
+#pragma unroll
+        for (int j = 0; j < S6_PC; ++j) commit(__builtin_amdgcn_readlane(rows.y, j), wreg[j]);
+      }
+      S6_STAMP(7)
+      reduce_store(acc, n, m, qg_cur, qslot < hfield(hdv, HD_TOTAL));
+      if constexpr (!(S6_ABLATE & 2)) {
+        if (has_next) {
+          const int passes = (hfield(hdv_nxt, HD_NENTER) + S6_PC - 1) / S6_PC;   // > 1 only for tall tiles
 #pragma unroll 1
-        for (int pass = 1; pass < passes; ++pass) {
-          load_rows(rows, hd, pass);
-          commit_rows(rows, pass, std::false_type{});
+          for (int pass = 1; pass < passes; ++pass) {
+#pragma unroll
+            for (int j = 0; j < S6_PC; ++j) wreg[j] = request(vrs, __builtin_amdgcn_readlane(rows.x, pass * S6_PC + j));
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+            for (int j = 0; j < S6_PC; ++j) commit(__builtin_amdgcn_readlane(rows.y, pass * S6_PC + j), wreg[j]);
+          }
         }
       }
-
-      // ---- D. sum the 4 points (DPP rows) of every query and store: after the two swap rounds row r of the wave holds the
-      // finished chunk slots 2 r and 2 r + 1 of each query = channel chunks (2 r) ^ rot8 and (2 r + 1) ^ rot8
-      {
-        float a32[32];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { a32[4 * j] = acc[j].x; a32[4 * j + 1] = acc[j].y; a32[4 * j + 2] = acc[j].z; a32[4 * j + 3] = acc[j].w; }
-        float s16[16], t8[8];
-#pragma unroll
-        for (int f = 0; f < 16; ++f) {
-          const t3u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a32[f]), __float_as_uint(a32[f + 16]), false, false);
-          s16[f] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
-        }
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          const t3u2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s16[f]), __float_as_uint(s16[f + 8]), false, false);
-          t8[f] = __uint_as_float(sw.x) + __uint_as_float(sw.y);
-        }
-        char* ob = reinterpret_cast<char*>(a.out + ((long long)n * S * M + m) * 32);                             // uniform
-        const unsigned oo = (unsigned)qg_cur * (unsigned)(M * 128) + ((((unsigned)pt << 1) ^ rot8) << 4);      // < 2^32 (host-checked)
-        *reinterpret_cast<t3v4*>(ob + oo) = (t3v4){t8[0], t8[1], t8[2], t8[3]};
-        *reinterpret_cast<t3v4*>(ob + (oo ^ 16u)) = (t3v4){t8[4], t8[5], t8[6], t8[7]};
-      }
+      S6_STAMP(8)
       __syncthreads();   // B: the next tile's rows are in place
+      S6_STAMP(9)
+#ifdef S6_TRACE
+      if (lane == 0 && trace_serial < S6_TRACE_ITEMS && blockIdx.x < 256) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g_s6_trace[(((long long)blockIdx.x * S6_TRACE_ITEMS + trace_serial) * 8 + wave) * 10 + k] = stamp[k];
+      }
+      ++trace_serial;
+#endif
       if (!has_next) break;
       hdv = hdv_nxt;
-      rows = (tile + 2 <= tlast) ? rows_n2 : (s6u3){0u, 0u, 0u};
+      rows = (tile + 2 <= tlast) ? rows_n2 : (t3u2){0u, 0u};
       qg_cur = qg_nxt;
       qg_nxt = qg_n2;
       in_cur = in_nxt;
@@ -465,7 +541,7 @@ static std::shared_ptr<S6Geo> s6_geometry(const LevelTable& lv, int L, int fine,
   S6Host h;
   s6_build_host(lv, L, fine, TH, TW, R, h);
   S6Geo* g = new S6Geo();
-  g->key = key; g->lv = h.lv; g->ntiles = h.ntiles; g->lds = h.lds; g->ok = h.ok && h.lds <= (size_t)S6_LDS_MAX; g->stamp = ++clock_;
+  g->key = key; g->lv = h.lv; g->ntiles = h.ntiles; g->lds = h.lds; g->ok = h.ok && h.lds + 1024 <= (size_t)S6_LDS_MAX; g->stamp = ++clock_;
   if (g->ok) {
     std::vector<S6Seg> segs;
     std::vector<int> begin;
@@ -495,8 +571,9 @@ static std::shared_ptr<S6Geo> s6_geometry(const LevelTable& lv, int L, int fine,
 template <int L>
 static void launch_heads(unsigned grid, hipStream_t st, const std::shared_ptr<S6Geo>& g, const S6Args& a) {
   auto kfn = msda_fwd_heads<L>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * S6_NW), g->lds, st, a, g->lv, g->tiles, g->pieces, g->qtable, g->segs, g->seg_begin);
+  const size_t lds = g->lds + 1024;   // + the dummy region masked-out lanes commit into
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * S6_NW), lds, st, a, g->lv, g->tiles, g->pieces, g->qtable, g->segs, g->seg_begin, (unsigned)g->lds);
 }
 
 // returns 1 if launched, 0 if preconditions do not hold (caller takes another path), <0 on error
@@ -517,9 +594,8 @@ int msda_forward_heads_f32(const float* vhm, const LevelTable& lv, const float* 
   if (expect != S) return 0;
 
   const UnivsConfig cfg = config();
-  const int TW = cfg.msda_strip_w > 0 ? cfg.msda_strip_w : 12, R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
-  int TH = cfg.msda_strip_h > 0 ? cfg.msda_strip_h : 8;
-  if (TH < 1 || TW < 1 || R < 0 || R > 64) return 0;
+  const int R = cfg.msda_halo > 0 ? cfg.msda_halo : 6;
+  if (R < 0 || R > 64 || cfg.msda_strip_w < 0 || cfg.msda_strip_h < 0) return 0;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
@@ -530,8 +606,15 @@ int msda_forward_heads_f32(const float* vhm, const LevelTable& lv, const float* 
     n_cu = v;
   }
   const int policy = cfg.msda_sched == 1 ? 0 : 1;   // default: lockstep rounds; 1: contiguous ranges (A / B runs)
+  // Tilings in order of preference; the first whose tables fit (windows + dummy region within one CU's LDS, <= S6_QCAP queries per
+  // tile) runs.  16 x 6 (128 queries per tile at the benchmark pyramids: every lane of the 8 waves owns a sample; 1.9 x the level's
+  // pixels fetched per column against 2.2 x at 12 x 8) measured 120 us against 126 us per launch at config 2
+  // (profiles/r06_msda_heads_*).  A caller's msda_strip_w / msda_strip_h come first.
+  const int cand[][2] = {{cfg.msda_strip_w > 0 ? cfg.msda_strip_w : (cfg.msda_strip_h > 0 ? 12 : 16), cfg.msda_strip_h > 0 ? cfg.msda_strip_h : (cfg.msda_strip_w > 0 ? 8 : 6)},
+                         {12, 8}, {12, 6}, {12, 4}, {8, 4}, {8, 2}, {4, 2}};
   std::shared_ptr<S6Geo> g;
-  for (; TH >= 2; TH -= 2) {   // the windows must fit one CU's LDS
+  for (const auto& c : cand) {
+    const int TW = c[0], TH = c[1];
     const long long ntiles = (long long)((lv.H[fine] + TH - 1) / TH) * ((lv.W[fine] + TW - 1) / TW);
     const long long nb = (long long)N * M * ntiles;
     if (nb <= 0 || nb > 0x7fffffffLL) return 0;
@@ -557,3 +640,10 @@ int msda_forward_heads_f32(const float* vhm, const LevelTable& lv, const float* 
 }
 
 }  // namespace univs
+
+#ifdef S6_TRACE
+extern "C" int univs_dbg_s6_trace(void* host, unsigned long long bytes) {   // (trace builds only: not in include/univs_hip.h)
+  if (bytes > sizeof(g_s6_trace)) bytes = sizeof(g_s6_trace);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_s6_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -59,10 +59,8 @@ __host__ __device__ __forceinline__ int s6_rot(unsigned p0) { return (int)((p0 >
 // One (row, 8-pixel column block) of one level's window: what one wave instruction moves (8 lanes x 16 B per pixel).
 struct S6Piece {
   unsigned a;   // S6_PX_BIAS + pixel index (start + y * W + x) of the block's first pixel within the frame (24 bits) |
-                // level slot << 24
-  unsigned b;   // byte offset of the block's first pixel in LDS
-  unsigned c;   // columns inside the level (load mask, 8 bits) | columns inside the window pitch (store mask) << 16
-  unsigned d;   // 0
+                // columns inside the level (load mask, 8 bits) << 24
+  unsigned b;   // byte offset of the block's first pixel in LDS (24 bits) | columns inside the window pitch (store mask) << 24
 };
 // A workgroup's work: `count` consecutive tiles of one column of one (frame, head) plane, first tile `tile0`.
 struct S6Seg {
@@ -199,7 +197,7 @@ static bool s6_build_host(const LevelTable& lv, int L, int fine, int TH, int TW,
   }
   g.lds = lds;
   g.tiles.assign((size_t)g.ntiles, S6Tile());
-  g.pieces.assign((size_t)g.ntiles * 2 * S6_NW * S6_PCAP, S6Piece{0u, 0u, 0u, 0u});
+  g.pieces.assign((size_t)g.ntiles * 2 * S6_NW * S6_PCAP, S6Piece{0u, 0u});
   g.qtab.assign((size_t)g.ntiles * S6_QCAP, 0);
   for (int tx = 0; tx < tiles_x; ++tx)
     for (int ty = 0; ty < tiles_y; ++ty) {
@@ -253,10 +251,8 @@ static bool s6_build_host(const LevelTable& lv, int L, int fine, int TH, int TW,
               }
               px = ldmask ? px + S6_PX_BIAS : 0;
               if (px < 0 || px >= (1 << 24) || ldsoff >= (1 << 20)) g.ok = false;
-              pc.a = ((unsigned)px & 0xffffffu) | ((unsigned)kk << 24);
-              pc.b = (unsigned)ldsoff;
-              pc.c = ldmask | (stmask << 16);
-              pc.d = 0u;
+              pc.a = ((unsigned)px & 0xffffffu) | (ldmask << 24);
+              pc.b = (unsigned)ldsoff | (stmask << 24);
               const int w = count % S6_NW, j = count / S6_NW;
               if (j < S6_PCAP) g.pieces[((tile * 2 + which) * S6_NW + w) * S6_PCAP + j] = pc;
               else g.ok = false;
@@ -281,9 +277,8 @@ static bool s6_build_host(const LevelTable& lv, int L, int fine, int TH, int TW,
 //     adjacent tiles do so at different times: each fetches its own halo columns from HBM.
 //   policy 1 -- lockstep rounds: every XCD owns a contiguous eighth of the sequence and its W = grid / 8 workgroups walk W
 //     ADJACENT columns top to bottom at the same time, round after round, so that the halo columns two neighbours share are
-//     fetched from HBM once and found in that XCD's L2 by the other; the columns left over after the last full round are
-//     cut into V equal pieces each (the V in 1..4 with the smallest estimated makespan, a cold start priced at `cold_steps`
-//     tiles) and dealt longest-first.
+//     fetched from HBM once and found in that XCD's L2 by the other; the columns left over after the last full round are cut
+//     into equal pieces or equal ranges, whichever estimates the smaller makespan (a cold start priced at `cold_steps` tiles).
 static bool s6_build_segments_lists(int planes, int tiles_x, int tiles_y, int grid, int policy, double cold_steps,
                                     std::vector<std::vector<S6Seg>>& lists) {
   lists.assign((size_t)std::max(grid, 0), std::vector<S6Seg>());
@@ -330,35 +325,55 @@ static bool s6_build_segments_lists(int planes, int tiles_x, int tiles_y, int gr
       if (!push((int)(x + nx * (i % W)), cols[i].col, cols[i].y0, cols[i].n)) return false;
     const size_t rem = cols.size() - full;
     if (!rem) continue;
-    int bestV = 1;
-    double best = 1e30;
-    for (int V = 1; V <= 4; ++V) {   // longest-first dealing of rem * V pieces onto W workgroups: the estimated makespan
-      std::vector<double> h;
+    // The columns left over after the last full round, two ways; the smaller estimated makespan (tiles + `cold_steps` per
+    // segment) wins:
+    //  (a) every column cut into V equal pieces (V in 1..4), dealt longest-first: one segment per piece;
+    //  (b) their tiles in sequence order cut into W equal ranges: balanced to one tile whatever the column count, a range that
+    //      crosses a column end is two segments.
+    struct Pc { long long col; int y0, n, wg; };
+    auto plan_a = [&](int V, std::vector<Pc>& pcs) -> double {
+      pcs.clear();
       for (size_t i = full; i < cols.size(); ++i)
         for (int v = 0; v < V; ++v) {
-          const int n = cols[i].n * (v + 1) / V - cols[i].n * v / V;
-          if (n > 0) h.push_back(n + cold_steps);
+          const int a = cols[i].n * v / V, b = cols[i].n * (v + 1) / V;
+          if (b > a) pcs.push_back(Pc{cols[i].col, cols[i].y0 + a, b - a, 0});
         }
-      std::sort(h.begin(), h.end(), [](double a, double b) { return a > b; });
+      std::stable_sort(pcs.begin(), pcs.end(), [](const Pc& a, const Pc& b) { return a.n > b.n; });
       std::vector<double> load((size_t)W, 0.0);
-      for (double v : h) *std::min_element(load.begin(), load.end()) += v;
-      const double ms = *std::max_element(load.begin(), load.end());
-      if (ms < best - 1e-9) { best = ms; bestV = V; }
-    }
-    struct Pc { long long col; int y0, n; };
-    std::vector<Pc> pcs;
-    for (size_t i = full; i < cols.size(); ++i)
-      for (int v = 0; v < bestV; ++v) {
-        const int a = cols[i].n * v / bestV, b = cols[i].n * (v + 1) / bestV;
-        if (b > a) pcs.push_back(Pc{cols[i].col, cols[i].y0 + a, b - a});
+      for (Pc& p : pcs) {
+        p.wg = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[p.wg] += p.n + cold_steps;
       }
-    std::stable_sort(pcs.begin(), pcs.end(), [](const Pc& a, const Pc& b) { return a.n > b.n; });
-    std::vector<double> load((size_t)W, 0.0);
-    for (const Pc& p : pcs) {
-      const int j = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-      load[j] += p.n + cold_steps;
-      if (!push(x + nx * j, p.col, p.y0, p.n)) return false;
+      return *std::max_element(load.begin(), load.end());
+    };
+    auto plan_b = [&](std::vector<Pc>& pcs) -> double {
+      pcs.clear();
+      long long rtot = 0;
+      for (size_t i = full; i < cols.size(); ++i) rtot += cols[i].n;
+      size_t ci = full;
+      int used = 0;   // tiles of cols[ci] already dealt
+      std::vector<double> load((size_t)W, 0.0);
+      for (int j = 0; j < W; ++j) {
+        long long want = rtot * (j + 1) / W - rtot * j / W;
+        while (want > 0 && ci < cols.size()) {
+          const int n = (int)std::min<long long>(want, cols[ci].n - used);
+          pcs.push_back(Pc{cols[ci].col, cols[ci].y0 + used, n, j});
+          load[j] += n + cold_steps;
+          used += n;
+          want -= n;
+          if (used == cols[ci].n) { ++ci; used = 0; }
+        }
+      }
+      return *std::max_element(load.begin(), load.end());
+    };
+    std::vector<Pc> best, cand;
+    double bestms = plan_b(best);
+    for (int V = 1; V <= 4; ++V) {
+      const double ms = plan_a(V, cand);
+      if (ms < bestms - 1e-9) { bestms = ms; best.swap(cand); }
     }
+    for (const Pc& p : best)
+      if (!push(x + nx * p.wg, p.col, p.y0, p.n)) return false;
   }
   return true;
 }
