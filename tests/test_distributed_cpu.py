@@ -241,7 +241,7 @@ LOOP_STATE_KEYS = ("logits", "masks", "mask_logits", "boxes", "embds", "ids", "f
                    "occurrence", "prompt_pe", "prompt_feats", "prompt_attn_masks", "frame_indices")
 
 
-def _loop_states(case, model, shard, **over):
+def _loop_states(case, model, shard, seed=1, **over):
     """Runs the clip loop (sharded if `shard`); returns ({tag_key: tensor}, results, clip starts, pixel-decoder calls)."""
     from tests import cases
     from univs_amd.inference.video_entity import ImageList, InferenceVideoEntity
@@ -268,7 +268,7 @@ def _loop_states(case, model, shard, **over):
         images = ImageList(x, [case["image_size"]] * case["n_frames"])
         targets = cases.loop_targets(case)
         with torch.no_grad():
-            torch.manual_seed(1)            # the prompt sampler draws from the CPU generator: same state on every rank
+            torch.manual_seed(seed)         # the prompt sampler draws from the CPU generator (the sharded loop installs rank 0's state)
             results = inf.inference_video(model, cases.loop_batched_inputs(case), images, targets, merge_results=False, on_clip=on_clip)
     finally:
         pd.forward_features = orig
@@ -291,7 +291,8 @@ def _clip_loop_worker(rank, world, port, case_over, kw_over):
         kw = dict(stability_score_thresh=0.0, **kw_over)
         with cpu_ops():
             ref, ref_results, ref_calls, ref_pd = _loop_states(case, model, None, **kw)
-            got, results, calls, pd_frames = _loop_states(case, model, FrameShard(), **kw)
+            # rank-dependent seeds (detectron2's seed + rank): the loop broadcasts rank 0's generator state at the start of the video
+            got, results, calls, pd_frames = _loop_states(case, model, FrameShard(), seed=1 + 1000 * rank, **kw)
         assert calls == ref_calls and len(calls) >= 2
         # the stateless part really is spread: this rank ran backbone + pixel decoder on ITS frames only, once per frame ...
         # (windows as the reference cuts them, :309-312: a new window starts with the first clip that reaches past the last one)

@@ -123,6 +123,15 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard):
     return out
 
 
+def begin_video(model, device, shard):
+    """The prompt sampler's per-video (re)seeding: modeling/prompt_encoder.py: VisualPromptEncoder.begin_video."""
+    try:
+        enc = model.sem_seg_head.predictor.visual_prompt_sampler.visual_prompt_encoder
+    except AttributeError:      # (a caller's head without our predictor: nothing to seed)
+        return None
+    return enc.begin_video(device, shard)
+
+
 def check_loop_shard(shard, num_frames):
     """None for a one-rank shard without forced collectives; raises when the group is larger than a clip."""
     if shard is not None and shard.world == 1 and not shard.always_collective:
@@ -291,6 +300,7 @@ class InferenceVideoEntity(nn.Module):
         win_start = win_end = 0
         feats_window = None
         shard = check_loop_shard(getattr(self, "frame_shard", None), T)
+        begin_video(model, x.device, shard)
         win_rows, win_pd = {}, None
         for i in range(0, n_total, stride):
             if is_last and i + T > n_total:

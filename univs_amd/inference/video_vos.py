@@ -138,7 +138,7 @@ class InferenceVideoVOS(nn.Module):
         self.frame_shard = shard
 
     def inference_video_vos(self, model, batched_inputs, images, targets, image_size=None, out_size=None):
-        from .video_entity import check_loop_shard, sharded_clip_forward, window_features_on_owner
+        from .video_entity import begin_video, check_loop_shard, sharded_clip_forward, window_features_on_owner
         x = images.tensor
         image_size = tuple(images.image_sizes[0])
         out_size = tuple(out_size) if out_size is not None else image_size
@@ -151,6 +151,7 @@ class InferenceVideoVOS(nn.Module):
         win_start = win_end = 0
         feats_window = None
         shard = check_loop_shard(getattr(self, "frame_shard", None), T)
+        begin_video(model, x.device, shard)
         win_rows, win_pd = {}, None
         for i in range(0, video_len, stride):
             if is_last and i + T > video_len:

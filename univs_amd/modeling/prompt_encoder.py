@@ -198,9 +198,36 @@ class VisualPromptEncoder:
         g = self._dev_gen.get(str(device))
         if g is None:
             g = torch.Generator(device=device)
-            g.manual_seed(torch.initial_seed() % (2 ** 63))
+            seed = getattr(self, "_video_seed", None)
+            g.manual_seed((torch.initial_seed() if seed is None else seed) % (2 ** 63))
             self._dev_gen[str(device)] = g
         return g
+
+    def begin_video(self, device, shard=None):
+        """Called by the clip loops at the start of every video (inference/video_entity.py, video_vos.py).
+        * "device" draws (the default for GPU tensors): the device generators are reseeded from ONE value drawn from the default
+          (CPU) generator, so `torch.manual_seed(s)` in front of a video makes its prompts reproducible on the GPU whatever ran
+          before it (without this the generator was seeded once per process and a video's draws depended on how many videos came
+          first: ADVICE r05).  The "reference" mode draws nothing here: its stream stays the reference's, draw for draw.
+        * `shard` (a frame-sharded loop, univs_amd.distributed.FrameShard: every rank runs the sampler on the replicated state and
+          must draw the SAME numbers): the state of rank 0's default generator is broadcast and installed on every rank of the
+          group first -- rank 0's stream is untouched (the sharded video equals the single-process video with rank 0's seed), and
+          rank-dependent seeding (detectron2's seed + rank) can no longer let the ranks sample different pixels and mix them in
+          the next collective."""
+        sharded = shard is not None and shard.world > 1
+        if sharded:
+            import torch.distributed as dist
+            state = torch.get_rng_state().to(device)
+            src = dist.get_global_rank(shard.group, 0) if shard.group is not None else 0
+            dist.broadcast(state, src=src, group=shard.group)
+            torch.set_rng_state(state.cpu())
+        if self._rng(device) == "reference":
+            return None
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)            # the default (CPU) generator: the same on every rank
+        self._video_seed = int(seed.item())
+        for g in self._dev_gen.values():
+            g.manual_seed(self._video_seed % (2 ** 63))
+        return self._video_seed
 
     def _point_pe(self, h_img, w_img, point_coords, key_fid, key_fid_original):
         size = (self.num_frames, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
