@@ -188,6 +188,50 @@ class OpTimer:
         return sum(s.elapsed_time(e) for kk, ev in self.events.items() if pred(kk) for s, e in ev) * 1e-3
 
 
+def op_rooflines(ops, run_clip, sync, T, S, Qp, C, H, W, passes=2):
+    """HBM rooflines of the two north-star operators inside ANOTHER config's clip (BASELINE configs 4 and 5: other S, other Q'):
+    HIP events around every msda_forward_heads / mask_decode call of `passes` extra clips (untimed region), net of an empty event
+    pair's own cost.  Algorithmic bytes as SURVEY.md 8d defines them: 3200 S T per MSDA launch, 4 (C HW + Q' C + Q' HW) T per
+    full-resolution mask decode."""
+    tm = OpTimer(ops, "msda_forward_heads", after=ops.msda_last_tiled_generation)
+    td = OpTimer(ops, "mask_decode", after=ops.mask_decode_last_impl)
+    try:
+        tm.enabled = td.enabled = True
+        for _ in range(passes):
+            run_clip()
+        sync()
+    finally:
+        tm.enabled = td.enabled = False
+        setattr(ops, tm.name, tm.orig)
+        setattr(ops, td.name, td.orig)
+    pairs = []
+    for _ in range(100):
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        e0.record()
+        pairs.append((s0, e0))
+    sync()
+    ovh = sorted(a_.elapsed_time(b_) for a_, b_ in pairs)[len(pairs) // 2] * 1e-3
+    out = {}
+    sec, n = tm.seconds()
+    if n and set(tm.notes.get("all", [])) == {6}:
+        alg, net = 3200.0 * S * T, max(sec - ovh, 0.5 * sec)
+        out["roofline"] = {"kernel": "msda_fwd_heads<3> (generation 6) + fused msda_prepare", "bound": "hbm", "achieved": alg / net / 1e9,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / net / HBM_PEAK, "traffic": None,
+                           "avg_launch_us": net * 1e6, "event_pair_us": sec * 1e6, "launches_per_step": n // passes,
+                           "algorithmic_bytes_per_launch": alg, "tokens_per_frame": S, "frames": T}
+    sec, n = td.seconds()
+    if n:
+        alg, net = 4.0 * (C * H * W + Qp * C + Qp * H * W) * T, max(sec - ovh, 0.5 * sec)
+        out["roofline_mask_decode"] = {"kernel": "skinny_gemm_bf16x6_n32 (full-resolution mask decode; more than 106 query rows run as "
+                                                 "balanced row passes over the same columns)", "bound": "hbm",
+                                       "achieved": alg / net / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / net / HBM_PEAK,
+                                       "traffic": None, "avg_launch_us": net * 1e6, "event_pair_us": sec * 1e6,
+                                       "launches_per_step": n // passes, "algorithmic_bytes_per_launch": alg, "queries": Qp,
+                                       "impl": sorted(set(td.notes.get("all", [])))}
+    return out
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -476,6 +520,8 @@ def run(args):
                                                     "window_attention_launches": sum(len(v) for v in wa.events.values())}
                 wa.events.clear()
             setattr(ops, "window_attention_image", wa.orig)
+            swin5.set_attention_mma("f16x3")
+            c5res.update(op_rooflines(ops, step5, sync, c5["T"], 34 * 60 + 68 * 120 + 136 * 240, c5["Q"], 256, 272, 480))
             res["config5_swinl_1080p"] = c5res
             del swin5, head5, fr5
             torch.cuda.empty_cache()
@@ -617,6 +663,8 @@ def run(args):
                 "workload": "BASELINE config 4: Swin-B (12 x 12 windows), T=5 @ 720p (736x1280 padded), 200 queries + 4 referring "
                             "expressions (grounding: lang->vision cross-attention, ProCA, 'sep-blocked' self-attention); 2 warm-up + 5 timed clips",
                 "ms_per_clip": dt4 * 1e3, "frames_per_s": c4["T"] / dt4, "queries": c4["Q"] + c4["n_exp"], "host_enqueue_ms": enq4 * 1e3}
+            res["config4_swinb_refvos"].update(op_rooflines(ops, step4, sync, c4["T"], 23 * 40 + 46 * 80 + 92 * 160,
+                                                            c4["Q"] + c4["n_exp"], 256, 184, 320))
             del swin4, head4
             torch.cuda.empty_cache()
         except Exception as e:  # pragma: no cover

@@ -57,6 +57,31 @@ def test_hand_derived_known_answers():
     assert R.rle_encode_masks(m)[0]["counts"] == "X1:"             # 40 -> 'X1', 10 -> ':'
 
 
+def test_multi_byte_counts_by_the_published_rule():
+    """pycocotools' maskApi.c (the package is absent from the image: RLE strings stay pinned by its PUBLISHED coding rule, worked by
+    hand): a count is written 5 bits at a time, least significant group first, bit 5 of a character = "more follows", and the
+    groups stop once the rest is 0 (bit 4 of the last group clear) or -1 (bit 4 set): rleToString."""
+    # 1000 = 0b11111_01000: group 8 + more -> 'X' (8 | 32 + 48); group 31, rest 0 but bit 4 is set -> more -> 'o' (31 | 32 + 48);
+    # group 0, rest 0 -> '0'
+    m = torch.zeros(1, 1100, dtype=torch.bool)
+    m[0, 1000:] = True
+    assert R.rle_encode_masks(m)[0]["counts"] == "Xo0" + "T3"       # 100 = 0b00011_00100: 4 + more -> 'T', then 3 -> '3'
+    # runs [3, 50, 2, 10]: the 4th is stored as 10 - 50 = -40: group (-40 & 31) = 24, rest -2 != -1 -> more -> 'h' (24 | 32 + 48);
+    # group (-2 & 31) = 30, rest -1 and bit 4 set -> stop -> 'N' (30 + 48).  50 = 0b00001_10010: 18 + more -> 'b', then 1 -> '1'
+    m = torch.zeros(1, 65, dtype=torch.bool)
+    m[0, 3:53] = True
+    m[0, 55:] = True
+    r = R.rle_encode_masks(m)[0]
+    assert list(R.rle_counts(r)) == [3, 50, 2, 10] and r["counts"] == "3b12hN"
+    # a difference that needs three groups: runs [0, 5000, 1, 1]: 1 - 5000 = -4999 = ...: by the scalar restatement AND by decoding
+    m = torch.zeros(1, 5002, dtype=torch.bool)
+    m[0, :5000] = True
+    m[0, 5001] = True
+    r = R.rle_encode_masks(m)[0]
+    assert list(R.rle_counts(r)) == [0, 5000, 1, 1] and r["counts"] == scalar_rle(m[0].numpy()[None].T.T)[1]
+    assert np.array_equal(R.rle_decode(r), m.numpy().astype(np.uint8))
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (3, 7, 5), (4, 60, 90), (2, 1, 33), (2, 33, 1), (5, 16, 16)], ids=str)
 def test_round_trip_and_scalar_restatement(shape):
     m = synth.uniform("rle/" + "x".join(map(str, shape)), shape) > 0.1

@@ -62,11 +62,11 @@ constexpr int XA_PART = 34;
 constexpr int XA_VS = UNIVS_XA_VS;
 
 // largest magnitude of the wave -> (power of two that brings it into [2^14, 2^15), its inverse), wave-uniform
-__device__ __forceinline__ void xa_wave_scale(float mx, float& s, float& inv) {
+__device__ __forceinline__ void xa_wave_scale(float mx, float& s, float& inv, int emin = -40, int emax = 128) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   int e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
-  e = max(-40, min(e, 128));
+  e = max(emin, min(e, emax));
   s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 + 14 - e) << 23));
   inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((127 - 14 + e) << 23));
 }
@@ -262,9 +262,11 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vr[e].x), fabsf(vr[e].y))), fmaxf(fabsf(vr[e].z), fabsf(vr[e].w)));
-      if (xa_out_of_range(mv, 0.0625f)) {
+      // (an all-zero block -- zero-valued keys -- has nothing to scale: left alone, it no longer multiplies O by 2^54 and back; the
+      // scale's exponent is clamped to [-30, 30], so O times the scale stays inside fp32 for any O the earlier blocks left: ADVICE r05)
+      if (xa_out_of_range(mv, 0.0625f) && __builtin_amdgcn_ballot_w64(mv > 0.f) != 0) {
         float sv;
-        xa_wave_scale(mv, sv, sv_inv);
+        xa_wave_scale(mv, sv, sv_inv, -16, 44);
         sv_fwd = sv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

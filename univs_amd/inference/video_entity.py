@@ -28,6 +28,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..registry import configurable
+from ..utils.memory import retry_if_oom
 from ..utils.comm import batched_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou
 from .comm import check_consistency_with_prev_frames, match_from_learnable_embds  # noqa: F401  (API parity)
 from scipy.optimize import linear_sum_assignment
@@ -84,7 +85,8 @@ def normalized_image_list(frames, pixel_mean, pixel_std, size_divisibility):
 
 
 def _resize(masks, size):
-    return F.interpolate(masks, size, mode="bilinear", align_corners=False)
+    # (the reference wraps these resizes in retry_if_cuda_oom, inference_video_entity.py:933 / :978 / :1104: utils/memory.py)
+    return retry_if_oom(F.interpolate)(masks, size, mode="bilinear", align_corners=False)
 
 
 def window_features_on_owner(model, x, frames, shard):
@@ -104,6 +106,9 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard):
     clip's frames all-gathered; class / re-id logits are replicated by construction)."""
     from ..distributed import ClipShard, cyclic_owners
     predictor = model.sem_seg_head.predictor
+    if getattr(predictor, "semantic_extraction_enable", False):
+        # (that mode returns pred_embds as [T_loc, C, Q'] and a per-rank `mask_features`: neither is gathered here -- ADVICE r05)
+        raise NotImplementedError("frame-sharded clip loop: MODEL.UniVS.TEST.SEMANTIC_EXTRACTION.ENABLE is not supported")
     owners = cyclic_owners(first, n_clip, shard.world)
     if len(set(owners)) < shard.world:
         # (a clip shorter than num_frames only arises when the video ends inside it; the reference's own memory-pool update raises on
@@ -272,8 +277,9 @@ class InferenceVideoEntity(nn.Module):
     def set_frame_shard(self, shard):
         """Run `inference_video` with the frames of the video spread over the ranks of `shard` (a univs_amd.distributed.FrameShard:
         group, rank, world; None switches back).  Frame f belongs to rank f % world: a window's backbone + pixel decoder run on the
-        rank's own frames only -- ONCE per frame, whatever the clip stride (the reference's loop, and the unsharded one here, run the
-        pixel decoder once per CLIP: five times per frame at stride 1) -- and every clip's decoder runs on all ranks, each with the
+        rank's own frames only, once per frame AND WINDOW: with `num_frames_window_test` > `num_frames` a frame serves every clip of its
+        window (the reference's loop runs the pixel decoder once per CLIP: five times per frame at stride 1); with the shipped
+        configs' window == clip length every clip opens a new window and its frames are recomputed -- and every clip's decoder runs on all ranks, each with the
         clip's frames it owns (ClipShard: one all-gather of the query states per layer).  The per-video state `targets[0]` stays
         REPLICATED: after a clip, the mask logits / embeddings of its frames are all-gathered and every rank does the same
         book-keeping.  Needs world <= num_frames (every rank must own a frame of every clip; on a larger node the other ranks take
@@ -720,7 +726,7 @@ class InferenceVideoEntity(nn.Module):
         if not is_last:
             masks = masks[:, :stride]
         masks = _resize(masks, interim_size)[:, :, : image_size[0], : image_size[1]]
-        masks = F.interpolate(masks.float(), size=out_size, mode="nearest")
+        masks = retry_if_oom(F.interpolate)(masks.float(), size=out_size, mode="nearest")
         logits = logits * calculate_mask_quality_scores(masks).view(-1, 1)
         semseg = torch.einsum("qc,qthw->cthw", logits, masks.sigmoid())
         return semseg.argmax(0).cpu()

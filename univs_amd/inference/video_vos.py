@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..registry import configurable
+from ..utils.memory import retry_if_oom
 from ..utils.comm import (batched_pair_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou)
 from .comm import check_consistency_with_prev_frames, match_from_learnable_embds
 
@@ -53,7 +54,8 @@ class FrameAnnotations:
 
 
 def _resize(masks, size):
-    return F.interpolate(masks, size, mode="bilinear", align_corners=False)
+    # (the reference wraps these resizes in retry_if_cuda_oom, inference_video_entity.py:933 / :978 / :1104: utils/memory.py)
+    return retry_if_oom(F.interpolate)(masks, size, mode="bilinear", align_corners=False)
 
 
 class InferenceVideoVOS(nn.Module):

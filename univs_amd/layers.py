@@ -149,7 +149,13 @@ class MultiheadAttention(nn.Module):
         if torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad)):
             return w[r0:r0 + n], (None if b is None else b[r0:r0 + n])
         from . import ops   # (writes through `.data` bump no version counter: ops.invalidate_presplit() is the documented call after them)
-        key = (r0, n, w._version, w.data_ptr(), None if b is None else b._version, ops.presplit_generation())
+
+        def ver(t):             # (tensors created under torch.inference_mode have no version counter: their identity is the key)
+            try:
+                return t._version
+            except RuntimeError:
+                return -1
+        key = (r0, n, ver(w), w.data_ptr(), None if b is None else ver(b), ops.presplit_generation())
         cache = self.__dict__.setdefault("_row_cache", {})
         hit = cache.get((r0, n))
         if hit is None or hit[0] != key:
@@ -157,6 +163,11 @@ class MultiheadAttention(nn.Module):
                 hit = (key, w[r0:r0 + n].detach().clone(), None if b is None else b[r0:r0 + n].detach().clone())
             cache[(r0, n)] = hit
         return hit[1], hit[2]
+
+    def __getstate__(self):     # the row cache is derived data: neither pickled (torch.save(module)) nor deep-copied
+        d = self.__dict__.copy()
+        d.pop("_row_cache", None)
+        return d
 
     def forward(self, query, key, value, attn_mask: Optional[torch.Tensor] = None, need_weights=False,
                 average_attn_weights=True, kv=None, query_add=None, residual=None, norm=None):
@@ -306,20 +317,38 @@ def layer_norm(norm, x, residual=None, return_sum=False, post_add=None):
 _LIBRARY_FALLBACKS = set()
 
 
+LIBRARY_LINEAR_COUNTS = {}      # (what, K, N) -> calls that ran on the library GEMM since `reset_library_linear_counts()`: tests assert
+                                # per config which Linears may leave the hand-written kernels
+
+
+def reset_library_linear_counts():
+    LIBRARY_LINEAR_COUNTS.clear()
+
+
 def _note_library_linear(x, weight, what="F.linear"):
-    """Log ONCE per (K, N, rows bucket) that a GPU Linear left the hand-written three-product kernels for the library's plain-fp32
-    GEMM: the arithmetic differs in the last bits from the tested path (an odd checkpoint width must not change the
-    numerics silently).  `logging.getLogger("univs_amd")`, level INFO."""
+    """Count, and log ONCE per (K, N, rows bucket), that a GPU Linear left the hand-written three-product kernels for the library's
+    plain-fp32 GEMM: the arithmetic differs in the last bits from the tested path (an odd checkpoint width must not
+    change the numerics silently).  The logged reason is the actual one: autograd on, a dtype other than float32, a switch off, or
+    the shape itself.  `logging.getLogger("univs_amd")`, level INFO."""
     if not x.is_cuda:
         return
     rows = x.numel() // max(int(x.shape[-1]), 1)
+    ck = (what, int(x.shape[-1]), int(weight.shape[0]))
+    LIBRARY_LINEAR_COUNTS[ck] = LIBRARY_LINEAR_COUNTS.get(ck, 0) + 1
     key = (what, int(x.shape[-1]), int(weight.shape[0]), rows.bit_length())
     if key in _LIBRARY_FALLBACKS:
         return
     _LIBRARY_FALLBACKS.add(key)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        why = "autograd is on (the hand-written kernels are inference-only)"
+    elif x.dtype != torch.float32 or weight.dtype != torch.float32:
+        why = f"dtype {x.dtype} / {weight.dtype} (the hand-written kernels take float32)"
+    elif not SWITCHES.split_linear:
+        why = "SWITCHES.split_linear is off"
+    else:
+        why = "shape not covered by the three-product kernels"
     import logging
-    logging.getLogger("univs_amd").info("Linear %d -> %d on %d rows runs on the library GEMM (%s): shape not covered by the "
-                                        "three-product kernels", key[1], key[2], rows, what)
+    logging.getLogger("univs_amd").info("Linear %d -> %d on %d rows runs on the library GEMM (%s): %s", key[1], key[2], rows, what, why)
 
 
 def linear(x, weight, bias=None):
