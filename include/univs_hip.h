@@ -602,6 +602,20 @@ int univs_group_norm_f32(const float* x, const float* gamma, const float* beta, 
  * ------------------------------------------------------------------------------------------- */
 int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, int L, int S, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ProCA attention: every prompt query attends only to its own prompt tokens (batch = Q_p * T, query length 1, key length 1 + L).
+ * Replaces: inside forward_transformer_prompt_self_attention_layer (...decoder_univs.py:456-496 -> CrossAttentionLayer.forward_post,
+ *           transformer_layers.py:95-115 -> nn.MultiheadAttention) the concatenation / transposition of the query state and the
+ *           dense prompt tokens into `memory` (and of their position embeddings), q k^T, the softmax and p v.
+ *   qkv0 [Q_p * T, 3 E]   query, first key and first value of every batch entry b = qp * T + t, already projected
+ *                         (q and k0 from state + position, v0 from the state: one univs_small_linear launch)
+ *   kd, vd [Q_p, L, T, E] the dense tokens' key / value projections, in the layout the tokens have in the memory pool
+ *   out [Q_p * T, E]      softmax(scale q [k0; kd]^T) [v0; vd], heads concatenated (the input of out_proj)
+ * Covered: head_dim == 32, (1 + L) * 4 bytes of LDS <= 64 KB; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_proca_attention_f32(const float* qkv0, const float* kd, const float* vd, int Qp, int L, int T, int heads, int head_dim,
+                              float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,68 @@ def test_head_matches_reference(cuda, golden_dir, name, dec_over, targets_fn, se
         helpers.check_head_outputs(out3, g, "clip3_", tol=1e-3)
 
 
+def test_fused_proca_equals_the_layered_path(cuda):
+    """ProCA without building `memory` (univs_decoder._proca_fused: q / k0 / v0 in one few-rows launch, the dense tokens' K / V
+    Linears on the tokens in place, ops.proca_attention, out_proj + residual + LayerNorm in one launch) == the reference's layered
+    sequence (concatenations, nn.MultiheadAttention) on the second clip of the visual-prompt scenario; and it is the path that runs."""
+    from univs_amd.switches import override
+    name, dec_over, targets_fn, seed = [s for s in helpers.HEAD_SCENARIOS if s[0] == "g7_head_visual_prompts"][0]
+    head = helpers.build_head(cases.HEAD_CASE, cuda, **dec_over)
+    calls = []
+    orig = ops.proca_attention
+    ops.proca_attention = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        outs = []
+        for fused in (True, False):
+            n0 = len(calls)
+            with torch.no_grad(), override(fused_proca=fused):
+                torch.manual_seed(seed)
+                outs.append(head(_to(cases.backbone_features(), cuda), targets=_targets_to(targets_fn(), cuda)))
+            assert (len(calls) - n0 > 0) == fused
+    finally:
+        ops.proca_attention = orig
+    assert len(calls) == len(head.predictor.transformer_prompt_self_attention_layers)     # one attention launch per ProCA layer
+    for k in ("pred_masks", "pred_logits", "pred_embds"):
+        err = (outs[0][k] - outs[1][k]).abs().max().item()
+        assert err < 2e-4 * max(1.0, outs[1][k].abs().max().item()), (k, err)
+    assert ((outs[0]["pred_masks"] > 0) != (outs[1]["pred_masks"] > 0))[outs[1]["pred_masks"].abs() > 1e-3].sum() == 0
+
+
+def test_prompted_clip_aten_operator_budget(cuda):
+    """The steady-state clip of a video (second clip, 10 entities carried as visual prompts, BASELINE config 2's size) is launch-bound on
+    the host: the number of ATen operators that launch a kernel -- what the prompt sampler, the memory-pool read and ProCA cost beside
+    the hand-written operators -- is part of the contract (584 in round 5's tree, 478 with ProCA fused and the frequency vectors
+    cached: tools/launch_sources.py lists them by source line).  The bound keeps it from creeping back."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from univs_amd import workloads
+    swin, head = workloads.build_model(cuda)
+    case = dict(workloads.CFG2, H=736, W=1280)
+    x = workloads.preprocess(workloads.cfg2_frames()).to(cuda)
+    tv0 = workloads.targets_with_entities(case, first_frame_idx=1, n_ent=10)[0]
+    tvd = {k: (v.to(cuda) if isinstance(v, torch.Tensor) else v) for k, v in tv0.items()}
+    views = ("view", "reshape", "expand", "permute", "transpose", "t.default", "slice", "select", "unsqueeze", "squeeze", "detach", "alias",
+             "as_strided", "unbind", "split", "chunk", "_unsafe_view", "empty", "sym_", "size", "stride", "is_", "unflatten", "narrow",
+             "movedim", "flatten", "lift_fresh", "_local_scalar_dense", "item", "resize_", "set_", "zeros.default", "result_type", "unfold")
+
+    class Count(TorchDispatchMode):
+        n = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func).replace("aten.", "")
+            if not any(name.startswith(p) or ("." + p) in name for p in views):
+                Count.n += 1
+            return func(*args, **(kwargs or {}))
+    with torch.no_grad():
+        feats = swin(x)
+        for _ in range(2):
+            head(feats, targets=[dict(tvd)])
+        with Count():
+            out = head(feats, targets=[dict(tvd)])
+    assert out["pred_masks"].shape[1] == 110
+    print(f"prompted clip: {Count.n} ATen operators that launch")
+    assert Count.n <= 520, Count.n
+
+
 def test_head_t10_q200_matches_reference(cuda, golden_dir):
     """The decoder at BASELINE config 5's length (T = 10, 200 queries: 2 000-token spatio-temporal self-attention, class means
     over 10 frames) against the reference head run on reduced-resolution synthetic features (golden g6c): mask logits within

@@ -1738,3 +1738,24 @@ def test_linear_tile_kernel_is_bit_identical_to_the_pass_kernel(cuda, M, K, N, a
         ref = ref + r.double()
     scale = (x.double().abs() @ w.double().abs().t()).max().item()
     assert (got.double() - ref).abs().max().item() < 2e-6 * scale
+
+
+@pytest.mark.parametrize("Qp,L,T", [(10, 896, 5), (3, 1, 2), (1, 0, 1), (7, 130, 3)], ids=str)
+def test_proca_attention_matches_the_reference_sequence(cuda, Qp, L, T):
+    """univs_proca_attention_f32 (csrc/proca_attn.hip) == the reference's ProCA attention (…decoder_univs.py:456-496 ->
+    nn.MultiheadAttention): memory = [state; dense tokens] per (prompt query, frame), q k^T / sqrt(d), softmax, p v -- here from
+    already projected operands, against torch in float64."""
+    E, h = 256, 8
+    qkv0 = synth.normal(f"proca/qkv{Qp}", (Qp * T, 3 * E)).to(cuda)
+    kd = synth.normal(f"proca/kd{Qp}", (Qp, L, T, E)).to(cuda)
+    vd = synth.normal(f"proca/vd{Qp}", (Qp, L, T, E)).to(cuda)
+    got = ops.proca_attention(qkv0, kd, vd, h)
+    assert got is not None and tuple(got.shape) == (Qp * T, E)
+    q, k0, v0 = qkv0.double().view(Qp, T, 3, h, 32).unbind(2)                              # [Qp, T, h, d]
+    k = torch.cat([k0[:, None], kd.double().view(Qp, L, T, h, 32)], 1)                   # [Qp, 1 + L, T, h, d]
+    v = torch.cat([v0[:, None], vd.double().view(Qp, L, T, h, 32)], 1)
+    s = torch.einsum("qthd,qlthd->qthl", q, k) / 32 ** 0.5
+    want = torch.einsum("qthl,qlthd->qthd", s.softmax(-1), v).reshape(Qp * T, E)
+    assert (got.double() - want).abs().max().item() < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.proca_attention(qkv0[:, :-1], kd, vd, h)

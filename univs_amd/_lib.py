@@ -81,6 +81,7 @@ SIGNATURES = {
     "univs_layer_norm_add_f32": (_I, [_P, _P, _P, _P, _P, _c.c_longlong, _c.c_longlong, _I, _c.c_float, _P, _P, _P, _P]),
     "univs_group_norm_f32": (_I, [_P, _P, _P, _I, _I, _c.c_longlong, _I, _c.c_float, _I, _P, _c.c_longlong, _P, _P]),
     "univs_masked_softmax_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "univs_proca_attention_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _c.c_float, _P, _P]),
 }
 
 _lib = None

@@ -67,6 +67,7 @@ int patch_merge_norm_f32(const float*, const float*, const float*, int, int, int
 int group_norm_f32(const float*, const float*, const float*, int, int, long long, int, float, int, float*, long long,
                    float*, hipStream_t);
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
+int proca_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float, float*, hipStream_t);
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
@@ -843,6 +844,27 @@ int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, i
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
   return masked_softmax_f32(scores, mask, N, h, L, S, static_cast<hipStream_t>(stream));
+}
+
+int univs_proca_attention_f32(const float* qkv0, const float* kd, const float* vd, int Qp, int L, int T, int heads, int head_dim,
+                              float scale, float* out, void* stream) {
+  clear_sticky_error();
+  if (Qp < 0 || L < 0 || T < 0 || heads < 1 || head_dim < 1) {
+    set_error("univs_proca_attention_f32: bad dimensions Qp=%d L=%d T=%d heads=%d head_dim=%d", Qp, L, T, heads, head_dim);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)Qp * T == 0) return UNIVS_OK;
+  if (!qkv0 || !out || (L > 0 && (!kd || !vd))) {
+    set_error("univs_proca_attention_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = proca_attention_f32(qkv0, kd, vd, Qp, L, T, heads, head_dim, scale, out, static_cast<hipStream_t>(stream));
+  if (rc > 0) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_proca_attention_f32: shape not covered (head_dim == 32, 1 + L <= 16384)");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
 }
 
 int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias,

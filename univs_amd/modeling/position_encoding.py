@@ -17,9 +17,17 @@ from torch import nn
 from ..layers import to_device_async
 
 
+_DIM_T = {}      # (num_feats, temperature, device) -> the frequency vector: a constant (five tiny launches per call otherwise, and the
+                 # prompt path asks for it a dozen times per clip)
+
+
 def _dim_t(num_feats, temperature, device):
-    i = torch.arange(num_feats, dtype=torch.float32, device=device)
-    return temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_feats)
+    key = (int(num_feats), float(temperature), str(device))
+    v = _DIM_T.get(key)
+    if v is None:
+        i = torch.arange(num_feats, dtype=torch.float32, device=device)
+        v = _DIM_T[key] = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_feats)
+    return v
 
 
 def _interleaved_sincos(v, dim_t):
@@ -118,11 +126,9 @@ class _Sine3DBase(nn.Module):
         F_ = self.num_pos_feats
         dim_t = _dim_t(F_, self.temperature, dev)
         dim_t_z = _dim_t(2 * F_, self.temperature, dev)
-        x, y = xy.unbind(-1)
-        pos_x = _interleaved_sincos(x * self.scale, dim_t)   # [n, F]
-        pos_y = _interleaved_sincos(y * self.scale, dim_t)
-        pos_z = _interleaved_sincos(z, dim_t_z)              # [t, 2F]
-        return torch.cat((pos_y, pos_x), dim=-1)[None] + pos_z[:, None, :]
+        pos_xy = _interleaved_sincos(xy * self.scale, dim_t)    # [n, 2 (x, y), F]: both coordinates in one pass
+        pos_z = _interleaved_sincos(z, dim_t_z)                 # [t, 2F]
+        return torch.cat((pos_xy[..., 1, :], pos_xy[..., 0, :]), dim=-1)[None] + pos_z[:, None, :]
 
 
 class PositionEmbeddingSine3D(_Sine3DBase):

@@ -168,6 +168,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         # None (default): a call without targets raises, as the reference's decoder does (it dereferences targets[0], :310)
         self.default_dataset_name = None
         self._clip_norm_cache = None
+        self._proca_kin = None       # (feats, pos, feats + pos, feats contiguous) of the clip in flight: _proca_fused
         self._sa_mask_cache = {}
         with torch.no_grad():  # the reference's init for the two temperatures (:233-236)
             self.cls_temp.weight.fill_(math.log(1 / 0.07))
@@ -216,6 +217,7 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
     @fp32_region
     def forward(self, x, mask_features, mask_features_bfe_conv=None, mask=None, targets=None):
         assert not self.training, "inference-only module (training is out of scope of the hot path)"
+        self._proca_kin = None
         bt, c_m, h_m, w_m = mask_features.shape
         bs, t = 1, bt  # all input frames form one video at inference (:310)
         assert len(x) == self.num_feature_levels
@@ -392,6 +394,12 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         nq = self.num_queries
         output_learn, output_prompt = output[:nq], output[nq:]
         query_emb_prompt = query_emb[nq:]
+        layer = self.transformer_prompt_self_attention_layers[i]
+        if (SWITCHES.fused_proca and output.is_cuda and output.dtype == torch.float32 and prompt_pos_dense is not None
+                and not layer.normalize_before and not layer.need_weights and not torch.is_grad_enabled()):
+            o = self._proca_fused(layer, output_prompt, query_emb_prompt, prompt_feats_dense, prompt_pos_dense)
+            if o is not None:
+                return torch.cat([output_learn, o])
         mem = torch.cat([output_prompt.unsqueeze(1), prompt_feats_dense], dim=1)     # Q_p x (1+L) x T x C
         mem = mem.transpose(0, 1).flatten(1, 2)                                     # (1+L) x Q_pT x C
         if prompt_pos_dense is not None:
@@ -403,6 +411,35 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
         o = self.transformer_prompt_self_attention_layers[i](output_prompt.flatten(0, 1)[None], mem,
                                                              pos=mpos, query_pos=qpos)
         return torch.cat([output_learn, o.view(Q_p, NT, -1)])
+
+    def _proca_fused(self, layer, output_prompt, query_emb_prompt, feats_dense, pos_dense):
+        """One ProCA layer (post-norm CrossAttentionLayer, transformer_layers.py:95-115) without building `memory`: the first key /
+        value are the prompt query's own state (k0 from state + query position, v0 from the state: the same few-rows launch as q);
+        the dense tokens' keys come from `feats + pos` -- the sum is made ONCE per clip, it does not change across the layers -- and
+        their values from `feats`, two tall Linears on the tokens in the memory pool's layout [Q_p, L, T, C]; one attention launch
+        (ops.proca_attention); out_proj + residual + LayerNorm in one few-rows launch.  None: not covered (the caller's path)."""
+        from ...layers import linear, linear_norm
+        mha = layer.multihead_attn
+        E, h = mha.embed_dim, mha.num_heads
+        Q_p, T, _ = output_prompt.shape
+        L = feats_dense.shape[1]
+        if E // h != 32 or tuple(feats_dense.shape) != (Q_p, L, T, E) or tuple(pos_dense.shape) != (Q_p, L, T, E):
+            return None
+        x = output_prompt.reshape(Q_p * T, E)
+        qkv0 = ops.small_linear(x, mha.in_proj_weight, mha.in_proj_bias, x_add=query_emb_prompt.reshape(Q_p * T, E), add_features=2 * E)
+        if qkv0 is None:
+            return None
+        c = self._proca_kin
+        if c is None or c[0] is not feats_dense or c[1] is not pos_dense:
+            c = self._proca_kin = (feats_dense, pos_dense, (feats_dense + pos_dense).contiguous(), feats_dense.contiguous())
+        wk, bk = mha._packed_rows(E, E)
+        wv, bv = mha._packed_rows(2 * E, E)
+        kd = linear(c[2].view(-1, E), wk, bk).view(Q_p, L, T, E)
+        vd = linear(c[3].view(-1, E), wv, bv).view(Q_p, L, T, E)
+        out = ops.proca_attention(qkv0, kd, vd, h)
+        if out is None:
+            return None
+        return linear_norm(out, mha.out_proj, x, layer.norm).view(Q_p, T, E)
 
     def _clip_normalized(self, like):
         c = self._clip_norm_cache

@@ -6,6 +6,7 @@ operator ("Not implemented on the CPU", ops/src/ms_deform_attn.h:43) and there i
 import contextlib
 import weakref
 import ctypes
+import math
 import os
 
 import torch
@@ -1239,6 +1240,27 @@ def masked_softmax_(scores, mask=None):
         rc = _lib.load().univs_masked_softmax_f32(_ptr(scores), mptr, N, h, L, S, _stream_ptr(scores))
     _lib.check(rc, "masked_softmax_")
     return scores
+
+
+def proca_attention(qkv0, kd, vd, num_heads):
+    """ProCA attention (include/univs_hip.h: univs_proca_attention_f32; csrc/proca_attn.hip): qkv0 [Q_p * T, 3 E] (query, first key,
+    first value of every (prompt query, frame)), kd / vd [Q_p, L, T, E] (the dense prompt tokens' key / value projections) ->
+    [Q_p * T, E] = softmax(q [k0; kd]^T / sqrt(d)) [v0; vd].  None when the shape is not covered (head_dim != 32)."""
+    _inference_only("proca_attention", qkv0, kd, vd)
+    _require_gpu("proca_attention", qkv0, kd, vd)
+    Qp, L, T, E = kd.shape
+    h = int(num_heads)
+    if (any(t.dtype != torch.float32 or not t.is_contiguous() for t in (qkv0, kd, vd)) or tuple(vd.shape) != tuple(kd.shape)
+            or tuple(qkv0.shape) != (Qp * T, 3 * E) or E % h):
+        raise RuntimeError("proca_attention: contiguous float32 qkv0 [Q_p T, 3 E], kd / vd [Q_p, L, T, E]")
+    out = torch.empty((Qp * T, E), dtype=torch.float32, device=kd.device)
+    with _on(kd):
+        rc = _lib.load().univs_proca_attention_f32(_ptr(qkv0), _ptr(kd), _ptr(vd), Qp, L, T, h, E // h, 1.0 / math.sqrt(E // h), _ptr(out),
+                                                   _stream_ptr(kd))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "proca_attention")
+    return out
 
 
 def _seq_first_ld(t, N, E):

@@ -60,6 +60,9 @@ class Switches:
     # stage to stage through LDS (csrc/small_linear.hip: small_chain_kernel; bit-identical to the separate launches); `small_mlp_norm`:
     # the `decoder_norm` LayerNorm in front of it inside the same launch (its own fp32 rounding: not bit-identical to ATen's kernel)
     small_mlp_chain: bool = True
+    # ProCA (a prompt query attends to its own prompt tokens) without the per-layer concatenations / transpositions: the dense tokens'
+    # K / V projections on the tokens where they lie, q / k0 / v0 in one few-rows launch, one attention launch (csrc/proca_attn.hip)
+    fused_proca: bool = True
     small_mlp_norm: bool = True
     # the W-resident Linears (K <= 768) stage their slab of W from the split image cached per weight tensor (a copy) instead of
     # splitting it in every workgroup of every launch (13 - 15 us per launch: profiles/r05_gemm_phase_trace_v1.txt)
@@ -80,7 +83,7 @@ SWITCHES = Switches(
     sampler=os.environ.get("UNIVS_SAMPLER", "auto"), graphs=_flag("UNIVS_GRAPHS", False),
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
     fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True),
-    resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True), small_mlp_chain=_flag("UNIVS_SMALL_MLP_CHAIN", True),
+    resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True), small_mlp_chain=_flag("UNIVS_SMALL_MLP_CHAIN", True), fused_proca=_flag("UNIVS_FUSED_PROCA", True),
     small_mlp_norm=_flag("UNIVS_SMALL_MLP_NORM", True))
 if SWITCHES.sampler not in ("auto", "reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'auto', 'reference' or 'device')")
