@@ -67,6 +67,27 @@ for b in range(256):
 per_wg = np.array(per_wg)
 print(f"workgroups {len(per_wg)}: span of traced items mean {per_wg[:, 0].mean():.0f} ticks (min {per_wg[:, 0].min()}, max {per_wg[:, 0].max()}), "
       f"between-item gaps (cold starts) mean {per_wg[:, 1].mean():.0f} max single {per_wg[:, 2].max()}, items per workgroup mean {per_wg[:, 3].mean():.1f}")
+# who is slow: the ten longest spans with their item / segment counts, and the XCD means (workgroup b runs on XCD b % 8)
+rows = []
+for b in range(256):
+    n = int(valid[b].sum())
+    if n < 1: continue
+    t = st[b, :n, 0, :]
+    gaps = t[1:, 0] - t[:-1, 9]
+    nseg = 1 + int((gaps > 3000).sum())
+    rows.append((int(t[-1, 9] - t[0, 0]), b, n, nseg, int(gaps[gaps > 3000].sum()) if n > 1 else 0, float((t[:, 9] - t[:, 0]).mean())))
+rows.sort(reverse=True)
+print("slowest workgroups (span, block, items, segments, cold gaps, mean item):", rows[:8])
+print("fastest workgroups:", rows[-5:])
+import collections
+byx = collections.defaultdict(list)
+for r in rows: byx[r[1] % 8].append(r)
+for x in sorted(byx):
+    v = byx[x]
+    print(f"  XCD {x}: span mean {np.mean([r[0] for r in v]):.0f} max {max(r[0] for r in v)}, items mean {np.mean([r[2] for r in v]):.2f}, segments mean {np.mean([r[3] for r in v]):.2f}, item mean {np.mean([r[5] for r in v]):.0f}")
+by = collections.defaultdict(list)
+for r in rows: by[(r[2], r[3])].append(r[0])
+print("span by (items, segments):", {k: (len(v), int(np.mean(v))) for k, v in sorted(by.items())})
 t0 = st[valid][:, 0, 0].min()
 ends = np.array([st[b, int(valid[b].sum()) - 1, 0, 9] for b in range(256) if valid[b].sum() > 0]) - t0
 starts = np.array([st[b, 0, 0, 0] for b in range(256) if valid[b].sum() > 0]) - t0
