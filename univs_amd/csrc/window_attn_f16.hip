@@ -69,14 +69,16 @@ __device__ __forceinline__ bool wh_out_of_range(float mx, float lo) {
   return __builtin_amdgcn_ballot_w64(!(mx < 32768.0f)) != 0 || __builtin_amdgcn_ballot_w64(mx >= lo) == 0;
 }
 
-template <int NB, bool MASK4, int TERMS>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
-__global__ __launch_bounds__(64 * wh_waves(NB, TERMS)) void window_attn_img_f16(const float* __restrict__ qkv,
+// NWV: waves per workgroup (wh_waves(NB, TERMS) by default; 12 for the three-product kernel on 7 x 7 windows where a launch's
+// rounds come out fewer: 156 VGPRs allow three waves per SIMD, 17 + 12 x 8.7 KB of LDS one workgroup per CU)
+template <int NB, bool MASK4, int TERMS, int NWV = wh_waves(NB, TERMS)>   // MASK4: ws*ws is a multiple of 4 (mask rows 16-byte aligned)
+__global__ __launch_bounds__(64 * NWV) void window_attn_img_f16(const float* __restrict__ qkv,
                                                                       const float* __restrict__ qkv_bias,
                                                                       const float* __restrict__ bias,
                                                                       const float* __restrict__ shift_mask, int B_, int nW,
                                                                       int nH, float scale, float* __restrict__ out,
                                                                       WinImage wi, int magic) {
-  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + WH_VT_PAD, WH_WAVES = wh_waves(NB, TERMS);
+  constexpr int HD = 32, NP = 16 * NB, BS = NP + 4, VS = NP + WH_VT_PAD, WH_WAVES = NWV;
   constexpr int VR = (NB + 1) / 2;   // V staging rounds: lanes 0-31 take key block r, lanes 32-63 block r + VR
   constexpr float LOG2E = 1.4426950408889634f;
   const int Ntok = wi.ws * wi.ws;
@@ -382,19 +384,26 @@ __global__ __launch_bounds__(64 * wh_waves(NB, TERMS)) void window_attn_img_f16(
   }
 }
 
-template <int NB, bool MASK4, int TERMS>
+template <int NB, bool MASK4, int TERMS, int NWV = wh_waves(NB, TERMS)>
 static int launch_f16(const float* qkv, const float* qkv_bias, const float* bias, const float* shift_mask, int B_, int nW,
                       int nH, float scale, float* out, const WinImage& wi, int n_cu, hipStream_t st) {
   constexpr int NP = 16 * NB;
-  constexpr int WH_WAVES = wh_waves(NB, TERMS);
+  constexpr int WH_WAVES = NWV;
   const size_t lds = (size_t)NP * (NP + 4) * sizeof(float) + (size_t)WH_WAVES * (TERMS == 3 ? 2 : 1) * 32 * (NP + WH_VT_PAD) * sizeof(_Float16);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
   // workgroups = resident slots rounded DOWN to a multiple of the head count: one extra workgroup would double the tail
   int gx = std::max(1, n_cu * per_cu / nH);
+  if constexpr (NB == 4 && TERMS == 3 && NWV == 8) {
+    // 7 x 7 windows: a workgroup of 12 waves (three per SIMD) takes ~1.28 x the time of one of 8 per round of windows (measured
+    // at the four Swin-T stages, gpurun_out/r06_u): it runs where it saves more rounds than that
+    const long long r8 = ((long long)B_ + (long long)gx * 8 - 1) / ((long long)gx * 8), r12 = ((long long)B_ + (long long)gx * 12 - 1) / ((long long)gx * 12);
+    if (1.28 * (double)r12 < (double)r8)
+      return launch_f16<NB, MASK4, TERMS, 12>(qkv, qkv_bias, bias, shift_mask, B_, nW, nH, scale, out, wi, n_cu, st);
+  }
   gx = std::min(gx, (B_ + WH_WAVES - 1) / WH_WAVES);
-  const void* fn = reinterpret_cast<const void*>(&window_attn_img_f16<NB, MASK4, TERMS>);
+  const void* fn = reinterpret_cast<const void*>(&window_attn_img_f16<NB, MASK4, TERMS, NWV>);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((window_attn_img_f16<NB, MASK4, TERMS>), dim3(gx, nH), dim3(64 * WH_WAVES), lds, st, qkv, qkv_bias, bias, shift_mask,
+  hipLaunchKernelGGL((window_attn_img_f16<NB, MASK4, TERMS, NWV>), dim3(gx, nH), dim3(64 * WH_WAVES), lds, st, qkv, qkv_bias, bias, shift_mask,
                      B_, nW, nH, scale, out, wi, (65536 + wi.ws - 1) / wi.ws);
   return check_launch("window_attn_img_f16");
 }
