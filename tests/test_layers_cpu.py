@@ -29,20 +29,30 @@ def test_library_fallback_is_logged_once(caplog):
     import logging
     from univs_amd import layers
 
-    class FakeCuda:                     # a stand-in with the three attributes the note reads
+    class FakeCuda:                     # a stand-in with the attributes the note reads
         is_cuda = True
         shape = (300, 100)
+        requires_grad = False
+        dtype = torch.float32
 
         def numel(self):
             return 300 * 100
     w = torch.zeros(7, 100)
     layers._LIBRARY_FALLBACKS.clear()
+    layers.reset_library_linear_counts()
     with caplog.at_level(logging.INFO, logger="univs_amd"):
-        layers._note_library_linear(FakeCuda(), w)
-        layers._note_library_linear(FakeCuda(), w)
+        with torch.no_grad():
+            layers._note_library_linear(FakeCuda(), w)
+            layers._note_library_linear(FakeCuda(), w)
         layers._note_library_linear(torch.zeros(3, 100), w)
+        half = FakeCuda()
+        half.shape, half.dtype = (300, 64), torch.float16
+        with torch.no_grad():
+            layers._note_library_linear(half, torch.zeros(5, 64, dtype=torch.float16))
     recs = [r for r in caplog.records if r.name == "univs_amd"]
-    assert len(recs) == 1 and "100 -> 7" in recs[0].getMessage()
+    assert len(recs) == 2 and "100 -> 7" in recs[0].getMessage() and "shape not covered" in recs[0].getMessage()
+    assert "64 -> 5" in recs[1].getMessage() and "float16" in recs[1].getMessage()          # the actual reason is logged
+    assert layers.LIBRARY_LINEAR_COUNTS == {("F.linear", 100, 7): 2, ("F.linear", 64, 5): 1}  # every call is counted
 
 
 def test_packed_in_projection_rows_are_cached_whole_tensors_without_autograd():
