@@ -96,7 +96,7 @@ def test_device_sampler_draws_are_reproducible_on_the_gpu(cuda):
     """The device-side prompt sampler on the GPU: after `begin_video` under the same `torch.manual_seed`, the same inputs give the same
     points and dense tokens bit for bit, whatever was drawn in between; another seed gives other draws; the draws lie inside the masks."""
     from tests.test_sampler_device_cpu import HF, R, S, WF, encoders, scene
-    dev = encoders()[1].to(cuda)
+    dev = encoders()[1]
     masks, feats, pos = (t.to(cuda) for t in scene())
     runs = []
     for seed in (5, 5, 6):
