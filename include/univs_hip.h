@@ -616,6 +616,43 @@ int univs_masked_softmax_f32(float* scores, const uint8_t* mask, int N, int h, i
 int univs_proca_attention_f32(const float* qkv0, const float* kd, const float* vd, int Qp, int L, int T, int heads, int head_dim,
                               float scale, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Visual-prompt sampler of a prompted clip (csrc/prompt_sampler.hip): the device part of VisualPromptEncoder.get_mask_prompt for the
+ * F key frames x n entities of a clip at once (entity-frame i = f * n + e).
+ * Replaces: univs/modeling/prompt_encoder/prompt_encoder.py:168-263 (get_mask_prompt), :362-442 (select_points_from_box_mask, mask
+ *           branch), :445-497 (get_dense_features) and univs/utils/comm.py:6-39 (convert_box_to_mask) -- per key frame ~110 ATen
+ *           launches in the reference (boolean indexing, nonzero, randperm on the host, gathers).
+ *
+ * univs_prompt_prefix_f32: everything that depends on the annotations only.
+ *   masks [F n, h, w] float32, boxes [F n, 4] normalised xyxy, scale = h / h_img (the masks' stride over the 1/8 feature map)
+ *   stats [2 F n + F] uint32, ZERO on entry (scratch: ordered-float maxima)
+ *   -> feat_masks [F n, h_img, w_img] (nearest), sel [F n, h, w] bytes (candidate pixels of the point draw: the central half of the
+ *      box where the mask reaches min(max, 0.75); without such a pixel the pixels >= min(max, 0.95)), rowcnt [F n, h] int32 (their
+ *      count per image row), fmb [F n, h_img w_img] bytes (feat_masks >= min(max over the frame, mask_thresh)), counts [F, 2 n] int32
+ *      (candidates per entity, then feature pixels per entity: the sizes of the reference's two randperm draws), valid / visible
+ *      [F n] bytes (max > mask_thresh / max > 0).
+ * univs_prompt_draw: the draws -> pixels.  Either (u [F n], keys [F n, HW]) uniform numbers in [0, 1) -- the point's rank =
+ *   floor(u count), the R dense pixels = the R largest keys among the mask's feature pixels in decreasing order when it has >= R,
+ *   its pixels cyclically when it has fewer -- or tab [F n, R + 2] int64 explicit ranks (R dense ranks, an "empty" flag, the point's
+ *   rank: the reference's randperm values); the other one NULL.
+ *   -> point_idx [F n] int64 (y w + x), point_coords [F n, 2] ((x + .5) / w, (y + .5) / h), dense_idx [F n, R] int64 (feature-map
+ *      pixels), empty [F n] bytes.  UNIVS_ERR_NOT_IMPLEMENTED when the keys of one entity exceed the LDS (HW > ~36 000).
+ * univs_prompt_tokens_f32: the dense tokens fd / pd [F n, R, T, C] = features / position embeddings at the sampled pixels of the key
+ *   frame's maps (feats / pos [F, C, HW] addressed through element strides {frame, channel, pixel}); the pooled token qfeat / qpe
+ *   [F n, C] for an empty mask; zeros for invalid entities; replicated over the T frames -- and the cross-attention masks attn
+ *   [F, T, 1, n, HW] bytes: at frame kf[f] everything outside the box of a valid entity, zero elsewhere.
+ * ------------------------------------------------------------------------------------------- */
+int univs_prompt_prefix_f32(const float* masks, const float* boxes, int F, int n, int h, int w, int scale, float mask_thresh,
+                            float* feat_masks, uint32_t* stats, uint8_t* sel, int32_t* rowcnt, uint8_t* fmb, int32_t* counts,
+                            uint8_t* valid, uint8_t* visible, void* stream);
+int univs_prompt_draw(const uint8_t* sel, const int32_t* rowcnt, const uint8_t* fmb, const int32_t* counts, const float* u,
+                      const float* keys, const int64_t* tab, int F, int n, int h, int w, int HW, int R, int64_t* point_idx,
+                      int64_t* dense_idx, uint8_t* empty, float* point_coords, void* stream);
+int univs_prompt_tokens_f32(const float* feats, const int64_t* feats_strides, const float* pos, const int64_t* pos_strides,
+                            const float* qfeat, const float* qpe, const int64_t* dense_idx, const uint8_t* empty, const uint8_t* valid,
+                            const float* boxes, const int64_t* kf, int F, int n, int R, int T, int C, int h_img, int w_img, float* fd,
+                            float* pd, uint8_t* attn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,9 @@ SIGNATURES = {
     "univs_group_norm_f32": (_I, [_P, _P, _P, _I, _I, _c.c_longlong, _I, _c.c_float, _I, _P, _c.c_longlong, _P, _P]),
     "univs_masked_softmax_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "univs_proca_attention_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _c.c_float, _P, _P]),
+    "univs_prompt_prefix_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _c.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "univs_prompt_draw": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "univs_prompt_tokens_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
 }
 
 _lib = None

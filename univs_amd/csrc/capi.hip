@@ -68,6 +68,13 @@ int group_norm_f32(const float*, const float*, const float*, int, int, long long
                    float*, hipStream_t);
 int masked_softmax_f32(float*, const unsigned char*, int, int, int, int, hipStream_t);
 int proca_attention_f32(const float*, const float*, const float*, int, int, int, int, int, float, float*, hipStream_t);
+int prompt_prefix_f32(const float*, const float*, int, int, int, int, int, float, float*, unsigned*, uint8_t*, int*, uint8_t*, int*, uint8_t*,
+                      uint8_t*, hipStream_t);
+int prompt_draw(const uint8_t*, const int*, const uint8_t*, const int*, const float*, const float*, const long long*, int, int, int, int, int,
+                int, long long*, long long*, uint8_t*, float*, hipStream_t);
+int prompt_tokens_f32(const float*, const long long*, const float*, const long long*, const float*, const float*, const long long*,
+                      const uint8_t*, const uint8_t*, const float*, const long long*, int, int, int, int, int, int, int, float*, float*,
+                      uint8_t*, hipStream_t);
 int window_attention_image_f32(const float*, const float*, const float*, const float*, int, int, int, int, int, int,
                                int, float, float*, hipStream_t);
 int presplit_f16x3(const float*, int, int, int, int, void*, float*, hipStream_t);
@@ -865,6 +872,72 @@ int univs_proca_attention_f32(const float* qkv0, const float* kd, const float* v
     return UNIVS_ERR_NOT_IMPLEMENTED;
   }
   return rc;
+}
+
+int univs_prompt_prefix_f32(const float* masks, const float* boxes, int F, int n, int h, int w, int scale, float mask_thresh,
+                            float* feat_masks, uint32_t* stats, uint8_t* sel, int32_t* rowcnt, uint8_t* fmb, int32_t* counts,
+                            uint8_t* valid, uint8_t* visible, void* stream) {
+  clear_sticky_error();
+  if (F < 0 || n < 0 || h < 1 || w < 1 || scale < 1 || h % scale || w % scale || (long long)F * n > 65535) {
+    set_error("univs_prompt_prefix_f32: bad dimensions F=%d n=%d h=%d w=%d scale=%d", F, n, h, w, scale);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)F * n == 0) return UNIVS_OK;
+  if (!masks || !boxes || !feat_masks || !stats || !sel || !rowcnt || !fmb || !counts || !valid || !visible) {
+    set_error("univs_prompt_prefix_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return prompt_prefix_f32(masks, boxes, F, n, h, w, scale, mask_thresh, feat_masks, stats, sel, rowcnt, fmb, counts, valid, visible,
+                           static_cast<hipStream_t>(stream));
+}
+
+int univs_prompt_draw(const uint8_t* sel, const int32_t* rowcnt, const uint8_t* fmb, const int32_t* counts, const float* u,
+                      const float* keys, const int64_t* tab, int F, int n, int h, int w, int HW, int R, int64_t* point_idx,
+                      int64_t* dense_idx, uint8_t* empty, float* point_coords, void* stream) {
+  clear_sticky_error();
+  if (F < 0 || n < 0 || h < 1 || w < 1 || HW < 1 || R < 1 || (long long)F * n > 65535) {
+    set_error("univs_prompt_draw: bad dimensions F=%d n=%d h=%d w=%d HW=%d R=%d", F, n, h, w, HW, R);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)F * n == 0) return UNIVS_OK;
+  if (!sel || !rowcnt || !fmb || !counts || !point_idx || !dense_idx || !empty || !point_coords) {
+    set_error("univs_prompt_draw: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((tab != nullptr) == (u != nullptr || keys != nullptr) || (!tab && (!u || !keys))) {
+    set_error("univs_prompt_draw: either (u, keys) or tab");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = prompt_draw(sel, rowcnt, fmb, counts, u, keys, reinterpret_cast<const long long*>(tab), F, n, h, w, HW, R,
+                             reinterpret_cast<long long*>(point_idx), reinterpret_cast<long long*>(dense_idx), empty, point_coords,
+                             static_cast<hipStream_t>(stream));
+  if (rc > 0) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_prompt_draw: the keys of one entity do not fit the LDS (HW = %d)", HW);
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
+}
+
+int univs_prompt_tokens_f32(const float* feats, const int64_t* feats_strides, const float* pos, const int64_t* pos_strides,
+                            const float* qfeat, const float* qpe, const int64_t* dense_idx, const uint8_t* empty, const uint8_t* valid,
+                            const float* boxes, const int64_t* kf, int F, int n, int R, int T, int C, int h_img, int w_img, float* fd,
+                            float* pd, uint8_t* attn, void* stream) {
+  clear_sticky_error();
+  if (F < 0 || n < 0 || R < 1 || T < 1 || C < 1 || h_img < 1 || w_img < 1 || (long long)F * T * n > 65535) {
+    set_error("univs_prompt_tokens_f32: bad dimensions F=%d n=%d R=%d T=%d C=%d h_img=%d w_img=%d", F, n, R, T, C, h_img, w_img);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)F * n == 0) return UNIVS_OK;
+  if (!feats || !feats_strides || !pos || !pos_strides || !qfeat || !qpe || !dense_idx || !empty || !valid || !boxes || !kf || !fd || !pd ||
+      !attn) {
+    set_error("univs_prompt_tokens_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return prompt_tokens_f32(feats, reinterpret_cast<const long long*>(feats_strides), pos, reinterpret_cast<const long long*>(pos_strides),
+                           qfeat, qpe, reinterpret_cast<const long long*>(dense_idx), empty, valid, boxes,
+                           reinterpret_cast<const long long*>(kf), F, n, R, T, C, h_img, w_img, fd, pd, attn,
+                           static_cast<hipStream_t>(stream));
 }
 
 int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias,

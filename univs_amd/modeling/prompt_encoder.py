@@ -286,6 +286,10 @@ class VisualPromptEncoder:
         s = self.img_feats_scale
         assert (h_img * s == h) and (w_img * s == w), \
             f"Input images must have same size with masks: {(h, w), (h_img * s, w_img * s)}"
+        if SWITCHES.fused_sampler and masks.is_cuda and boxes is not None and Fk * n > 0 and mask_thresh == 0.5:
+            # three launches instead of ~80 (csrc/prompt_sampler.hip), the same values bit for bit
+            from .. import ops
+            return ops.prompt_prefix(masks.float(), boxes.float().to(masks.device), s, mask_thresh)
         flat = masks.reshape(Fk * n, h, w)
         mx = flat.amax(2).amax(1)                             # two short reductions
         valid = mx > mask_thresh                              # some pixel above the threshold
@@ -393,7 +397,10 @@ class VisualPromptEncoder:
         valid, feat_masks, fmb = pre["valid"].reshape(N), pre["feat_masks"], pre["feat_masks_binary"]
         m = fmb.reshape(N, HW)
         # ---- the draws: a rank among the candidate pixels per entity, R ranks among the mask's feature pixels per entity
-        dense_idx = None
+        dense_idx = point_coords = None
+        fused = SWITCHES.fused_sampler and img_features.is_cuda and all(pre[k].is_contiguous() for k in ("sel", "rowcnt", "feat_masks_binary", "counts"))
+        if fused:
+            from .. import ops
         if self._replay is not None:
             assert len(self._replay) >= Fk, "sampler replay: more get_mask_prompt calls than recorded draws"
             rec = [self._replay.popleft() for _ in range(Fk)]
@@ -403,6 +410,13 @@ class VisualPromptEncoder:
             dense_idx = to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
             empty = (dense_idx[:, :1] < 0).view(-1, 1, 1)
             dense_idx = dense_idx.clamp(min=0)
+        elif fused and self._rng(device) == "device":
+            u = torch.rand((N, 1), device=device, generator=self._generator(device))           # the same draws, in the same order, as below
+            keys = torch.rand(m.shape, device=device, generator=self._generator(device))
+            drawn = ops.prompt_draw(pre, R, u=u, keys=keys)
+            assert drawn is not None, "prompt_draw: shape not covered"
+            point_idx, point_coords, dense_idx, empty = drawn
+            empty = empty.view(-1, 1, 1)
         elif self._rng(device) == "device":
             rowcnt = pre["rowcnt"].reshape(N, h)
             cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
@@ -433,12 +447,18 @@ class VisualPromptEncoder:
                     else:
                         rows_d.append(torch.cat([torch.randperm(c)[:R], torch.zeros(1, dtype=torch.int64)]))
             tab = to_device_async(torch.cat([torch.stack(rows_d), torch.stack(rows_p)], dim=1), device)   # one transfer
-            point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), tab[:, R + 1:], pre["rowcnt"].reshape(N, h))[:, 0]
-            dense_idx = _kth_true(m, tab[:, :R])
-            empty = (tab[:, R] != 0).view(-1, 1, 1)
+            drawn = ops.prompt_draw(pre, R, tab=tab) if fused else None
+            if drawn is not None:
+                point_idx, point_coords, dense_idx, empty = drawn
+                empty = empty.view(-1, 1, 1)
+            else:
+                point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), tab[:, R + 1:], pre["rowcnt"].reshape(N, h))[:, 0]
+                dense_idx = _kth_true(m, tab[:, :R])
+                empty = (tab[:, R] != 0).view(-1, 1, 1)
         if self.draw_log is not None:
             self._log_draws(point_idx.view(Fk, n), dense_idx.view(Fk, n, R), empty.view(Fk, n))
-        point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
+        if point_coords is None:
+            point_coords = torch.stack([((point_idx % w).float() + 0.5) / w, ((point_idx // w).float() + 0.5) / h], dim=-1)
         # ---- position token of the sampled point at its key frame, replicated over the clip's frames
         kf = torch.arange(Fk, device=device) if list(key_fids) == list(range(Fk)) else _ints_to_device(key_fids, device)
         size = (T, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
@@ -450,11 +470,17 @@ class VisualPromptEncoder:
             z = kfo / self.pe_layer.num_max_frames * self.pe_layer.scale
             ar = torch.arange(Fk, device=device)
             query_pe = self.pe_layer._points(z, point_coords).view(Fk, Fk, n, -1)[ar, ar]
-        query_pe = query_pe.reshape(N, 1, -1).repeat(1, T, 1)                                      # [N, T, C]
         # ---- mask-pooled feature token
         fw = feat_masks * fmb                                                                       # [F, n, h_img, w_img]
         feats = img_features.flatten(-2).transpose(1, 2)                                            # [F, HW, C]
         pf = torch.bmm(fw.flatten(-2).float(), feats) / fw.sum((-2, -1)).clamp(min=mask_thresh)[..., None]
+        if fused:
+            # the dense tokens and the cross-attention masks: two launches (csrc/prompt_sampler.hip)
+            out = ops.prompt_tokens(img_features, img_pos, pf.reshape(N, C), query_pe.reshape(N, -1), dense_idx, empty.view(-1), valid,
+                                    boxes.float().to(device), kf, T)
+            if out is not None:
+                return point_coords.view(Fk, n, 2), out[1], out[0], out[2]
+        query_pe = query_pe.reshape(N, 1, -1).repeat(1, T, 1)                                      # [N, T, C]
         query_feats = pf.reshape(N, 1, C).repeat(1, T, 1)
         # ---- cross-attention mask: everything outside the box, at the key frame only
         attn = torch.zeros((Fk, T, 1, n, HW), dtype=torch.bool, device=device)

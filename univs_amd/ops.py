@@ -1263,6 +1263,108 @@ def proca_attention(qkv0, kd, vd, num_heads):
     return out
 
 
+def prompt_prefix(masks, boxes, scale, mask_thresh=0.5):
+    """The annotation-only part of VisualPromptEncoder.get_mask_prompt for F key frames x n entities in three launches
+    (include/univs_hip.h: univs_prompt_prefix_f32; csrc/prompt_sampler.hip).  masks [F, n, h, w] float32, boxes [F, n, 4] normalised
+    xyxy -> the dict of `annotation_prefix` (univs_amd/modeling/prompt_encoder.py), bit for bit."""
+    _inference_only("prompt_prefix", masks, boxes)
+    masks, boxes = masks.contiguous(), boxes.contiguous()
+    _require_gpu("prompt_prefix", masks, boxes)
+    Fk, n, h, w = masks.shape
+    if masks.dtype != torch.float32 or boxes.dtype != torch.float32 or tuple(boxes.shape) != (Fk, n, 4) or h % scale or w % scale:
+        raise RuntimeError("prompt_prefix: float32 masks [F, n, h, w] with h, w multiples of the scale, boxes [F, n, 4]")
+    dev, N, hi, wi = masks.device, Fk * n, h // scale, w // scale
+    feat_masks = torch.empty((Fk, n, hi, wi), dtype=torch.float32, device=dev)
+    stats = torch.zeros(2 * N + Fk, dtype=torch.int32, device=dev)
+    sel = torch.empty((Fk, n, h, w), dtype=torch.bool, device=dev)
+    rowcnt = torch.empty((Fk, n, h), dtype=torch.int32, device=dev)
+    fmb = torch.empty((Fk, n, hi, wi), dtype=torch.bool, device=dev)
+    counts = torch.empty((Fk, 2 * n), dtype=torch.int32, device=dev)
+    flags = torch.empty((2, Fk, n), dtype=torch.bool, device=dev)
+    with _on(masks):
+        rc = _lib.load().univs_prompt_prefix_f32(_ptr(masks), _ptr(boxes), Fk, n, h, w, int(scale), float(mask_thresh), _ptr(feat_masks),
+                                                 _ptr(stats), _ptr(sel), _ptr(rowcnt), _ptr(fmb), _ptr(counts), _ptr(flags[0]),
+                                                 _ptr(flags[1]), _stream_ptr(masks))
+    _lib.check(rc, "prompt_prefix")
+    return {"valid": flags[0], "visible": flags[1], "feat_masks": feat_masks, "feat_masks_binary": fmb, "sel": sel, "rowcnt": rowcnt,
+            "counts": counts}
+
+
+def prompt_draw(pre, R, u=None, keys=None, tab=None):
+    """The draws of a clip's key frames -> pixels, one launch (univs_prompt_draw).  `pre` = the dict of `prompt_prefix` /
+    `annotation_prefix`; either u [N, 1] and keys [N, HW] (uniform numbers of the device generator) or tab [N, R + 2] int64 (the
+    reference's host draws: R dense ranks, the "empty" flag, the point's rank).  Returns (point_idx [N] int64, point_coords [N, 2],
+    dense_idx [N, R] int64, empty [N] bool), or None when the shape is not covered."""
+    sel, rowcnt, fmb, counts = pre["sel"], pre["rowcnt"], pre["feat_masks_binary"], pre["counts"]
+    _require_gpu("prompt_draw", sel)
+    Fk, n, h, w = sel.shape
+    N, HW = Fk * n, fmb.shape[-2] * fmb.shape[-1]
+    if any(not t.is_contiguous() for t in (sel, rowcnt, fmb, counts)) or sel.dtype != torch.bool or fmb.dtype != torch.bool \
+            or rowcnt.dtype != torch.int32 or counts.dtype != torch.int32:
+        return None
+    if tab is not None:
+        if tab.dtype != torch.int64 or tuple(tab.shape) != (N, R + 2):
+            raise RuntimeError("prompt_draw: tab [N, R + 2] int64")
+        tab = tab.contiguous()
+    else:
+        if u.dtype != torch.float32 or keys.dtype != torch.float32 or u.numel() != N or tuple(keys.shape) != (N, HW) or HW < R:
+            return None
+        u, keys = u.contiguous(), keys.contiguous()
+    dev = sel.device
+    point_idx = torch.empty(N, dtype=torch.int64, device=dev)
+    dense_idx = torch.empty((N, R), dtype=torch.int64, device=dev)
+    empty = torch.empty(N, dtype=torch.bool, device=dev)
+    coords = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    null = ctypes.c_void_p(0)
+    with _on(sel):
+        rc = _lib.load().univs_prompt_draw(_ptr(sel), _ptr(rowcnt), _ptr(fmb), _ptr(counts), null if tab is not None else _ptr(u),
+                                           null if tab is not None else _ptr(keys), null if tab is None else _ptr(tab), Fk, n, h, w, HW,
+                                           int(R), _ptr(point_idx), _ptr(dense_idx), _ptr(empty), _ptr(coords), _stream_ptr(sel))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "prompt_draw")
+    return point_idx, coords, dense_idx, empty
+
+
+def _fcp_strides(t):
+    """(frame, channel, pixel) element strides of a [F, C, h, w] map whose pixels are evenly spaced (dense or channels-last)"""
+    if t.stride(2) != t.shape[3] * t.stride(3):
+        return None
+    return (t.stride(0), t.stride(1), t.stride(3))
+
+
+def prompt_tokens(img_features, img_pos, query_feats, query_pe, dense_idx, empty, valid, boxes, kf, T):
+    """The dense prompt tokens and cross-attention masks of a clip's key frames in two launches (univs_prompt_tokens_f32):
+    img_features / img_pos [F, C, h_img, w_img], query_feats / query_pe [N, C] (the pooled tokens, used for empty masks), dense_idx
+    [N, R], empty / valid [N] bool, boxes [F, n, 4], kf [F] int64 (the key frame's position in the clip) ->
+    fd, pd [F, n, R, T, C], attn [F, T, 1, n, HW] bool.  None when a layout is not covered."""
+    _inference_only("prompt_tokens", img_features, img_pos)
+    if not (img_features.is_cuda and img_pos.is_cuda):
+        raise RuntimeError("prompt_tokens: Not implemented on the CPU; the HIP extension is the only implementation")
+    Fk, C, hi, wi = img_features.shape
+    n = boxes.shape[1]
+    N, R = dense_idx.shape
+    fs, ps = _fcp_strides(img_features), _fcp_strides(img_pos)
+    if (fs is None or ps is None or img_features.dtype != torch.float32 or img_pos.dtype != torch.float32 or tuple(img_pos.shape) != (Fk, C, hi, wi)
+            or N != Fk * n or tuple(query_feats.shape) != (N, C) or tuple(query_pe.shape) != (N, C) or query_feats.dtype != torch.float32
+            or query_pe.dtype != torch.float32 or empty.dtype != torch.bool or valid.dtype != torch.bool or kf.dtype != torch.int64):
+        return None
+    query_feats, query_pe, dense_idx, boxes = query_feats.contiguous(), query_pe.contiguous(), dense_idx.contiguous(), boxes.contiguous()
+    empty, valid, kf = empty.contiguous().view(-1), valid.contiguous().view(-1), kf.contiguous()
+    dev = img_features.device
+    fd = torch.empty((Fk, n, R, T, C), dtype=torch.float32, device=dev)
+    pd = torch.empty((Fk, n, R, T, C), dtype=torch.float32, device=dev)
+    attn = torch.empty((Fk, T, 1, n, hi * wi), dtype=torch.bool, device=dev)
+    fs_c, ps_c = (ctypes.c_int64 * 3)(*fs), (ctypes.c_int64 * 3)(*ps)
+    with _on(img_features):
+        rc = _lib.load().univs_prompt_tokens_f32(_ptr(img_features), ctypes.cast(fs_c, ctypes.c_void_p), _ptr(img_pos),
+                                                 ctypes.cast(ps_c, ctypes.c_void_p), _ptr(query_feats), _ptr(query_pe), _ptr(dense_idx),
+                                                 _ptr(empty), _ptr(valid), _ptr(boxes), _ptr(kf), Fk, n, R, int(T), C, hi, wi, _ptr(fd),
+                                                 _ptr(pd), _ptr(attn), _stream_ptr(img_features))
+    _lib.check(rc, "prompt_tokens")
+    return fd, pd, attn
+
+
 def _seq_first_ld(t, N, E):
     """Leading dimension (floats between batch entries) of a sequence-first [S, N, E] tensor that is dense or a column slice of a
     wider dense [S, N, E'] tensor; None when the layout is anything else."""

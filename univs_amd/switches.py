@@ -63,6 +63,9 @@ class Switches:
     # ProCA (a prompt query attends to its own prompt tokens) without the per-layer concatenations / transpositions: the dense tokens'
     # K / V projections on the tokens where they lie, q / k0 / v0 in one few-rows launch, one attention launch (csrc/proca_attn.hip)
     fused_proca: bool = True
+    # the visual-prompt sampler of a prompted clip (candidate pixels, draws -> pixels, dense tokens, cross-attention masks) as a handful
+    # of kernels instead of ~250 ATen launches (csrc/prompt_sampler.hip; bit-identical to the ATen formulation, which stays the CPU path)
+    fused_sampler: bool = True
     small_mlp_norm: bool = True
     # the W-resident Linears (K <= 768) stage their slab of W from the split image cached per weight tensor (a copy) instead of
     # splitting it in every workgroup of every launch (13 - 15 us per launch: profiles/r05_gemm_phase_trace_v1.txt)
@@ -84,7 +87,7 @@ SWITCHES = Switches(
     presplit_kmin=int(os.environ.get("UNIVS_PRESPLIT_KMIN", "768")), fused_mlp=_flag("UNIVS_FUSED_MLP", True),
     fused_cross_attention=_flag("UNIVS_FUSED_XATTN", True), fused_norm1=_flag("UNIVS_FUSED_NORM1", True), small_linear=_flag("UNIVS_SMALL_LINEAR", True),
     resident_presplit=_flag("UNIVS_RESIDENT_PRESPLIT", True), small_mlp_chain=_flag("UNIVS_SMALL_MLP_CHAIN", True), fused_proca=_flag("UNIVS_FUSED_PROCA", True),
-    small_mlp_norm=_flag("UNIVS_SMALL_MLP_NORM", True))
+    fused_sampler=_flag("UNIVS_FUSED_SAMPLER", True), small_mlp_norm=_flag("UNIVS_SMALL_MLP_NORM", True))
 if SWITCHES.sampler not in ("auto", "reference", "device"):
     raise ValueError(f"UNIVS_SAMPLER={SWITCHES.sampler!r} (expected 'auto', 'reference' or 'device')")
 
