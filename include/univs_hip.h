@@ -437,10 +437,11 @@ int univs_decoder_memory_f32(const float* x, const float* level_embed, const flo
  *        projection (the K or V of several decoder layers that attend to the same level, computed by one Linear)
  *   mask [N, L, S] uint8 / bool, non-zero = key masked out for that query, shared by the heads; or NULL
  *        (rows in which every key is masked yield NaN, as nn.MultiheadAttention; the decoder resets such rows beforehand,
- *        ...decoder_univs.py:390 -- univs_mask_decode_attn_f32 does)
+ *        ...decoder_univs.py:390 -- univs_mask_decode_attn_f32 does).  When S % 4 != 0 every mask row is PADDED to the next
+ *        multiple of four bytes ([N, L, (S + 3) & ~3]; the padding bytes are ignored): the kernel reads a row in aligned dwords
  *   workspace  univs_cross_attention_workspace(L, S, N, H) floats (per-segment partial results; no allocation inside)
  * Arithmetic: both products as three products of two-part fp16 splits with fp32 accumulation (the class of
- * univs_linear_fused_f32), softmax in fp32.  Covered: head_dim == 32, S >= 32, S % 4 == 0 with a mask, N * H <= 65535;
+ * univs_linear_fused_f32), softmax in fp32.  Covered: head_dim == 32, S >= 32, N * H <= 65535 (a row-flagged mask: S % 4 == 0);
  * otherwise UNIVS_ERR_NOT_IMPLEMENTED (the caller keeps GEMM + univs_masked_softmax_f32 + GEMM).
  * ------------------------------------------------------------------------------------------- */
 long long univs_cross_attention_workspace(int L, int S, int N, int H);

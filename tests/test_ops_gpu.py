@@ -685,12 +685,15 @@ def _xattn_reference(q, k, v, mask, H, scale):
 
 @pytest.mark.parametrize("L,S,N,H,masked", [(100, 920, 5, 8, True), (100, 14720, 2, 8, True), (20, 3680, 3, 8, True), (100, 3680, 5, 8, False),
                                              (7, 1000, 1, 2, True), (130, 1504, 2, 4, True), (112, 516, 1, 8, True),
-                                             (500, 500, 1, 8, True), (2000, 2000, 1, 8, True), (300, 260, 2, 4, False)], ids=lambda v: str(v))
+                                             (500, 500, 1, 8, True), (2000, 2000, 1, 8, True), (300, 260, 2, 4, False),
+                                             (550, 550, 1, 8, True), (100, 701, 2, 4, True), (64, 67, 3, 2, True), (110, 110, 5, 8, False)],
+                         ids=lambda v: str(v))
 def test_cross_attention_matches_torch(cuda, L, S, N, H, masked):
     """ops.cross_attention (csrc/cross_attn.hip: scores, mask, softmax and P V in one pass over the keys, three-product fp16
     arithmetic, per-segment partials merged by a second kernel) == nn.MultiheadAttention's core
     (transformer_layers.py:95-115) in fp64 to fp32 rounding; masks with whole 32-key blocks and whole segments masked for
-    some queries, a query with one visible key, more than 128 queries (chunks), S not a multiple of 32."""
+    some queries, a query with one visible key, more than 128 queries (chunks), S not a multiple of 32, S not a multiple of 4 (the mask
+    rows are padded to whole dwords: 550 = the prompted clip's 110 queries x 5 frames)."""
     E = 32 * H
     q = synth.normal(f"xa/q/{L}x{N}x{E}", (L, N, E))
     k = synth.normal(f"xa/k/{S}x{N}x{E}", (S, N, E))
@@ -779,17 +782,22 @@ def test_cross_attention_ranges_and_module_path(cuda):
     assert torch.equal(given, fused)
     # the decoder's spatio-temporal self-attention (...decoder_univs.py:408-414): one batch entry, Q' T tokens, a [L, S] mask,
     # q and k from ONE projection of tgt + pos, v from tgt
-    Ls = 500
-    with torch.no_grad():
-        t1 = synth.normal("xa2/sa/tgt", (Ls, 1, E)).to(cuda)
-        qk = t1 + synth.normal("xa2/sa/pos", (Ls, 1, E)).to(cuda)
-        m2 = (torch.rand(Ls, Ls, generator=torch.Generator().manual_seed(6)) < 0.4).to(cuda)
-        m2[torch.arange(Ls), torch.arange(Ls)] = False
-        for mm in (m2, None):
-            sa_fused = mha(qk, qk, t1, attn_mask=mm)[0]
-            with override(fused_cross_attention=False):
-                sa_plain = mha(qk, qk, t1, attn_mask=mm)[0]
-            assert (sa_fused - sa_plain).abs().max().item() < 2e-5
+    for Ls in (500, 550):                                    # (550: rows that are not whole dwords -- padded once per mask object)
+        with torch.no_grad():
+            t1 = synth.normal(f"xa2/sa/tgt{Ls}", (Ls, 1, E)).to(cuda)
+            qk = t1 + synth.normal(f"xa2/sa/pos{Ls}", (Ls, 1, E)).to(cuda)
+            m2 = (torch.rand(Ls, Ls, generator=torch.Generator().manual_seed(6)) < 0.4).to(cuda)
+            m2[torch.arange(Ls), torch.arange(Ls)] = False
+            for mm in (m2, None):
+                sa_fused = mha(qk, qk, t1, attn_mask=mm)[0]
+                sa_again = mha(qk, qk, t1, attn_mask=mm)[0]
+                with override(fused_cross_attention=False):
+                    sa_plain = mha(qk, qk, t1, attn_mask=mm)[0]
+                assert (sa_fused - sa_plain).abs().max().item() < 2e-5 and torch.equal(sa_fused, sa_again)
+            if Ls % 4:
+                assert ops.pad4_mask(m2) is ops.pad4_mask(m2) and ops.pad4_mask(m2).shape == (Ls, (Ls + 3) // 4 * 4)
+                m2[0, 1] = ~m2[0, 1]                             # an in-place change: a new padded copy
+                assert bool(ops.pad4_mask(m2)[0, 1]) == bool(m2[0, 1])
     assert ops.cross_attention(torch.zeros(4, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda), torch.zeros(16, 1, 64, device=cuda),
                                None, 2, 1.0) is None                                            # fewer than 32 keys
     assert ops.cross_attention(torch.zeros(4, 1, 64), torch.zeros(64, 1, 64), torch.zeros(64, 1, 64), None, 2, 1.0) is None   # CPU

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 R, S = 16, 8
 
 
-def scene(Fk, n, hi, wi, dev, seed):
+def scene(Fk, n, hi, wi, dev, seed, S=S):
     """F key frames x n entities: blobs with soft edges (values in [0, 1]), one empty entity, one tiny one, one whose box misses its mask
     (no central pixel: the fallback to the most confident pixels), one below the validity threshold"""
     g = torch.Generator().manual_seed(seed)
@@ -27,7 +27,7 @@ def scene(Fk, n, hi, wi, dev, seed):
             if kind == 0:
                 continue                                                       # empty: zero mask, zero box
             cy, cx = float(torch.rand(1, generator=g)) * h, float(torch.rand(1, generator=g)) * w
-            ry, rx = (11.0, 15.0) if kind == 1 else (h * (0.05 + 0.3 * float(torch.rand(1, generator=g))), w * (0.05 + 0.3 * float(torch.rand(1, generator=g))))
+            ry, rx = (1.4 * S, 1.9 * S) if kind == 1 else (h * (0.05 + 0.3 * float(torch.rand(1, generator=g))), w * (0.05 + 0.3 * float(torch.rand(1, generator=g))))
             d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
             m = (1.2 - d).clamp(0, 1)
             if kind == 2:
@@ -47,9 +47,10 @@ def scene(Fk, n, hi, wi, dev, seed):
     return masks.to(dev), boxes.to(dev), feats.to(dev), pos.to(dev)
 
 
-def encoder(mode, T=3):
+def encoder(mode, T=3, scale=S):
     enc = VisualPromptEncoder(hidden_dim=256, num_frames=T, num_dense_points=R, position_embedding_sin3d_type="ArbitraryT")
     enc.sampler_rng = mode
+    enc.img_feats_scale = scale
     return enc
 
 
@@ -70,11 +71,12 @@ def run(enc, masks, boxes, feats, pos, fused, seed=11, replay=None):
     return pre, out, log
 
 
-@pytest.mark.parametrize("Fk,n,hi,wi", [(2, 6, 16, 24), (1, 7, 23, 40), (2, 10, 92, 160)])
+@pytest.mark.parametrize("Fk,n,hi,wi,scale", [(2, 6, 16, 24, 8), (1, 7, 23, 40, 8), (2, 10, 92, 160, 8), (1, 6, 75, 101, 1), (2, 6, 30, 45, 3)])
 @pytest.mark.parametrize("mode", ["device", "reference"])
-def test_fused_sampler_equals_the_aten_formulation(cuda, Fk, n, hi, wi, mode):
-    masks, boxes, feats, pos = scene(Fk, n, hi, wi, cuda, seed=Fk * 100 + n)
-    enc = encoder(mode)
+def test_fused_sampler_equals_the_aten_formulation(cuda, Fk, n, hi, wi, scale, mode):
+    """(scale 1 and 3: mask rows that are not multiples of 16 bytes -- the kernels' scalar path)"""
+    masks, boxes, feats, pos = scene(Fk, n, hi, wi, cuda, seed=Fk * 100 + n, S=scale)
+    enc = encoder(mode, scale=scale)
     pre_a, out_a, log_a = run(enc, masks, boxes, feats, pos, fused=False)
     pre_f, out_f, log_f = run(enc, masks, boxes, feats, pos, fused=True)
     assert sorted(pre_a) == sorted(pre_f)
@@ -92,7 +94,7 @@ def test_fused_sampler_equals_the_aten_formulation(cuda, Fk, n, hi, wi, mode):
     for (pa, da), (pf_, df) in zip(log_a, log_f):
         assert torch.equal(pa, pf_) and torch.equal(da, df)
     # replaying the recorded pixels through the fused token kernel gives the same tokens again
-    enc_r = encoder(mode)
+    enc_r = encoder(mode, scale=scale)
     _, out_r, _ = run(enc_r, masks, boxes, feats, pos, fused=True, replay=log_f)
     for a, b in zip(out_f, out_r):
         assert torch.equal(a, b)

@@ -21,7 +21,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     pr.disable()
 st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(90)
 for line in st.getvalue().splitlines():
     if "univs_amd" in line or "ncalls" in line:
         print(line[:170])

@@ -200,10 +200,11 @@ __global__ __launch_bounds__(64, 2) void xattn_partial(const XaArgs a) {
       for (int kb = 0; kb < 2; ++kb) {
         mwn[qb][kb] = 0u;
         if (mrow[qb]) {
-          // S % 4 == 0 (host-checked): a lane's four keys are one aligned dword of its query's mask row
+          // a lane's four keys are one aligned dword of its query's mask row (rows are padded to a multiple of four bytes when S is not one)
           const int qi = min(l0 + 16 * qb + j, a.Lfull - 1);
-          const int sbc = min(s0 + 16 * kb + 4 * g, S - 4);
-          mwn[qb][kb] = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * S + sbc);
+          const int pitch = (S + 3) & ~3;
+          const int sbc = min(s0 + 16 * kb + 4 * g, pitch - 4);
+          mwn[qb][kb] = *reinterpret_cast<const unsigned*>(a.mask + ((long long)n * a.Lfull + qi) * pitch + sbc);
         }
       }
   };
@@ -451,7 +452,7 @@ int cross_attention_f32(const float* q, const float* k, const float* v, const un
                         float* out, hipStream_t st) {
   if (L <= 0 || N <= 0 || H <= 0) return UNIVS_OK;
   auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (hd != 32 || S < 32 || (mask && (S % 4 != 0 || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
+  if (hd != 32 || S < 32 || (mask && ((row_flags && S % 4 != 0) || (reinterpret_cast<uintptr_t>(mask) & 3))) || mis(q) || mis(k) || mis(v) || mis(out) ||
       mis(ws) || (long long)N * H > 65535)
     return UNIVS_ERR_NOT_IMPLEMENTED;
   const int nseg = xa_segments(L, S, N, H);

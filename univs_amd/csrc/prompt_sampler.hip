@@ -55,68 +55,122 @@ __device__ __forceinline__ PsBox ps_box(const float* __restrict__ boxes, int i) 
   return PsBox{(x0 + x1) * 0.5f, (y0 + y1) * 0.5f, x1 - x0, y1 - y0};
 }
 // pixel centre k of an axis of n pixels inside the central half of the box: |(k + 0.5) / n - c| < 0.25 extent.  (ATen's GPU division of
-// a tensor by a host scalar multiplies by the scalar's fp32 reciprocal -- BinaryDivTrueKernel.cu -- and so does this.)
-__device__ __forceinline__ bool ps_central(int k, int n, float c, float extent) {
-  const float p = ((float)k + 0.5f) * (1.0f / (float)n);
-  return fabsf(p - c) < 0.25f * extent;
+// a tensor by a host scalar multiplies by the scalar's fp32 reciprocal -- BinaryDivTrueKernel.cu -- and so does this: `inv` = 1 / n.)
+__device__ __forceinline__ bool ps_central(int k, float inv, float c, float quarter) {
+  const float p = ((float)k + 0.5f) * inv;
+  return fabsf(p - c) < quarter;
 }
 
+constexpr int PS_ROWS = 16;                // image rows per workgroup of the two passes over the masks (4 waves x 4 rows)
+
 // ---- pass 1 over the masks: per entity the maximum and the maximum inside the central half of the box; the feature-resolution
-// mask (nearest: pixel (s y, s x)) and its maximum per frame.  One wave per image row.
+// mask (nearest: pixel (s y, s x)) and its maximum per frame.  A wave walks whole image rows (16-byte loads when the row allows);
+// one atomic per statistic and workgroup.
+template <bool VEC>
 __global__ __launch_bounds__(256) void ps_mask_stats(const float* __restrict__ masks, const float* __restrict__ boxes, int N, int n, int h,
                                                      int w, int s, float* __restrict__ feat_masks, unsigned* __restrict__ stats) {
-  const int i = blockIdx.y, y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (y >= h) return;
+  __shared__ unsigned red[3][4];
+  const int i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const PsBox b = ps_box(boxes, i);
-  const bool in_y = ps_central(y, h, b.cy, b.bh);
-  const float* row = masks + ((size_t)i * h + y) * w;
-  const bool feat_row = (y % s) == 0;
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h, qw = 0.25f * b.bw, qh = 0.25f * b.bh;
   const int w_img = w / s;
-  float* frow = feat_masks + ((size_t)i * (h / s) + y / s) * w_img;
   unsigned mx = 0u, mxc = 0u, fmx = 0u;
-  for (int x = lane; x < w; x += 64) {
-    const float v = row[x];
-    const unsigned k = ps_key(v);
-    mx = max(mx, k);
-    if (in_y && ps_central(x, w, b.cx, b.bw)) mxc = max(mxc, k);
-    if (feat_row && (x % s) == 0) {
-      frow[x / s] = v;
-      fmx = max(fmx, k);
+  for (int q = 0; q < PS_ROWS / 4; ++q) {
+    const int y = blockIdx.x * PS_ROWS + wave * (PS_ROWS / 4) + q;
+    if (y >= h) break;
+    const bool in_y = ps_central(y, inv_h, b.cy, qh);
+    const float* row = masks + ((size_t)i * h + y) * w;
+    if constexpr (VEC) {
+      for (int x = 4 * lane; x < w; x += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + x);
+        const unsigned k0 = ps_key(v.x), k1 = ps_key(v.y), k2 = ps_key(v.z), k3 = ps_key(v.w);
+        mx = max(max(mx, max(k0, k1)), max(k2, k3));
+        if (in_y) {
+          if (ps_central(x, inv_w, b.cx, qw)) mxc = max(mxc, k0);
+          if (ps_central(x + 1, inv_w, b.cx, qw)) mxc = max(mxc, k1);
+          if (ps_central(x + 2, inv_w, b.cx, qw)) mxc = max(mxc, k2);
+          if (ps_central(x + 3, inv_w, b.cx, qw)) mxc = max(mxc, k3);
+        }
+      }
+    } else {
+      for (int x = lane; x < w; x += 64) {
+        const unsigned k = ps_key(row[x]);
+        mx = max(mx, k);
+        if (in_y && ps_central(x, inv_w, b.cx, qw)) mxc = max(mxc, k);
+      }
+    }
+    if (y % s == 0) {                                          // a row of the feature-resolution mask (the row was just read: cache hits)
+      float* frow = feat_masks + ((size_t)i * (h / s) + y / s) * w_img;
+      for (int xi = lane; xi < w_img; xi += 64) {
+        const float v = row[(size_t)xi * s];
+        frow[xi] = v;
+        fmx = max(fmx, ps_key(v));
+      }
     }
   }
   mx = ps_wave_max(mx);
   mxc = ps_wave_max(mxc);
   fmx = ps_wave_max(fmx);
   if (lane == 0) {
-    atomicMax(&stats[i], mx);
-    if (mxc) atomicMax(&stats[N + i], mxc);
-    if (fmx) atomicMax(&stats[2 * N + i / n], fmx);
+    red[0][wave] = mx;
+    red[1][wave] = mxc;
+    red[2][wave] = fmx;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned v = max(max(red[threadIdx.x][0], red[threadIdx.x][1]), max(red[threadIdx.x][2], red[threadIdx.x][3]));
+    if (v) atomicMax(&stats[threadIdx.x == 0 ? i : threadIdx.x == 1 ? N + i : 2 * N + i / n], v);
   }
 }
 
-// ---- pass 2: the candidate pixels of every entity and their count per image row.  One wave per image row.
+// ---- pass 2: the candidate pixels of every entity and their count per image row
+template <bool VEC>
 __global__ __launch_bounds__(256) void ps_candidates(const float* __restrict__ masks, const float* __restrict__ boxes,
                                                      const unsigned* __restrict__ stats, int N, int h, int w, uint8_t* __restrict__ sel,
                                                      int* __restrict__ rowcnt) {
-  const int i = blockIdx.y, y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (y >= h) return;
+  const int i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const PsBox b = ps_box(boxes, i);
+  const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h, qw = 0.25f * b.bw, qh = 0.25f * b.bh;
   const float mx = ps_unkey(stats[i]);
   const unsigned mxc_k = stats[N + i];
   const float t_ctr = fminf(mx, 0.75f), t_hi = fminf(mx, 0.95f);
   const bool any_ctr = mxc_k != 0u && ps_unkey(mxc_k) >= t_ctr;   // some pixel of the central half reaches the threshold
-  const bool in_y = ps_central(y, h, b.cy, b.bh);
-  const float* row = masks + ((size_t)i * h + y) * w;
-  uint8_t* srow = sel + ((size_t)i * h + y) * w;
-  int cnt = 0;
-  for (int x = lane; x < w; x += 64) {
-    const float v = row[x];
-    const bool c = any_ctr ? (in_y && ps_central(x, w, b.cx, b.bw) && v >= t_ctr) : (v >= t_hi);
-    srow[x] = c ? 1 : 0;
-    cnt += c ? 1 : 0;
+  for (int q = 0; q < PS_ROWS / 4; ++q) {
+    const int y = blockIdx.x * PS_ROWS + wave * (PS_ROWS / 4) + q;
+    if (y >= h) break;
+    const bool in_y = ps_central(y, inv_h, b.cy, qh);
+    const float* row = masks + ((size_t)i * h + y) * w;
+    uint8_t* srow = sel + ((size_t)i * h + y) * w;
+    int cnt = 0;
+    if constexpr (VEC) {
+      for (int x = 4 * lane; x < w; x += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + x);
+        bool c0, c1, c2, c3;
+        if (any_ctr) {
+          c0 = in_y && ps_central(x, inv_w, b.cx, qw) && v.x >= t_ctr;
+          c1 = in_y && ps_central(x + 1, inv_w, b.cx, qw) && v.y >= t_ctr;
+          c2 = in_y && ps_central(x + 2, inv_w, b.cx, qw) && v.z >= t_ctr;
+          c3 = in_y && ps_central(x + 3, inv_w, b.cx, qw) && v.w >= t_ctr;
+        } else {
+          c0 = v.x >= t_hi;
+          c1 = v.y >= t_hi;
+          c2 = v.z >= t_hi;
+          c3 = v.w >= t_hi;
+        }
+        *reinterpret_cast<unsigned*>(srow + x) = (c0 ? 1u : 0u) | (c1 ? 0x100u : 0u) | (c2 ? 0x10000u : 0u) | (c3 ? 0x1000000u : 0u);
+        cnt += (int)c0 + (int)c1 + (int)c2 + (int)c3;
+      }
+    } else {
+      for (int x = lane; x < w; x += 64) {
+        const float v = row[x];
+        const bool c = any_ctr ? (in_y && ps_central(x, inv_w, b.cx, qw) && v >= t_ctr) : (v >= t_hi);
+        srow[x] = c ? 1 : 0;
+        cnt += c ? 1 : 0;
+      }
+    }
+    cnt = ps_wave_sum(cnt);
+    if (lane == 0) rowcnt[(size_t)i * h + y] = cnt;
   }
-  cnt = ps_wave_sum(cnt);
-  if (lane == 0) rowcnt[(size_t)i * h + y] = cnt;
 }
 
 // ---- per entity: the binary feature mask, the two draw sizes, validity
@@ -365,9 +419,15 @@ int prompt_prefix_f32(const float* masks, const float* boxes, int Fk, int n, int
                       float* feat_masks, unsigned* stats, uint8_t* sel, int* rowcnt, uint8_t* fmb, int* counts, uint8_t* valid,
                       uint8_t* visible, hipStream_t st) {
   const int N = Fk * n;
-  dim3 grid((h + 3) / 4, N);
-  hipLaunchKernelGGL(ps_mask_stats, grid, dim3(256), 0, st, masks, boxes, N, n, h, w, scale, feat_masks, stats);
-  hipLaunchKernelGGL(ps_candidates, grid, dim3(256), 0, st, masks, boxes, stats, N, h, w, sel, rowcnt);
+  dim3 grid((h + PS_ROWS - 1) / PS_ROWS, N);
+  const bool vec = w % 4 == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0 && (reinterpret_cast<uintptr_t>(sel) & 3) == 0;
+  if (vec) {
+    hipLaunchKernelGGL(ps_mask_stats<true>, grid, dim3(256), 0, st, masks, boxes, N, n, h, w, scale, feat_masks, stats);
+    hipLaunchKernelGGL(ps_candidates<true>, grid, dim3(256), 0, st, masks, boxes, stats, N, h, w, sel, rowcnt);
+  } else {
+    hipLaunchKernelGGL(ps_mask_stats<false>, grid, dim3(256), 0, st, masks, boxes, N, n, h, w, scale, feat_masks, stats);
+    hipLaunchKernelGGL(ps_candidates<false>, grid, dim3(256), 0, st, masks, boxes, stats, N, h, w, sel, rowcnt);
+  }
   hipLaunchKernelGGL(ps_finalize, dim3(N), dim3(256), 0, st, feat_masks, stats, rowcnt, N, n, h, (h / scale) * (w / scale), feat_thresh, fmb,
                      counts, valid, visible);
   return check_launch("prompt_prefix_f32");

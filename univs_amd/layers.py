@@ -221,14 +221,19 @@ class MultiheadAttention(nn.Module):
                 y = linear(out, self.out_proj.weight, self.out_proj.bias)
                 return y if residual is None else residual + y
             return linear_norm(out, self.out_proj, residual, norm)
-        if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 256 and L <= 2048
+        if (SWITCHES.fused_cross_attention and query.is_cuda and not need_weights and d == 32 and S >= 64 and L <= 2048
                 and (attn_mask is None or (attn_mask.dtype in (torch.bool, torch.uint8)
                                            and ((attn_mask.dim() == 3 and attn_mask.shape[0] == N) or (attn_mask.dim() == 2 and N == 1))))):
             # scores, mask, softmax and P V in one pass over the keys, the [N h, L, S] scores never exist: the decoder's masked
             # cross-attention over the H_l W_l pixels of a level, and its spatio-temporal self-attention over the Q' T query tokens
             # (one batch entry, a [L, S] mask)
             from . import ops
-            m3 = attn_mask.view(1, L, S) if (attn_mask is not None and attn_mask.dim() == 2) else attn_mask
+            m3 = attn_mask
+            if isinstance(attn_mask, torch.Tensor):
+                if S % 4:
+                    m3 = ops.pad4_mask(attn_mask)                # (cached per mask object: one padded copy for all layers)
+                if m3.dim() == 2:
+                    m3 = m3.view(1, L, m3.shape[-1])
             out = ops.cross_attention(q, k, v, m3, h, 1.0 / math.sqrt(d))
             if out is not None:
                 return project(out), None

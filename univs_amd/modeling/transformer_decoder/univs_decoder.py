@@ -431,15 +431,43 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             return None
         c = self._proca_kin
         if c is None or c[0] is not feats_dense or c[1] is not pos_dense:
-            c = self._proca_kin = (feats_dense, pos_dense, (feats_dense + pos_dense).contiguous(), feats_dense.contiguous())
-        wk, bk = mha._packed_rows(E, E)
-        wv, bv = mha._packed_rows(2 * E, E)
-        kd = linear(c[2].view(-1, E), wk, bk).view(Q_p, L, T, E)
-        vd = linear(c[3].view(-1, E), wv, bv).view(Q_p, L, T, E)
+            # the dense tokens do not change across the layers: their keys / values for ALL ProCA layers come out of ONE Linear each
+            # (9 E output features, stored layer by layer: a column-blocked epilogue), as the cross-attention's do per level (_cross_kv)
+            kin, vin = (feats_dense + pos_dense).contiguous(), feats_dense.contiguous()
+            kv_all = self._proca_kv_all(kin.view(-1, E), vin.view(-1, E), E)
+            c = self._proca_kin = (feats_dense, pos_dense, kin, vin, kv_all)
+        li = next((j for j, m in enumerate(self.transformer_prompt_self_attention_layers) if m is layer), None)
+        if c[4] is not None and li is not None:
+            kd, vd = c[4][0][li].view(Q_p, L, T, E), c[4][1][li].view(Q_p, L, T, E)
+        else:
+            wk, bk = mha._packed_rows(E, E)
+            wv, bv = mha._packed_rows(2 * E, E)
+            kd = linear(c[2].view(-1, E), wk, bk).view(Q_p, L, T, E)
+            vd = linear(c[3].view(-1, E), wv, bv).view(Q_p, L, T, E)
         out = ops.proca_attention(qkv0, kd, vd, h)
         if out is None:
             return None
         return linear_norm(out, mha.out_proj, x, layer.norm).view(Q_p, T, E)
+
+    def _proca_kv_all(self, kin, vin, E):
+        """(K, V) of the dense prompt tokens for every ProCA layer: two [n_layers, rows, E] tensors from two Linears with n_layers E
+        output features (the layers' key / value rows of `in_proj`, concatenated once per weight version); None when not covered."""
+        mods = [layer.multihead_attn for layer in self.transformer_prompt_self_attention_layers]
+        if any(m.embed_dim != E for m in mods) or not kin.is_cuda:
+            return None
+        key = tuple((m.in_proj_weight.data_ptr(), m.in_proj_weight._version, m.in_proj_bias._version) for m in mods) + (str(kin.device),)
+        c = self.__dict__.get("_proca_kv_cache")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, torch.cat([m.in_proj_weight[E:2 * E] for m in mods]).contiguous(), torch.cat([m.in_proj_bias[E:2 * E] for m in mods]).contiguous(),
+                     torch.cat([m.in_proj_weight[2 * E:] for m in mods]).contiguous(), torch.cat([m.in_proj_bias[2 * E:] for m in mods]).contiguous())
+            self.__dict__["_proca_kv_cache"] = c
+        rows = kin.shape[0]
+        k_all = ops.linear_blocked(kin, c[1], c[2], rows, E)
+        v_all = ops.linear_blocked(vin, c[3], c[4], rows, E) if k_all is not None else None
+        if v_all is None:
+            return None
+        return k_all[0], v_all[0]                                    # [n_layers, rows, E]
 
     def _clip_normalized(self, like):
         c = self._clip_norm_cache

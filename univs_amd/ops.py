@@ -1376,6 +1376,25 @@ def _seq_first_ld(t, N, E):
     return ld
 
 
+_PAD4 = {}      # id(mask) -> (weak reference to the mask, its version, its rows padded to a multiple of four bytes)
+
+
+def pad4_mask(mask):
+    """[..., S] bool / uint8 -> [..., (S + 3) & ~3], zero-padded: the attention kernel reads mask rows in aligned dwords.  Cached per
+    tensor OBJECT and version -- the decoder's self-attention mask is one cached tensor for all layers and clips of a shape -- so
+    callers pass the tensor they hold, not a view made per call."""
+    if mask.shape[-1] % 4 == 0:
+        return mask.contiguous()
+    hit = _PAD4.get(id(mask))
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+        return hit[2]
+    padded = torch.nn.functional.pad(mask, (0, (-mask.shape[-1]) % 4)).contiguous()
+    if len(_PAD4) > 32:
+        _PAD4.clear()
+    _PAD4[id(mask)] = (weakref.ref(mask), mask._version, padded)
+    return padded
+
+
 def cross_attention(q, k, v, mask, num_heads, scale):
     """softmax(scale q k^T, masked) v per (batch entry, head) in one pass over the keys (include/univs_hip.h:
     univs_cross_attention_f32; csrc/cross_attn.hip): the attention core of nn.MultiheadAttention as the decoder's
@@ -1401,9 +1420,9 @@ def cross_attention(q, k, v, mask, num_heads, scale):
             mask.check_fresh()
             mask, flags, gen = mask.mask, mask.flags, mask.gen
     elif mask is not None:
-        if tuple(mask.shape) != (N, L, S) or mask.dtype not in (torch.bool, torch.uint8) or S % 4 != 0 or not mask.is_cuda:
+        if tuple(mask.shape) not in ((N, L, S), (N, L, (S + 3) & ~3)) or mask.dtype not in (torch.bool, torch.uint8) or not mask.is_cuda:
             return None
-        mask = mask.contiguous()
+        mask = pad4_mask(mask) if mask.shape[-1] % 4 else mask.contiguous()      # (rows padded to dwords: see pad4_mask)
     lds_ = []
     for t in (q, k, v):
         ld = _seq_first_ld(t, N, E)
