@@ -654,6 +654,25 @@ int univs_prompt_tokens_f32(const float* feats, const int64_t* feats_strides, co
                             const float* boxes, const int64_t* kf, int F, int n, int R, int T, int C, int h_img, int w_img, float* fd,
                             float* pd, uint8_t* attn, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Position tokens of sampled points (csrc/prompt_sampler.hip): out[i] = cat(sincos(y_i scale / dim_t), sincos(x_i scale / dim_t)) +
+ * sincos(z[i / n] / dim_tz), sincos = (sin on even channels, cos on odd ones).
+ * Replaces: PositionEmbeddingSine3D*.forward_points_with_size (univs/modeling/transformer_decoder/position_encoding.py:88-110, :170-236)
+ *           as get_mask_prompt calls it (prompt_encoder.py:209-212): ~25 ATen launches per call, the same bits.
+ *   xy [F n, 2] normalised (x, y); z [F] the frames' scaled temporal coordinate; dim_t [Fq], dim_tz [2 Fq] the frequency vectors
+ *   (temperature^(2 floor(k / 2) / len)); scale = 2 pi; out [F n, 2 Fq].
+ * ------------------------------------------------------------------------------------------- */
+int univs_prompt_point_pe_f32(const float* xy, const float* z, const float* dim_t, const float* dim_tz, float scale, int F, int n, int Fq,
+                              float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mean over the non-blank tokens: x [n, L, T, C] -> out [n, T, C] = sum_l x[:, l] / max(1, #{l : x[., l, ., :] is not all zero}) (+ add [C]).
+ * Replaces: univs/modeling/transformer_decoder/video_mask2former_transformer_decoder_univs.py:640-650 (the initial prompt query / its
+ *           position: compare, all, not, sum, clamp, sum, divide, add -- eight launches per tensor).  fp32, summed token by token.
+ * Covered: C <= 1024, L <= 15360; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_token_mean_f32(const float* x, const float* add, int n, int L, int T, int C, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

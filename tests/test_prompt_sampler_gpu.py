@@ -136,3 +136,53 @@ def test_prompt_kernels_reject_bad_arguments(cuda):
     with pytest.raises(RuntimeError):
         ops.prompt_draw(pre, R, tab=torch.zeros(3, R, dtype=torch.int64, device=cuda))
     assert ops.prompt_prefix(masks[:0], boxes[:0], 8)["counts"].shape == (0, 6)
+
+
+@pytest.mark.parametrize("kind", ["ArbitraryT", "FixedT"])
+def test_point_position_tokens_are_the_aten_bits(cuda, kind):
+    """ops.prompt_point_pe == the diagonal of position_encoding._points (every frame's z against every point), bit for bit"""
+    from univs_amd import ops
+    from univs_amd.modeling.position_encoding import _axis, _dim_t
+    Fk, n, T = 3, 7, 5
+    enc = VisualPromptEncoder(hidden_dim=256, num_frames=T, num_dense_points=R, position_embedding_sin3d_type=kind)
+    pl = enc.pe_layer
+    xy = torch.rand(Fk * n, 2, generator=torch.Generator().manual_seed(3)).to(cuda)
+    xy[0] = 0.0
+    xy[1] = 1.0
+    if kind == "FixedT":
+        z = _axis(T, pl.scale, cuda)[torch.tensor([0, 2, 4], device=cuda)]
+    else:
+        z = torch.tensor([0, 17, 127], device=cuda) / pl.num_max_frames * pl.scale
+    ar = torch.arange(Fk, device=cuda)
+    want = pl._points(z, xy).view(Fk, Fk, n, -1)[ar, ar].reshape(Fk * n, -1)
+    got = ops.prompt_point_pe(xy, z, _dim_t(pl.num_pos_feats, pl.temperature, cuda), _dim_t(2 * pl.num_pos_feats, pl.temperature, cuda), pl.scale, n)
+    assert got.shape == want.shape == (Fk * n, 256) and torch.equal(got, want)
+
+
+def test_token_mean_counts_non_blank_tokens(cuda):
+    """ops.token_mean == x.sum(1) / clamp(number of tokens that are not all zero, 1) (+ add): blank tokens (all channels zero) do not
+    count, an entity without any token gives the bare `add`, a token with ONE non-zero channel counts"""
+    from univs_amd import ops
+    n, L, T, C = 5, 33, 3, 256
+    x = synth.normal("tokmean/x", (n, L, T, C))
+    x[0, 5:] = 0.0                                   # 5 tokens
+    x[1] = 0.0                                       # none
+    x[2, 7] = 0.0
+    x[2, 7, 1, 200] = 3.0                            # one channel of one frame
+    x[3, :, 2] = 0.0                                 # frame 2 blank for entity 3
+    add = synth.normal("tokmean/add", (C,))
+    xd, ad = x.to(cuda), add.to(cuda)
+    for a in (ad, None):
+        got = ops.token_mean(xd, a)
+        nb = torch.logical_not((xd == 0).all(dim=-1)).unsqueeze(-1).sum(1).clamp(min=1)
+        want = xd.sum(1) / nb
+        if a is not None:
+            want = want + a.view(1, 1, -1)
+        assert got.shape == (n, T, C)
+        assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    assert torch.equal(ops.token_mean(xd, ad)[1], ad.view(1, C).expand(T, C))
+    assert torch.equal(ops.token_mean(xd, None)[3, 2], torch.zeros(C, device=cuda))
+    x64 = x.double()
+    exact = x64.sum(1) / torch.logical_not((x64 == 0).all(-1)).unsqueeze(-1).sum(1).clamp(min=1)
+    assert (ops.token_mean(xd).double().cpu() - exact).abs().max().item() < 5e-6
+    assert ops.token_mean(x) is None                 # CPU tensors: the caller keeps the ATen formulation

@@ -72,6 +72,8 @@ int prompt_prefix_f32(const float*, const float*, int, int, int, int, int, float
                       uint8_t*, hipStream_t);
 int prompt_draw(const uint8_t*, const int*, const uint8_t*, const int*, const float*, const float*, const long long*, int, int, int, int, int,
                 int, long long*, long long*, uint8_t*, float*, hipStream_t);
+int prompt_point_pe_f32(const float*, const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
+int token_mean_f32(const float*, const float*, int, int, int, int, float*, hipStream_t);
 int prompt_tokens_f32(const float*, const long long*, const float*, const long long*, const float*, const float*, const long long*,
                       const uint8_t*, const uint8_t*, const float*, const long long*, int, int, int, int, int, int, int, float*, float*,
                       uint8_t*, hipStream_t);
@@ -938,6 +940,41 @@ int univs_prompt_tokens_f32(const float* feats, const int64_t* feats_strides, co
                            qfeat, qpe, reinterpret_cast<const long long*>(dense_idx), empty, valid, boxes,
                            reinterpret_cast<const long long*>(kf), F, n, R, T, C, h_img, w_img, fd, pd, attn,
                            static_cast<hipStream_t>(stream));
+}
+
+int univs_prompt_point_pe_f32(const float* xy, const float* z, const float* dim_t, const float* dim_tz, float scale, int F, int n, int Fq,
+                              float* out, void* stream) {
+  clear_sticky_error();
+  if (F < 0 || n < 0 || Fq < 1) {
+    set_error("univs_prompt_point_pe_f32: bad dimensions F=%d n=%d Fq=%d", F, n, Fq);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)F * n == 0) return UNIVS_OK;
+  if (!xy || !z || !dim_t || !dim_tz || !out) {
+    set_error("univs_prompt_point_pe_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  return prompt_point_pe_f32(xy, z, dim_t, dim_tz, scale, F, n, Fq, out, static_cast<hipStream_t>(stream));
+}
+
+int univs_token_mean_f32(const float* x, const float* add, int n, int L, int T, int C, float* out, void* stream) {
+  clear_sticky_error();
+  if (n < 0 || L < 0 || T < 0 || C < 1) {
+    set_error("univs_token_mean_f32: bad dimensions n=%d L=%d T=%d C=%d", n, L, T, C);
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  if ((long long)n * T == 0) return UNIVS_OK;
+  if (!x || !out) {
+    set_error("univs_token_mean_f32: NULL data pointer");
+    return UNIVS_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = token_mean_f32(x, add, n, L, T, C, out, static_cast<hipStream_t>(stream));
+  if (rc > 0) return UNIVS_OK;
+  if (rc == 0) {
+    set_error("univs_token_mean_f32: shape not covered (C <= 1024, L <= 15360)");
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return rc;
 }
 
 int univs_window_attention_image_f32(const float* qkv, const float* qkv_bias, const float* bias,

@@ -413,6 +413,60 @@ __global__ __launch_bounds__(256) void ps_attn_mask(const float* __restrict__ bo
   }
 }
 
+// ---- the position token of every sampled point: sin / cos embeddings of (y, x) at the frequencies dim_t [F] and of the frame
+// coordinate z at the frequencies dim_tz [2 F], channel 2 k = sin, 2 k + 1 = cos (position_encoding.py:_points: cat(pos_y, pos_x) + pos_z;
+// univs/modeling/transformer_decoder/position_encoding.py:170-236).  Same operations in the same order as the ATen formulation
+// (scale, divide, sin / cos, add), so the same bits.
+__global__ __launch_bounds__(256) void ps_point_pe(const float* __restrict__ xy, const float* __restrict__ z, const float* __restrict__ dim_t,
+                                                   const float* __restrict__ dim_tz, float scale, int n, int F, float* __restrict__ out) {
+  const int i = blockIdx.x, f = i / n;
+  const float px = xy[2 * i] * scale, py = xy[2 * i + 1] * scale, pz = z[f];
+  for (int c = threadIdx.x; c < 2 * F; c += 256) {
+    const int k = c < F ? c : c - F;
+    const float a = (c < F ? py : px) / dim_t[k];
+    const float b = pz / dim_tz[c];
+    const float v = (c & 1) ? cosf(a) : sinf(a);
+    const float u = (c & 1) ? cosf(b) : sinf(b);
+    out[(size_t)i * 2 * F + c] = v + u;
+  }
+}
+
+// ---- mean over the non-blank tokens of every (entity, frame): x [n, L, T, C] -> out [n, T, C] = sum_l x / max(1, #{l : x[., l, ., :] != 0})
+// (+ add [C]); ...decoder_univs.py:640-650.  One workgroup per (entity, frame), a thread per channel.
+__global__ __launch_bounds__(256) void ps_token_mean(const float* __restrict__ x, const float* __restrict__ add, int L, int T, int C,
+                                                     float* __restrict__ out) {
+  extern __shared__ unsigned char tm_flag[];                      // [4][L]: wave w saw a non-zero channel of token l
+  const int e = blockIdx.x / T, t = blockIdx.x - e * T, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                           // channels threadIdx.x + 256 q (C <= 1024)
+  for (int l = 0; l < L; ++l) {
+    bool nz = false;
+    const float* row = x + (((size_t)e * L + l) * T + t) * C;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = threadIdx.x + 256 * q;
+      if (c < C) {
+        const float v = row[c];
+        acc[q] += v;
+        nz = nz || v != 0.f;
+      }
+    }
+    const unsigned long long any = __ballot(nz);
+    if (lane == 0) tm_flag[wave * L + l] = any != 0ull ? 1 : 0;
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int l = 0; l < L; ++l) cnt += (tm_flag[l] | tm_flag[L + l] | tm_flag[2 * L + l] | tm_flag[3 * L + l]) ? 1 : 0;
+  const float d = (float)max(cnt, 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    if (c < C) {
+      const float m = acc[q] / d;
+      out[((size_t)e * T + t) * C + c] = add ? m + add[c] : m;
+    }
+  }
+}
+
 }  // namespace
 
 int prompt_prefix_f32(const float* masks, const float* boxes, int Fk, int n, int h, int w, int scale, float feat_thresh,
@@ -460,6 +514,23 @@ int prompt_tokens_f32(const float* feats, const long long* fs, const float* pos,
   hipLaunchKernelGGL(ps_attn_mask, dim3(std::min((HW + 255) / 256, 16), Fk * T * n), dim3(256), 0, st, boxes, valid, kf, n, T, h_img,
                      w_img, attn);
   return check_launch("prompt_tokens_f32");
+}
+
+}  // namespace univs
+
+namespace univs {
+
+int prompt_point_pe_f32(const float* xy, const float* z, const float* dim_t, const float* dim_tz, float scale, int Fk, int n, int F,
+                        float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ps_point_pe, dim3(Fk * n), dim3(256), 0, st, xy, z, dim_t, dim_tz, scale, n, F, out);
+  return check_launch("prompt_point_pe_f32");
+}
+
+int token_mean_f32(const float* x, const float* add, int n, int L, int T, int C, float* out, hipStream_t st) {
+  if (C > 1024 || 4 * L > 60 * 1024) return 0;
+  hipLaunchKernelGGL(ps_token_mean, dim3(n * T), dim3(256), (size_t)4 * L, st, x, add, L, T, C, out);
+  const int rc = check_launch("token_mean_f32");
+  return rc == UNIVS_OK ? 1 : rc;
 }
 
 }  // namespace univs

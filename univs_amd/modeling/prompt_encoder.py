@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from ..layers import point_sample, to_device_async
 from ..switches import SWITCHES
-from .position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT
+from .position_encoding import PositionEmbeddingSine3D, PositionEmbeddingSine3DArbitraryT, _axis, _dim_t
 
 
 # ---- box / mask helpers (univs/utils/comm.py:6-91) ---------------------------------------------------
@@ -462,7 +462,20 @@ class VisualPromptEncoder:
         # ---- position token of the sampled point at its key frame, replicated over the clip's frames
         kf = torch.arange(Fk, device=device) if list(key_fids) == list(range(Fk)) else _ints_to_device(key_fids, device)
         size = (T, h_img * self.img_feats_scale, w_img * self.img_feats_scale)
-        if self.position_embedding_sin3d_type == "FixedT":
+        query_pe = None
+        if fused:
+            # one launch for the F n position tokens (csrc/prompt_sampler.hip: ps_point_pe; the ATen formulation below makes them for
+            # every (frame, point) pair in ~25 launches and keeps the diagonal), the same bits
+            pl = self.pe_layer
+            if self.position_embedding_sin3d_type == "FixedT":
+                zf = _axis(T, pl.scale, device)[kf]
+            else:
+                zf = _ints_to_device(key_fids_original, device) / pl.num_max_frames * pl.scale
+            query_pe = ops.prompt_point_pe(point_coords.reshape(N, 2), zf.float(), _dim_t(pl.num_pos_feats, pl.temperature, device),
+                                           _dim_t(2 * pl.num_pos_feats, pl.temperature, device), pl.scale, n)
+        if query_pe is not None:
+            pass
+        elif self.position_embedding_sin3d_type == "FixedT":
             pe = self.pe_layer.forward_points_with_size(size, point_coords)                        # [T, N, C]
             query_pe = pe.view(T, Fk, n, -1)[kf, torch.arange(Fk, device=device)]                 # [F, n, C]
         else:
@@ -843,8 +856,9 @@ class VisualPromptSampler:
                 # that would cost a host round trip per frame)
                 valid = pre["visible"][key_fid].view(-1, 1, 1, 1) if prompt_type == "masks" else \
                     (gt_masks[:, key_fid].amax(2).amax(1) > 0).view(-1, 1, 1, 1)
-                tv["prompt_pe"][:, :, s_idx:] = torch.where(valid, pe_d[:, :, key_fid:], tv["prompt_pe"][:, :, s_idx:])
-                tv["prompt_feats"][:, :, s_idx:] = torch.where(valid, f_d[:, :, key_fid:], tv["prompt_feats"][:, :, s_idx:])
+                for name, new in (("prompt_pe", pe_d), ("prompt_feats", f_d)):
+                    dst = tv[name][:, :, s_idx:]
+                    torch.where(valid, new[:, :, key_fid:], dst, out=dst)     # in place: one launch, no temporary + copy
                 tv["prompt_attn_masks"][s_idx:] = m_d[key_fid:]
         if "prompt_pe" not in tv:
             return None, None, None

@@ -574,12 +574,17 @@ class VideoMultiScaleMaskedTransformerDecoderUniVS(nn.Module):
             if prompt_feats_dense is None:
                 return None, None, None, None, None
             # mean over non-blank tokens (blank = all-zero embedding), :640-650
-            nb_f = torch.logical_not((prompt_feats_dense == 0).all(dim=-1)).unsqueeze(-1).sum(1).clamp(min=1)
-            nb_p = torch.logical_not((prompt_pe_dense == 0).all(dim=-1)).unsqueeze(-1).sum(1).clamp(min=1)
-            prompt_feats_mean = prompt_feats_dense.sum(1) / nb_f
-            prompt_pe_mean = prompt_pe_dense.sum(1) / nb_p
-            query_embed_prompt = prompt_pe_mean
-            output_prompt = prompt_feats_mean + self.prompt_sot.weight.view(1, 1, -1)
+            output_prompt = query_embed_prompt = None
+            if SWITCHES.fused_sampler and prompt_feats_dense.is_cuda:     # two launches instead of sixteen (csrc/prompt_sampler.hip: ps_token_mean)
+                output_prompt = ops.token_mean(prompt_feats_dense, self.prompt_sot.weight)
+                query_embed_prompt = ops.token_mean(prompt_pe_dense) if output_prompt is not None else None
+            if query_embed_prompt is None:
+                nb_f = torch.logical_not((prompt_feats_dense == 0).all(dim=-1)).unsqueeze(-1).sum(1).clamp(min=1)
+                nb_p = torch.logical_not((prompt_pe_dense == 0).all(dim=-1)).unsqueeze(-1).sum(1).clamp(min=1)
+                prompt_feats_mean = prompt_feats_dense.sum(1) / nb_f
+                prompt_pe_mean = prompt_pe_dense.sum(1) / nb_p
+                query_embed_prompt = prompt_pe_mean
+                output_prompt = prompt_feats_mean + self.prompt_sot.weight.view(1, 1, -1)
             if "prompt_feats" in targets[0]:
                 assert len(targets) == 1, "Only support batch size is 1 now"
                 prompt_pe_dense, prompt_feats_dense = self.extract_prompt_features_from_memoey_pool(

@@ -1326,6 +1326,41 @@ def prompt_draw(pre, R, u=None, keys=None, tab=None):
     return point_idx, coords, dense_idx, empty
 
 
+def prompt_point_pe(xy, z, dim_t, dim_tz, scale, n):
+    """Position tokens of F n sampled points in one launch (univs_prompt_point_pe_f32): xy [F n, 2], z [F] (scaled frame coordinate),
+    the frequency vectors dim_t [Fq] / dim_tz [2 Fq] -> [F n, 2 Fq], the bits of position_encoding._points."""
+    N, Fk, Fq = xy.shape[0], z.shape[0], dim_t.shape[0]
+    ts = (xy, z, dim_t, dim_tz)
+    if any(t.dtype != torch.float32 or not t.is_cuda for t in ts) or N != Fk * n or dim_tz.shape[0] != 2 * Fq or tuple(xy.shape) != (N, 2):
+        return None
+    xy, z, dim_t, dim_tz = (t.contiguous() for t in ts)
+    out = torch.empty((N, 2 * Fq), dtype=torch.float32, device=xy.device)
+    with _on(xy):
+        rc = _lib.load().univs_prompt_point_pe_f32(_ptr(xy), _ptr(z), _ptr(dim_t), _ptr(dim_tz), float(scale), Fk, int(n), Fq, _ptr(out),
+                                                   _stream_ptr(xy))
+    _lib.check(rc, "prompt_point_pe")
+    return out
+
+
+def token_mean(x, add=None):
+    """Mean over the non-blank tokens (univs_token_mean_f32): x [n, L, T, C] -> [n, T, C] = x.sum(1) / max(1, number of tokens l whose
+    C channels are not all zero) (+ add [C]).  None when not covered."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or needs_grad(x, add):
+        return None
+    n, L, T, C = x.shape
+    if add is not None and (add.dtype != torch.float32 or add.numel() != C or not add.is_cuda):
+        return None
+    x = x.contiguous()
+    a = add.contiguous().view(-1) if add is not None else None
+    out = torch.empty((n, T, C), dtype=torch.float32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_token_mean_f32(_ptr(x), _ptr(a) if a is not None else None, n, L, T, C, _ptr(out), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "token_mean")
+    return out
+
+
 def _fcp_strides(t):
     """(frame, channel, pixel) element strides of a [F, C, h, w] map whose pixels are evenly spaced (dense or channels-last)"""
     if t.stride(2) != t.shape[3] * t.stride(3):
