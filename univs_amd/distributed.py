@@ -11,6 +11,8 @@ which `tests/test_distributed_cpu.py` checks with a 2-rank gloo group.
 
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -26,6 +28,45 @@ class FrameShard:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.always_collective = always_collective
+        # bytes this rank RECEIVED per kind of collective ("all_gather", "all_reduce", "broadcast"; "result:*" = the clip loop's
+        # gathers of mask logits / embeddings): tests and DESIGN.md section 6 read them; a ClipShard adds to its parent's counter
+        self.bytes = collections.Counter()
+        self._subgroups = {}
+
+    def global_rank(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def subgroup(self, ranks):
+        """The process group of the group ranks `ranks` (sorted, distinct), made once per set.  `dist.new_group` is a collective over
+        the WHOLE job: every rank of this shard must ask for the same sets in the same order (the clip loops do: every rank walks
+        every clip)."""
+        key = tuple(int(r) for r in ranks)
+        g = self._subgroups.get(key)
+        if g is None:
+            g = self._subgroups[key] = dist.new_group(ranks=[self.global_rank(r) for r in key])
+        return g
+
+    def broadcast_state(self, src: int, tensors, device):
+        """`tensors` ({name: tensor} on the source rank `src` (group rank), anything elsewhere) -> the same dict on every rank: one
+        small object broadcast (names, shapes, dtypes) and one broadcast per tensor.  CPU tensors travel through `device` when the
+        backend needs device memory (RCCL)."""
+        gsrc = self.global_rank(src)
+        meta = [[(k, tuple(v.shape), v.dtype, v.device.type) for k, v in tensors.items()] if self.rank == src else None]
+        dist.broadcast_object_list(meta, src=gsrc, group=self.group)
+        via_device = dist.get_backend(self.group) != "gloo"
+        out = {}
+        for k, shape, dtype, dev_type in meta[0]:
+            if self.rank == src:
+                t = tensors[k].contiguous()
+                t = t.to(device) if (via_device and dev_type == "cpu") else t
+            else:
+                t = torch.empty(shape, dtype=dtype, device=device if (via_device or dev_type != "cpu") else "cpu")
+            if t.numel():
+                dist.broadcast(t, src=gsrc, group=self.group)
+                if self.rank != src:
+                    self.bytes["broadcast"] += t.numel() * t.element_size()
+            out[k] = t.cpu() if dev_type == "cpu" and t.device.type != "cpu" else t
+        return out
 
     def total(self, t_local: int) -> int:
         return t_local * self.world
@@ -42,6 +83,7 @@ class FrameShard:
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x, group=self.group)   # rank-major along dim 0 (the form both RCCL and gloo take)
+        self.bytes["all_gather"] += (out.numel() - x.numel()) * x.element_size()
         if dim == 0:
             return out
         # [world, ..., n_dim, ...] -> [..., world * n_dim, ...]
@@ -53,6 +95,7 @@ class FrameShard:
             return x
         x = x.contiguous()
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        self.bytes["all_reduce"] += x.numel() * x.element_size()
         return x
 
 
@@ -65,8 +108,10 @@ class ClipShard(FrameShard):
       all_gather_frames(x, dim): pads every rank's block to the largest count, ONE all_gather_into_tensor, then a gather of the valid
       rows into clip order."""
 
-    def __init__(self, owners, group=None, always_collective=False):
+    def __init__(self, owners, group=None, always_collective=False, counter=None):
         super().__init__(group=group, always_collective=always_collective)
+        if counter is not None:
+            self.bytes = counter                                   # the loop's shard keeps the totals
         self.owners = [int(o) for o in owners]
         self.t_total = len(self.owners)
         assert self.t_total > 0 and all(0 <= o < self.world for o in self.owners), (self.owners, self.world)
@@ -102,6 +147,7 @@ class ClipShard(FrameShard):
         xm = xm.contiguous()
         out = torch.empty((self.world * self.max_count,) + tuple(xm.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, xm, group=self.group)
+        self.bytes["all_gather"] += (out.numel() - xm.numel()) * x.element_size()
         idx = self._order_cache.get(x.device)
         if idx is None:
             idx = self._order_cache[x.device] = torch.tensor(self._order, dtype=torch.long).to(x.device, non_blocking=True)

@@ -100,31 +100,80 @@ def window_features_on_owner(model, x, frames, shard):
     return {f: k for k, f in enumerate(mine)}, (mf, bfe, list(ms))
 
 
-def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard):
+POOL_KEYS = ("prompt_pe", "prompt_feats", "prompt_attn_masks")     # the prompt memory pool in targets[0] (modeling/prompt_encoder.py)
+
+
+def _sampler_encoder(model):
+    try:
+        return model.sem_seg_head.predictor.visual_prompt_sampler.visual_prompt_encoder
+    except AttributeError:
+        return None
+
+
+def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=None):
     """The head's predictor on the clip [first, first + n_clip) whose frames are spread over the ranks of `shard` (ClipShard: one
     all-gather of the query states per decoder layer) -> the full-clip output dict on every rank (mask logits and embeddings of the
-    clip's frames all-gathered; class / re-id logits are replicated by construction)."""
+    clip's frames all-gathered; class / re-id logits are replicated by construction).
+    MORE RANKS THAN FRAMES (an 8-GPU node on 5-frame clips): the decoder runs on the TEAM of ranks that own a frame of this clip -- a
+    sub-group, made once per distinct team -- while the others have nothing to do for this clip (their share of the node's work is the
+    backbone + pixel decoder of the frames they own, `window_features_on_owner`); the clip's outputs, the prompt memory pool and the
+    state of the random generators then go from the team's first rank to the ranks outside it, so that the replicated per-video
+    state stays identical everywhere (every rank is in the team of some later clip)."""
     from ..distributed import ClipShard, cyclic_owners
     predictor = model.sem_seg_head.predictor
     if getattr(predictor, "semantic_extraction_enable", False):
         # (that mode returns pred_embds as [T_loc, C, Q'] and a per-rank `mask_features`: neither is gathered here -- ADVICE r05)
         raise NotImplementedError("frame-sharded clip loop: MODEL.UniVS.TEST.SEMANTIC_EXTRACTION.ENABLE is not supported")
     owners = cyclic_owners(first, n_clip, shard.world)
-    if len(set(owners)) < shard.world:
-        # (a clip shorter than num_frames only arises when the video ends inside it; the reference's own memory-pool update raises on
-        # such clips once entities exist, inference_video_entity.py:326-339 -- nothing to stay compatible with)
-        raise ValueError(f"frame-sharded clip loop: the clip at frame {first} has {n_clip} frames for {shard.world} ranks")
-    cs = ClipShard(owners, group=shard.group, always_collective=shard.always_collective)
-    k = [rows[first + p] for p in cs.local_positions]
-    sel = (lambda t: t[k[0]:k[0] + len(k)]) if k == list(range(k[0], k[0] + len(k))) else (lambda t: t[k])
-    mf, bfe, ms = pd
-    predictor.frame_shard = cs
-    try:
-        out = predictor([sel(lv) for lv in ms], sel(mf), sel(bfe) if bfe is not None else None, None, targets)
-    finally:
-        predictor.frame_shard = None
-    out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
-    out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
+    team = sorted(set(owners))
+    whole = len(team) == shard.world
+    group = shard.group if whole else shard.subgroup(team)
+    tv = targets[0]
+    out = None
+    if shard.rank in team:
+        cs = ClipShard([team.index(o) for o in owners], group=group, always_collective=shard.always_collective, counter=shard.bytes)
+        k = [rows[first + p] for p in cs.local_positions]
+        sel = (lambda t: t[k[0]:k[0] + len(k)]) if k == list(range(k[0], k[0] + len(k))) else (lambda t: t[k])
+        mf, bfe, ms = pd
+        predictor.frame_shard = cs
+        try:
+            out = predictor([sel(lv) for lv in ms], sel(mf), sel(bfe) if bfe is not None else None, None, targets)
+        finally:
+            predictor.frame_shard = None
+        before = shard.bytes["all_gather"]
+        out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
+        out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
+        shard.bytes["result:all_gather"] += shard.bytes["all_gather"] - before
+        shard.bytes["all_gather"] = before
+    if whole:
+        return out
+    # ---- the ranks outside the team: outputs, memory pool, generator states from the team's first rank
+    if device is None:
+        device = pd[0].device if pd is not None else torch.device("cpu")
+    enc = _sampler_encoder(model)
+    src = team[0]
+    state = {}
+    if shard.rank == src:
+        state = {f"out:{k_}": v for k_, v in out.items() if isinstance(v, torch.Tensor)}
+        state.update({f"pool:{k_}": tv[k_] for k_ in POOL_KEYS if k_ in tv})
+        state["rng:cpu"] = torch.get_rng_state()
+        if enc is not None and str(device) in enc._dev_gen:           # (the device generator of the sampler's "device" mode)
+            state["rng:dev"] = enc._dev_gen[str(device)].get_state()
+    before = shard.bytes["broadcast"]
+    got = shard.broadcast_state(src, state, device)
+    shard.bytes["result:broadcast"] += shard.bytes["broadcast"] - before
+    shard.bytes["broadcast"] = before
+    if shard.rank not in team:
+        out = {k_[4:]: v for k_, v in got.items() if k_.startswith("out:")}
+        out.setdefault("pred_reid_logits", None)
+        for k_, v in got.items():
+            if k_.startswith("pool:"):
+                tv[k_[5:]] = v
+        if any(k_.startswith("pool:") for k_ in got):
+            tv["prompt_obj_ids"] = tv["ids"]
+        torch.set_rng_state(got["rng:cpu"])
+        if enc is not None and "rng:dev" in got:
+            enc._generator(device).set_state(got["rng:dev"])
     return out
 
 
@@ -138,12 +187,10 @@ def begin_video(model, device, shard):
 
 
 def check_loop_shard(shard, num_frames):
-    """None for a one-rank shard without forced collectives; raises when the group is larger than a clip."""
+    """None for a one-rank shard without forced collectives.  (A group larger than a clip is fine: sharded_clip_forward runs every
+    clip's decoder on the ranks that own one of its frames.)"""
     if shard is not None and shard.world == 1 and not shard.always_collective:
         return None
-    if shard is not None and shard.world > num_frames:
-        raise ValueError(f"frame-sharded clip loop: {shard.world} ranks for clips of {num_frames} frames -- every rank must own a frame of "
-                         "every clip (give the loop a group of at most num_frames ranks; other ranks take other videos)")
     return shard
 
 
@@ -321,7 +368,7 @@ class InferenceVideoEntity(nn.Module):
                 if i + T > win_end:  # the window's frames: backbone AND pixel decoder, on their owners, once per frame
                     win_start, win_end = i, i + self.num_frames_window_test
                     win_rows, win_pd = window_features_on_owner(model, x, list(range(win_start, min(win_end, n_total))), shard)
-                out = sharded_clip_forward(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard)
+                out = sharded_clip_forward(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard, device=x.device)
             else:
                 if i + T > win_end:      # the backbone runs once per window of frames
                     win_start, win_end = i, i + self.num_frames_window_test

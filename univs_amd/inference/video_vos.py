@@ -170,7 +170,7 @@ class InferenceVideoVOS(nn.Module):
             self.write_targets_into_annotations_per_clip(targets, i, stride)
             # 2. the hot path
             if shard is not None:
-                out = sharded_clip_forward(model, targets, i, min(T, video_len - i), win_rows, win_pd, shard)
+                out = sharded_clip_forward(model, targets, i, min(T, video_len - i), win_rows, win_pd, shard, device=x.device)
             else:
                 o = i - win_start
                 feats = {k: v[o:o + T] for k, v in feats_window.items()}
