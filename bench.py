@@ -33,7 +33,7 @@ Informational objects (never `value`): `steady_state_with_prompts` (second clip 
 (BASELINE config 4: Swin-B, 200 queries + 4 referring expressions), `config5_swinl_1080p`, `frame_sharded_n1` (one 40-frame clip under a
 one-rank RCCL group) and `sliding_clip_loop` (config 3 as the reference RUNS a long video: the sliding 5-frame clip loop with the prompt
 memory pool over a 20-frame video -- at N = 1 in the reference's call pattern and in this build's default; at N > 1 with the frames of
-the video spread over min(N, 5) ranks, InferenceVideoEntity.set_frame_shard).
+the video spread over the N ranks, InferenceVideoEntity.set_frame_shard).
 """
 import argparse
 import ctypes
@@ -534,8 +534,8 @@ def run(args):
     # the prompt memory pool carried from clip to clip, over a 20-frame 720p video at the reference's default stride 1 (16 clips).
     #   N = 1: (a) the reference's call pattern (window 5: backbone and pixel decoder once per CLIP), (b) one 20-frame window with the
     #          pixel decoder once per FRAME (inference/video_entity.py: pixel_decoder_once_per_window);
-    #   N > 1: the frames of the video spread over min(N, 5) ranks (frame f on rank f % world: InferenceVideoEntity.set_frame_shard),
-    #          every clip's decoder on those ranks with one all-gather of the query states per layer, per-video state replicated.
+    #   N > 1: the frames of the video spread over the N ranks (frame f on rank f % N: InferenceVideoEntity.set_frame_shard), every
+    #          clip's decoder on the ranks that own its frames with one all-gather of the query states per layer, per-video state replicated.
     if not args.no_sliding_loop:
         try:
             import types
@@ -603,7 +603,7 @@ def run(args):
                                     "note": "the default configuration of this build (UNIVS_SAMPLER unset: 'auto' = device draws on the GPU)"}
             else:
                 from univs_amd.distributed import FrameShard
-                team = min(world, T)
+                team = world                       # (more ranks than a clip has frames: every clip's decoder on the ranks that own its frames)
                 import datetime
                 # a group of its own with a short timeout: a failure on one rank must not hang the others for the default ten minutes
                 grp = dist.new_group(ranks=list(range(team)), timeout=datetime.timedelta(seconds=180))
@@ -611,7 +611,9 @@ def run(args):
                 if rank < team:
                     try:         # (a failing rank still reaches the world-wide reduction below: nobody waits for it in vain)
                         lp = make_loop(NF)
-                        lp.set_frame_shard(FrameShard(group=grp))
+                        fs_loop = FrameShard(group=grp)
+                        fs_loop.timeout = datetime.timedelta(seconds=180)        # its sub-groups (one per team of clip owners) too
+                        lp.set_frame_shard(fs_loop)
                         dts, n_ent = time_video(lp)
                         sl["entities_at_end"] = n_ent
                     except Exception as e_:  # pragma: no cover
@@ -625,9 +627,11 @@ def run(args):
                     raise RuntimeError("the frame-sharded sliding clip loop failed on another rank")
                 sl["frame_sharded"] = {"ranks_used": team, "ranks_idle": world - team, "window": NF, "ms_per_video": dts * 1e3,
                                        "frames_per_s": NF / dts,
-                                       "note": "frame f on rank f % ranks_used: backbone + pixel decoder on owned frames, every clip's decoder "
-                                               "on all used ranks (ClipShard), targets[0] replicated; ranks beyond num_frames idle here "
-                                               "(they would take other videos)"}
+                                       "note": "frame f on rank f % N: backbone + pixel decoder on owned frames, every clip's decoder on the "
+                                               "ranks that own one of its frames (ClipShard on a sub-group when N > num_frames), targets[0] "
+                                               "replicated: the clip's mask logits are gathered / broadcast to every rank"}
+                if rank == 0 and "fs_loop" in locals():
+                    sl["frame_sharded"]["bytes_received_rank0"] = {k_: int(v_) for k_, v_ in fs_loop.bytes.items()}
             res["sliding_clip_loop"] = sl
         except Exception as e:  # pragma: no cover
             import traceback

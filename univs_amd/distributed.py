@@ -43,7 +43,8 @@ class FrameShard:
         key = tuple(int(r) for r in ranks)
         g = self._subgroups.get(key)
         if g is None:
-            g = self._subgroups[key] = dist.new_group(ranks=[self.global_rank(r) for r in key])
+            kw = {"timeout": self.timeout} if getattr(self, "timeout", None) is not None else {}
+            g = self._subgroups[key] = dist.new_group(ranks=[self.global_rank(r) for r in key], **kw)
         return g
 
     def broadcast_state(self, src: int, tensors, device):
