@@ -74,7 +74,9 @@ ABLATIONS = {"plainsplit": ("UNIVS_SPLIT_PLAIN",), "nosplit": ("UNIVS_ABLATE_NOS
              # csrc/msda_heads.hip (S6_ABLATE bits): no gather stream / no row movement / no reduction + stores / no records
              "heads_nostream": ("S6_ABLATE=1",), "heads_norows": ("S6_ABLATE=2",), "heads_noreduce": ("S6_ABLATE=4",),
              "heads_norecords": ("S6_ABLATE=8",), "heads_nostream_norows": ("S6_ABLATE=3",), "heads_onlyrows": ("S6_ABLATE=13",),
-             "heads_skeleton": ("S6_ABLATE=15",), "heads_trace": ("S6_TRACE",)}
+             "heads_skeleton": ("S6_ABLATE=15",), "heads_trace": ("S6_TRACE",),
+             # csrc/mlp_f16x3.hip: the weight stream staged through registers (round 5's form) instead of LDS-DMA
+             "mlp_regstage": ("UNIVS_MLP_REGSTAGE",)}
 
 
 def build_ablation(name, verbose=False):

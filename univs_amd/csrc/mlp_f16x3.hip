@@ -102,6 +102,26 @@ constexpr int ml_commits_in(int t, int upt, int nbat) {
   for (int v = 0; v < upt; ++v) n += (ml_fs(v, upt, nbat) + ml_dist(nbat) == t) ? 1 : 0;
   return n;
 }
+// LDS-DMA form of the stream (DB kernels): unit v goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no
+// ds_write), requested in batch slot ml_dma_slot(v) of the chunk BEFORE the one that reads it -- the first half of the chunk's slots,
+// so every request has at least half a chunk to land -- and awaited (vmcnt(0)) in front of the barrier that opens its chunk.
+// Register staging held three 16-byte units per thread in flight: 24 KB per CU against an L2 latency of ~1.5k - 3k clocks
+// = 8 - 16 bytes per clock and CU, i.e. 4k - 8k clocks for a chunk's 64 KB -- the stream's latency, not the matrix pipe, set the
+// chunk time (7.5k clocks measured; 3k of MFMA per SIMD).
+constexpr int ml_dma_slot(int v, int upt, int nbat) { return v * (nbat / 2) / upt; }
+#ifdef UNIVS_MLP_REGSTAGE       // (A / B: the register-staged stream everywhere)
+constexpr bool ML_GLDS = false;
+#else
+constexpr bool ML_GLDS = true;
+#endif
+// one wave's 1-KB piece: lane l's 16 bytes at `gsrc` -> LDS byte address `lds_dst` + 16 l (`lds_dst` wave-uniform).  M0 carries the
+// destination and is written in the statement that uses it (the compiler does not preserve it around asm statements).
+__device__ __forceinline__ void ml_glds16(const u32x4* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 constexpr int ml_ring(int upt, int nbat) {          // most units in flight at once (after a slot's commits and fetches)
   int worst = 1;
   for (int t = 0; t < nbat; ++t) {
@@ -129,6 +149,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
   constexpr int UPH = W1U / THREADS;                             // !DB: units per thread and phase (W1U == W2U)
   constexpr int WR = DB ? ml_ring(UPT, NBAT) : ml_ring(UPH, KS1), WD = DB ? ml_dist(NBAT) : ml_dist(KS1);
   constexpr int NBUF = DB ? 2 : 1;
+  constexpr bool GLDS = DB && ML_GLDS;                           // the weight stream by LDS-DMA (see ml_dma_slot)
   static_assert(W1U % THREADS == 0, "phase geometry");
   static_assert(CHU % THREADS == 0 && NOB == 2 * KS1 && NBAT >= 4, "chunk geometry");
   constexpr int RG = NW * 16 * CT;                               // rows per workgroup round
@@ -176,7 +197,8 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
 #pragma unroll
     for (int v = 0; v < U0; ++v) Lds[tid + THREADS * v] = w0[v];
   }
-  u32x4 wreg[WR];
+  [[maybe_unused]] u32x4 wreg[WR];
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Lds);   // LDS byte address of the chunk images
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long long)M * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
@@ -281,12 +303,14 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
 
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c, ++gq) {
+      if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of chunk gq's image have landed (asm loads are not in hipcc's count)
       __syncthreads();                                           // chunk gq's image is complete; the other buffer is free
       const int cn = (c + 1 == NCH) ? 0 : c + 1;
       const int bufc = DB ? (gq & 1) : 0;
       const unsigned a1 = a1_lane + (unsigned)(bufc * CHU * 16);
       const unsigned a2 = a2_lane + (unsigned)(bufc * CHU * 16);
       u32x4* const wdst = Lds + (DB ? (bufc ^ 1) * CHU : 0) + tid;
+      [[maybe_unused]] const unsigned wdma = lds_base + (unsigned)(((bufc ^ 1) * CHU + 64 * wave) * 16);   // this wave's first piece of the other image
       read_batch(afr[0], a1, 512u);
       read_batch(afr[1], a1 + 4096u, 512u);
 
@@ -300,7 +324,18 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
       // one batch slot: this slot's share of the weight stream, wait for batch T's fragments, request batch T + 2, six CT MFMAs
       auto slot = [&](auto tc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value;
-        if constexpr (DB) {
+        if constexpr (GLDS) {
+          ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value;
+            if constexpr (ml_dma_slot(V, UPT, NBAT) == T) ml_glds16(w_src(cn, V), wdma + (unsigned)(THREADS * V * 16));
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          if (ABL != 2) ml_wait_lgkm<(T + 1 < NBAT ? 4 : 0)>(afr[T % 3]);     // (no LDS operation of mine behind the next batch's reads)
+          if constexpr (T + 2 < NBAT) {
+            if constexpr (T + 2 < KS1) read_batch(afr[(T + 2) % 3], a1 + (unsigned)((T + 2) * 4096), 512u);
+            else read_batch(afr[(T + 2) % 3], a2 + (unsigned)((T + 2 - KS1) * 512), (unsigned)(C * 16));
+          }
+        } else if constexpr (DB) {
           ml_static_for<0, UPT>([&](auto vc) __attribute__((always_inline)) {
             constexpr int V = decltype(vc)::value;
             if constexpr (ml_fs(V, UPT, NBAT) + WD == T) wdst[THREADS * V] = wreg[V % WR];
@@ -530,6 +565,7 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
       }
     }
   }
+  if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last chunk requested chunk 0 again: nothing may land after the exit)
 }
 
 static int ml_cus() {
