@@ -151,7 +151,8 @@ typedef struct UnivsConfig {
                              6 = univs_linear_presplit_f32 keeps the row-range x pass kernel (gemm_f16x3_stream) where it would take the
                              two-dimensional tiling (gemm_f16x3_tile; bit-identical results: A / B runs); 7 / 8 / 9 = that kernel with 2 / 3 / 4
                              k-steps of loads in flight where K allows (kernel benchmarks; with linear_grid_x = 3..5 as its CT and
-                             linear_rows_per_pass = 128 / 192 / 256 as its feature-tile width) */
+                             linear_rows_per_pass = 128 / 192 / 256 as its feature-tile width); 10 = univs_mlp_presplit_f32 at C = 128 / 192 / 256
+                             runs its phase-shifted form (the two waves of a SIMD half a chunk apart: mlp_f16x3_ps; same results, A / B runs) */
   int mask_decode_chunked;/* 1: the exact-f32 mask kernel always in its chunked form (kernel benchmarks; default 0: small maps with
                              C == 256 request every row of their columns at once, skinny_gemm_f32_oneshot) */
   int mask_decode_wave_tiles; /* split-bf16 mask decode: column tiles a wave should get before a workgroup is added (default 1;

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default=os.path.basename(os.environ.get("UNIVS_HIP_LIB", "default")))
     ap.add_argument("--T", type=int, default=5)
-    ap.add_argument("--linear-ablate", type=int, default=0, help="UnivsConfig.linear_ablate (5: no XCD-aware (row range, pass) order)")
+    ap.add_argument("--linear-ablate", type=int, default=0, help="UnivsConfig.linear_ablate (5: no XCD-aware (row range, pass) order; 10: the phase-shifted fused MLP)")
     args = ap.parse_args()
     if args.linear_ablate:
         ops.configure(linear_ablate=args.linear_ablate)

@@ -27,6 +27,10 @@ __device__ __forceinline__ void block(f32x4 (&c)[8], f16x8 a, f16x8 b, unsigned 
             : "v"(a), "v"(b) /*8,9*/, "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]) /*10-13 (placeholders)*/, "v"(x), "v"(y) /*14,15*/, "v"(addr) /*16*/
   if constexpr (KIND == 0) asm volatile(M16(0) M16(1) M16(2) M16(3) M16(4) M16(5) M16(6) M16(7) : OPS);
   else if constexpr (KIND == 11) asm volatile(M16(0) M16(0) M16(0) M16(0) M16(0) M16(0) M16(0) M16(0) : OPS);
+  else if constexpr (KIND == 13) asm volatile(M16(0) M16(1) M16(0) M16(1) M16(0) M16(1) M16(0) M16(1) : OPS);      // two accumulators, alternating
+  else if constexpr (KIND == 14) asm volatile(M16(0) M16(0) M16(0) M16(0) M16(1) M16(1) M16(1) M16(1) : OPS);      // two accumulators, runs of four
+  else if constexpr (KIND == 15) asm volatile(M16(0) M16(1) M16(2) M16(0) M16(1) M16(2) M16(0) M16(1) : OPS);      // three accumulators, round-robin
+  else if constexpr (KIND == 16) asm volatile(M16(0) M16(1) M16(2) M16(3) M16(0) M16(1) M16(2) M16(3) : OPS);      // four accumulators, round-robin
   else if constexpr (KIND == 1 || KIND == 9) {
     unsigned d0, d1, d2, d3;
     if constexpr (KIND == 1)
@@ -123,6 +127,13 @@ int main() {
   run<0, 0>("8 MFMA 16x16x32 f16 (8 accumulators)", 4, dout, sink);
   run<0, 0>("8 MFMA, both waves of the SIMD", 8, dout, sink);
   run<11, 11>("8 MFMA on ONE accumulator", 4, dout, sink);
+  run<13, 13>("8 MFMA, TWO accumulators alternating (a b a b ...)", 4, dout, sink);
+  run<14, 14>("8 MFMA, two accumulators in runs (a a a a b b b b)", 4, dout, sink);
+  run<15, 15>("8 MFMA, three accumulators round-robin", 4, dout, sink);
+  run<16, 16>("8 MFMA, four accumulators round-robin", 4, dout, sink);
+  run<13, 13>("8 MFMA, two accumulators alternating, both waves", 8, dout, sink);
+  run<14, 14>("8 MFMA, two accumulators in runs, both waves", 8, dout, sink);
+  run<11, 11>("8 MFMA on one accumulator, both waves", 8, dout, sink);
   run<1, 1>("24 v_fma_mixlo", 4, dout, sink);
   run<1, 1>("24 v_fma_mixlo, both waves", 8, dout, sink);
   run<9, 9>("24 v_mul_f32", 4, dout, sink);

@@ -76,7 +76,8 @@ ABLATIONS = {"plainsplit": ("UNIVS_SPLIT_PLAIN",), "nosplit": ("UNIVS_ABLATE_NOS
              "heads_norecords": ("S6_ABLATE=8",), "heads_nostream_norows": ("S6_ABLATE=3",), "heads_onlyrows": ("S6_ABLATE=13",),
              "heads_skeleton": ("S6_ABLATE=15",), "heads_trace": ("S6_TRACE",),
              # csrc/mlp_f16x3.hip: the weight stream staged through registers (round 5's form) instead of LDS-DMA
-             "mlp_regstage": ("UNIVS_MLP_REGSTAGE",)}
+             "mlp_regstage": ("UNIVS_MLP_REGSTAGE",), "mlp_trace": ("UNIVS_TRACE_MLP",),
+             "mlp_trace_nomfma": ("UNIVS_TRACE_MLP", "ML_PS_ABL=1"), "mlp_trace_noreads": ("UNIVS_TRACE_MLP", "ML_PS_ABL=2")}
 
 
 def build_ablation(name, verbose=False):

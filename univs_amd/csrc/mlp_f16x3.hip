@@ -118,8 +118,9 @@ constexpr bool ML_GLDS = true;
 // destination and is written in the statement that uses it (the compiler does not preserve it around asm statements).
 __device__ __forceinline__ void ml_glds16(const u32x4* gsrc, unsigned lds_dst) {
   unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);  // (an "s" operand the compiler holds in a vector register is passed as one)
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
 constexpr int ml_ring(int upt, int nbat) {          // most units in flight at once (after a slot's commits and fetches)
@@ -568,6 +569,402 @@ __global__ __launch_bounds__(64 * NW, DB ? 2 : 1) void mlp_f16x3(const MlpArgs a
   if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last chunk requested chunk 0 again: nothing may land after the exit)
 }
 
+// -----------------------------------------------------------------------------------------------------------------------------------
+// The same MLP with the two waves of every SIMD HALF A CHUNK APART (round 6; C = 128 / 192 / 256, 8 waves, 16 rows per wave).
+// What the probes of round 6 measured (profiles/r06_mfma_overlap_probe_v1.txt): one wave saturates its SIMD's matrix pipe; vector work
+// between a wave's OWN matrix instructions adds to its time; a vector-busy wave BESIDE a matrix-busy wave overlaps it.  In the kernel
+// above both waves of a SIMD run the same phase at the same time (one barrier per chunk): first both want the matrix pipe, then both
+// do the activation / split of the hidden values -- the chunk time was the SUM of the matrix, LDS-read and vector parts (7.2k clocks
+// for 3.1k of matrix instructions).  Here a chunk is two PHASES -- P1 = GEMM 1 + activation, P2 = GEMM 2 -- with a barrier behind each,
+// waves 0-3 (one per SIMD) run phase s in slot s and waves 4-7 phase s - 1: beside every P1 runs a P2.  The wave in P1 has the higher
+// priority: its 6 KS1 matrix instructions go first, its activation then runs under the other wave's GEMM 2.
+// The weights stream through a ring of FOUR half-images (W1 rows of a chunk | W2 k-step of a chunk, 8 C units each) by LDS-DMA: in
+// slot s every wave requests its share of half-image s + 2 (its ring slot was last read in slot s - 1) and waits, in front of the
+// slot's barrier, for everything but those requests (memory reads return in order).  Row groups follow each other without a gap:
+// a wave stores group k's rows and loads group k + 1's at the head of its first phase of group k + 1, under its partner's GEMM 2.
+#ifdef UNIVS_TRACE_MLP            // instrumented build (`--ablate mlp_trace`): s_memtime stamps of workgroup 0's waves in their first slots
+constexpr int ML_TR_SLOTS = 24, ML_TR_ST = 6;
+static __device__ unsigned long long g_ml_trace[8 * ML_TR_SLOTS * ML_TR_ST];
+#define ML_TR(slot, k)                                                                                                  \
+  do {                                                                                                                  \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < ML_TR_SLOTS)                                             \
+      g_ml_trace[((threadIdx.x >> 6) * ML_TR_SLOTS + (slot)) * ML_TR_ST + (k)] = __builtin_amdgcn_s_memtime();          \
+  } while (0)
+#else
+#define ML_TR(slot, k) do { } while (0)
+#endif
+
+#if defined(ML_PS_ABL) && (ML_PS_ABL & 1)
+__device__ __forceinline__ f32x4 ml_ps_fake_mfma(f16x8 a_, f16x8 b_, f32x4 c_) {
+  asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_));
+  return c_;
+}
+#define ML_PS_MMA(a_, b_, c_) ml_ps_fake_mfma(a_, b_, c_)
+#else
+#define ML_PS_MMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+#endif
+
+template <int KS1, int ACT>
+__global__ __launch_bounds__(512, 1) void mlp_f16x3_ps(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 Lds[];
+  constexpr int THREADS = 512, NW = 8, C = 32 * KS1, NOB = C / 16, NRING = 4;
+  constexpr int HU = 8 * C;                                      // 16-byte units of a half-image
+  constexpr int UPH = HU / THREADS;                              // ... per thread
+  constexpr int RG = NW * 16;                                    // rows per workgroup round
+  static_assert(HU % THREADS == 0 && NOB == 2 * KS1 && KS1 >= 3 && UPH <= 8, "geometry");
+  const int M = a.M, Hd = a.Hd, NCH = Hd >> 5, nwg = a.nwg;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  float* b1_lds = reinterpret_cast<float*>(Lds + NRING * HU);
+  float* w1inv_lds = b1_lds + Hd;
+  float* b2_lds = w1inv_lds + Hd;
+  float* w2inv_lds = b2_lds + C;
+  float* lng_lds = w2inv_lds + C;
+  float* lnb_lds = lng_lds + C;
+  float* plng_lds = lnb_lds + C;
+  float* plnb_lds = plng_lds + C;
+  const bool with_ln = a.ln_g != nullptr;                        // uniform
+  const bool with_pln = a.pln_g != nullptr;                      // uniform
+  const int ngroups = (M + RG - 1) / RG;
+  if ((int)blockIdx.x >= ngroups) return;
+  const int G = (ngroups - 1 - (int)blockIdx.x) / nwg + 1;       // row groups of this workgroup
+  const int P = 2 * NCH * G;                                     // phases of a wave
+
+  for (int r = tid; r < Hd; r += THREADS) {
+    b1_lds[r] = a.b1 ? a.b1[r] : 0.f;
+    w1inv_lds[r] = a.w1inv[r];
+  }
+  for (int r = tid; r < C; r += THREADS) {
+    b2_lds[r] = a.b2 ? a.b2[r] : 0.f;
+    w2inv_lds[r] = a.w2inv[r];
+    lng_lds[r] = with_ln ? a.ln_g[r] : 1.f;
+    lnb_lds[r] = (with_ln && a.ln_b) ? a.ln_b[r] : 0.f;
+    plng_lds[r] = with_pln ? a.pln_g[r] : 1.f;
+    plnb_lds[r] = (with_pln && a.pln_b) ? a.pln_b[r] : 0.f;
+  }
+  // half-image p: part p & 1 (0: W1 rows [32 c, 32 c + 32), 1: W2 k-step c) of chunk c = (p / 2) % NCH; unit i = tid + THREADS v
+  auto w_src = [&](int p, int v) __attribute__((always_inline)) -> const u32x4* {
+    const int i = tid + THREADS * v;
+    const int c = (p >> 1) % NCH;
+    return (p & 1) ? a.W2p + ((size_t)c * HU + i) : a.W1p + ((size_t)(i >> 5) * Hd + 32 * c + (i & 31));
+  };
+  {
+    u32x4 w0[2 * UPH];                                           // half-images 0 and 1 (chunk 0) through registers
+#pragma unroll
+    for (int v = 0; v < 2 * UPH; ++v) w0[v] = *w_src(v / UPH, v % UPH);
+#pragma unroll
+    for (int v = 0; v < 2 * UPH; ++v) Lds[(v / UPH) * HU + tid + THREADS * (v % UPH)] = w0[v];
+  }
+  __syncthreads();                                               // parameters and half-images 0, 1 are in place
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)Lds);
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
+  const bool res_normed = a.res_normed != 0;                      // uniform
+  const bool with_res = a.Res != nullptr || res_normed;
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(res_normed ? a.Y : a.Res ? a.Res : a.X), 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.Y2 ? a.Y2 : a.Y, 0, (int)((long long)M * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.padd ? a.padd : a.X), 0, (int)((long long)(a.padd ? a.padd_rows : M) * C * 4), 0x00020000);
+
+  constexpr int AR = 3;                           // fragment batches in flight + 1 (C = 256: registers allow one in flight)
+  u32x4 afr[AR][2][2];                                           // [ring][block][part]
+  auto read_batch = [&](u32x4 (&d)[2][2], unsigned addr, unsigned pstride) __attribute__((always_inline)) {
+#ifdef ML_PS_ABL
+    if (ML_PS_ABL & 2) return;
+#endif
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned ah = addr + (unsigned)(q * 256);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(d[q][0]), "=&v"(d[q][1]) : "v"(ah), "v"(ah + pstride) : "memory");
+    }
+  };
+  const unsigned a1_lane = (unsigned)((g * 64 + j) * 16);        // W1 half-image: ((t 4 + g) 2 + part) 32 + 16 q + j units
+  const unsigned a2_lane = (unsigned)((g * 2 * C + j) * 16);     // W2 half-image: (g 2 + part) C + 16 (2 t + q) + j units
+
+  // ---- the state of a row group
+  f16x8 xh[KS1], xm[KS1], hh, hm;
+  float sx_inv = 1.f, sh = 1.f, sh_inv = 1.f;
+  int eset = -1000;
+  f32x4 acc1[2], acc2[NOB];
+
+  auto group_row0 = [&](int gi) __attribute__((always_inline)) { return ((int)blockIdx.x + gi * nwg) * RG + wave * 16; };
+
+  // x tile of a group: read once, optional LayerNorm, exact row maximum, two fp16 parts in registers
+  auto prologue = [&](int gi) __attribute__((always_inline)) {
+    const int row0 = group_row0(gi);
+    const int m = min(row0 + j, M - 1);                           // rows past the end repeat the last row (not stored)
+    const unsigned vo = ((unsigned)m * (unsigned)C + (unsigned)(8 * g)) * 4u;
+    f32x4 raw[KS1][2];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      raw[ks][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, ks * 128, 0));
+      raw[ks][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 16u, ks * 128, 0));
+    }
+    if (with_ln) {
+      float sm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm += raw[ks][0][e] + raw[ks][1][e];
+      const float mean = ml_row_sum(sm) * (1.0f / C);
+      float sq = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          raw[ks][h2] -= mean;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq = fmaf(raw[ks][h2][e], raw[ks][h2][e], sq);
+        }
+      const float rstd = 1.0f / sqrtf(ml_row_sum(sq) * (1.0f / C) + a.ln_eps);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(lng_lds + 32 * ks + 8 * g + 4 * h2);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(lnb_lds + 32 * ks + 8 * g + 4 * h2);
+          raw[ks][h2] = (raw[ks][h2] * rstd) * gm + bt;
+          if (res_normed)                                        // park the residual row (rows past the end: dropped)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, raw[ks][h2]), yrs,
+                                                   row0 + j < M ? vo + (unsigned)(16 * h2) : 0xFFFFFFF0u, ks * 128, 0);
+        }
+    }
+    unsigned mx = 0u;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) mx = max(mx, l3_absmax8(raw[ks][0], raw[ks][1]));
+    mx = l3_row_max(mx);
+    float s_, inv;
+    l3_scale(mx, 14, s_, inv);
+    sx_inv = inv;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) l3_split8(raw[ks][0], raw[ks][1], s_, xh[ks], xm[ks]);
+  };
+
+  // y of a group: D[i = feature][j = row]: a lane holds four consecutive features of its row
+  auto epilogue = [&](int gi) __attribute__((always_inline)) {
+    const int m = group_row0(gi) + j;
+    const unsigned rowoff = m < M ? (unsigned)m * (unsigned)C * 4u : 0xFFFFFFF0u;   // out of range: loads give 0, stores are dropped
+    constexpr int RBAT = NOB < 8 ? NOB : 8;
+    f32x4 resv[RBAT];
+    auto load_res = [&](int ob0) __attribute__((always_inline)) {
+      if (with_res) {
+#pragma unroll
+        for (int q = 0; q < RBAT; ++q) {
+          const int f = min(ob0 + q, NOB - 1) * 16 + 4 * g;
+          const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+          resv[q] = res_normed ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 1))
+                               : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, offc, 0, 0));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < RBAT; ++q) resv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    if (!with_pln) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        if (ob % RBAT == 0) load_res(ob);
+        const int f = ob * 16 + 4 * g;
+        const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
+        f32x4 v = (acc2[ob] * sh_inv) * wi + bi;
+        const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+        if (with_res) v += resv[ob % RBAT];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+      }
+    } else {
+      float sm = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        if (ob % RBAT == 0) load_res(ob);
+        const int f = ob * 16 + 4 * g;
+        const f32x4 wi = *reinterpret_cast<const f32x4*>(w2inv_lds + f);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(b2_lds + f);
+        f32x4 v = (acc2[ob] * sh_inv) * wi + bi;
+        const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+        if (with_res) v += resv[ob % RBAT];
+        acc2[ob] = v;
+        if (a.dual) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, offc, 0, 0);
+        sm += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      const float mean = ml_row_sum(sm) * (1.0f / C);
+      float sq = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        acc2[ob] -= mean;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq = fmaf(acc2[ob][e], acc2[ob][e], sq);
+      }
+      const float rstd = 1.0f / sqrtf(ml_row_sum(sq) * (1.0f / C) + a.pln_eps);
+      const unsigned prow = a.padd ? (unsigned)(min(m, M - 1) % a.padd_rows) * (unsigned)C * 4u : 0u;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int f = ob * 16 + 4 * g;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(plng_lds + f);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(plnb_lds + f);
+        const f32x4 y = (acc2[ob] * rstd) * gm + bt;
+        const unsigned offc = m < M ? rowoff + (unsigned)f * 4u : 0xFFFFFFF0u;
+        if (a.dual) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), y2rs, offc, 0, 0);
+          continue;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), yrs, offc, 0, 0);
+        if (a.Y2) {
+          f32x4 y2 = y;
+          if (a.padd) y2 += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pars, prow + (unsigned)f * 4u, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y2), y2rs, offc, 0, 0);
+        }
+      }
+    }
+  };
+
+  // half-image p -> ring slot p & 3 by LDS-DMA, requested by the FOUR waves that run a P2 in that slot (wave & 3 takes a quarter: 2 UPH
+  // pieces of 1 KB): issuing a piece costs a wave 100 - 150 clocks of its instruction stream (traced), and the wave in P1 -- GEMM 1,
+  // then the activation -- is the slot's critical path
+  auto request_half = [&](int p) __attribute__((always_inline)) {
+    const int c = (p >> 1) % NCH;
+    const unsigned dst0 = lds_base + (unsigned)((p & (NRING - 1)) * HU * 16);
+#pragma unroll
+    for (int v = 0; v < 2 * UPH; ++v) {
+      const int piece = (wave & 3) * 2 * UPH + v;
+      const int i = piece * 64 + lane;
+      const u32x4* src = (p & 1) ? a.W2p + ((size_t)c * HU + i) : a.W1p + ((size_t)(i >> 5) * Hd + 32 * c + (i & 31));
+      ml_glds16(src, dst0 + (unsigned)(piece * 1024));
+    }
+  };
+
+  // P1 of chunk c: acc1[block] = W1[chunk rows] x^T over KS1 k-steps, then bias, activation, running row scale, two fp16 parts
+  int sl = 0;                                                    // the slot this wave is in
+  auto phase1 = [&](int c, int ring) __attribute__((always_inline)) {
+    ML_TR(sl, 0);
+    const unsigned a1 = a1_lane + (unsigned)(ring * HU * 16);
+    read_batch(afr[0], a1, 512u);
+    if constexpr (AR == 3) read_batch(afr[1], a1 + 4096u, 512u);
+    acc1[0] = acc1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ml_static_for<0, KS1>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int T = decltype(tc)::value;
+      // AR == 3: batch T + 2 is requested behind the wait for batch T; AR == 2: batch T + 1 in front of it (its slot was batch T - 1's)
+      if constexpr (AR == 2 && T + 1 < KS1) read_batch(afr[(T + 1) % AR], a1 + (unsigned)((T + 1) * 4096), 512u);
+      ml_wait_lgkm<(T + 1 < KS1 ? 4 : 0)>(afr[T % AR]);
+      if constexpr (AR == 3 && T + 2 < KS1) read_batch(afr[(T + 2) % AR], a1 + (unsigned)((T + 2) * 4096), 512u);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[T % AR][0][0]), am0 = __builtin_bit_cast(f16x8, afr[T % AR][0][1]);
+      const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[T % AR][1][0]), am1 = __builtin_bit_cast(f16x8, afr[T % AR][1][1]);
+      acc1[0] = ML_PS_MMA(am0, xh[T], acc1[0]);   // smallest terms first: m h', h m', h h'
+      acc1[1] = ML_PS_MMA(am1, xh[T], acc1[1]);
+      acc1[0] = ML_PS_MMA(ah0, xm[T], acc1[0]);
+      acc1[1] = ML_PS_MMA(ah1, xm[T], acc1[1]);
+      acc1[0] = ML_PS_MMA(ah0, xh[T], acc1[0]);
+      acc1[1] = ML_PS_MMA(ah1, xh[T], acc1[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ML_TR(sl, 1);
+    const int hf = 32 * c + 4 * g;
+    const f32x4 wi0 = *reinterpret_cast<const f32x4*>(w1inv_lds + hf), wi1 = *reinterpret_cast<const f32x4*>(w1inv_lds + hf + 16);
+    const f32x4 bi0 = *reinterpret_cast<const f32x4*>(b1_lds + hf), bi1 = *reinterpret_cast<const f32x4*>(b1_lds + hf + 16);
+    f32x4 v0 = (acc1[0] * sx_inv) * wi0 + bi0;                   // two exact unscalings, then the bias
+    f32x4 v1 = (acc1[1] * sx_inv) * wi1 + bi1;
+    if (ACT == ML_ACT_RELU) {                                    // NaN-propagating maximum, as torch's relu
+      v0 = __builtin_elementwise_maximum(v0, (f32x4){0.f, 0.f, 0.f, 0.f});
+      v1 = __builtin_elementwise_maximum(v1, (f32x4){0.f, 0.f, 0.f, 0.f});
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = l3_gelu(v0[e]);
+        v1[e] = l3_gelu(v1[e]);
+      }
+    }
+    const unsigned mk = l3_row_max(l3_absmax8(v0, v1));
+    const int enew = max(-100, min((int)((mk >> 23) & 255u) - 127, 128));   // 2^e <= max < 2^(e+1)
+    const bool need = enew > eset + 2;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {                // rare after the first chunk
+      const int en = need ? enew : eset;
+      const float ratio = __builtin_bit_cast(float, (unsigned)(127 + max(eset - en, -126)) << 23);   // 2^(old - new) <= 1
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) acc2[ob] *= ratio;
+      eset = en;
+      sh = __builtin_bit_cast(float, (unsigned)(127 + 12 - en) << 23);
+      sh_inv = __builtin_bit_cast(float, (unsigned)(127 - 12 + en) << 23);
+    }
+    l3_split8(v0, v1, sh, hh, hm);
+    ML_TR(sl, 2);
+  };
+
+  // P2 of chunk c: acc2[blocks] += W2[rows][k-step c] h^T
+  auto phase2 = [&](int ring, int next_half) __attribute__((always_inline)) {
+    ML_TR(sl, 0);
+    const unsigned a2 = a2_lane + (unsigned)(ring * HU * 16);
+    read_batch(afr[0], a2, (unsigned)(C * 16));
+    if constexpr (AR == 3) read_batch(afr[1], a2 + 512u, (unsigned)(C * 16));
+    if (next_half >= 0) request_half(next_half);
+    ml_static_for<0, KS1>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int T = decltype(tc)::value;
+      constexpr int B0 = 2 * T, B1 = B0 + 1;
+      if constexpr (AR == 2 && T + 1 < KS1) read_batch(afr[(T + 1) % AR], a2 + (unsigned)((T + 1) * 512), (unsigned)(C * 16));
+      ml_wait_lgkm<(T + 1 < KS1 ? 4 : 0)>(afr[T % AR]);
+      if constexpr (AR == 3 && T + 2 < KS1) read_batch(afr[(T + 2) % AR], a2 + (unsigned)((T + 2) * 512), (unsigned)(C * 16));
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 ah0 = __builtin_bit_cast(f16x8, afr[T % AR][0][0]), am0 = __builtin_bit_cast(f16x8, afr[T % AR][0][1]);
+      const f16x8 ah1 = __builtin_bit_cast(f16x8, afr[T % AR][1][0]), am1 = __builtin_bit_cast(f16x8, afr[T % AR][1][1]);
+      acc2[B0] = ML_PS_MMA(am0, hh, acc2[B0]);
+      acc2[B1] = ML_PS_MMA(am1, hh, acc2[B1]);
+      acc2[B0] = ML_PS_MMA(ah0, hm, acc2[B0]);
+      acc2[B1] = ML_PS_MMA(ah1, hm, acc2[B1]);
+      acc2[B0] = ML_PS_MMA(ah0, hh, acc2[B0]);
+      acc2[B1] = ML_PS_MMA(ah1, hh, acc2[B1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ML_TR(sl, 1);
+    ML_TR(sl, 2);
+  };
+
+  // a slot's end.  A wave requests weights only in its P2 slots (half-image slot + 2) and needs them landed one slot later: it waits
+  // for all its requests at the end of its P1 slots and for nothing at the end of its P2 slots
+  auto slot_end = [&](bool wait_all) __attribute__((always_inline)) {
+    ML_TR(sl, 3);
+    if (wait_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ML_TR(sl, 4);
+    __builtin_amdgcn_s_barrier();
+    ML_TR(sl, 5);
+  };
+  const int late = wave >> 2;                                    // waves 4-7 run one slot behind waves 0-3
+  prologue(0);
+  if (late) {                                                    // slot 0 of the late waves: half-image 2 (nobody runs a P2 in slot 0)
+    if (2 < P) request_half(2);
+    slot_end(true);
+    ++sl;
+  }
+#pragma unroll 1
+  for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc2[ob] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    eset = -1000;
+    sh = sh_inv = 1.0f;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      const int ph = (gi * NCH + c) * 2;                         // = sl - late
+      __builtin_amdgcn_s_setprio(1);                             // P1: my matrix instructions first, my activation under the partner's GEMM 2
+      phase1(c, ph & (NRING - 1));
+      slot_end(true);
+      ++sl;
+      const int nh = sl + 2 < P ? sl + 2 : -1;
+      __builtin_amdgcn_s_setprio(0);
+      phase2((ph + 1) & (NRING - 1), nh);
+      slot_end(false);
+      ++sl;
+    }
+    // the seam between two row groups sits at the head of this wave's next slot: store group gi, load group gi + 1
+    epilogue(gi);
+    if (gi + 1 < G) prologue(gi + 1);
+  }
+  if (!late) slot_end(true);                                     // slot P of the early waves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
 static int ml_cus() {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -619,6 +1016,21 @@ static int ml_launch(const MlpArgs& a, int act, hipStream_t st) {
       return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 3>(a, lds, ngroups, st);
     }
   }
+  if constexpr (DB && NW == 8 && CT == 1 && KS1 >= 4 && ML_GLDS) {
+    // the phase-shifted kernel (waves 4-7 half a chunk behind waves 0-3): UnivsConfig.linear_ablate = 10.  NOT the default: it measured
+    // 329 us against the lockstep kernel's 321 on the encoder FFN (profiles/r06_mlp_phase_shift_v1.txt) -- kept for A / B runs
+    const size_t lds_ps = (size_t)4 * 8 * C * 16 + (size_t)(2 * a.Hd + 6 * C) * 4;
+    if (abl == 10 && lds_ps <= 160 * 1024) {
+      MlpArgs b = a;
+      b.nwg = std::min(ml_cus(), ngroups);
+      const void* fn = act == ML_ACT_RELU ? reinterpret_cast<const void*>(&mlp_f16x3_ps<KS1, ML_ACT_RELU>)
+                                          : reinterpret_cast<const void*>(&mlp_f16x3_ps<KS1, ML_ACT_GELU>);
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+      if (act == ML_ACT_RELU) hipLaunchKernelGGL((mlp_f16x3_ps<KS1, ML_ACT_RELU>), dim3((unsigned)b.nwg), dim3(512), lds_ps, st, b);
+      else hipLaunchKernelGGL((mlp_f16x3_ps<KS1, ML_ACT_GELU>), dim3((unsigned)b.nwg), dim3(512), lds_ps, st, b);
+      return check_launch("mlp_f16x3_ps");
+    }
+  }
   if (act == ML_ACT_RELU) return ml_launch1<KS1, CT, ML_ACT_RELU, NW, 0, DB>(a, lds, ngroups, st);
   return ml_launch1<KS1, CT, ML_ACT_GELU, NW, 0, DB>(a, lds, ngroups, st);
 }
@@ -655,3 +1067,10 @@ int mlp_f16x3_f32(const float* x, const void* w1p, const float* w1inv, const flo
 }
 
 }  // namespace univs
+
+#ifdef UNIVS_TRACE_MLP
+extern "C" int univs_debug_mlp_trace(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(univs::g_ml_trace), sizeof(unsigned long long) * 8 * univs::ML_TR_SLOTS * univs::ML_TR_ST);
+}
+#endif

@@ -492,11 +492,9 @@ int prompt_draw(const uint8_t* sel, const int* rowcnt, const uint8_t* fmb, const
                 uint8_t* empty, float* point_coords, hipStream_t st) {
   const size_t lds = (size_t)(PS_NT + 1 + PS_NW + 4 + PS_NW + PS_NW + 3) * 4 + (tab ? 0 : (size_t)HW * 4);
   if (lds > 150 * 1024) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE)
+  if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_draw), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(ps_draw, dim3(Fk * n), dim3(PS_NT), lds, st, sel, rowcnt, fmb, counts, u, keys, tab, n, h, w, HW, R, point_idx,
                      dense_idx, empty, point_coords);
   const int rc = check_launch("prompt_draw");
