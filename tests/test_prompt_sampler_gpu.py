@@ -186,3 +186,19 @@ def test_token_mean_counts_non_blank_tokens(cuda):
     exact = x64.sum(1) / torch.logical_not((x64 == 0).all(-1)).unsqueeze(-1).sum(1).clamp(min=1)
     assert (ops.token_mean(xd).double().cpu() - exact).abs().max().item() < 5e-6
     assert ops.token_mean(x) is None                 # CPU tensors: the caller keeps the ATen formulation
+
+
+def test_feature_maps_smaller_than_the_token_count_fall_back(cuda):
+    """fewer feature pixels than dense tokens (3 x 5 < R = 16): `prompt_draw` declines and the ATen formulation turns the SAME draws into
+    pixels; prefix and token kernels still run -- the clip's tensors equal the pure ATen run"""
+    from univs_amd import ops
+    Fk, n, hi, wi = 1, 4, 3, 5
+    masks, boxes, feats, pos = scene(Fk, n, hi, wi, cuda, seed=77)
+    pre = ops.prompt_prefix(masks, boxes, S)
+    assert ops.prompt_draw(pre, R, u=torch.rand(Fk * n, 1, device=cuda), keys=torch.rand(Fk * n, hi * wi, device=cuda)) is None
+    enc = encoder("device")
+    _, out_a, log_a = run(enc, masks, boxes, feats, pos, fused=False)
+    _, out_f, log_f = run(enc, masks, boxes, feats, pos, fused=True)
+    for a, b in zip(out_a, out_f):
+        assert torch.equal(a, b)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(log_a, log_f))

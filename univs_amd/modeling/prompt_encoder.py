@@ -397,7 +397,7 @@ class VisualPromptEncoder:
         valid, feat_masks, fmb = pre["valid"].reshape(N), pre["feat_masks"], pre["feat_masks_binary"]
         m = fmb.reshape(N, HW)
         # ---- the draws: a rank among the candidate pixels per entity, R ranks among the mask's feature pixels per entity
-        dense_idx = point_coords = None
+        dense_idx = point_coords = drawn = None
         fused = SWITCHES.fused_sampler and img_features.is_cuda and all(pre[k].is_contiguous() for k in ("sel", "rowcnt", "feat_masks_binary", "counts"))
         if fused:
             from .. import ops
@@ -410,23 +410,25 @@ class VisualPromptEncoder:
             dense_idx = to_device_async(torch.cat([r[1].to(torch.int64) for r in rec]), device)
             empty = (dense_idx[:, :1] < 0).view(-1, 1, 1)
             dense_idx = dense_idx.clamp(min=0)
-        elif fused and self._rng(device) == "device":
-            u = torch.rand((N, 1), device=device, generator=self._generator(device))           # the same draws, in the same order, as below
+        elif self._rng(device) == "device":
+            # two draws per call, in this order, whichever formulation turns them into pixels
+            u = torch.rand((N, 1), device=device, generator=self._generator(device))
             keys = torch.rand(m.shape, device=device, generator=self._generator(device))
-            drawn = ops.prompt_draw(pre, R, u=u, keys=keys)
-            assert drawn is not None, "prompt_draw: shape not covered"
+            drawn = ops.prompt_draw(pre, R, u=u, keys=keys) if fused else None
+        if dense_idx is not None:
+            pass                                                                # replayed pixels
+        elif drawn is not None:
             point_idx, point_coords, dense_idx, empty = drawn
             empty = empty.view(-1, 1, 1)
         elif self._rng(device) == "device":
             rowcnt = pre["rowcnt"].reshape(N, h)
             cnt = rowcnt.sum(1, dtype=torch.int64).clamp(min=1)
-            u = torch.rand((N, 1), device=device, generator=self._generator(device))
             ranks = (u * cnt[:, None]).long().clamp(max=cnt[:, None] - 1)
             point_idx = _kth_true_2d(pre["sel"].reshape(N, h, w), ranks, rowcnt)[:, 0]
             dcnt = m.sum(1)
             cyc = torch.arange(R, device=device)[None] % dcnt.clamp(min=1)[:, None]
             idx_small = _kth_true(m, cyc)
-            keys = torch.rand(m.shape, device=device, generator=self._generator(device)).masked_fill(~m.bool(), -1.0)
+            keys = keys.masked_fill(~m.bool(), -1.0)
             idx_big = keys.topk(min(R, HW), dim=1).indices
             if idx_big.shape[1] < R:
                 idx_big = torch.cat([idx_big, idx_big[:, :1].expand(-1, R - idx_big.shape[1])], dim=1)
