@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--cprofile", type=int, default=-1, help="cProfile the predictor call of this clip (host side)")
+    ap.add_argument("--cprofile-post", default="", help="cProfile every call of this method of the loop (e.g. detect_newly_entities_per_clip_instance)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     case = cases.CFG2
@@ -98,6 +99,23 @@ def main():
         run()
         head.predictor.forward = fwd
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    if args.cprofile_post:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        orig = getattr(loop, args.cprofile_post)
+
+        def prof_post(*a, **k):
+            torch.cuda.synchronize()
+            pr.enable()
+            r = orig(*a, **k)
+            torch.cuda.synchronize()
+            pr.disable()
+            return r
+        setattr(loop, args.cprofile_post, prof_post)
+        run()
+        setattr(loop, args.cprofile_post, orig)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
     if args.kernels:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
