@@ -71,7 +71,8 @@ def run(enc, masks, boxes, feats, pos, fused, seed=11, replay=None):
     return pre, out, log
 
 
-@pytest.mark.parametrize("Fk,n,hi,wi,scale", [(2, 6, 16, 24, 8), (1, 7, 23, 40, 8), (2, 10, 92, 160, 8), (1, 6, 75, 101, 1), (2, 6, 30, 45, 3)])
+@pytest.mark.parametrize("Fk,n,hi,wi,scale", [(2, 6, 16, 24, 8), (1, 7, 23, 40, 8), (2, 10, 92, 160, 8), (1, 6, 75, 101, 1), (2, 6, 30, 45, 3),
+                                              (1, 8, 136, 240, 8)])     # (the last: BASELINE config 5's 1088 x 1920, 32 640 keys per entity in LDS)
 @pytest.mark.parametrize("mode", ["device", "reference"])
 def test_fused_sampler_equals_the_aten_formulation(cuda, Fk, n, hi, wi, scale, mode):
     """(scale 1 and 3: mask rows that are not multiples of 16 bytes -- the kernels' scalar path)"""
