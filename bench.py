@@ -104,6 +104,12 @@ def init_distributed(args):
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         if args.dry_run:
             dist.init_process_group("gloo")
+        elif os.environ.get("UNIVS_BENCH_ONE_GPU_DEBUG") == "1":
+            # DEVELOPMENT ONLY (never set by the driver): all N ranks on GPU 0 with gloo collectives on device tensors -- the N > 1 code
+            # paths (replicas, frame_sharded, the sharded sliding loop with its teams) run end to end on the one-GPU boxes; the times mean nothing
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

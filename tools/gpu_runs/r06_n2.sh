@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 6: the N > 1 paths of bench.py end to end on ONE GPU (all ranks on GPU 0, gloo collectives on device tensors: UNIVS_BENCH_ONE_GPU_DEBUG=1) -- a
+# correctness run of the replica line, the frame-sharded clip and the sharded sliding loop (teams at N = 8); the times mean nothing
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r06_n2
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp UNIVS_BENCH_ONE_GPU_DEBUG=1
+for N in 2 8; do
+  timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + N)) bench.py --gpus $N --steps 2 --warmup 1 > $O/bench_n$N.json 2> $O/bench_n$N.err
+  echo "N=$N rc $?"
+  python - <<PY
+import json
+try:
+    r = json.loads(open("gpurun_out/r06_n2/bench_n$N.json").read().strip().splitlines()[-1])
+    print({k: r.get(k) for k in ("n_gpus", "value", "ms_per_step", "scaling", "mask_logit_max_abs_err", "mask_sign_flips")})
+    print(" frame_sharded", json.dumps(r.get("frame_sharded"))[:600])
+    print(" sliding", json.dumps(r.get("sliding_clip_loop"))[:1200])
+except Exception as e:
+    print("no json line:", e)
+    print(open("gpurun_out/r06_n2/bench_n$N.err").read()[-3000:])
+PY
+done
