@@ -92,3 +92,35 @@ def test_resident_kernel_reads_fragments_with_immediate_offsets(resident):
     # the k loop's waits are counted (16 x loads in flight per wave)
     waits = [int(m.group(1)) for l in body for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
     assert sum(w >= 12 for w in waits) >= 12, waits
+
+
+def test_library_has_no_packed_f32_low_result_from_a_high_half():
+    """gfx950 hazard across waves (csrc/common.h: fma_single; tools/race_probe8.py measured it): v_pk_{fma,mul,add}_f32 whose LOW result
+    selects the HIGH half of src1 / src2 reads 0 there in lanes 48..63 while another wave of the SIMD issues v_mfma_f32_16x16x32_{f16,bf16}
+    -- a kernel on another stream is enough.  hipcc forms such instructions from scalar code, so the BUILT library is scanned (every
+    gfx950 code object of libunivs_hip.so, disassembled): a source edit or a compiler update that brings the form back fails here."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import isa_scan
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists(os.path.join(isa_scan.LLVM, "llvm-objdump")) or shutil.which("objcopy") is None:
+        pytest.skip("llvm-objdump / objcopy not found")
+    from univs_amd import build
+    lib = build.build()                                        # (a no-op when the binary is newer than the sources)
+    objects = isa_scan.code_objects(lib)
+    assert len(objects) >= 20, len(objects)                    # one code object per .hip file
+    found = {}
+    kernels = 0
+    for co in objects:
+        text = isa_scan.disassemble(co)
+        kernels += len(re.findall(r"^[0-9a-f]+ <_Z\w+>:", text, flags=re.M))
+        found.update(isa_scan.vulnerable_by_kernel(text))
+    assert kernels > 100, kernels                              # (the scan saw the kernels)
+    assert not found, {k: v[:3] for k, v in found.items()}
+    # the scanner itself: the measured form, its src1 variant, and forms measured immune
+    probe = ("0000 <_Z1kv>:\n v_pk_fma_f32 v[0:1], v[0:1], v[4:5], v[4:5] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n"
+             " v_pk_add_f32 v[8:9], v[8:9], v[8:9] op_sel:[0,1] op_sel_hi:[1,0]\n v_pk_mul_f32 v[2:3], v[2:3], v[4:5] op_sel:[1,0]\n"
+             " v_pk_fma_f32 v[2:3], v[2:3], v[4:5], v[6:7] op_sel_hi:[1,1,0]\n")
+    assert len(isa_scan.vulnerable_by_kernel(probe)["_Z1kv"]) == 2

@@ -121,6 +121,81 @@ extern "C" int cohab_one_instruction(int kind, int workgroups, int iters, float*
   return (int)hipGetLastError();
 }
 
+
+// Packed-f32 victims by operand position: which cross-half selections lose their operand beside MFMA waves?  a = (x[2 i], x[2 i + 1]),
+// b = the row's (scale, bias) pair; the expected values are formed on the host (tools/race_probe8.py: PK_FORMS).
+template <int FORM>
+__global__ __launch_bounds__(256) void pk_forms(const float* __restrict__ x, const float* __restrict__ aff, float* __restrict__ y, int R, int C) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int r = blockIdx.y * 16 + ty, c = blockIdx.x * 32 + 2 * tx;
+  if (r >= R || c >= C) return;
+  f32x2 a = *reinterpret_cast<const f32x2*>(x + (long long)r * C + c);
+  const f32x2 b = *reinterpret_cast<const f32x2*>(aff + (long long)r * 2);
+  f32x2 d = {0.f, 0.f};
+  if (FORM == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));       // (a0 b1, a1 b1)
+  if (FORM == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));       // (a1 b0, a1 b1)
+  if (FORM == 2) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));       // (a0 + b1, a1 + b1)
+  if (FORM == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b));   // (a0 b1 + b0, a1 b1 + b0)
+  if (FORM == 4) asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));   // (a1 b0 + b0, a1 b0 + b1)
+  if (FORM == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b));   // (a0 b0 + b1, a1 b0 + b1): the known one
+  if (FORM == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b));   // (a0 b0 + b0, a1 b1 + b0): high result <- low half
+  if (FORM == 7) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));           // (a0 b0, a1 b0): high result <- low half
+  *reinterpret_cast<f32x2*>(y + (long long)r * C + c) = d;
+}
+
+extern "C" int cohab_pk_form(int form, const float* x, const float* aff, float* y, int R, int C, void* stream) {
+  dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 15) / 16)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (form) {
+#define F_(k) case k: hipLaunchKernelGGL(pk_forms<k>, grid, block, 0, st, x, aff, y, R, C); break
+    F_(0); F_(1); F_(2); F_(3); F_(4); F_(5); F_(6); F_(7);
+#undef F_
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+// MFMA aggressors by instruction kind (dependent chains, 8 waves per workgroup)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ __launch_bounds__(512) void mfma_kinds(int iters, float* sink) {
+  f16x8 ha, hb;
+  bf16x8 ba, bb;
+  f16x4 qa, qb;
+  for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(threadIdx.x + i); hb[i] = (_Float16)(1.5f - i); ba[i] = (__bf16)(float)(threadIdx.x + i); bb[i] = (__bf16)(1.5f - i); }
+  for (int i = 0; i < 4; ++i) { qa[i] = ha[i]; qb[i] = hb[i]; }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {1.f, 1.f, 1.f, 1.f};
+  f32x16 big = {};
+  float fa = (float)threadIdx.x, fb = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (KIND == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc, 0, 0, 0);                         // dependent chain (tools default)
+      if (KIND == 1) { acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb, ha, acc2, 0, 0, 0); }   // two independent chains
+      if (KIND == 2) big = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, big, 0, 0, 0);
+      if (KIND == 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc, 0, 0, 0);
+      if (KIND == 4) acc = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, qb, acc, 0, 0, 0);
+      if (KIND == 5) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc, 0, 0, 0);
+      if (KIND == 6) { acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc, 0, 0, 0); asm volatile("s_nop 7\n\ts_nop 7"); }      // sparse issue
+    }
+  }
+  if (acc[0] + acc2[1] + big[3] == 12345.f) *sink = 1.f;
+}
+
+extern "C" int cohab_mfma_kind(int kind, int workgroups, int iters, float* sink, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 g(workgroups), b(512);
+  switch (kind) {
+#define M_(k) case k: hipLaunchKernelGGL(mfma_kinds<k>, g, b, 0, st, iters, sink); break
+    M_(0); M_(1); M_(2); M_(3); M_(4); M_(5); M_(6);
+#undef M_
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
 extern "C" int cohab_affine(int var, const float* x, const float* aff, float* y, int R, int C, void* stream) {
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 15) / 16)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);

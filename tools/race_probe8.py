@@ -21,7 +21,7 @@ NAMES = {0: "0 hipcc pk_fma op_sel", 1: "1 asm pk_fma op_sel, regs held (7, 1)",
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
-    ap.add_argument("--set", default="base", choices=["base", "micro", "tile", "gemms"], help="aggressors: base (tile GEMM, library matmul, LDS squatters), "
+    ap.add_argument("--set", default="base", choices=["base", "micro", "tile", "gemms", "forms"], help="aggressors: base (tile GEMM, library matmul, LDS squatters), "
                     "micro (kernels of ONE repeated instruction), tile (the tile GEMM only: run under UNIVS_HIP_LIB=<an ablation build>)")
     ap.add_argument("--variants", default="0,1,2,3,4")
     args = ap.parse_args()
@@ -35,6 +35,8 @@ def main():
     lib = ctypes.CDLL(so)
     lib.cohab_affine.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.cohab_squat.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cohab_pk_form.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.cohab_mfma_kind.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.cohab_one_instruction.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     dev = torch.device("cuda:0")
     torch.set_grad_enabled(False)
@@ -44,6 +46,9 @@ def main():
     aff = torch.stack([torch.rand(R, generator=g) + 0.5, torch.randn(R, generator=g) * 0.5 + 3.0], 1).contiguous().to(dev)
     sink = torch.zeros(4, device=dev)
     side = torch.cuda.Stream()
+
+    if args.set == "forms":
+        return forms(args, lib, x, aff, sink, side)
 
     def victim(var):
         y = torch.empty_like(x)
@@ -118,6 +123,60 @@ def main():
             torch.cuda.synchronize()
             extra = f"; wrong elements by kind {kinds}; by quarter-wave {lanes.tolist()}; by component {comps.tolist()}" if bad else ""
             print(f"   {vn}: {bad} of {args.iters} runs differ{extra}", flush=True)
+
+
+PK_FORMS = {      # name, expected (low, high) from a = (a0, a1), b = (b0, b1), and what the low / high result would be with the cross-half operand read as 0
+    0: ("v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1]  (low <- src1.hi)", lambda a0, a1, b0, b1: (a0 * b1, a1 * b1)),
+    1: ("v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,1]  (low <- src0.hi)", lambda a0, a1, b0, b1: (a1 * b0, a1 * b1)),
+    2: ("v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,1]  (low <- src1.hi)", lambda a0, a1, b0, b1: (a0 + b1, a1 + b1)),
+    3: ("v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0]  (low <- src1.hi, high <- src2.lo)", lambda a0, a1, b0, b1: (a0 * b1 + b0, a1 * b1 + b0)),
+    4: ("v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[1,0,1]  (low <- src0.hi, high <- src1.lo)", lambda a0, a1, b0, b1: (a1 * b0 + b0, a1 * b0 + b1)),
+    5: ("v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,0,1]  (low <- src2.hi, high <- src1.lo): the form of the transposes", lambda a0, a1, b0, b1: (a0 * b0 + b1, a1 * b0 + b1)),
+    6: ("v_pk_fma_f32 op_sel:[0,0,0] op_sel_hi:[1,1,0]  (high <- src2.lo)", lambda a0, a1, b0, b1: (a0 * b0 + b0, a1 * b1 + b0)),
+    7: ("v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[1,0]  (high <- src1.lo)", lambda a0, a1, b0, b1: (a0 * b0, a1 * b0)),
+}
+MFMA_KINDS = ["v_mfma_f32_16x16x32_f16, one dependent chain", "v_mfma_f32_16x16x32_f16, two chains", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16",
+              "v_mfma_f32_16x16x16_f16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x32_f16 with 16 idle cycles between"]
+
+
+def forms(args, lib, x, aff, sink, side):
+    """Every cross-half operand selection of the packed f32 instructions beside every kind of MFMA wave."""
+    R, C = x.shape
+    a0, a1 = x[:, 0::2].double(), x[:, 1::2].double()
+    b0, b1 = aff[:, 0:1].double(), aff[:, 1:2].double()
+
+    def run(form):
+        y = torch.empty_like(x)
+        rc = lib.cohab_pk_form(form, x.data_ptr(), aff.data_ptr(), y.data_ptr(), R, C, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        return y
+    refs = {}
+    for f_, (name, fn) in PK_FORMS.items():
+        refs[f_] = run(f_).clone()
+        lo, hi = fn(a0, a1, b0, b1)
+        exp = torch.stack([lo, hi], -1).flatten(1).float()
+        print(f"form {f_} alone: {int((refs[f_] != exp).sum())} elements differ from the expected values   [{name}]")
+    torch.cuda.synchronize()
+    for k, kn in enumerate(MFMA_KINDS):
+        print(f"== beside waves of {kn}", flush=True)
+        for f_, (name, fn) in PK_FORMS.items():
+            if k > 0 and f_ not in (0, 1, 5):
+                continue
+            bad, n_wrong, quarter, half, zero_like = 0, 0, torch.zeros(4, dtype=torch.long), torch.zeros(2, dtype=torch.long), 0
+            for it in range(args.iters):
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        lib.cohab_mfma_kind(k, 1024, 300, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                y = run(f_)
+                d = (y != refs[f_]).nonzero()
+                if len(d):
+                    bad += 1
+                    n_wrong += len(d)
+                    quarter += torch.bincount(((d[:, 0] % 16) % 4).cpu(), minlength=4)
+                    half += torch.bincount((d[:, 1] % 2).cpu(), minlength=2)
+            torch.cuda.synchronize()
+            extra = f"; {n_wrong} wrong elements; by quarter-wave {quarter.tolist()}; low / high result {half.tolist()}" if bad else ""
+            print(f"   form {f_}: {bad} of {args.iters} runs differ{extra}", flush=True)
 
 
 if __name__ == "__main__":

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void msda_bwd_f32_kernel(const float* __restri
       const float v10 = (b_ok && l_ok) ? value[o10 + c] : 0.f;
       const float v11 = (b_ok && r_ok) ? value[o11 + c] : 0.f;
       g_a += g * (hh * hw * v00 + hh * lw * v01 + lh * hw * v10 + lh * lw * v11);
-      d_h += g * (hw * (v10 - v00) + lw * (v11 - v01));
-      d_w += g * (hh * (v01 - v00) + lh * (v11 - v10));
+      // (single subtractions: hipcc's packed pair of differences is the form common.h describes)
+      d_h += g * (hw * sub_single(v10, v00) + lw * sub_single(v11, v01));
+      d_w += g * (hh * sub_single(v01, v00) + lh * sub_single(v11, v10));
       const float ga = g * aw;
       if (t_ok && l_ok) atomicAdd(grad_value + o00 + c, ga * hh * hw);
       if (t_ok && r_ok) atomicAdd(grad_value + o01 + c, ga * hh * lw);

@@ -179,8 +179,9 @@ __global__ __launch_bounds__(64 * S5_NW, 4) void msda_fwd_strips(S5Args a, S5Lev
       // and a is far from the ends of the exponent range, so the corrected quotient is the correctly rounded one --
       // tools/strips_emulate.cpp compares it with the division on every sample)
       const float qx = r.v[2 * kk] * lv.rW[kk], qy = r.v[2 * kk + 1] * lv.rH[kk];
-      const float ox = fmaf(fmaf(-qx, Wf[kk], r.v[2 * kk]), lv.rW[kk], qx);
-      const float oy = fmaf(fmaf(-qy, Hf[kk], r.v[2 * kk + 1]), lv.rH[kk], qy);
+      // (the remainders as single FMAs: hipcc packs the pair with (W, H) in swapped halves -- the form common.h describes)
+      const float ox = fmaf(fnma_single(qx, Wf[kk], r.v[2 * kk]), lv.rW[kk], qx);
+      const float oy = fmaf(fnma_single(qy, Hf[kk], r.v[2 * kk + 1]), lv.rH[kk], qy);
       iv.x[kk] = r.rp.x + ox;
       iv.y[kk] = r.rp.y + oy;
     }

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __rest
     v4f_ ad = *reinterpret_cast<const v4f_*>(addend + off);
     if (affine) {
       const float scale = affine[2 * p], bias = affine[2 * p + 1];
-      ad = __builtin_elementwise_fma(ad, (v4f_){scale, scale, scale, scale}, (v4f_){bias, bias, bias, bias});   // as gn_apply_kernel
+      // as gn_apply_kernel; one fused multiply-add per component, kept out of the packed form (common.h: fma_single)
+      ad = (v4f_){fma_single(ad.x, scale, bias), fma_single(ad.y, scale, bias), fma_single(ad.z, scale, bias), fma_single(ad.w, scale, bias)};
     }
     if (active) *reinterpret_cast<v4f_*>(out + off) = (v4f_){ad.x + o[0], ad.y + o[1], ad.z + o[2], ad.w + o[3]};
   }

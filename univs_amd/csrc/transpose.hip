@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
       v = *reinterpret_cast<const float4*>(in + ibase + (long long)r * C + c);   // C % 4 == 0 (host-checked)
       if (row_affine) {
         const float sc = row_affine[((long long)blockIdx.z * R + r) * 2], bi = row_affine[((long long)blockIdx.z * R + r) * 2 + 1];
-        v = make_float4(fmaf(v.x, sc, bi), fmaf(v.y, sc, bi), fmaf(v.z, sc, bi), fmaf(v.w, sc, bi));
+        v = make_float4(fma_single(v.x, sc, bi), fma_single(v.y, sc, bi), fma_single(v.z, sc, bi), fma_single(v.w, sc, bi));   // (common.h)
       }
     }
     tile[p + ty][4 * tx + 0] = v.x;
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void patch_embed4_kernel(const float* __restri
   if (ln_g) {   // LayerNorm over the token's E channels: two-pass statistics, the eight lanes of the token reduced by xor-shuffles
     float sm = 0.f;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) sm += (acc[i].x + acc[i].y) + (acc[i].z + acc[i].w);
+    for (int i = 0; i < NG; ++i)   // (single adds: hipcc's packed horizontal sum is the form common.h describes)
+      sm = add_single(sm, add_single(add_single(acc[i].x, acc[i].y), add_single(acc[i].z, acc[i].w)));
     sm += __shfl_xor(sm, 1, 64);
     sm += __shfl_xor(sm, 2, 64);
     sm += __shfl_xor(sm, 4, 64);
