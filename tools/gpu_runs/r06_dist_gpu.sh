@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r06_fix
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_distributed_gpu.py -q -m gpu -x > $O/pytest_dist_gpu.log 2>&1; echo "rc $?"; tail -15 $O/pytest_dist_gpu.log
