@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--window", type=int, default=20)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--kernels", action="store_true")
+    ap.add_argument("--syncs", action="store_true", help="list the implicit host synchronisations of one video by call site (torch.cuda.set_sync_debug_mode)")
     ap.add_argument("--cprofile", type=int, default=-1, help="cProfile the predictor call of this clip (host side)")
     ap.add_argument("--cprofile-post", default="", help="cProfile every call of this method of the loop (e.g. detect_newly_entities_per_clip_instance)")
     args = ap.parse_args()
@@ -78,6 +79,25 @@ def main():
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
         print(f"  {v * 1e3:9.1f} ms  {cnt[k]:3d} calls  {k}")
     print(f"  {(total - sum(acc.values())) * 1e3:9.1f} ms  everything else (slicing, class-score post-processing, loop glue)")
+    if args.syncs:
+        import traceback
+        import warnings
+        sites = collections.Counter()
+
+        def hook(message, category, filename, lineno, file=None, line=None):
+            if "synchroniz" in str(message):
+                st = [f for f in traceback.extract_stack() if "univs_amd" in f.filename]
+                sites[" <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-3:])] += 1
+        old_show = warnings.showwarning
+        warnings.showwarning = hook
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        run()
+        torch.cuda.set_sync_debug_mode("default")
+        warnings.showwarning = old_show
+        print(f"implicit synchronisations of one video ({NF - T + 1} clips): {sum(sites.values())}")
+        for k, v in sites.most_common(60):
+            print(f"  {v:4d}  {k}")
     if args.cprofile >= 0:
         import cProfile
         import pstats

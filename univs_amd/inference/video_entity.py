@@ -23,12 +23,14 @@ Sub-tasks: 'vis' / 'entity_vis_*' (instance-style), 'vps' (panoptic: things + st
 import math
 from typing import Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ..registry import configurable
 from ..utils.memory import retry_if_oom
+from ..layers import to_device_async
 from ..utils.comm import batched_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou
 from .comm import check_consistency_with_prev_frames, match_from_learnable_embds  # noqa: F401  (API parity)
 from scipy.optimize import linear_sum_assignment
@@ -87,6 +89,21 @@ def normalized_image_list(frames, pixel_mean, pixel_std, size_divisibility):
 def _resize(masks, size):
     # (the reference wraps these resizes in retry_if_cuda_oom, inference_video_entity.py:933 / :978 / :1104: utils/memory.py)
     return retry_if_oom(F.interpolate)(masks, size, mode="bilinear", align_corners=False)
+
+
+_NORM4 = {}
+
+
+def _norm4(w, h, device):
+    """[w, h, w, h] on `device`, made once per size: `torch.as_tensor(list, device=...)` is a pageable host-to-device copy, which waits
+    for everything enqueued on the stream before it (hazard 14) -- a hidden synchronisation per call."""
+    key = (int(w), int(h), str(device))
+    t = _NORM4.get(key)
+    if t is None:
+        if len(_NORM4) > 64:
+            _NORM4.clear()
+        t = _NORM4[key] = torch.as_tensor([w, h, w, h], device=device)
+    return t
 
 
 def window_features_on_owner(model, x, frames, shard):
@@ -471,10 +488,10 @@ class InferenceVideoEntity(nn.Module):
             ratio = own.sum(1) / fg.sum(1).clamp(min=1)
             keep = keep & (ratio > self.overlap_threshold_entity) & ((own & fg).sum(1) > 0)
 
-        if keep.any():
-            idx = keep.nonzero(as_tuple=True)[0]
+        idx = keep.nonzero(as_tuple=True)[0]                   # (one host round trip: the count tells whether anything is kept)
+        if idx.numel():
             m = pred_masks[idx]
-            norm = torch.as_tensor([interim_size[1], interim_size[0], interim_size[1], interim_size[0]], device=m.device)
+            norm = _norm4(interim_size[1], interim_size[0], m.device)
             tv["occurrence"][idx, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
             tv["mask_logits"][idx, -T:] += m
             tv["boxes"][idx, -T:] = convert_mask_to_box(tv["mask_logits"][idx, -T:] > 0) / norm.view(1, 1, -1)
@@ -488,6 +505,123 @@ class InferenceVideoEntity(nn.Module):
     # step 2: new entities
     # ------------------------------------------------------------------------------------------
     def detect_newly_entities_per_clip_instance(self, out_learn, targets, interim_size):
+        """New entities among the learnable queries of a clip (inference_video_entity.py:560-652).  Same decisions and the same values
+        as `_detect_newly_entities_per_clip_instance_direct`, arranged for a device: the per-pixel reductions (quality counts, boxes)
+        run once for all queries, ONE device-to-host copy brings their results (exact small integers) and the class scores over, the
+        stability filter / score order / box NMS / thresholds are evaluated on the host on [Q]-sized tensors -- the same IEEE
+        operations on the same numbers --, and the mask tensor is touched by index only: rows matched to known entities and rows that
+        become new entities are gathered once each.  Host round trips per clip: 1 on a video's first clip, 3 later (the assignment
+        problem is solved on the host in the reference too), against ~10 boolean-index round trips before."""
+        if not self.use_quasi_track:       # (never set by the reference's configs: its other matcher stays on the direct form)
+            return self._detect_newly_entities_per_clip_instance_direct(out_learn, targets, interim_size)
+        tv = targets[0]
+        logits = out_learn["pred_logits"].float()     # [Q, K] probabilities
+        masks = out_learn["pred_masks"].float()       # [Q, T, h, w]
+        embds = out_learn["pred_embds"].float()       # [Q, T, C]
+        dev = masks.device
+        Q, T = masks.shape[:2]
+        h, w = masks.shape[-2:]
+        first = "masks" not in tv
+
+        # ---- device, all queries: |{logit > 1}|, |{logit > -1}| (calculate_mask_quality_scores), integer boxes
+        flat = masks.flatten(1)
+        hi = (flat > 1.0).sum(-1)
+        lo = (flat > -1.0).sum(-1).clamp(min=1)
+        quality_d = hi / lo
+        logits_d = logits * quality_d.view(-1, 1)
+        boxes_i = convert_mask_to_box(masks > 0)                                               # [Q, T, 4] int64
+        norm_d = _norm4(w, h, dev)
+        # ---- one copy to the host (counts and box corners are integers below 2^24: exact in float32).  The host side is NUMPY on
+        # purpose: a torch CPU operator on ~10^5 elements opens an OpenMP region, and on a 256-thread host the pool's spin-waiting
+        # afterwards slowed the whole clip loop four-fold (measured: 186 -> 760 ms per video); numpy's float32 arithmetic is the
+        # same IEEE operation per element
+        K = logits.shape[-1]
+        host = torch.cat([hi.float()[:, None], lo.float()[:, None], boxes_i.flatten(1).float(), logits], 1).cpu().numpy()
+        quality = host[:, 0] / host[:, 1]
+        boxes = host[:, 2:2 + 4 * T].reshape(Q, T, 4) / np.asarray([w, h, w, h], dtype=np.float32)
+        lg = host[:, 2 + 4 * T:2 + 4 * T + K] * quality[:, None]
+        idx = np.arange(Q)                                                                      # surviving rows -> query index
+        if self.stability_score_thresh > 0.0:
+            k = quality > np.float32(self.stability_score_thresh)
+            lg, boxes, quality, idx = lg[k], boxes[k], quality[k], idx[k]
+        scores = lg.max(-1) if len(idx) else np.zeros((0,), np.float32)
+        top = np.argsort(-scores, kind="stable")[: self.test_topk_per_image]
+        lg, boxes, quality, idx, scores = lg[top], boxes[top], quality[top], idx[top], scores[top]
+        if len(idx) > 1:
+            order = np.argsort(-scores, kind="stable")
+            bo = boxes[order]
+            area = (bo[..., 2] - bo[..., 0]) * (bo[..., 3] - bo[..., 1])                         # utils/comm.py: video_box_iou, same order
+            lt = np.maximum(bo[:, None, :, :2], bo[None, :, :, :2])
+            rb = np.minimum(bo[:, None, :, 2:], bo[None, :, :, 2:])
+            wh = np.maximum(rb - lt, np.float32(0))
+            inter = wh[..., 0] * wh[..., 1]
+            union = np.maximum(area[:, None] + area[None] - inter, np.float32(1e-3))
+            biou = (inter / union).max(-1)
+            worst = np.triu(biou, k=1).max(0)
+            k = order[worst < np.float32(self.box_nms_thresh)]
+            lg, boxes, quality, idx = lg[k], boxes[k], quality[k], idx[k]
+        n = len(idx)
+        best = lg.max(-1) if n else np.zeros((0,), np.float32)
+        idx = torch.from_numpy(np.ascontiguousarray(idx))
+
+        if first:
+            new = torch.from_numpy(best > np.float32(max(self.apply_cls_thres, 0.1)))
+        else:
+            idx_d = to_device_async(idx, dev)            # (pinned staging: a pageable copy would wait for the stream, hazard 14)
+            embds_s = embds.index_select(0, idx_d)
+            gt_embds = tv["embds"]
+            tgt = gt_embds[:, -3:]
+            sim = torch.einsum("ntc,mfc->nmtf", tgt, embds_s).flatten(2)
+            sim = (sim.softmax(1) + sim.softmax(0)).mean(-1) / 2.0
+            sim = torch.where(sim < self.detect_newly_object_threshold, torch.zeros_like(sim), sim).cpu().numpy()   # (round trip 2)
+            rows, cols = linear_sum_assignment(np.float32(1) - sim)
+            msim = sim[rows, cols]
+            rows, cols = torch.from_numpy(rows.astype(np.int64)), torch.from_numpy(cols.astype(np.int64))
+
+            ok = torch.from_numpy(msim > np.float32(self.detect_newly_object_threshold))
+            r, c = to_device_async(rows[ok], dev), to_device_async(cols[ok], dev)
+            # the stored class scores / embeddings follow the learnable queries (prompt and learnable
+            # queries live in slightly different feature spaces)
+            tv["logits"][r, -1] = 0.5 * (tv["logits"][r, -1] + logits_d[idx_d[c]])
+            last = gt_embds[r, -1]
+            gt_embds[r, -1] = (last + embds_s[c].mean(1)) / ((last != 0).any(-1)[..., None] + 1.0)
+
+            ok2 = torch.from_numpy(msim > np.float32(2 * self.detect_newly_object_threshold))
+            c2_h = cols[ok2]
+            r2, c2 = to_device_async(rows[ok2], dev), idx_d[to_device_async(c2_h, dev)]       # (c2: query indices)
+            m = _resize(masks[c2], interim_size)
+            tv["occurrence"][r2, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
+            tv["mask_logits"][r2, -T:] += m
+            tv["mask_quality_scores"][r2] += quality_d[c2]
+            tv["masks"] = tv["mask_logits"].gt(0.0).float()
+
+            # a query is a NEW entity if it is unmatched, confident, and overlaps no known entity
+            # (mask IoU < 0.5 in every frame of the clip)
+            cand = torch.ones(n, dtype=torch.bool)
+            cand[c2_h] = False     # (the reference excludes the strongly matched queries here, :640-642)
+            cand &= torch.from_numpy(best > np.float32(self.apply_cls_thres))
+            n_known = tv["mask_logits"].shape[0]
+            if n_known > 0 and n > 0:
+                ci = cand.nonzero(as_tuple=True)[0]
+                if len(ci):        # (the IoU only of the rows that can still qualify: the host knows them)
+                    known = _resize(tv["mask_logits"][:, -T:], (h, w)).transpose(0, 1).gt(0.0)          # [T, N, h, w]
+                    miou = batched_mask_iou(masks[idx_d[to_device_async(ci, dev)]].transpose(0, 1).gt(0.0), known)    # [T, n_c, N]
+                    cand[ci] = (miou.amax(dim=(0, 2)) < 0.5).cpu()
+            else:
+                cand &= False          # reference: an empty IoU matrix never qualifies (:644)
+            new = cand
+
+        sel = to_device_async(idx[new], dev)
+        out_learn["pred_logits"] = logits_d[sel]
+        out_learn["pred_masks"] = masks[sel]
+        out_learn["pred_embds"] = embds[sel]
+        out_learn["pred_boxes"] = boxes_i[sel] / norm_d
+        out_learn["mask_quality_scores"] = quality_d[sel]
+
+    def _detect_newly_entities_per_clip_instance_direct(self, out_learn, targets, interim_size):
+        """The reference's formulation line by line (inference_video_entity.py:560-652): every filter is a boolean index of the mask
+        tensor (a host round trip and a copy of up to [Q, T, h, w] each).  Kept as the oracle of `detect_newly_entities_per_clip_instance`
+        (tests/test_clip_loop_cpu.py compares the two on random scenes)."""
         tv = targets[0]
         logits = out_learn["pred_logits"].float()     # [Q, K] probabilities
         masks = out_learn["pred_masks"].float()       # [Q, T, h, w]
@@ -506,7 +640,7 @@ class InferenceVideoEntity(nn.Module):
         logits, masks, embds, quality, scores = logits[top], masks[top], embds[top], quality[top], scores[top]
 
         h, w = masks.shape[-2:]
-        boxes = convert_mask_to_box(masks > 0) / torch.as_tensor([w, h, w, h], device=masks.device)
+        boxes = convert_mask_to_box(masks > 0) / _norm4(w, h, masks.device)
         if masks.shape[0] > 1:
             # box-IoU NMS over the clip: drop a query whose boxes overlap a better one's in any frame
             order = scores.sort(descending=True)[1]
@@ -575,7 +709,7 @@ class InferenceVideoEntity(nn.Module):
         embds = out_learn["pred_embds"].float()
         h, w = masks.shape[-2:]
         T = masks.shape[1]
-        boxes = convert_mask_to_box(masks > 0) / torch.as_tensor([w, h, w, h], device=masks.device)
+        boxes = convert_mask_to_box(masks > 0) / _norm4(w, h, masks.device)
         quality = calculate_mask_quality_scores(masks)
         logits = logits * quality.view(-1, 1)
         scores, labels = logits.max(-1)
