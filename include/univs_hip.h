@@ -667,6 +667,18 @@ int univs_prompt_point_pe_f32(const float* xy, const float* z, const float* dim_
                               float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-plane statistics of mask logits in one pass: x [planes, H, W] -> out [planes, 8] int32 =
+ *   {|{x > t_hi}|, |{x > t_lo}|, left, top, right, bottom of {x > t_box} (inclusive pixel indices; zeros when empty), non-empty, 0}
+ * over the valid region rows [0, h_valid) x columns [0, w_valid) of every plane (h_valid <= H, w_valid <= W).
+ * Replaces: univs/utils/comm.py:104-112 (calculate_mask_quality_scores: two compares + two sums over the clip's mask logits) and
+ *           univs/utils/comm.py:10-38 (convert_mask_to_box: compare, two `any`, four where / min / max passes, stack, product) as the
+ *           clip loop calls them on [Q, T, h, w] (univs/inference/inference_video_entity.py:452-470, :566-590): ~25 launches, 5 passes.
+ * NaN exceeds no threshold (as in ATen).  planes <= 65535; otherwise UNIVS_ERR_NOT_IMPLEMENTED.
+ * ------------------------------------------------------------------------------------------- */
+int univs_mask_stats_f32(const float* x, long long planes, int H, int W, int h_valid, int w_valid, float t_hi, float t_lo, float t_box,
+                         int32_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Mean over the non-blank tokens: x [n, L, T, C] -> out [n, T, C] = sum_l x[:, l] / max(1, #{l : x[., l, ., :] is not all zero}) (+ add [C]).
  * Replaces: univs/modeling/transformer_decoder/video_mask2former_transformer_decoder_univs.py:640-650 (the initial prompt query / its
  *           position: compare, all, not, sum, clamp, sum, divide, add -- eight launches per tensor).  fp32, summed token by token.

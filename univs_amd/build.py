@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunivs_hip.so")
-SOURCES = ["capi.hip", "msda_fwd.hip", "msda_tiled2.hip", "msda_strips.hip", "msda_heads.hip", "msda_bwd.hip", "msda_prepare.hip", "mask_decode.hip", "linear_split.hip", "linear_f16x3.hip", "gemm_f16x3_stream.hip", "gemm_f16x3_tile.hip", "mlp_f16x3.hip", "small_linear.hip", "cross_attn.hip", "window_attn.hip", "window_attn_f16.hip", "resample.hip", "layer_norm.hip", "group_norm.hip", "softmax.hip", "proca_attn.hip", "prompt_sampler.hip", "transpose.hip"]
+SOURCES = ["capi.hip", "msda_fwd.hip", "msda_tiled2.hip", "msda_strips.hip", "msda_heads.hip", "msda_bwd.hip", "msda_prepare.hip", "mask_decode.hip", "linear_split.hip", "linear_f16x3.hip", "gemm_f16x3_stream.hip", "gemm_f16x3_tile.hip", "mlp_f16x3.hip", "small_linear.hip", "cross_attn.hip", "window_attn.hip", "window_attn_f16.hip", "resample.hip", "layer_norm.hip", "group_norm.hip", "softmax.hip", "proca_attn.hip", "prompt_sampler.hip", "transpose.hip", "mask_stats.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "msda_common.h"), os.path.join(CSRC, "msda_geometry.h"), os.path.join(CSRC, "msda_dev.h"), os.path.join(CSRC, "msda_strips_geom.h"), os.path.join(CSRC, "msda_heads_geom.h"), os.path.join(CSRC, "config.h"), os.path.join(CSRC, "window_attn.h"), os.path.join(CSRC, "f16x3.h"),
            os.path.join(HERE, "..", "include", "univs_hip.h")]
 

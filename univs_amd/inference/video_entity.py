@@ -106,6 +106,29 @@ def _norm4(w, h, device):
     return t
 
 
+def _quality_counts_and_boxes(x, valid=None, boxes=True):
+    """Logits x [N, T, H, W] -> (|{x > 1}| per entity [N] int64, |{x > -1}| per entity clamped to >= 1 [N] int64 -- the two counts of
+    `calculate_mask_quality_scores` over rows / columns below `valid` --, integer boxes of {x > 0} [N, T, 4] int64 over the WHOLE plane as
+    `convert_mask_to_box` returns them, or None).  On the GPU: one pass of `ops.mask_stats` per distinct region instead of ~25 launches;
+    elsewhere (and for shapes it does not cover) the ATen formulation."""
+    st = None
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0:
+        from .. import ops
+        st = ops.mask_stats(x, 1.0, -1.0, 0.0, valid=valid)
+    if st is None:
+        cur = x if valid is None else x[..., : valid[0], : valid[1]]
+        hi = (cur > 1.0).flatten(1).sum(-1)
+        lo = (cur > -1.0).flatten(1).sum(-1).clamp(min=1)
+        return hi, lo, (convert_mask_to_box(x > 0) if boxes else None)
+    hi = st[..., 0].sum(-1)
+    lo = st[..., 1].sum(-1).clamp(min=1)
+    bx = None
+    if boxes:
+        full = valid is None or (valid[0] >= x.shape[-2] and valid[1] >= x.shape[-1])
+        bx = (st if full else ops.mask_stats(x, 1.0, -1.0, 0.0))[..., 2:6].long()
+    return hi, lo, bx
+
+
 def window_features_on_owner(model, x, frames, shard):
     """backbone + pixel decoder of `frames` (absolute indices of the video) on the frames THIS rank owns (frame f belongs to rank
     f % world) -> ({frame: row}, (mask_features, mask_features_bfe_conv, multi_scale_features) of those rows)."""
@@ -475,7 +498,8 @@ class InferenceVideoEntity(nn.Module):
                                                        return_similarity=True)
 
         cur = pred_masks[:, :, : image_size[0], : image_size[1]]
-        quality = calculate_mask_quality_scores(cur)
+        q_hi, q_lo, _ = _quality_counts_and_boxes(pred_masks, valid=image_size, boxes=False)
+        quality = q_hi / q_lo                                 # calculate_mask_quality_scores(cur)
         if "vis" in tv["sub_task"]:
             # every pixel goes to the entity with the highest score x probability; an entity survives
             # if it keeps enough of its own area
@@ -494,7 +518,7 @@ class InferenceVideoEntity(nn.Module):
             norm = _norm4(interim_size[1], interim_size[0], m.device)
             tv["occurrence"][idx, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
             tv["mask_logits"][idx, -T:] += m
-            tv["boxes"][idx, -T:] = convert_mask_to_box(tv["mask_logits"][idx, -T:] > 0) / norm.view(1, 1, -1)
+            tv["boxes"][idx, -T:] = _quality_counts_and_boxes(tv["mask_logits"][idx, -T:])[2] / norm.view(1, 1, -1)
             last = tv["embds"][idx, -1]
             nonblank = (last != 0).any(-1)
             tv["embds"][idx, -1] = (last + pred_embds[idx].mean(1)) / (nonblank[..., None] + 1.0)
@@ -524,12 +548,9 @@ class InferenceVideoEntity(nn.Module):
         first = "masks" not in tv
 
         # ---- device, all queries: |{logit > 1}|, |{logit > -1}| (calculate_mask_quality_scores), integer boxes
-        flat = masks.flatten(1)
-        hi = (flat > 1.0).sum(-1)
-        lo = (flat > -1.0).sum(-1).clamp(min=1)
+        hi, lo, boxes_i = _quality_counts_and_boxes(masks)                                     # [Q], [Q], [Q, T, 4] int64
         quality_d = hi / lo
         logits_d = logits * quality_d.view(-1, 1)
-        boxes_i = convert_mask_to_box(masks > 0)                                               # [Q, T, 4] int64
         norm_d = _norm4(w, h, dev)
         # ---- one copy to the host (counts and box corners are integers below 2^24: exact in float32).  The host side is NUMPY on
         # purpose: a torch CPU operator on ~10^5 elements opens an OpenMP region, and on a 256-thread host the pool's spin-waiting

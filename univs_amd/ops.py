@@ -359,9 +359,10 @@ def presplit_weights(weight, conv=False, mode=None):
     e = _PRESPLIT.get((id(weight), mode))
     if e is not None and e[0]() is weight and e[1] == key:
         # made on another stream (the prompt sampler's side stream, a caller's own): order this stream behind the split, once
-        cur = torch.cuda.current_stream(weight.device)
-        sid = cur.cuda_stream
+        # (the raw handle first: building the Stream object costs ~5 us, and this is the path of ~190 calls per clip)
+        sid = _stream_ptr(weight)
         if sid not in e[5] and not torch.cuda.is_current_stream_capturing():   # (a capture follows eager warm-up calls: graphs.py)
+            cur = torch.cuda.current_stream(weight.device)
             cur.wait_event(e[4])
             e[2].record_stream(cur)
             e[3].record_stream(cur)
@@ -1339,6 +1340,29 @@ def prompt_point_pe(xy, z, dim_t, dim_tz, scale, n):
         rc = _lib.load().univs_prompt_point_pe_f32(_ptr(xy), _ptr(z), _ptr(dim_t), _ptr(dim_tz), float(scale), Fk, int(n), Fq, _ptr(out),
                                                    _stream_ptr(xy))
     _lib.check(rc, "prompt_point_pe")
+    return out
+
+
+def mask_stats(x, t_hi=1.0, t_lo=-1.0, t_box=0.0, valid=None):
+    """Per-plane statistics of mask logits in one pass (include/univs_hip.h: univs_mask_stats_f32; csrc/mask_stats.hip): x [..., H, W]
+    contiguous float32 on the GPU -> int32 [..., 8] = (|{x > t_hi}|, |{x > t_lo}|, left, top, right, bottom of {x > t_box} -- inclusive,
+    zeros when empty --, non-empty, 0) over rows [0, valid[0]) x columns [0, valid[1]) (the whole plane by default): what
+    `calculate_mask_quality_scores` and `convert_mask_to_box` (utils/comm.py) compute with ~25 launches.  None when not covered
+    (more than 65 535 planes, autograd needed)."""
+    _require_gpu("mask_stats", x)
+    if x.dtype != torch.float32 or x.dim() < 2:
+        raise RuntimeError("mask_stats: float32 [..., H, W] only")
+    H, W = int(x.shape[-2]), int(x.shape[-1])
+    hv, wv = (H, W) if valid is None else (min(int(valid[0]), H), min(int(valid[1]), W))
+    planes = x.numel() // max(H * W, 1)
+    if planes > 65535 or needs_grad(x) or H * W == 0:
+        return None
+    out = torch.empty(tuple(x.shape[:-2]) + (8,), dtype=torch.int32, device=x.device)
+    with _on(x):
+        rc = _lib.load().univs_mask_stats_f32(_ptr(x), planes, H, W, hv, wv, float(t_hi), float(t_lo), float(t_box), _ptr(out), _stream_ptr(x))
+    if rc == _lib.ERR_NOT_IMPLEMENTED:
+        return None
+    _lib.check(rc, "mask_stats")
     return out
 
 
