@@ -73,3 +73,28 @@ def _worker(rank, world, port, scenario):
 def test_frame_sharded_decoder_on_two_ranks_sharing_the_gpu(scenario):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), scenario), nprocs=world, join=True)
+
+
+def test_bench_line_of_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` end to end with both ranks on GPU 0 (UNIVS_BENCH_ONE_GPU_DEBUG=1: gloo instead of RCCL, the times mean nothing):
+    the launcher, the replica step with its parity check against golden g12 on the timed output, the frame-sharded 10-frame clip and the
+    sharded sliding loop run on the real kernels; the line keeps the reference within 1e-3 with no sign flip (0.097 / 16 flips before
+    hazard 23 was cleared from the library)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNIVS_BENCH_ONE_GPU_DEBUG="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["mask_logit_max_abs_err"] <= 1e-3 and r["mask_sign_flips"] == 0, (r["mask_logit_max_abs_err"], r["mask_sign_flips"])
+    assert "error" not in r.get("frame_sharded", {"error": "missing"}), r.get("frame_sharded")
+    assert r["frame_sharded"]["frames_per_clip"] == 10 and r["frame_sharded"]["value"] > 0
+    sl = r.get("sliding_clip_loop", {})
+    assert "error" not in sl and sl.get("frame_sharded", {}).get("ranks_used") == 2, sl

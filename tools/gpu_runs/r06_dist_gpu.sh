@@ -4,4 +4,4 @@ O=$R/gpurun_out/r06_fix
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_distributed_gpu.py -q -m gpu -x > $O/pytest_dist_gpu.log 2>&1; echo "rc $?"; tail -15 $O/pytest_dist_gpu.log
+timeout 1500 python -m pytest tests/test_distributed_gpu.py -q -m gpu -x --durations=5 > $O/pytest_dist_gpu.log 2>&1; echo "rc $?"; tail -25 $O/pytest_dist_gpu.log
