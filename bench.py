@@ -635,9 +635,13 @@ def run(args):
                                        "frames_per_s": NF / dts,
                                        "note": "frame f on rank f % N: backbone + pixel decoder on owned frames, every clip's decoder on the "
                                                "ranks that own one of its frames (ClipShard on a sub-group when N > num_frames), targets[0] "
-                                               "replicated: the clip's mask logits are gathered / broadcast to every rank"}
+                                               "replicated; the clip's mask logits stay on the ranks of their frames (ClipMaskRows: per-plane "
+                                               "statistics of all rows, the logits of the rows that enter targets[0], candidates' IoU by a maximum)"}
                 if rank == 0 and "fs_loop" in locals():
+                    clips_ = 3 * (NF - T + 1)                                    # 1 warm-up + 2 timed videos
                     sl["frame_sharded"]["bytes_received_rank0"] = {k_: int(v_) for k_, v_ in fs_loop.bytes.items()}
+                    sl["frame_sharded"]["bytes_received_rank0_per_clip"] = {k_: int(v_) // clips_ for k_, v_ in fs_loop.bytes.items()}
+                    sl["frame_sharded"]["bytes_per_clip_if_every_row_were_replicated"] = int(4 * (case["Q"] + int(n_ent)) * T * (case["H"] // 4 + 4) * (case["W"] // 4))
             res["sliding_clip_loop"] = sl
         except Exception as e:  # pragma: no cover
             import traceback

@@ -241,12 +241,13 @@ LOOP_STATE_KEYS = ("logits", "masks", "mask_logits", "boxes", "embds", "ids", "f
                    "occurrence", "prompt_pe", "prompt_feats", "prompt_attn_masks", "frame_indices")
 
 
-def _loop_states(case, model, shard, seed=1, **over):
+def _loop_states(case, model, shard, seed=1, replicate_clip_masks=False, **over):
     """Runs the clip loop (sharded if `shard`); returns ({tag_key: tensor}, results, clip starts, pixel-decoder calls)."""
     from tests import cases
     from univs_amd.inference.video_entity import ImageList, InferenceVideoEntity
     inf = InferenceVideoEntity(**cases.loop_kwargs(case, **over))
     inf.set_frame_shard(shard)
+    inf.replicate_clip_masks = replicate_clip_masks      # True: every rank receives every query's mask logits (the form before ClipMaskRows)
     if shard is None:
         inf.pixel_decoder_once_per_window = False      # the comparison run: the reference's call pattern (pixel decoder per clip)
     dumps, calls = {}, []
@@ -295,6 +296,16 @@ def _clip_loop_worker(rank, world, port, case_over, kw_over):
             shard = FrameShard()
             got, results, calls, pd_frames = _loop_states(case, model, shard, seed=1 + 1000 * rank, **kw)
         assert calls == ref_calls and len(calls) >= 2
+        if world == 2 and case_over:
+            # the clip's mask logits stay sharded (ClipMaskRows: statistics of all rows, the logits of the few rows that enter the
+            # per-video state, the candidates' IoU by a maximum): fewer result bytes than replicating every row, the same states
+            with cpu_ops():
+                shard_r = FrameShard()
+                got_r, _, _, _ = _loop_states(case, model, shard_r, seed=1 + 1000 * rank, replicate_clip_masks=True, **kw)
+            lazy_b = shard.bytes["result:all_gather"] + shard.bytes["result:all_reduce"]
+            print(f"rank {rank}/{world}: result bytes per clip {lazy_b // len(calls)} with sharded mask logits, {shard_r.bytes['result:all_gather'] // len(calls)} replicated")
+            assert 0 < lazy_b < 0.6 * shard_r.bytes["result:all_gather"], (lazy_b, dict(shard_r.bytes))
+            assert sorted(got_r) == sorted(got) and all(torch.equal(got_r[k], got[k]) for k in got), [k for k in got if not torch.equal(got_r[k], got[k])]
         # what crossed the ranks (bytes received by this rank): the decoder's own collectives -- one all-gather of the query states per
         # layer, the sums of the sampled prompt tokens -- stay small; the bulk is the replication of the clip's mask logits for the
         # book-keeping that every rank repeats (DESIGN.md section 6 states it; SURVEY 8e's sharded post-processing is not built)

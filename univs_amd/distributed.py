@@ -91,6 +91,14 @@ class FrameShard:
         out = out.view((self.world,) + tuple(x.shape))
         return out.movedim(0, dim).reshape(tuple(x.shape[:dim]) + (self.world * x.shape[dim],) + tuple(x.shape[dim + 1:]))
 
+    def all_reduce_max(self, x: torch.Tensor) -> torch.Tensor:
+        if self.world == 1 and not self.always_collective:
+            return x
+        x = x.contiguous()
+        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group)
+        self.bytes["all_reduce"] += x.numel() * x.element_size()
+        return x
+
     def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
         if self.world == 1 and not self.always_collective:
             return x

@@ -106,27 +106,108 @@ def _norm4(w, h, device):
     return t
 
 
-def _quality_counts_and_boxes(x, valid=None, boxes=True):
-    """Logits x [N, T, H, W] -> (|{x > 1}| per entity [N] int64, |{x > -1}| per entity clamped to >= 1 [N] int64 -- the two counts of
-    `calculate_mask_quality_scores` over rows / columns below `valid` --, integer boxes of {x > 0} [N, T, 4] int64 over the WHOLE plane as
-    `convert_mask_to_box` returns them, or None).  On the GPU: one pass of `ops.mask_stats` per distinct region instead of ~25 launches;
-    elsewhere (and for shapes it does not cover) the ATen formulation."""
-    st = None
+def _plane_stats(x, valid=None):
+    """Logits x [N, T, H, W] -> integer statistics per plane [N, T, 8]: (|{x > 1}|, |{x > -1}|, left, top, right, bottom of {x > 0} --
+    inclusive, zeros when empty --, non-empty, 0) over rows / columns below `valid` (the whole plane by default).  On the GPU one pass of
+    `ops.mask_stats` (csrc/mask_stats.hip) instead of ~25 launches; elsewhere (and for shapes it does not cover) the ATen formulation of
+    `calculate_mask_quality_scores` / `convert_mask_to_box`, packed the same way."""
     if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0:
         from .. import ops
         st = ops.mask_stats(x, 1.0, -1.0, 0.0, valid=valid)
-    if st is None:
-        cur = x if valid is None else x[..., : valid[0], : valid[1]]
-        hi = (cur > 1.0).flatten(1).sum(-1)
-        lo = (cur > -1.0).flatten(1).sum(-1).clamp(min=1)
-        return hi, lo, (convert_mask_to_box(x > 0) if boxes else None)
+        if st is not None:
+            return st
+    cur = x if valid is None else x[..., : valid[0], : valid[1]]
+    hi = (cur > 1.0).flatten(-2).sum(-1)
+    lo = (cur > -1.0).flatten(-2).sum(-1)
+    fg = cur > 0
+    box = convert_mask_to_box(fg).to(hi.dtype)
+    ne = fg.flatten(-2).any(-1).to(hi.dtype)
+    return torch.cat([hi[..., None], lo[..., None], box, ne[..., None], torch.zeros_like(hi)[..., None]], -1)
+
+
+def _quality_counts_and_boxes(x, valid=None, boxes=True, stats=None):
+    """Logits x [N, T, H, W] (or their `_plane_stats`) -> (|{x > 1}| per entity [N] int64, |{x > -1}| per entity clamped to >= 1 [N]
+    int64 -- the two counts of `calculate_mask_quality_scores` over rows / columns below `valid` --, integer boxes of {x > 0} [N, T, 4]
+    int64 over the WHOLE plane as `convert_mask_to_box` returns them, or None)."""
+    st = _plane_stats(x, valid) if stats is None else stats
     hi = st[..., 0].sum(-1)
     lo = st[..., 1].sum(-1).clamp(min=1)
     bx = None
     if boxes:
-        full = valid is None or (valid[0] >= x.shape[-2] and valid[1] >= x.shape[-1])
-        bx = (st if full else ops.mask_stats(x, 1.0, -1.0, 0.0))[..., 2:6].long()
+        full = stats is not None or valid is None or (valid[0] >= x.shape[-2] and valid[1] >= x.shape[-1])
+        bx = (st if full else _plane_stats(x))[..., 2:6].long()
     return hi, lo, bx
+
+
+class ClipMaskRows:
+    """The mask logits of a clip that STAY on the ranks that computed them (frame-sharded clip loop; SURVEY 8e: masks kept sharded, counts
+    and boxes exchanged): the book-keeping asks for per-plane statistics of all rows (tiny), for the full-clip logits of the FEW rows that
+    enter the replicated per-video state (prompt queries, matched and new entities) and for the mask IoU of candidate rows against the
+    known entities (evaluated per frame where the frame lives, reduced by a maximum) -- instead of every rank receiving every row.
+    Every method is a collective over the loop's group: all ranks call it with the same (replicated) arguments; ranks outside the clip's
+    team (more ranks than frames) receive the result from the team's first rank."""
+
+    def __init__(self, shard, team, cs, local, n_rows, n_frames, hw, device):
+        self.shard, self.team, self.cs, self.local = shard, team, cs, local          # cs / local: None outside the team
+        self.n_rows, self.T, self.hw, self.device = int(n_rows), int(n_frames), (int(hw[0]), int(hw[1])), device
+        self.whole = len(team) == shard.world
+
+    def _account(self, kind, before):
+        b = self.shard.bytes
+        b["result:" + kind] += b[kind] - before
+        b[kind] = before
+
+    def _to_outside(self, t, shape, dtype):
+        if self.whole:
+            return t
+        import torch.distributed as dist
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+        t = t.contiguous()
+        if t.numel():
+            dist.broadcast(t, src=self.shard.global_rank(self.team[0]), group=self.shard.group)
+            if self.shard.rank != self.team[0]:
+                self.shard.bytes["result:broadcast"] += t.numel() * t.element_size()
+        return t
+
+    def _index(self, idx):
+        return to_device_async(torch.as_tensor(idx, dtype=torch.long).cpu(), self.device) if not (isinstance(idx, torch.Tensor) and idx.device == self.device) else idx
+
+    def stats(self):
+        """`_plane_stats` of every row and frame of the clip: [n_rows, T, 8]."""
+        full = None
+        if self.cs is not None:
+            st = _plane_stats(self.local).to(torch.int32)
+            before = self.shard.bytes["all_gather"]
+            full = self.cs.all_gather_frames(st, dim=1)
+            self._account("all_gather", before)
+        return self._to_outside(full, (self.n_rows, self.T, 8), torch.int32)
+
+    def rows(self, idx):
+        """Full-clip logits [len(idx), T, h, w] of the rows `idx`."""
+        n = len(idx)
+        if n == 0:
+            return torch.zeros((0, self.T) + self.hw, device=self.device)
+        full = None
+        if self.cs is not None:
+            before = self.shard.bytes["all_gather"]
+            full = self.cs.all_gather_frames(self.local.index_select(0, self._index(idx)), dim=1)
+            self._account("all_gather", before)
+        return self._to_outside(full, (n, self.T) + self.hw, torch.float32)
+
+    def iou_max(self, idx, known):
+        """max over the clip's frames and the known entities of the mask IoU of rows `idx` ({logit > 0}) with `known` [T, N, h, w] bool
+        (replicated): [len(idx)] float32."""
+        n = len(idx)
+        v = None
+        if self.cs is not None:
+            pos = torch.as_tensor(self.cs.local_positions, device=known.device)
+            m = self.local.index_select(0, self._index(idx)).transpose(0, 1).gt(0.0)          # [T_loc, n, h, w]
+            v = batched_mask_iou(m, known.index_select(0, pos)).amax(dim=(0, 2))
+            before = self.shard.bytes["all_reduce"]
+            v = self.cs.all_reduce_max(v)
+            self._account("all_reduce", before)
+        return self._to_outside(v, (n,), torch.float32)
 
 
 def window_features_on_owner(model, x, frames, shard):
@@ -150,7 +231,7 @@ def _sampler_encoder(model):
         return None
 
 
-def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=None):
+def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=None, lazy_masks=False):
     """The head's predictor on the clip [first, first + n_clip) whose frames are spread over the ranks of `shard` (ClipShard: one
     all-gather of the query states per decoder layer) -> the full-clip output dict on every rank (mask logits and embeddings of the
     clip's frames all-gathered; class / re-id logits are replicated by construction).
@@ -158,7 +239,9 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=
     sub-group, made once per distinct team -- while the others have nothing to do for this clip (their share of the node's work is the
     backbone + pixel decoder of the frames they own, `window_features_on_owner`); the clip's outputs, the prompt memory pool and the
     state of the random generators then go from the team's first rank to the ranks outside it, so that the replicated per-video
-    state stays identical everywhere (every rank is in the team of some later clip)."""
+    state stays identical everywhere (every rank is in the team of some later clip).
+    `lazy_masks`: returns (out, ClipMaskRows) -- the mask logits are NOT gathered: `out["pred_masks"]` holds this rank's frames (None
+    outside the team) and the book-keeping asks the ClipMaskRows for what it needs (the 'vis' loop does)."""
     from ..distributed import ClipShard, cyclic_owners
     predictor = model.sem_seg_head.predictor
     if getattr(predictor, "semantic_extraction_enable", False):
@@ -181,12 +264,16 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=
         finally:
             predictor.frame_shard = None
         before = shard.bytes["all_gather"]
-        out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)         # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
+        if not lazy_masks:
+            out["pred_masks"] = cs.all_gather_frames(out["pred_masks"], dim=2)     # [1, Q', T_loc, h, w] -> [1, Q', T, h, w]
         out["pred_embds"] = cs.all_gather_frames(out["pred_embds"], dim=2)         # [1, Q', T_loc, C]
         shard.bytes["result:all_gather"] += shard.bytes["all_gather"] - before
         shard.bytes["all_gather"] = before
+        if lazy_masks:
+            pm = out["pred_masks"]
+            lazy = ClipMaskRows(shard, team, cs, pm[0].float().contiguous(), pm.shape[1], n_clip, pm.shape[-2:], pm.device)
     if whole:
-        return out
+        return (out, lazy) if lazy_masks else out
     # ---- the ranks outside the team: outputs, memory pool, generator states from the team's first rank
     if device is None:
         device = pd[0].device if pd is not None else torch.device("cpu")
@@ -194,7 +281,9 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=
     src = team[0]
     state = {}
     if shard.rank == src:
-        state = {f"out:{k_}": v for k_, v in out.items() if isinstance(v, torch.Tensor)}
+        state = {f"out:{k_}": v for k_, v in out.items() if isinstance(v, torch.Tensor) and not (lazy_masks and k_ == "pred_masks")}
+        if lazy_masks:
+            state["masks_shape"] = torch.tensor([out["pred_masks"].shape[1], out["pred_masks"].shape[-2], out["pred_masks"].shape[-1]])
         state.update({f"pool:{k_}": tv[k_] for k_ in POOL_KEYS if k_ in tv})
         state["rng:cpu"] = torch.get_rng_state()
         if enc is not None and str(device) in enc._dev_gen:           # (the device generator of the sampler's "device" mode)
@@ -214,7 +303,11 @@ def sharded_clip_forward(model, targets, first, n_clip, rows, pd, shard, device=
         torch.set_rng_state(got["rng:cpu"])
         if enc is not None and "rng:dev" in got:
             enc._generator(device).set_state(got["rng:dev"])
-    return out
+        if lazy_masks:
+            out["pred_masks"] = None
+            qp, mh, mw = (int(v) for v in got["masks_shape"].tolist())
+            lazy = ClipMaskRows(shard, team, None, None, qp, n_clip, (mh, mw), device)
+    return (out, lazy) if lazy_masks else out
 
 
 def begin_video(model, device, shard):
@@ -393,6 +486,9 @@ class InferenceVideoEntity(nn.Module):
         win_start = win_end = 0
         feats_window = None
         shard = check_loop_shard(getattr(self, "frame_shard", None), T)
+        # instance sub-task in a sharded loop: the clip's mask logits stay where they were computed (ClipMaskRows)
+        lazy_ok = shard is not None and "vis" in sub_task and self.use_quasi_track and not getattr(self, "replicate_clip_masks", False)
+        lazy = None
         begin_video(model, x.device, shard)
         win_rows, win_pd = {}, None
         for i in range(0, n_total, stride):
@@ -408,7 +504,10 @@ class InferenceVideoEntity(nn.Module):
                 if i + T > win_end:  # the window's frames: backbone AND pixel decoder, on their owners, once per frame
                     win_start, win_end = i, i + self.num_frames_window_test
                     win_rows, win_pd = window_features_on_owner(model, x, list(range(win_start, min(win_end, n_total))), shard)
-                out = sharded_clip_forward(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard, device=x.device)
+                out = sharded_clip_forward(model, targets, i, min(T, n_total - i), win_rows, win_pd, shard, device=x.device,
+                                           lazy_masks=lazy_ok)
+                if lazy_ok:
+                    out, lazy = out
             else:
                 if i + T > win_end:      # the backbone runs once per window of frames
                     win_start, win_end = i, i + self.num_frames_window_test
@@ -442,6 +541,10 @@ class InferenceVideoEntity(nn.Module):
             out = {k: v for k, v in out.items() if v is not None}          # e.g. pred_reid_logits = [None]
             out_learn = {k: v[: self.num_queries] for k, v in out.items()}
             out_prompt = {k: v[self.num_queries:] for k, v in out.items()}
+            if lazy is not None:
+                # the prompt queries' logits enter the replicated state whole: gathered (few rows); the learnable queries' stay sharded
+                out_prompt["pred_masks"] = lazy.rows(torch.arange(self.num_queries, lazy.n_rows))
+                out_learn.pop("pred_masks", None)
 
             if "vss" in sub_task:
                 # semantic segmentation needs no entity bookkeeping: classes x masks of the learnable queries
@@ -452,7 +555,7 @@ class InferenceVideoEntity(nn.Module):
             # 2. new entities from the learnable queries
             if i % self.detect_newly_interval_frames == 0 or tv["masks"].nelement() == 0:
                 if "vis" in sub_task:
-                    self.detect_newly_entities_per_clip_instance(out_learn, targets, interim_size)
+                    self.detect_newly_entities_per_clip_instance(out_learn, targets, interim_size, sharded=lazy)
                 else:
                     self.detect_newly_entities_per_clip_pixel(out_learn, targets, interim_size)
                 self.write_newly_entities_into_annotations_per_clip(i, out_learn, targets, interim_size)
@@ -528,7 +631,7 @@ class InferenceVideoEntity(nn.Module):
     # ------------------------------------------------------------------------------------------
     # step 2: new entities
     # ------------------------------------------------------------------------------------------
-    def detect_newly_entities_per_clip_instance(self, out_learn, targets, interim_size):
+    def detect_newly_entities_per_clip_instance(self, out_learn, targets, interim_size, sharded=None):
         """New entities among the learnable queries of a clip (inference_video_entity.py:560-652).  Same decisions and the same values
         as `_detect_newly_entities_per_clip_instance_direct`, arranged for a device: the per-pixel reductions (quality counts, boxes)
         run once for all queries, ONE device-to-host copy brings their results (exact small integers) and the class scores over, the
@@ -540,15 +643,24 @@ class InferenceVideoEntity(nn.Module):
             return self._detect_newly_entities_per_clip_instance_direct(out_learn, targets, interim_size)
         tv = targets[0]
         logits = out_learn["pred_logits"].float()     # [Q, K] probabilities
-        masks = out_learn["pred_masks"].float()       # [Q, T, h, w]
         embds = out_learn["pred_embds"].float()       # [Q, T, C]
-        dev = masks.device
-        Q, T = masks.shape[:2]
-        h, w = masks.shape[-2:]
+        if sharded is None:
+            masks = out_learn["pred_masks"].float()   # [Q, T, h, w]
+            dev = masks.device
+            Q, T = masks.shape[:2]
+            h, w = masks.shape[-2:]
+            take = lambda rows_: masks[rows_]                                                  # noqa: E731
+        else:
+            # frame-sharded loop (`sharded`: ClipMaskRows): the logits stay on the ranks of their frames; the learnable queries are its
+            # first rows.  Statistics, the few rows that enter the per-video state and the candidates' IoU are collectives
+            masks, dev = None, logits.device
+            Q, T = logits.shape[0], sharded.T
+            h, w = sharded.hw
+            take = sharded.rows
         first = "masks" not in tv
 
         # ---- device, all queries: |{logit > 1}|, |{logit > -1}| (calculate_mask_quality_scores), integer boxes
-        hi, lo, boxes_i = _quality_counts_and_boxes(masks)                                     # [Q], [Q], [Q, T, 4] int64
+        hi, lo, boxes_i = _quality_counts_and_boxes(masks, stats=None if sharded is None else sharded.stats()[:Q])   # [Q], [Q], [Q, T, 4]
         quality_d = hi / lo
         logits_d = logits * quality_d.view(-1, 1)
         norm_d = _norm4(w, h, dev)
@@ -610,7 +722,7 @@ class InferenceVideoEntity(nn.Module):
             ok2 = torch.from_numpy(msim > np.float32(2 * self.detect_newly_object_threshold))
             c2_h = cols[ok2]
             r2, c2 = to_device_async(rows[ok2], dev), idx_d[to_device_async(c2_h, dev)]       # (c2: query indices)
-            m = _resize(masks[c2], interim_size)
+            m = _resize(take(c2), interim_size)
             tv["occurrence"][r2, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
             tv["mask_logits"][r2, -T:] += m
             tv["mask_quality_scores"][r2] += quality_d[c2]
@@ -626,15 +738,19 @@ class InferenceVideoEntity(nn.Module):
                 ci = cand.nonzero(as_tuple=True)[0]
                 if len(ci):        # (the IoU only of the rows that can still qualify: the host knows them)
                     known = _resize(tv["mask_logits"][:, -T:], (h, w)).transpose(0, 1).gt(0.0)          # [T, N, h, w]
-                    miou = batched_mask_iou(masks[idx_d[to_device_async(ci, dev)]].transpose(0, 1).gt(0.0), known)    # [T, n_c, N]
-                    cand[ci] = (miou.amax(dim=(0, 2)) < 0.5).cpu()
+                    rows_c = idx_d[to_device_async(ci, dev)]
+                    if sharded is None:
+                        worst_iou = batched_mask_iou(masks[rows_c].transpose(0, 1).gt(0.0), known).amax(dim=(0, 2))    # [T, n_c, N] -> [n_c]
+                    else:
+                        worst_iou = sharded.iou_max(rows_c, known)
+                    cand[ci] = (worst_iou < 0.5).cpu()
             else:
                 cand &= False          # reference: an empty IoU matrix never qualifies (:644)
             new = cand
 
         sel = to_device_async(idx[new], dev)
         out_learn["pred_logits"] = logits_d[sel]
-        out_learn["pred_masks"] = masks[sel]
+        out_learn["pred_masks"] = take(sel)
         out_learn["pred_embds"] = embds[sel]
         out_learn["pred_boxes"] = boxes_i[sel] / norm_d
         out_learn["mask_quality_scores"] = quality_d[sel]
