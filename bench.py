@@ -620,6 +620,7 @@ def run(args):
                         fs_loop = FrameShard(group=grp)
                         fs_loop.timeout = datetime.timedelta(seconds=180)        # its sub-groups (one per team of clip owners) too
                         lp.set_frame_shard(fs_loop)
+                        lp.replicate_clip_masks = os.environ.get("UNIVS_REPLICATE_CLIP_MASKS") == "1"   # (measurement of the old form only)
                         dts, n_ent = time_video(lp)
                         sl["entities_at_end"] = n_ent
                     except Exception as e_:  # pragma: no cover
