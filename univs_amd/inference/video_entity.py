@@ -171,7 +171,10 @@ class ClipMaskRows:
         return t
 
     def _index(self, idx):
-        return to_device_async(torch.as_tensor(idx, dtype=torch.long).cpu(), self.device) if not (isinstance(idx, torch.Tensor) and idx.device == self.device) else idx
+        """Row indices as a long tensor on the masks' device (host indices through pinned staging: hazard 14)."""
+        if isinstance(idx, torch.Tensor) and idx.device == self.device:
+            return idx
+        return to_device_async(torch.as_tensor(idx, dtype=torch.long).cpu(), self.device)
 
     def stats(self):
         """`_plane_stats` of every row and frame of the clip: [n_rows, T, 8]."""
