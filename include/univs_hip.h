@@ -677,6 +677,11 @@ int univs_prompt_point_pe_f32(const float* xy, const float* z, const float* dim_
  * ------------------------------------------------------------------------------------------- */
 int univs_mask_stats_f32(const float* x, long long planes, int H, int W, int h_valid, int w_valid, float t_hi, float t_lo, float t_box,
                          int32_t* out, void* stream);
+/* The same over an [outer, inner, H, W] VIEW with two plane strides (in floats): plane (o, i) starts at x + o * stride_outer + i * stride_inner
+ * -- the last T frames of the per-video history `mask_logits[:, -T:]` (inference_video_entity.py:466-468) without a copy of them.  out
+ * [outer, inner, 8]. */
+int univs_mask_stats_strided_f32(const float* x, long long outer, int inner, long long stride_outer, long long stride_inner, int H, int W,
+                                 int h_valid, int w_valid, float t_hi, float t_lo, float t_box, int32_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Mean over the non-blank tokens: x [n, L, T, C] -> out [n, T, C] = sum_l x[:, l] / max(1, #{l : x[., l, ., :] is not all zero}) (+ add [C]).

@@ -49,3 +49,17 @@ def test_mask_stats_refuses_what_it_does_not_cover(cuda):
         ops.mask_stats(torch.zeros(2, 4, 4, device=cuda)[:, :, ::2])           # not contiguous
     assert ops.mask_stats(torch.zeros(70000, 2, 2, device=cuda)) is None        # more planes than the grid takes: the caller keeps ATen
     assert tuple(ops.mask_stats(torch.zeros(0, 3, 4, 4, device=cuda)).shape) == (0, 3, 8)
+
+
+def test_mask_stats_reads_a_history_view_in_place(cuda):
+    """`history[:, -T:]` ([N, T, H, W] with plane strides (hist * H * W, H * W)): the statistics of the view without a copy of it."""
+    g = torch.Generator().manual_seed(11)
+    hist = (torch.randn(6, 9, 20, 28, generator=g) * 2.0).to(cuda)
+    hist[2, -2] = -3.0
+    for T in (1, 4, 9):
+        view = hist[:, -T:]
+        assert not view.is_contiguous() or T == 9
+        got = ops.mask_stats(view, 1.0, -1.0, 0.0, valid=(19, 27))
+        assert torch.equal(got.long(), reference(view.contiguous(), 1.0, -1.0, 0.0, (19, 27))), T
+    odd = (torch.randn(3, 5, 7, 9, generator=g)).to(cuda)[:, 1:4]                 # odd width: the scalar path on a view
+    assert torch.equal(ops.mask_stats(odd).long(), reference(odd.contiguous(), 1.0, -1.0, 0.0, None))

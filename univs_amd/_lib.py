@@ -87,6 +87,7 @@ SIGNATURES = {
     "univs_prompt_point_pe_f32": (_I, [_P, _P, _P, _P, _c.c_float, _I, _I, _I, _P, _P]),
     "univs_token_mean_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "univs_mask_stats_f32": (_I, [_P, _c.c_longlong, _I, _I, _I, _I, _c.c_float, _c.c_float, _c.c_float, _P, _P]),
+    "univs_mask_stats_strided_f32": (_I, [_P, _c.c_longlong, _I, _c.c_longlong, _c.c_longlong, _I, _I, _I, _I, _c.c_float, _c.c_float, _c.c_float, _P, _P]),
     "univs_prompt_tokens_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
 }
 

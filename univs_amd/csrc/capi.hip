@@ -74,7 +74,7 @@ int prompt_draw(const uint8_t*, const int*, const uint8_t*, const int*, const fl
                 int, long long*, long long*, uint8_t*, float*, hipStream_t);
 int prompt_point_pe_f32(const float*, const float*, const float*, const float*, float, int, int, int, float*, hipStream_t);
 int token_mean_f32(const float*, const float*, int, int, int, int, float*, hipStream_t);
-int mask_stats_f32(const float*, long long, int, int, int, int, float, float, float, int*, hipStream_t);
+int mask_stats_f32(const float*, long long, int, long long, long long, int, int, int, int, float, float, float, int*, hipStream_t);
 int prompt_tokens_f32(const float*, const long long*, const float*, const long long*, const float*, const float*, const long long*,
                       const uint8_t*, const uint8_t*, const float*, const long long*, int, int, int, int, int, int, int, float*, float*,
                       uint8_t*, hipStream_t);
@@ -958,21 +958,35 @@ int univs_prompt_point_pe_f32(const float* xy, const float* z, const float* dim_
   return prompt_point_pe_f32(xy, z, dim_t, dim_tz, scale, F, n, Fq, out, static_cast<hipStream_t>(stream));
 }
 
-int univs_mask_stats_f32(const float* x, long long planes, int H, int W, int h_valid, int w_valid, float t_hi, float t_lo, float t_box,
-                         int32_t* out, void* stream) {
+int univs_mask_stats_strided_f32(const float* x, long long outer, int inner, long long stride_outer, long long stride_inner, int H, int W,
+                                 int h_valid, int w_valid, float t_hi, float t_lo, float t_box, int32_t* out, void* stream) {
   clear_sticky_error();
-  if (planes < 0 || H < 1 || W < 1 || h_valid < 0 || w_valid < 0 || h_valid > H || w_valid > W) {
-    set_error("univs_mask_stats_f32: bad dimensions planes=%lld H=%d W=%d h_valid=%d w_valid=%d", planes, H, W, h_valid, w_valid);
+  if (outer < 0 || inner < 1 || H < 1 || W < 1 || h_valid < 0 || w_valid < 0 || h_valid > H || w_valid > W || stride_outer < 0 ||
+      stride_inner < (long long)H * W) {
+    set_error("univs_mask_stats_f32: bad dimensions outer=%lld inner=%d H=%d W=%d h_valid=%d w_valid=%d strides %lld / %lld", outer, inner, H, W,
+              h_valid, w_valid, stride_outer, stride_inner);
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  if (planes == 0) return UNIVS_OK;
+  if (outer == 0) return UNIVS_OK;
   if (!x || !out) {
     set_error("univs_mask_stats_f32: NULL data pointer");
     return UNIVS_ERR_INVALID_ARGUMENT;
   }
-  const int rc = mask_stats_f32(x, planes, H, W, h_valid, w_valid, t_hi, t_lo, t_box, out, static_cast<hipStream_t>(stream));
-  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_mask_stats_f32: planes=%lld not covered (<= 65535)", planes);
+  const int rc = mask_stats_f32(x, outer * inner, inner, stride_outer, stride_inner, H, W, h_valid, w_valid, t_hi, t_lo, t_box, out,
+                                static_cast<hipStream_t>(stream));
+  if (rc == UNIVS_ERR_NOT_IMPLEMENTED) set_error("univs_mask_stats_f32: planes=%lld not covered (<= 65535)", outer * inner);
   return rc;
+}
+
+int univs_mask_stats_f32(const float* x, long long planes, int H, int W, int h_valid, int w_valid, float t_hi, float t_lo, float t_box,
+                         int32_t* out, void* stream) {
+  if (planes > 0x7fffffffLL) {
+    clear_sticky_error();
+    set_error("univs_mask_stats_f32: planes=%lld not covered (<= 65535)", planes);
+    return UNIVS_ERR_NOT_IMPLEMENTED;
+  }
+  return univs_mask_stats_strided_f32(x, planes > 0 ? 1 : 0, (int)std::max<long long>(planes, 1), 0, (long long)H * W, H, W, h_valid, w_valid, t_hi,
+                                      t_lo, t_box, out, stream);
 }
 
 int univs_token_mean_f32(const float* x, const float* add, int n, int L, int T, int C, float* out, void* stream) {

@@ -52,12 +52,14 @@ __device__ __forceinline__ int wave_max(int v) {
 // grid (segments, planes): a workgroup walks rows [y0, y1) of its plane, a thread 4 consecutive columns at a time (16-byte loads when
 // the row pitch and the base allow, scalar otherwise)
 template <bool VEC4>
-__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ x, int* __restrict__ out, int H, int W, int hv, int wv,
-                                                         int rows_per_seg, float t_hi, float t_lo, float t_box) {
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ x, int* __restrict__ out, int W, int hv, int wv,
+                                                         int rows_per_seg, float t_hi, float t_lo, float t_box, int inner,
+                                                         long long stride_outer, long long stride_inner) {
   const long long p = blockIdx.y;
   const int y0 = blockIdx.x * rows_per_seg, y1 = min(hv, y0 + rows_per_seg);
-  if (y0 >= y1) return;
-  const float* base = x + p * (long long)H * W;
+  if (y0 >= y1) return;                                           // (the whole workgroup: no barrier is skipped by a part of it)
+  // plane p = (outer index p / inner, inner index p % inner): a [N, T, H, W] view of a longer history has two plane strides
+  const float* base = x + (p / inner) * stride_outer + (p % inner) * stride_inner;
   const int wq = (wv + 3) >> 2;                                   // column groups of 4 in the valid width
   const int n = (y1 - y0) * wq;
   int hi = 0, lo = 0, xmin = INT_MAX, ymin = INT_MAX, xmax = -1, ymax = -1;
@@ -91,7 +93,24 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict
   ymin = wave_min(ymin);
   xmax = wave_max(xmax);
   ymax = wave_max(ymax);
+  // the four waves meet in LDS: ONE set of atomics per workgroup (with one per wave, a plane's ~2 000 atomics on a single cache line took
+  // longer than the pass over its pixels when few planes are cut into many segments)
+  __shared__ int part[4][6];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
+    part[wave][0] = hi; part[wave][1] = lo; part[wave][2] = xmin; part[wave][3] = ymin; part[wave][4] = xmax; part[wave][5] = ymax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      hi += part[k][0];
+      lo += part[k][1];
+      xmin = min(xmin, part[k][2]);
+      ymin = min(ymin, part[k][3]);
+      xmax = max(xmax, part[k][4]);
+      ymax = max(ymax, part[k][5]);
+    }
     int* o = out + p * 8;
     if (hi) atomicAdd(o + 0, hi);
     if (lo) atomicAdd(o + 1, lo);
@@ -104,11 +123,12 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict
   }
 }
 
-// returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED for more than 2^31 - 1 planes' worth of grid / planes > 65535 * 32768
-int mask_stats_f32(const float* x, long long planes, int H, int W, int hv, int wv, float t_hi, float t_lo, float t_box, int* out,
-                   hipStream_t st) {
+// plane p of the input starts at x + (p / inner) * stride_outer + (p % inner) * stride_inner floats (dense planes: inner = planes, stride_inner =
+// H * W).  Returns UNIVS_OK, or UNIVS_ERR_NOT_IMPLEMENTED for more than 65 535 planes
+int mask_stats_f32(const float* x, long long planes, int inner, long long stride_outer, long long stride_inner, int H, int W, int hv, int wv,
+                   float t_hi, float t_lo, float t_box, int* out, hipStream_t st) {
   if (planes <= 0) return UNIVS_OK;
-  if (planes > 65535) return UNIVS_ERR_NOT_IMPLEMENTED;
+  if (planes > 65535 || inner < 1) return UNIVS_ERR_NOT_IMPLEMENTED;
   const unsigned pb = (unsigned)((planes + 255) / 256);
   hipLaunchKernelGGL(mask_stats_init_kernel, dim3(pb), dim3(256), 0, st, out, planes);
   if (hv > 0 && wv > 0) {
@@ -117,10 +137,10 @@ int mask_stats_f32(const float* x, long long planes, int H, int W, int hv, int w
     int segs = (int)std::min<long long>(std::max<long long>(want, 1), std::max(1, hv / 8));
     const int rows_per_seg = (hv + segs - 1) / segs;
     segs = (hv + rows_per_seg - 1) / rows_per_seg;
-    const bool vec4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool vec4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && stride_outer % 4 == 0 && stride_inner % 4 == 0;
     dim3 grid((unsigned)segs, (unsigned)planes);
-    if (vec4) hipLaunchKernelGGL(mask_stats_kernel<true>, grid, dim3(256), 0, st, x, out, H, W, hv, wv, rows_per_seg, t_hi, t_lo, t_box);
-    else hipLaunchKernelGGL(mask_stats_kernel<false>, grid, dim3(256), 0, st, x, out, H, W, hv, wv, rows_per_seg, t_hi, t_lo, t_box);
+    if (vec4) hipLaunchKernelGGL(mask_stats_kernel<true>, grid, dim3(256), 0, st, x, out, W, hv, wv, rows_per_seg, t_hi, t_lo, t_box, inner, stride_outer, stride_inner);
+    else hipLaunchKernelGGL(mask_stats_kernel<false>, grid, dim3(256), 0, st, x, out, W, hv, wv, rows_per_seg, t_hi, t_lo, t_box, inner, stride_outer, stride_inner);
   }
   hipLaunchKernelGGL(mask_stats_finish_kernel, dim3(pb), dim3(256), 0, st, out, planes);
   return check_launch("mask_stats_f32");

@@ -111,9 +111,10 @@ def _plane_stats(x, valid=None):
     inclusive, zeros when empty --, non-empty, 0) over rows / columns below `valid` (the whole plane by default).  On the GPU one pass of
     `ops.mask_stats` (csrc/mask_stats.hip) instead of ~25 launches; elsewhere (and for shapes it does not cover) the ATen formulation of
     `calculate_mask_quality_scores` / `convert_mask_to_box`, packed the same way."""
-    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0:
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and (x.is_contiguous() or (
+            x.dim() == 4 and x.stride(-1) == 1 and x.stride(-2) == x.shape[-1] and x.stride(1) >= x.shape[-2] * x.shape[-1])):
         from .. import ops
-        st = ops.mask_stats(x, 1.0, -1.0, 0.0, valid=valid)
+        st = ops.mask_stats(x, 1.0, -1.0, 0.0, valid=valid)      # (a [N, T, H, W] view of a longer history is read in place)
         if st is not None:
             return st
     cur = x if valid is None else x[..., : valid[0], : valid[1]]
@@ -137,6 +138,18 @@ def _quality_counts_and_boxes(x, valid=None, boxes=True, stats=None):
         full = stats is not None or valid is None or (valid[0] >= x.shape[-2] and valid[1] >= x.shape[-1])
         bx = (st if full else _plane_stats(x))[..., 2:6].long()
     return hi, lo, bx
+
+
+def _refresh_recent_masks(tv, T):
+    """`tv["masks"] = tv["mask_logits"].gt(0).float()` (:476, :634) when only the last T frames of the logits changed: the binarised
+    history is kept equal to the logits' sign by everything that touches it (padding, newcomers, the output window), so the earlier
+    frames need no second pass over `[N, history, H, W]` (0.75 GB at ten entities and ten frames of history).  The first clip stores
+    the masks as bool (write_newly_entities_into_annotations_per_clip, as the reference does): then the whole tensor is rebuilt."""
+    ml, mk = tv["mask_logits"], tv["masks"]
+    if mk.dtype == torch.float32 and mk.shape == ml.shape and mk.device == ml.device and 0 < T <= ml.shape[1]:
+        mk[:, -T:] = ml[:, -T:].gt(0.0)
+    else:
+        tv["masks"] = ml.gt(0.0).float()
 
 
 class ClipMaskRows:
@@ -615,21 +628,34 @@ class InferenceVideoEntity(nn.Module):
             owner = (score.view(-1, 1) * prob).argmax(0)
             owner = torch.where((prob < 0.5).all(0), torch.full_like(owner, -1), owner)   # background pixels
             own = owner[None] == torch.arange(len(prob), device=prob.device).view(-1, 1)
-            ratio = own.sum(1) / fg.sum(1).clamp(min=1)
-            keep = keep & (ratio > self.overlap_threshold_entity) & ((own & fg).sum(1) > 0)
+            # pixel counts per entity in two stages (image rows first): ATen reduces a [N, 4.6 M] bool tensor along its long axis with a
+            # few workgroups per row -- 1.4 ms per sum at ten entities, 4.3 of the 5.9 ms this step took (tools/bench_write_prompt_pieces.py)
+            wlast = cur.shape[-1]
+
+            def count(b):
+                return b.view(b.shape[0], -1, wlast).sum(-1).sum(-1)
+            ratio = count(own) / count(fg).clamp(min=1)
+            keep = keep & (ratio > self.overlap_threshold_entity) & (count(own & fg) > 0)
 
         idx = keep.nonzero(as_tuple=True)[0]                   # (one host round trip: the count tells whether anything is kept)
         if idx.numel():
-            m = pred_masks[idx]
-            norm = _norm4(interim_size[1], interim_size[0], m.device)
-            tv["occurrence"][idx, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
-            tv["mask_logits"][idx, -T:] += m
-            tv["boxes"][idx, -T:] = _quality_counts_and_boxes(tv["mask_logits"][idx, -T:])[2] / norm.view(1, 1, -1)
+            # The reference's lines (:466-475) on index sets -- `x[idx, -T:] += m` etc. -- each copy the kept entities' full-resolution
+            # logits (188 MB at ten entities) several times; here the same values with the history updated in place: the kept rows are
+            # added into the view of the last T frames, occurrence and boxes come from per-plane statistics read in place
+            norm = _norm4(interim_size[1], interim_size[0], pred_masks.device)
+            all_kept = idx.numel() == pred_masks.shape[0]
+            recent = tv["mask_logits"][:, -T:]                # a view: [N, T, H, W]
+            tv["occurrence"][idx, -T:] += _plane_stats(pred_masks)[..., 6].float()[idx]      # m.flatten(-2).gt(0).any(-1)
+            if all_kept:
+                recent += pred_masks
+            else:
+                recent.index_add_(0, idx, pred_masks.index_select(0, idx))
+            tv["boxes"][idx, -T:] = (_plane_stats(recent)[..., 2:6].long()[idx] / norm.view(1, 1, -1)).to(tv["boxes"].dtype)
             last = tv["embds"][idx, -1]
             nonblank = (last != 0).any(-1)
             tv["embds"][idx, -1] = (last + pred_embds[idx].mean(1)) / (nonblank[..., None] + 1.0)
             tv["mask_quality_scores"][idx] += quality[idx]
-        tv["masks"] = tv["mask_logits"].gt(0.0).float()
+        _refresh_recent_masks(tv, T)
 
     # ------------------------------------------------------------------------------------------
     # step 2: new entities
@@ -726,10 +752,10 @@ class InferenceVideoEntity(nn.Module):
             c2_h = cols[ok2]
             r2, c2 = to_device_async(rows[ok2], dev), idx_d[to_device_async(c2_h, dev)]       # (c2: query indices)
             m = _resize(take(c2), interim_size)
-            tv["occurrence"][r2, -T:] += m.flatten(-2).gt(0.0).any(-1).float()
+            tv["occurrence"][r2, -T:] += _plane_stats(m)[..., 6].float()                          # m.flatten(-2).gt(0).any(-1)
             tv["mask_logits"][r2, -T:] += m
             tv["mask_quality_scores"][r2] += quality_d[c2]
-            tv["masks"] = tv["mask_logits"].gt(0.0).float()
+            _refresh_recent_masks(tv, T)
 
             # a query is a NEW entity if it is unmatched, confident, and overlaps no known entity
             # (mask IoU < 0.5 in every frame of the clip)

@@ -1344,12 +1344,14 @@ def prompt_point_pe(xy, z, dim_t, dim_tz, scale, n):
 
 
 def mask_stats(x, t_hi=1.0, t_lo=-1.0, t_box=0.0, valid=None):
-    """Per-plane statistics of mask logits in one pass (include/univs_hip.h: univs_mask_stats_f32; csrc/mask_stats.hip): x [..., H, W]
-    contiguous float32 on the GPU -> int32 [..., 8] = (|{x > t_hi}|, |{x > t_lo}|, left, top, right, bottom of {x > t_box} -- inclusive,
+    """Per-plane statistics of mask logits in one pass (include/univs_hip.h: univs_mask_stats_f32 / _strided_f32; csrc/mask_stats.hip): x
+    [..., H, W] float32 on the GPU -> int32 [..., 8] = (|{x > t_hi}|, |{x > t_lo}|, left, top, right, bottom of {x > t_box} -- inclusive,
     zeros when empty --, non-empty, 0) over rows [0, valid[0]) x columns [0, valid[1]) (the whole plane by default): what
-    `calculate_mask_quality_scores` and `convert_mask_to_box` (utils/comm.py) compute with ~25 launches.  None when not covered
+    `calculate_mask_quality_scores` and `convert_mask_to_box` (utils/comm.py) compute with ~25 launches.  x is contiguous, or a 4-D view
+    [N, T, H, W] whose planes are dense and whose two leading strides are free (`history[:, -T:]`: no copy).  None when not covered
     (more than 65 535 planes, autograd needed)."""
-    _require_gpu("mask_stats", x)
+    if not x.is_cuda:
+        raise RuntimeError(f"mask_stats: Not implemented on the CPU (tensor on {x.device}); the HIP extension is the only implementation")
     if x.dtype != torch.float32 or x.dim() < 2:
         raise RuntimeError("mask_stats: float32 [..., H, W] only")
     H, W = int(x.shape[-2]), int(x.shape[-1])
@@ -1357,9 +1359,19 @@ def mask_stats(x, t_hi=1.0, t_lo=-1.0, t_box=0.0, valid=None):
     planes = x.numel() // max(H * W, 1)
     if planes > 65535 or needs_grad(x) or H * W == 0:
         return None
+    dense_planes = x.stride(-1) == 1 and x.stride(-2) == W
+    if x.is_contiguous():
+        outer, inner, so, si = (1 if planes else 0), max(planes, 1), 0, H * W
+    elif x.dim() == 4 and dense_planes and x.stride(1) >= H * W and x.stride(0) >= 0:
+        outer, inner, so, si = int(x.shape[0]), int(x.shape[1]), int(x.stride(0)), int(x.stride(1))
+    else:
+        raise RuntimeError("mask_stats: all tensors have to be contiguous (or a [N, T, H, W] view with dense planes)")
     out = torch.empty(tuple(x.shape[:-2]) + (8,), dtype=torch.int32, device=x.device)
+    if planes == 0:
+        return out
     with _on(x):
-        rc = _lib.load().univs_mask_stats_f32(_ptr(x), planes, H, W, hv, wv, float(t_hi), float(t_lo), float(t_box), _ptr(out), _stream_ptr(x))
+        rc = _lib.load().univs_mask_stats_strided_f32(_ptr(x), outer, inner, so, si, H, W, hv, wv, float(t_hi), float(t_lo), float(t_box),
+                                                      _ptr(out), _stream_ptr(x))
     if rc == _lib.ERR_NOT_IMPLEMENTED:
         return None
     _lib.check(rc, "mask_stats")

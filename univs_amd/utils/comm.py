@@ -35,9 +35,10 @@ def convert_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
 
 def calculate_mask_quality_scores(mask_pred: torch.Tensor, threshold: float = 1.0) -> torch.Tensor:
     """|{logit > thr}| / max(|{logit > -thr}|, 1) per leading entry (mask_pred: [N, ...] logits)."""
-    hi = (mask_pred > threshold).flatten(1).sum(-1)
-    lo = (mask_pred > -threshold).flatten(1).sum(-1).clamp(min=1)
-    return hi / lo
+    # (counted in two stages, image rows first: a reduction along an axis of 10^6 elements with few rows runs on a few workgroups)
+    hi = (mask_pred > threshold).sum(-1).flatten(1).sum(-1) if mask_pred.dim() > 2 else (mask_pred > threshold).flatten(1).sum(-1)
+    lo = (mask_pred > -threshold).sum(-1).flatten(1).sum(-1) if mask_pred.dim() > 2 else (mask_pred > -threshold).flatten(1).sum(-1)
+    return hi / lo.clamp(min=1)
 
 
 def box_area(boxes: torch.Tensor) -> torch.Tensor:
