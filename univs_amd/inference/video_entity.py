@@ -31,7 +31,7 @@ from torch import nn
 from ..registry import configurable
 from ..utils.memory import retry_if_oom
 from ..layers import to_device_async
-from ..utils.comm import batched_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou
+from ..utils.comm import batched_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, count_true, video_box_iou
 from .comm import check_consistency_with_prev_frames, match_from_learnable_embds  # noqa: F401  (API parity)
 from scipy.optimize import linear_sum_assignment
 
@@ -633,7 +633,7 @@ class InferenceVideoEntity(nn.Module):
             wlast = cur.shape[-1]
 
             def count(b):
-                return b.view(b.shape[0], -1, wlast).sum(-1).sum(-1)
+                return count_true(b.view(b.shape[0], -1, wlast))
             ratio = count(own) / count(fg).clamp(min=1)
             keep = keep & (ratio > self.overlap_threshold_entity) & (count(own & fg) > 0)
 
@@ -1035,9 +1035,9 @@ class InferenceVideoEntity(nn.Module):
         owner = torch.where((prob < 0.5).all(0), torch.full_like(owner, -1), owner)
         onehot = owner[None] == torch.arange(n, device=owner.device).view(-1, 1, 1, 1)
         fg = prob >= 0.5
-        area = onehot.flatten(1).sum(1).tolist()
-        orig = fg.flatten(1).sum(1).tolist()
-        inter = (onehot & fg).flatten(1).sum(1).tolist()
+        area = count_true(onehot).tolist()
+        orig = count_true(fg).tolist()
+        inter = count_true(onehot & fg).tolist()
         seg_of = [0] * n
         nxt = max(known_ids) + 1 if known_ids else 0
         for k in range(n):

@@ -27,7 +27,7 @@ from torch import nn
 
 from ..registry import configurable
 from ..utils.memory import retry_if_oom
-from ..utils.comm import (batched_pair_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, video_box_iou)
+from ..utils.comm import (batched_pair_mask_iou, calculate_mask_quality_scores, convert_mask_to_box, count_true, video_box_iou)
 from .comm import check_consistency_with_prev_frames, match_from_learnable_embds
 
 
@@ -347,8 +347,8 @@ class InferenceVideoVOS(nn.Module):
                 sim = (sim_p + sim_l) / (sim_p.gt(0.0).float() + sim_l.gt(0.0).float()).clamp(min=1)
                 den = (sim_p + sim_l).clamp(min=1e-5)
                 w_pq, w_lq = sim_p / den, sim_l / den
-                inter = (masks_p.gt(0) & masks_l.gt(0)).flatten(1).sum(1)
-                union = (masks_p.gt(0) | masks_l.gt(0)).flatten(1).sum(1)
+                inter = count_true(masks_p.gt(0) & masks_l.gt(0))
+                union = count_true(masks_p.gt(0) | masks_l.gt(0))
                 disagree = inter / union.clamp(min=1) < 0.5          # the two sources see different things: trust the prompt
                 w_pq = torch.where(disagree, torch.ones_like(w_pq), w_pq)
                 w_lq = torch.where(disagree, torch.zeros_like(w_lq), w_lq)
@@ -363,7 +363,7 @@ class InferenceVideoVOS(nn.Module):
             if task == "sot":
                 # every pixel to the object with the highest sim^2 x quality x probability; drop objects that keep
                 # less than a quarter of their own area
-                orig = (m_masks > 0).flatten(1).sum(1).clamp(min=1)
+                orig = count_true(m_masks > 0).clamp(min=1)
                 prob = m_masks.sigmoid()
                 if sem_mask is not None:
                     for i_, label in enumerate(labels[seen].tolist()):
@@ -375,7 +375,7 @@ class InferenceVideoVOS(nn.Module):
                 owner = (prob * (sim ** 2 * m_q).view(-1, 1, 1, 1)).argmax(0)
                 owner = torch.where(is_bg, torch.full_like(owner, -1), owner)
                 binary = (owner[None] == torch.arange(m_masks.shape[0], device=owner.device).view(-1, 1, 1, 1)).float()
-                area = binary.flatten(1).sum(1)
+                area = count_true(binary)                 # (0 / 1 floats: exact)
                 ok = ((area / orig) > 0.25) & (orig > 0) & (area > 0)
                 m_masks = m_masks * binary * ok.view(-1, 1, 1, 1).float()
             gt_logits[seen, -T:] += m_masks

@@ -41,6 +41,15 @@ def calculate_mask_quality_scores(mask_pred: torch.Tensor, threshold: float = 1.
     return hi / lo.clamp(min=1)
 
 
+def count_true(mask: torch.Tensor) -> torch.Tensor:
+    """`mask.flatten(1).sum(1)` of a bool / 0-1 tensor [N, ..., W] counted in two stages, rows of W first: ATen reduces along an axis of
+    10^6 elements with a few workgroups per row (1.4 ms per sum of a [10, 4.6 M] tensor on an MI355X; 0.05 ms this way).  Integer counts
+    (and 0 / 1 floats below 2^24) are exact whatever the order."""
+    if mask.dim() <= 2:
+        return mask.flatten(1).sum(1)
+    return mask.sum(-1).flatten(1).sum(1)
+
+
 def box_area(boxes: torch.Tensor) -> torch.Tensor:
     return (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
 
