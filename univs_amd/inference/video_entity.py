@@ -753,7 +753,7 @@ class InferenceVideoEntity(nn.Module):
             r2, c2 = to_device_async(rows[ok2], dev), idx_d[to_device_async(c2_h, dev)]       # (c2: query indices)
             m = _resize(take(c2), interim_size)
             tv["occurrence"][r2, -T:] += _plane_stats(m)[..., 6].float()                          # m.flatten(-2).gt(0).any(-1)
-            tv["mask_logits"][r2, -T:] += m
+            tv["mask_logits"][:, -T:].index_add_(0, r2, m)       # x[r2, -T:] += m without the copy out and back (r2: distinct rows)
             tv["mask_quality_scores"][r2] += quality_d[c2]
             _refresh_recent_masks(tv, T)
 
