@@ -52,6 +52,37 @@ __global__ __launch_bounds__(512) void only_mfma(int iters, float* sink) {
   if (acc[0] == 12345.f) *sink = 1.f;
 }
 
+// The same arithmetic with the matrix instructions in the SAME wave (one stream, nothing else on the GPU): every lane issues 16 MFMAs, then the
+// packed form on freshly loaded data, `rounds` times; mode 1: only the odd waves of a workgroup issue MFMAs (neighbours on the SIMD do, the
+// wave itself does not).
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_then_affine(const float* __restrict__ x, const float* __restrict__ aff, float* __restrict__ y, int R, int C,
+                                                        float* sink) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int r = blockIdx.y * 16 + ty, c = blockIdx.x * 64 + 4 * tx;
+  f16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x + i); b[i] = (_Float16)(1.5f - i); }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool mm = MODE == 0 || ((threadIdx.x >> 6) & 1);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int round = 0; round < 8; ++round) {
+    if (mm) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+    if (r < R && c < C && (MODE == 0 || !mm)) {
+      const float* px = x + (long long)r * C + c;
+      const float* pa = aff + 2 * r;
+      asm volatile("" : "+v"(px), "+v"(pa));                        // (opaque: the loads and the packed FMAs stay inside the loop)
+      v = *reinterpret_cast<const float4*>(px);
+      const float sc = pa[0], bi = pa[1];
+      v = make_float4(fmaf(v.x, sc, bi), fmaf(v.y, sc, bi), fmaf(v.z, sc, bi), fmaf(v.w, sc, bi));
+      *reinterpret_cast<float4*>(y + (long long)r * C + c) = v;
+    }
+  }
+  if (acc[0] == 12345.f) *sink = 1.f;
+}
+
 int main() {
   const int R = 1280, C = 14720, RUNS = 20;
   std::vector<float> hx((size_t)R * C), ha(2 * R), hy((size_t)R * C);
@@ -102,5 +133,27 @@ int main() {
              lanes48, low_half);
       if (busy && !single) packed_wrong_busy = bad_runs;
     }
+  // ---- one stream: the MFMAs in the same wave / in the neighbouring waves of the same workgroup
+  for (int mode = 0; mode < 2; ++mode) {
+    long long wrong = 0;
+    int bad_runs = 0;
+    for (int run = 0; run < RUNS; ++run) {
+      CHECK(hipMemset(y, 0, hy.size() * 4));
+      if (mode == 0) hipLaunchKernelGGL(mfma_then_affine<0>, grid, block, 0, sa, x, aff, y, R, C, sink);
+      else hipLaunchKernelGGL(mfma_then_affine<1>, grid, block, 0, sa, x, aff, y, R, C, sink);
+      CHECK(hipStreamSynchronize(sa));
+      CHECK(hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost));
+      long long w = 0;
+      for (int r = 0; r < R; ++r) {
+        if (mode == 1 && (((r % 16) >> 2) & 1)) continue;                 // (rows of the waves that issue MFMAs instead)
+        for (int c = 0; c < C; ++c) w += hy[(size_t)r * C + c] != __builtin_fmaf(hx[(size_t)r * C + c], ha[2 * r], ha[2 * r + 1]);
+      }
+      wrong += w;
+      bad_runs += w != 0;
+    }
+    printf("one stream, one kernel, %-66s %2d of %d runs wrong; %lld elements\n",
+           mode == 0 ? "every wave: 16 MFMAs, then the packed form (the compiler's waits apply):" : "even waves: the packed form; odd waves of the workgroup: MFMAs only:",
+           bad_runs, RUNS, wrong);
+  }
   return packed_wrong_busy ? 1 : 0;
 }
